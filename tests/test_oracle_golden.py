@@ -1,0 +1,124 @@
+"""CPU: the oracle (oracle/) against the golden vectors captured from the unmodified
+reference (tools/make_goldens.py).  Integer work is compared by hash (bit-exact); float
+work with the tolerance written at each assert (the goldens come from torch CPU kernels,
+which may differ in the last bits between hosts)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bev_ref, cases, policy_ref
+from util import NULL_GRAD, T, golden, make_params, sha
+
+
+@pytest.mark.parametrize("name", list(cases.BEV_CASES))
+def test_g1_bev_index_and_scatter_bit_exact(name):
+    g = golden("g1_bev.npz")
+    c = cases.bev_inputs(name)
+    proj, lin, inv, x, y, v = bev_ref.project_to_ground(c["feat"], c["depth"], c["E"])
+    assert sha(np.stack([x, y], 1).astype(np.int64)) == str(g[name + ".locs_sha"])
+    assert sha(v[:, None].astype(np.uint8)) == str(g[name + ".valid_sha"])
+    assert sha(lin.astype(np.int32)) == str(g[name + ".lin_idx_sha"])
+    assert sha(inv.astype(np.uint8)) == str(g[name + ".invalid_sha"])
+    assert sha(proj.astype(np.float32)) == str(g[name + ".proj_sha"])
+    assert int((~inv).sum()) == int(g[name + ".n_valid"])
+    np.testing.assert_array_equal(lin.reshape(-1)[::97], g[name + ".lin_idx_sample"])
+
+
+def test_g1_edge_cases_present():
+    """the fixture really contains the edge cases the domain has: an all-invalid image,
+    out-of-range cells, and .5 ties in front of round()."""
+    c = cases.bev_inputs("e100_c64_f256")
+    proj, lin, inv, x, y, v = bev_ref.project_to_ground(c["feat"], c["depth"], c["E"])
+    assert inv[-1].all() and np.all(proj[-1] == 0)
+    assert ((x < 0) | (x >= 100)).any() and (y < 0).any()
+    z = c["depth"][1, :, :, 0] * np.float32(10)
+    frac = (-(z / np.float32(0.12)) + np.float32(49.5)) % 1
+    assert (frac == 0.5).sum() > 100
+
+
+def test_g2_map_sequence():
+    g = golden("g2_mapseq.npz")
+    m = bev_ref.MapperRef(2)
+    for s in range(cases.MAP_SEQ["steps"]):
+        c = cases.mapseq_inputs(s)
+        ego = m.step(T(c["feat"]), T(c["depth"]), T(c["gps"]), T(c["compass"]), T(c["masks"]))
+        d = cases.summarize(ego.numpy())
+        # tolerance: bilinear weights move by a few ulp of a coordinate ~ 1e-5 * |feature| <= 2
+        np.testing.assert_allclose(d["sample"], g[f"s{s}.ego.sample"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(ego[:, ::16, 40:56, 44:60].numpy(), g[f"s{s}.ego_patch"], atol=1e-4, rtol=0)
+        assert abs(d["abssum"] - g[f"s{s}.ego.abssum"]) <= 1e-5 * g[f"s{s}.ego.abssum"]
+        nnz = int((m.full_global_map != 0).sum())
+        assert abs(nnz - int(g[f"s{s}.global_nnz"])) <= 64
+
+
+def _run_update():
+    P = make_params()
+    ref = policy_ref.PolicyRef(P, num_proc=2)
+    ref.aux_active = True
+    obs_np, prev, masks, weights = cases.update_inputs(4, 2)
+    obs = {k: T(v) for k, v in obs_np.items()}
+    w = T(weights).view(4, 2)
+    pred, aux, h, sem = ref.forward(obs, torch.zeros(2, 2, 512), T(prev), T(masks), w)
+    loss, al = policy_ref.dagger_loss(pred, aux, obs["waypoint"], w)
+    loss.backward()
+    return P, ref, pred, aux, loss, h
+
+
+def test_g3_update_forward_backward():
+    g = golden("g3_update.npz")
+    P, ref, pred, aux, loss, h = _run_update()
+    np.testing.assert_allclose(pred.detach().numpy(), g["pred"], atol=2e-5, rtol=0)  # bar is 1e-4 on logits
+    assert abs(float(aux) - float(g["aux_loss"])) < 2e-5
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    for n in ["prediction_monitor", "contrastive_monitor", "progress_monitor"]:
+        np.testing.assert_allclose(ref.losses[n][0].detach().numpy(), g["aux." + n], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(ref.att_map_t_m.detach().numpy(), g["att_map_t_m"], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(h.detach().numpy(), g["h_out"], atol=2e-5, rtol=0)
+    for k in g.files:
+        if k.startswith("bn."):
+            np.testing.assert_allclose(P[k[3:]].detach().numpy(), g[k], atol=1e-5, rtol=1e-5)
+    for i, n in enumerate(g["grad.names"]):
+        n = str(n)
+        if n in NULL_GRAD:
+            continue
+        gr = P[n].grad.numpy()
+        nr = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+        assert abs(nr - g["grad.norm"][i]) <= 1e-3 * g["grad.norm"][i] + 1e-9, n
+    # the 50 trainable tensors the reference never reaches stay without gradient
+    assert {str(s) for s in g["grad.none"]} >= {"critic.fc.weight", "action_distribution.logstd._bias"}
+
+
+@pytest.mark.parametrize("hw", [224, 256])
+def test_g4_rollout_act(hw):
+    g = golden("g4_act.npz")
+    P = make_params(grad=False)
+    ref = policy_ref.PolicyRef(P, num_proc=2)
+    ref.train_mode = False
+    h, prev = torch.zeros(2, 2, 512), torch.zeros(2, 2)
+    with torch.no_grad():
+        for step in range(3):
+            obs_np, masks = cases.act_inputs(step, rgb_hw=hw)
+            obs = {k: T(v) for k, v in obs_np.items()}
+            p = f"r{hw}.s{step}"
+            if step == 1:
+                ref.update_map(obs, T(masks))
+            else:
+                value, action, logp, h = ref.act(obs, h, prev, T(masks))
+                prev = action
+                np.testing.assert_allclose(action.numpy(), g[p + ".action"], atol=5e-5, rtol=0)
+                np.testing.assert_allclose(value.numpy(), g[p + ".value"], atol=5e-5, rtol=0)
+                np.testing.assert_allclose(ref.prog.numpy(), g[p + ".prog"], atol=5e-5, rtol=0)
+                np.testing.assert_allclose(logp.numpy(), g[p + ".logp"], atol=1e-5, rtol=0)
+            e = cases.summarize(obs["rgb_ego_map"].numpy())
+            np.testing.assert_allclose(e["sample"], g[p + ".ego.sample"], atol=1e-4, rtol=0)
+
+
+def test_g5_attention():
+    g = golden("g5_attn.npz")
+    q, k, v, m = cases.attn_inputs()
+    o, a = policy_ref.attn(T(q), T(k), T(v), T(m))
+    np.testing.assert_allclose(o.numpy(), g["out"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(a.numpy(), g["attn"], atol=1e-7, rtol=1e-5)
+    assert np.all(a.numpy()[1, 1:] == 0)  # fully masked tail gets exactly 0 weight
+    o2, a2 = policy_ref.attn(T(q), T(k), T(v), None)
+    np.testing.assert_allclose(o2.numpy(), g["out_nomask"], atol=1e-6, rtol=1e-5)

@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Capture golden vectors by running the UNMODIFIED reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference does not exist on the GPU box).  It
+imports the reference's own files under the sys.modules stubs of tools/ref_stubs.py,
+feeds them the seeded inputs of oracle/cases.py with weights from oracle/detfill.py, and
+writes small .npz fixtures (data only: inputs are re-derivable, outputs are digests /
+small tensors) to tests/golden/.
+
+    python tools/make_goldens.py [g1 g2 g3 g4 g5]
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_stubs  # noqa: E402
+
+Config = ref_stubs.install()
+sys.path.insert(0, "/root/reference")
+
+from oracle import cases, detfill  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def flat_summary(prefix, a, out):
+    for k, v in cases.summarize(a.detach().cpu().numpy() if torch.is_tensor(a) else a).items():
+        out[f"{prefix}.{k}"] = v
+
+
+class _TorchProxy:
+    """`torch` as seen by rgb_mapping.py, with device() forced to CPU (reference
+    hard-codes torch.device('cuda', gpu_id): rgb_mapping.py:14)."""
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    @staticmethod
+    def device(*a, **k):
+        return torch.device("cpu")
+
+
+def model_config(E=100, C=64, G=240, num_proc=2):
+    return Config(
+        INSTRUCTION_ENCODER=Config(vocab_size=2504, embedding_size=50, use_pretrained_embeddings=False,
+                                   hidden_size=128, rnn_type="LSTM", final_state_only=False, bidirectional=True),
+        RGB_ENCODER=Config(output_size=256, pretrain_model="__synthetic__"),
+        DEPTH_ENCODER=Config(output_size=128, ddppo_checkpoint="NONE", backbone="resnet50"),
+        MAP_ENCODER=Config(ego_map_size=E, output_size=256),
+        STATE_ENCODER=Config(hidden_size=512, rnn_type="GRU", input_type=["rgb", "depth", "map"]),
+        PROGRESS_MONITOR=Config(use=True, alpha=1.0),
+        CONTRASTIVE_MONITOR=Config(use=True, alpha=1.0, target_tau=0.07),
+        PREDICTION_MONITOR=Config(use=True, alpha=0.1),
+        RGBMAPPING=Config(map_depth=C, global_map_size=G, egocentric_map_size=E, resolution=0.12, gpu_id=0,
+                          num_proc=num_proc),
+    )
+
+
+def build_policy(num_proc=2):
+    import vlnce_baselines.common.rgb_mapping as rm
+    rm.torch = _TorchProxy()
+    import vlnce_baselines.models.encoders.unet_encoder as ue
+    from vlnce_baselines.models.policy import BasePolicy
+    import gym.spaces as sp
+
+    real_load = torch.load
+
+    def fake_load(path, *a, **k):  # UNet.__init__ loads a segmentation checkpoint (unet_encoder.py:19-22)
+        sd = ue.ResNetUNet(3, 27).state_dict()
+        return {"models": {"img_segm_model": {"module.model." + k_: v for k_, v in sd.items()}}}
+
+    torch.load = fake_load
+    try:
+        obs_space = sp.Dict({"depth": sp.Box(shape=(256, 256, 1)), "rgb": sp.Box(shape=(224, 224, 3))})
+        pol = BasePolicy(obs_space, sp.Box(shape=(2,)), model_config(num_proc=num_proc))
+    finally:
+        torch.load = real_load
+    sd = pol.state_dict()
+    new = {k: T(detfill.state_value(k, tuple(v.shape))).to(v.dtype) for k, v in sd.items()}
+    pol.load_state_dict(new, strict=True)
+    # reference default: frozen pre-trained word embeddings (instruction_encoder.py:31-35, default.py:85,92)
+    pol.net.instruction_encoder.embedding_layer.weight.requires_grad_(False)
+    return pol
+
+
+# ============================================================================= state_dict contract
+def shapes():
+    """Key names / shapes / dtypes / trainability of BasePolicy.state_dict(): the checkpoint
+    compatibility contract (common_trainer.py:71-75,99,131)."""
+    import json
+    pol = build_policy()
+    req = {k: bool(p.requires_grad) for k, p in pol.named_parameters(remove_duplicate=False)}
+    spec = {k: dict(shape=list(v.shape), dtype=str(v.dtype).replace("torch.", ""), param=k in req,
+                    trainable=req.get(k, False)) for k, v in pol.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_spec.json"), "w") as f:
+        json.dump(spec, f, indent=0, sort_keys=True)
+    print("shapes:", len(spec), "entries,", sum(int(np.prod(v["shape"])) for v in spec.values()), "elements")
+
+
+# ============================================================================= G1
+def g1():
+    import vlnce_baselines.common.rgb_mapping as rm
+    rm.torch = _TorchProxy()
+    out = {}
+    for name in cases.BEV_CASES:
+        c = cases.bev_inputs(name)
+        E = c["E"]
+        cmin, cmax = -240 * 0.12 / 2, 240 * 0.12 / 2
+        csl = rm.ComputeSpatialLocs(E, 240, torch.device("cpu"), cmin, cmax)
+        pgp = rm.ProjectToGroundPlane(E, torch.device("cpu"))
+        locs, valid = csl.forward(T(c["depth"]) * 10)
+        locs_np = locs.numpy().copy()
+        proj = pgp.forward(T(c["feat"]), locs, valid)
+        idx = ref_stubs.CAPTURE["index"][:, 0, :].numpy()  # [B, Hf*Wf] linear cell (0 for invalid)
+        src = ref_stubs.CAPTURE["src"]
+        invalid = (src[:, 0, :] == -1e16).numpy() & (T(c["feat"]).reshape(c["B"], c["C"], -1)[:, 0, :] != -1e16).numpy()
+        out[f"{name}.locs_sha"] = sha(locs_np.astype(np.int64))
+        out[f"{name}.valid_sha"] = sha(valid.numpy().astype(np.uint8))
+        out[f"{name}.lin_idx_sha"] = sha(idx.astype(np.int32))
+        out[f"{name}.invalid_sha"] = sha(invalid.astype(np.uint8))
+        out[f"{name}.proj_sha"] = sha(proj.numpy().astype(np.float32))
+        out[f"{name}.locs_sample"] = locs_np.reshape(-1)[::251].astype(np.int64)
+        out[f"{name}.lin_idx_sample"] = idx.reshape(-1)[::97].astype(np.int32)
+        out[f"{name}.n_valid"] = np.int64((~invalid).sum())
+        flat_summary(f"{name}.proj", proj, out)
+        print("g1", name, "valid", int((~invalid).sum()), "of", invalid.size, "proj abssum", float(proj.abs().sum()))
+    np.savez_compressed(os.path.join(OUT, "g1_bev.npz"), **out)
+
+
+# ============================================================================= G2
+def g2():
+    import vlnce_baselines.common.rgb_mapping as rm
+    rm.torch = _TorchProxy()
+    m = cases.MAP_SEQ
+    mapper = rm.RGBMapping(model_config(num_proc=m["B"]).RGBMAPPING)
+    out = {}
+    for step in range(m["steps"]):
+        c = cases.mapseq_inputs(step)
+        obs = {"depth": T(c["depth"]), "gps": T(c["gps"]), "compass": T(c["compass"])}
+        ego = mapper.forward(T(c["feat"]), obs, T(c["masks"]))
+        flat_summary(f"s{step}.ego", ego, out)
+        flat_summary(f"s{step}.global", mapper.full_global_map, out)
+        out[f"s{step}.global_nnz"] = np.int64((mapper.full_global_map != 0).sum())
+        out[f"s{step}.ego_patch"] = ego[:, ::16, 40:56, 44:60].numpy().copy()
+        print("g2 step", step, "ego abssum", float(ego.abs().sum()), "global nnz", int(out[f"s{step}.global_nnz"]))
+    np.savez_compressed(os.path.join(OUT, "g2_mapseq.npz"), **out)
+
+
+# ============================================================================= G3
+def g3():
+    from vlnce_baselines.common.aux_losses import AuxLosses
+    pol = build_policy()
+    pol.train()
+    pol.net.depth_encoder.eval()
+    pol.net.rgb_encoder.eval()
+    T_, N = 4, 2
+    obs_np, prev, masks, weights = cases.update_inputs(T_, N)
+    obs = {k: T(v) for k, v in obs_np.items()}
+    AuxLosses.activate()
+    AuxLosses.clear()
+    h0 = torch.zeros(pol.net.num_recurrent_layers, N, 512)
+    pred, aux_loss = pol(obs, h0, T(prev), T(masks), T(weights))
+    out = {"pred": pred.detach().numpy(), "aux_loss": aux_loss.detach().numpy()}
+    for name in ["prediction_monitor", "contrastive_monitor", "progress_monitor"]:
+        out[f"aux.{name}"] = AuxLosses.get_loss(name).detach().numpy()
+    out["att_map_t_m"] = pol.net.att_map_t_m.detach().numpy()
+    out["prog"] = pol.prog.detach().numpy()
+    # loss of dagger_trainer.py:526-533
+    logits = torch.tanh(pred).view(T_, N, -1)
+    w = T(weights)
+    action_loss = torch.nn.functional.mse_loss(logits, obs["waypoint"][:, :2].view(T_, N, -1), reduction="none").sum(2)
+    action_loss = ((w * action_loss).sum(0) / w.sum(0)).mean()
+    loss = action_loss + aux_loss
+    loss.backward()
+    out["action_loss"] = action_loss.detach().numpy()
+    out["loss"] = loss.detach().numpy()
+    out["h_out"] = h0.detach().numpy()  # mutated in place by the net (mg_map_policy.py:220-227,242-249)
+    sd = pol.state_dict()
+    for k in ["net.map_encoder.cnn.1.running_mean", "net.map_encoder.cnn.1.running_var",
+              "net.map_decoder.conv_up0.1.running_mean", "net.map_decoder.conv_up0.1.running_var",
+              "net.map_classfier.1.running_mean", "net.map_classfier.4.running_var",
+              "net.map_decoder.base_model.layer1.1.bn2.running_var", "net.map_decoder.layer0_1x1.1.running_mean"]:
+        out["bn." + k] = sd[k].numpy()
+    gn, gs, names, nograd = [], [], [], []
+    seen = set()
+    for k, p in pol.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        if p.grad is None:
+            if p.requires_grad:
+                nograd.append(k)
+            continue
+        g = p.grad.detach().numpy().reshape(-1)
+        names.append(k)
+        gn.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        s = np.zeros(8, np.float32)
+        pick = g[:: max(1, g.size // 8)][:8]
+        s[: pick.size] = pick
+        gs.append(s)
+    out["grad.names"] = np.array(names)
+    out["grad.norm"] = np.array(gn, np.float64)
+    out["grad.sample"] = np.stack(gs)
+    out["grad.none"] = np.array(nograd)
+    # pred_sem_map is returned by the net, not kept: re-run the net for its digest (BN stats move again; fine)
+    with torch.no_grad():
+        AuxLosses.clear()
+        h1 = torch.zeros(2, N, 512)
+        pol.eval()
+        _, _, sem = pol.net(obs, h1, T(prev), T(masks))
+        flat_summary("eval.pred_sem_map", sem, out)
+        out["eval.pred"] = pol.action_distribution(pol.net(obs, torch.zeros(2, N, 512), T(prev), T(masks))[0]).mean.numpy()
+    AuxLosses.deactivate()
+    print("g3 pred", out["pred"].ravel()[:4], "aux", float(out["aux_loss"]), "loss", float(out["loss"]),
+          "params with grad", len(names), "trainable without grad", len(nograd))
+    np.savez_compressed(os.path.join(OUT, "g3_update.npz"), **out)
+
+
+# ============================================================================= G4
+def g4():
+    from vlnce_baselines.common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    out = {}
+    for rgb_hw in (224, 256):
+        pol = build_policy(num_proc=2)
+        pol.eval()
+        h = torch.zeros(2, 2, 512)
+        prev = torch.zeros(2, 2)
+        with torch.no_grad():
+            for step in range(3):
+                obs_np, masks = cases.act_inputs(step, rgb_hw=rgb_hw)
+                obs = {k: T(v) for k, v in obs_np.items()}
+                if step == 1:  # update_map-only step (dagger_trainer.py:438-439)
+                    pol.update_map(obs, T(masks))
+                    flat_summary(f"r{rgb_hw}.s{step}.ego", obs["rgb_ego_map"], out)
+                    continue
+                value, action, logp, h = pol.act(obs, h, prev, T(masks), deterministic=True)
+                prev = action
+                p = f"r{rgb_hw}.s{step}"
+                out[p + ".value"] = value.numpy()
+                out[p + ".action"] = action.numpy()
+                out[p + ".logp"] = logp.numpy()
+                out[p + ".prog"] = pol.prog.numpy()
+                flat_summary(p + ".h", h, out)
+                flat_summary(p + ".ego", obs["rgb_ego_map"], out)
+                flat_summary(p + ".att", pol.net.att_map_t_m, out)
+                print("g4", p, "action", action.numpy().ravel(), "value", value.numpy().ravel())
+        flat_summary(f"r{rgb_hw}.global", pol.net.rgb_mapping_module.full_global_map, out)
+    np.savez_compressed(os.path.join(OUT, "g4_act.npz"), **out)
+
+
+# ============================================================================= G5
+def g5():
+    pol = build_policy()
+    q, k, v, mask = cases.attn_inputs()
+    o, a = pol.net._attn(T(q), T(k), T(v), T(mask))
+    o2, a2 = pol.net._attn(T(q), T(k), T(v), None)
+    np.savez_compressed(os.path.join(OUT, "g5_attn.npz"), out=o.detach().numpy(), attn=a.detach().numpy(),
+                        out_nomask=o2.detach().numpy(), attn_nomask=a2.detach().numpy())
+    print("g5 out", o.detach().numpy().ravel()[:4])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["shapes", "g1", "g2", "g3", "g4", "g5"]
+    for w in which:
+        globals()[w]()
