@@ -1,0 +1,156 @@
+/* wsmgmap.h — C ABI of libwsmgmap.so: the MI355X (gfx950) kernels behind WS-MGMap's
+ * per-step policy hot path.
+ *
+ * The reference (PeihaoChen/WS-MGMap) has no FFI: its hot path is Python calling
+ * torch / cuDNN / torch_scatter operators.  Each entry point below replaces the library
+ * operator(s) the reference invokes at the cited call site (paths relative to
+ * /root/reference/vlnce_baselines/).  A host binds them with ctypes (see INTEGRATION.md;
+ * ws-mgmap_amd/wsmgmap/_abi.py is that binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA storage); the library
+ *     never allocates, frees or synchronises; `stream` is a hipStream_t (NULL = default);
+ *   - return value: 0 on success, a positive hipError_t if a launch failed, negative
+ *     WSMG_E* for rejected arguments;
+ *   - activations of the map stack are NHWC float32 ("pixel-major": [B][H][W][C], C
+ *     contiguous); conv weights are OHWI ([Cout][KH][KW][Cin]) for forward /
+ *     backward-weight and IHWO ([Cin][KH][KW][Cout]) for backward-data;
+ *   - all channel counts seen by the conv engine are multiples of 32 (27-class tensors are
+ *     padded to 32 by the caller).
+ */
+#ifndef WSMGMAP_H
+#define WSMGMAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wsmg_stream_t;
+
+#define WSMG_EINVAL (-1)   /* bad size / alignment / unsupported combination */
+#define WSMG_ENOMEM (-2)   /* workspace too small */
+
+/* library / build identification ("gfx950", ABI version) */
+int wsmg_abi_version(void);
+const char* wsmg_build_info(void);
+
+/* ============================ operator 1: RGB-D -> egocentric BEV ============================ */
+
+/* ComputeSpatialLocs.forward + the sub-sampling / validity / linearisation part of
+ * ProjectToGroundPlane.forward (common/rgb_mapping.py:153-176,188-216).
+ * depth [B][Hd][Wd] sensor units (x depth_scale = metres). lin_idx [B][Hf*Wf] int32: y*E+x, or -1
+ * for a source the reference routes to cell 0 with -1e16 (out of range / depth 0 / height filter). */
+int wsmg_bev_index(const float* depth, int B, int Hd, int Wd, float depth_scale, int Hf, int Wf, int E,
+                   float local_scale, int32_t* lin_idx, wsmg_stream_t stream);
+
+/* adaptive_max_pool1d over channels (rgb_mapping.py:81-84) fused with torch_scatter.scatter_max +
+ * the eps fix-up (rgb_mapping.py:206-232).  feat [B][Cf][Hf][Wf] NCHW, out [B][C][E][E] NCHW; cells
+ * without a valid source are 0.  One E x E tile per (sample, channel group) lives in LDS. */
+int wsmg_bev_scatter_max(const float* feat, const int32_t* lin_idx, int B, int Cf, int Hf, int Wf, int C,
+                         int E, float* out, wsmg_stream_t stream);
+
+/* RotateTensor.forward (rgb_mapping.py:239-250): affine_grid + bilinear grid_sample (zeros padding,
+ * align_corners=False) with A=[[c,s,0],[-s,c,0]], c,s = cos/sin(sign*heading[b]).
+ * in [B][C][E][E] (NCHW, the scatter's planes); out [B][E][E][C] (NHWC, as everything downstream). C <= 64. */
+int wsmg_bev_rotate(const float* in, const float* heading, float sign, int B, int C, int E, float* out,
+                    wsmg_stream_t stream);
+
+/* Mapping.project_feat_to_map, global-map half (rgb_mapping.py:34-35,40-56): episode reset
+ * (global *= mask), paste the rotated E x E projection into the centre of a G x G agent view,
+ * translate it to the agent's cell (bilinear, as get_grid + grid_sample do) and max-fuse into the
+ * persistent map.  global_map [P][G][G][C] (NHWC, in/out), ego_rot [B][E][E][C] (NHWC), gps [B][2], masks [B].
+ * Only the (E+4)^2 window the pasted view can reach is read-modify-written. */
+int wsmg_map_fuse(const float* ego_rot, float* global_map, const float* gps, const float* masks, int B,
+                  int C, int E, int G, float resolution, wsmg_stream_t stream);
+
+/* Retrieval half (rgb_mapping.py:57-70): translate the global map back, crop the centre E x E,
+ * rotate by +compass.  scratch [B][E][E][C] (intermediate crop) and out [B][E][E][C] are NHWC; the host
+ * exposes `out` as a channels-last view of the reference's [B][C][E][E] tensor. */
+int wsmg_map_retrieve(const float* global_map, const float* gps, const float* compass, int B, int C, int E,
+                      int G, float resolution, float* scratch, float* out, wsmg_stream_t stream);
+
+/* ============================ operator 2: map conv / UNet decoder engine ============================ */
+/* cuDNN conv2d forward / backward at map_encoder.py:19-29,94-112, mg_map_policy.py:78-100,127,130.
+ * Implicit GEMM on the f32 MFMA (v_mfma_f32_32x32x2_f32): exact float32 products, k-ordered
+ * accumulation.  x [B][H][W][Cin], y [B][OH][OW][Cout]; bias may be NULL. */
+int wsmg_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int B, int H, int W,
+                    int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                    wsmg_stream_t stream);
+
+/* dX of the same convolution (also the FORWARD of ConvTranspose2d, mg_map_policy.py:79).
+ * dy [B][OH][OW][Cout], w_ihwo [Cin][KH][KW][Cout], dx [B][H][W][Cin]. */
+int wsmg_conv2d_bwd_data(const float* dy, const float* w_ihwo, float* dx, int B, int H, int W, int Cin,
+                         int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                         wsmg_stream_t stream);
+
+/* dW (OHWI, float32) accumulated with atomics into dw, which must be zeroed by the caller. */
+int wsmg_conv2d_bwd_weight(const float* x, const float* dy, float* dw_ohwi, int B, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                           wsmg_stream_t stream);
+
+/* per-channel column sums of a [rows][C] matrix (bias gradients).  out [C] is overwritten. */
+int wsmg_channel_sum(const float* x, int64_t rows, int C, float* out, double* workspace,
+                     int64_t workspace_bytes, wsmg_stream_t stream);
+int64_t wsmg_channel_reduce_workspace_bytes(int64_t rows, int C);
+
+/* BatchNorm2d (+ optional residual add) (+ ReLU), training or eval statistics
+ * (nn.BatchNorm2d / F.relu at map_encoder.py:10-12,21-28; torchvision BasicBlock).
+ *   train=1: batch statistics in float64, running stats updated in place
+ *            (momentum, unbiased variance), save_mean / save_invstd [C] written;
+ *   train=0: running statistics.
+ * x, y, residual: [rows][C]; y may alias x. */
+int wsmg_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int train,
+                    int relu, int64_t rows, int C, float* y, float* save_mean, float* save_invstd,
+                    double* workspace, int64_t workspace_bytes, wsmg_stream_t stream);
+
+/* backward of the above (train statistics).  dy, x, y: [rows][C]; writes dx, dgamma, dbeta and, if
+ * dresidual != NULL, the gradient of the residual input (= masked dy). */
+int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                    const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
+                    float* dx, float* dresidual, float* dgamma, float* dbeta, double* workspace,
+                    int64_t workspace_bytes, wsmg_stream_t stream);
+
+/* bias-less activation helpers of the decoder (NHWC):
+ *   relu:        F.relu after the bias-carrying convs of mg_map_policy.py:89-100
+ *   maxpool:     MaxPool2d(3,2,1)            torchvision resnet18 child 3 (map_encoder.py:80)
+ *   upsample2x:  nn.Upsample(bilinear, align_corners=True) (map_encoder.py:84)
+ *   avgpool2:    F.avg_pool2d(2,2)           (mg_map_policy.py:197) */
+int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t stream);
+int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t stream);
+int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW,
+                          wsmg_stream_t stream);
+int wsmg_maxpool3x3s2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH,
+                          int OW, wsmg_stream_t stream);
+int wsmg_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream);
+
+/* layout changes at the boundary of the NHWC engine (ego map arrives NCHW: rgb_mapping.py:86;
+ * pred_sem_map leaves NCHW: mg_map_policy.py:195).  c_src / c_dst allow channel padding
+ * (27 <-> 32): channels >= c_src are written as 0, channels >= c_dst are dropped. */
+int wsmg_nchw_to_nhwc(const float* x, float* y, int B, int C_src, int H, int W, int C_dst,
+                      wsmg_stream_t stream);
+int wsmg_nhwc_to_nchw(const float* x, float* y, int B, int C_src, int H, int W, int C_dst,
+                      wsmg_stream_t stream);
+
+/* ============================ operator 3: cross-modal single-query attention ============================ */
+/* MGMapNet._attn (mg_map_policy.py:173-178): logits = q.k - 1e8*mask; attn = softmax(logits*scale);
+ * out = attn.v.  q [B][C]; k, v [B][I][C] (token-major, C contiguous); mask [B][I] bytes or NULL;
+ * out [B][C]; attn [B][I].  C must be 256. */
+int wsmg_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float scale, int B,
+                  int I, int C, float* out, float* attn, wsmg_stream_t stream);
+
+/* backward: given dout [B][C] and dattn [B][I] (NULL = zeros; the contrastive monitor differentiates
+ * the weights themselves, policy.py:80-84) write dq [B][C], dk [B][I][C], dv [B][I][C]. */
+int wsmg_attn_bwd(const float* q, const float* k, const float* v, const float* attn, const float* dout,
+                  const float* dattn, float scale, int B, int I, int C, float* dq, float* dk, float* dv,
+                  wsmg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSMGMAP_H */

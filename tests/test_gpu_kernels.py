@@ -1,0 +1,285 @@
+"""GPU parity, kernel level: every entry point of libwsmgmap.so (called through the C ABI via
+wsmgmap.ops) against the oracle / a float64 CPU evaluation of the same operator on seeded
+inputs.  Bars: bit-exact for the integer BEV index and the scatter-max; float tolerances are
+written at each assert."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import bev_ref, cases, policy_ref
+from oracle import detfill as df
+from util import T, golden, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from wsmgmap import ops as o
+    return o
+
+
+def dev(a):
+    return (a if torch.is_tensor(a) else T(a)).cuda()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(name, got, ref, rtol, atol):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    worst = float((err - bound).max())
+    assert worst <= 0, f"{name}: max abs err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e}), exceeds by {worst:.3e}"
+
+
+# (name, B, Cin, Cout, k, stride, pad, H) — every conv shape of the map stack
+CONVS = [
+    ("enc0_k8s2", 2, 64, 64, 8, 2, 3, 100),
+    ("enc3_k5s2", 3, 64, 128, 5, 2, 1, 50),
+    ("enc6_k3", 3, 128, 256, 3, 1, 1, 24),
+    ("dec_stem_k7s2", 3, 256, 64, 7, 2, 3, 24),
+    ("dec_1x1", 5, 64, 64, 1, 1, 0, 6),
+    ("dec_block_k3_6", 5, 64, 64, 3, 1, 1, 6),
+    ("dec_up0", 3, 128, 128, 3, 1, 1, 12),
+    ("dec_orig2", 2, 192, 64, 3, 1, 1, 24),
+    ("cls_k3_48", 2, 32, 32, 3, 1, 1, 48),
+    ("cls_1x1_48", 2, 32, 32, 1, 1, 0, 48),
+    ("cated_k3", 2, 256, 256, 3, 1, 1, 24),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS, ids=[c[0] for c in CONVS])
+def test_conv2d_fwd_bwd(ops, cfg):
+    name, B, Cin, Cout, k, s, p, H = cfg
+    x = T(df.uniform(f"conv.{name}.x", (B, Cin, H, H), 2.0))
+    w = T(df.uniform(f"conv.{name}.w", (Cout, Cin, k, k), float(np.sqrt(12.0 / (Cin * k * k)))))
+    b = T(df.uniform(f"conv.{name}.b", (Cout,), 0.5))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    gy = T(df.uniform(f"conv.{name}.gy", tuple(yr.shape), 2.0))
+    yr.backward(gy.double())
+
+    xg = nhwc(x).cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, s, p)
+    y.backward(nhwc(gy).cuda())
+    # f32 MFMA = fmaf chain over K = Cin*k*k terms of magnitude <= ~0.5: error ~ K * 2^-24 * |terms|
+    close(name + ".y", nchw(y), yr, 2e-5, 2e-5)
+    close(name + ".dx", nchw(xg.grad), xr.grad, 2e-5, 2e-5)
+    close(name + ".dw", wg.grad, wr.grad, 2e-5, 2e-4 * float(wr.grad.abs().max()) + 1e-6)
+    close(name + ".db", bg.grad, br.grad, 2e-5, 2e-4 * float(br.grad.abs().max()) + 1e-6)
+
+
+def test_conv_transpose2d(ops):
+    B, Ci, Co, H = 2, 64, 32, 24
+    x = T(df.uniform("convt.x", (B, Ci, H, H), 2.0))
+    w = T(df.uniform("convt.w", (Ci, Co, 4, 4), 0.2))
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1)
+    gy = T(df.uniform("convt.gy", tuple(yr.shape), 2.0))
+    yr.backward(gy.double())
+    xg = nhwc(x).cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    y = ops.conv_transpose2d(xg, wg, 2, 1)
+    assert tuple(y.shape) == (B, 2 * H, 2 * H, Co)
+    y.backward(nhwc(gy).cuda())
+    close("convt.y", nchw(y), yr, 2e-5, 2e-5)
+    close("convt.dx", nchw(xg.grad), xr.grad, 2e-5, 2e-5)
+    close("convt.dw", wg.grad, wr.grad, 2e-5, 2e-4 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,H,B,res,relu", [(64, 50, 3, False, True), (256, 24, 2, False, True), (64, 6, 5, True, True),
+                                            (32, 48, 2, False, True), (128, 12, 3, False, False)])
+def test_bn_act_train(ops, C, H, B, res, relu):
+    x = T(df.uniform(f"bn.x.{C}.{H}", (B, C, H, H), 3.0)) + T(df.uniform(f"bn.off.{C}", (1, C, 1, 1), 2.0))
+    r = T(df.uniform(f"bn.r.{C}.{H}", (B, C, H, H), 2.0)) if res else None
+    g = T(df.positive(f"bn.g.{C}", (C,)))
+    bt = T(df.uniform(f"bn.b.{C}", (C,), 0.5))
+    rm, rv = T(df.uniform(f"bn.rm.{C}", (C,), 0.2)), T(df.positive(f"bn.rv.{C}", (C,)))
+    xr, gr, br = x.double().requires_grad_(True), g.double().requires_grad_(True), bt.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    gy = T(df.uniform(f"bn.gy.{C}.{H}", tuple(yr.shape), 2.0))
+    yr.backward(gy.double())
+
+    xg = nhwc(x).cuda().requires_grad_(True)
+    gg, bg = g.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
+    rg = nhwc(r).cuda().requires_grad_(True) if res else None
+    rmg, rvg = rm.cuda(), rv.cuda()
+    y = ops.bn_act(xg, gg, bg, rmg, rvg, True, relu, rg, 0.1, 1e-5)
+    y.backward(nhwc(gy).cuda())
+    close("bn.y", nchw(y), yr, 1e-5, 1e-5)
+    close("bn.running_mean", rmg, rmr, 1e-6, 1e-6)
+    close("bn.running_var", rvg, rvr, 1e-5, 1e-6)
+    close("bn.dx", nchw(xg.grad), xr.grad, 1e-4, 2e-5)
+    close("bn.dgamma", gg.grad, gr.grad, 1e-4, 1e-4 * float(gr.grad.abs().max()))
+    close("bn.dbeta", bg.grad, br.grad, 1e-4, 1e-4 * float(br.grad.abs().max()))
+    if res:
+        close("bn.dres", nchw(rg.grad), rr.grad, 0, 0)
+
+
+def test_bn_eval(ops):
+    C, H, B = 64, 12, 2
+    x = T(df.uniform("bne.x", (B, C, H, H), 3.0))
+    g, bt = T(df.positive("bne.g", (C,))), T(df.uniform("bne.b", (C,), 0.5))
+    rm, rv = T(df.uniform("bne.rm", (C,), 0.2)), T(df.positive("bne.rv", (C,)))
+    yr = F.relu(F.batch_norm(x.double(), rm.double(), rv.double(), g.double(), bt.double(), training=False, eps=1e-5))
+    rmg, rvg = rm.cuda(), rv.cuda()
+    y = ops.bn_act(nhwc(x).cuda(), g.cuda(), bt.cuda(), rmg, rvg, False, True, None, 0.1, 1e-5)
+    close("bn_eval.y", nchw(y), yr, 1e-5, 1e-5)
+    assert torch.equal(rmg.cpu(), rm) and torch.equal(rvg.cpu(), rv)
+
+
+def test_small_nhwc_ops(ops):
+    B, C, H = 3, 64, 12
+    # post-ReLU-like input with many exact zeros: exercises max-pool tie breaking
+    x = torch.relu(T(df.uniform("pool.x", (B, C, H, H), 2.0)))
+    for nm, fn_ref, fn in [
+        ("maxpool", lambda t: F.max_pool2d(t, 3, 2, 1), ops.maxpool3x3s2),
+        ("upsample", lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x),
+        ("avgpool", lambda t: F.avg_pool2d(t, 2, 2), ops.avgpool2),
+        ("relu", lambda t: F.relu(t - 0.3), lambda t: ops.relu(t - 0.3)),
+    ]:
+        xr = x.double().requires_grad_(True)
+        yr = fn_ref(xr)
+        gy = T(df.uniform(f"pool.gy.{nm}", tuple(yr.shape), 2.0))
+        yr.backward(gy.double())
+        xg = nhwc(x).cuda().requires_grad_(True)
+        y = fn(xg)
+        y.backward(nhwc(gy).cuda())
+        close(nm + ".y", nchw(y), yr, 1e-6, 1e-6)
+        close(nm + ".dx", nchw(xg.grad), xr.grad, 1e-5, 1e-6)
+
+
+def test_layout_roundtrip_and_padding(ops):
+    x = T(df.uniform("lay.x", (3, 27, 48, 48), 2.0)).cuda().requires_grad_(True)
+    y = ops.to_nhwc(x, 32)
+    assert tuple(y.shape) == (3, 48, 48, 32)
+    assert torch.equal(y[..., :27], x.detach().permute(0, 2, 3, 1)) and float(y[..., 27:].abs().max()) == 0
+    z = ops.to_nchw(y, 27)
+    assert torch.equal(z, x.detach())
+    z.backward(torch.ones_like(z))
+    assert torch.equal(x.grad, torch.ones_like(x))
+    e = T(df.uniform("lay.e", (2, 64, 100, 100), 2.0)).cuda()
+    assert torch.equal(ops.to_nhwc(e), e.permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("masked", [True, False])
+def test_attention_fwd_bwd(ops, masked):
+    g = golden("g5_attn.npz")
+    q, k, v, m = cases.attn_inputs()
+    qr, kr, vr = (T(a).double().requires_grad_(True) for a in (q, k, v))
+    o_ref, a_ref = policy_ref.attn(qr, kr, vr, T(m) if masked else None)
+    go = T(df.uniform("attn.go", tuple(o_ref.shape), 2.0))
+    ga = T(df.uniform("attn.ga", tuple(a_ref.shape), 2.0))
+    (o_ref * go.double()).sum().backward(retain_graph=True)
+    (a_ref * ga.double()).sum().backward()
+
+    qg = T(q).cuda().requires_grad_(True)
+    kg = T(k).permute(0, 2, 1).contiguous().cuda().requires_grad_(True)   # token-major [B,I,C]
+    vg = T(v).permute(0, 2, 1).contiguous().cuda().requires_grad_(True)
+    o, a = ops.attention(qg, kg, vg, T(m).cuda() if masked else None, 1.0 / 16)
+    ((o * go.cuda()).sum() + (a * ga.cuda()).sum()).backward()
+    close("attn.out", o, o_ref, 1e-5, 1e-6)
+    close("attn.attn", a, a_ref, 1e-5, 1e-7)
+    np.testing.assert_allclose(o.detach().cpu().numpy(), g["out" if masked else "out_nomask"], rtol=1e-5, atol=1e-6)
+    if masked:
+        assert float(a[1, 1:].abs().max()) == 0.0
+    close("attn.dq", qg.grad, qr.grad, 1e-4, 1e-6)
+    close("attn.dk", kg.grad.permute(0, 2, 1), kr.grad, 1e-4, 1e-7)
+    close("attn.dv", vg.grad.permute(0, 2, 1), vr.grad, 1e-4, 1e-7)
+
+
+def test_attention_map_sized(ops):
+    """I = 576 map cells, no mask, B = 9 (the map-attention call site)."""
+    q = T(df.uniform("attn2.q", (9, 256), 6.0))
+    kv = T(df.uniform("attn2.kv", (9, 576, 256), 3.0))
+    o_ref, a_ref = policy_ref.attn(q.double(), kv.double().permute(0, 2, 1), kv.double().permute(0, 2, 1))
+    o, a = ops.attention(q.cuda(), kv.cuda(), kv.cuda(), None, 1.0 / 16)
+    close("attn576.out", o, o_ref, 1e-5, 1e-6)
+    close("attn576.attn", a, a_ref, 1e-5, 1e-8)
+
+
+# ----------------------------------------------------------------------------- BEV: the integer gate
+@pytest.mark.parametrize("name", list(cases.BEV_CASES))
+def test_bev_index_and_scatter_bit_exact(ops, name):
+    g = golden("g1_bev.npz")
+    c = cases.bev_inputs(name)
+    E, C, Hf = c["E"], c["C"], c["Hf"]
+    proj_ref, lin_ref, inv_ref, *_ = bev_ref.project_to_ground(c["feat"], c["depth"], E)
+    lin = ops.bev_index(dev(c["depth"][..., 0]), Hf, Hf, E)
+    lin_h = lin.cpu().numpy()
+    got_inv = lin_h < 0
+    assert np.array_equal(got_inv, inv_ref), f"{int((got_inv != inv_ref).sum())} validity flags differ"
+    assert np.array_equal(np.where(got_inv, 0, lin_h), lin_ref), "linear cell index differs"
+    assert sha(np.where(got_inv, 0, lin_h).astype(np.int32)) == str(g[name + ".lin_idx_sha"])
+    assert sha(got_inv.astype(np.uint8)) == str(g[name + ".invalid_sha"])
+    proj = ops.bev_scatter_max(dev(c["feat"]), lin, C, E).cpu().numpy()
+    assert np.array_equal(proj.view(np.uint32), proj_ref.view(np.uint32)), \
+        f"scatter-max differs in {int((proj != proj_ref).sum())} cells"
+    assert sha(proj) == str(g[name + ".proj_sha"])
+
+
+def test_bev_scatter_channel_pool(ops):
+    """64 -> 40 channel adaptive max-pool fused into the scatter (cfg4 geometry)."""
+    c = cases.bev_inputs("e200_c40_f256")
+    feat64 = df.uniform("g1.pool.feat64", (c["B"], 64, 256, 256), 4.0)
+    pooled = bev_ref.channel_maxpool(T(feat64), 40).numpy()
+    proj_ref, *_ = bev_ref.project_to_ground(pooled, c["depth"], 200)
+    lin = ops.bev_index(dev(c["depth"][..., 0]), 256, 256, 200)
+    proj = ops.bev_scatter_max(dev(feat64), lin, 40, 200).cpu().numpy()
+    assert np.array_equal(proj.view(np.uint32), proj_ref.view(np.uint32))
+
+
+def test_bev_idempotent_and_empty(ops):
+    """size-independent properties: all-invalid depth -> all-zero map; scattering twice is idempotent."""
+    B, C, E, Hf = 2, 64, 100, 256
+    feat = dev(df.uniform("bev.prop.feat", (B, C, Hf, Hf), 4.0))
+    depth = torch.zeros(B, 256, 256, device="cuda")
+    lin = ops.bev_index(depth, Hf, Hf, E)
+    assert int((lin >= 0).sum()) == 0
+    assert float(ops.bev_scatter_max(feat, lin, C, E).abs().max()) == 0.0
+    depth = dev(df.uniform("bev.prop.depth", (B, 256, 256)) + np.float32(0.5))
+    lin = ops.bev_index(depth, Hf, Hf, E)
+    a = ops.bev_scatter_max(feat, lin, C, E)
+    b = ops.bev_scatter_max(feat, lin, C, E)
+    assert torch.equal(a, b)
+
+
+def test_map_sequence_vs_oracle(ops):
+    """rotate / paste / translate / max-fuse / retrieve over 4 steps with a mid-sequence episode
+    reset (G2).  Tolerance: bilinear weights depend on float32 grid coordinates whose last bits
+    differ between ATen's CPU kernels and ours (SURVEY §7 'Exactness of K3'): <= 1e-5 * G
+    in the weights, times |feature| <= 2 -> 2e-4 absolute."""
+    g = golden("g2_mapseq.npz")
+    m = cases.MAP_SEQ
+    ref = bev_ref.MapperRef(m["B"])
+    gm = torch.zeros(m["B"], m["G"], m["G"], m["C"], device="cuda")
+    for s in range(m["steps"]):
+        c = cases.mapseq_inputs(s)
+        ego_ref = ref.step(T(c["feat"]), T(c["depth"]), T(c["gps"]), T(c["compass"]), T(c["masks"]))
+        lin = ops.bev_index(dev(c["depth"][..., 0]), m["Hf"], m["Hf"], m["E"])
+        planes = ops.bev_scatter_max(dev(c["feat"]), lin, m["C"], m["E"])
+        compass = dev(c["compass"]).reshape(-1).contiguous()
+        gps = dev(c["gps"])
+        rot = ops.bev_rotate(planes, compass, -1.0)
+        ops.map_fuse(rot, gm, gps, dev(c["masks"]).reshape(-1).contiguous(), 0.12)
+        ego = ops.map_retrieve(gm, gps, compass, m["E"], 0.12).permute(0, 3, 1, 2)
+        close(f"s{s}.global", gm, ref.full_global_map, 0, 2e-4)
+        close(f"s{s}.ego", ego, ego_ref, 0, 2e-4)
+        np.testing.assert_allclose(ego[:, ::16, 40:56, 44:60].cpu().numpy(), g[f"s{s}.ego_patch"], atol=2e-4, rtol=0)

@@ -1,0 +1,178 @@
+"""GPU parity, policy level: the drop-in `BasePolicy` (HIP kernels behind it) against the golden
+vectors captured from the reference and against the oracle run on this box's CPU on the same
+seeded inputs.  Bar from BASELINE.json: fp32 action logits within 1e-4 of the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, policy_ref
+from util import NULL_GRAD, T, golden, make_params, state_dict_values
+
+pytestmark = pytest.mark.gpu
+
+
+class _Box:
+    shape = (2,)
+
+
+def build_policy(num_proc=2):
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.policy import BasePolicy
+    pol = BasePolicy(None, _Box(), default_model_config(num_proc=num_proc))
+    pol.load_state_dict(state_dict_values(), strict=True)
+    # reference default: frozen word embeddings (golden capture did the same)
+    pol.net.instruction_encoder.embedding_layer.weight.requires_grad_(False)
+    return pol.cuda()
+
+
+def cuda_obs(obs_np):
+    return {k: T(v).cuda() for k, v in obs_np.items()}
+
+
+def test_update_path_forward_backward_g3():
+    from wsmgmap.common.aux_losses import AuxLosses
+    g = golden("g3_update.npz")
+    pol = build_policy()
+    pol.train()
+    pol.net.depth_encoder.eval()
+    pol.net.rgb_encoder.eval()
+    Tn, N = 4, 2
+    obs_np, prev, masks, weights = cases.update_inputs(Tn, N)
+    obs = cuda_obs(obs_np)
+    w = T(weights).cuda()
+    AuxLosses.activate()
+    AuxLosses.clear()
+    h0 = torch.zeros(pol.net.num_recurrent_layers, N, 512, device="cuda")
+    pred, aux = pol(obs, h0, T(prev).cuda(), T(masks).cuda(), w)
+    loss, _ = policy_ref.dagger_loss(pred, aux, obs["waypoint"], w.view(Tn, N))
+    loss.backward()
+    torch.cuda.synchronize()
+
+    err = np.abs(pred.detach().cpu().numpy() - g["pred"]).max()
+    assert err <= 1e-4, f"action logits differ from the reference by {err:.3e} (bar 1e-4)"
+    assert abs(float(aux) - float(g["aux_loss"])) <= 1e-4
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4
+    for n in ["prediction_monitor", "contrastive_monitor", "progress_monitor"]:
+        np.testing.assert_allclose(AuxLosses.get_loss(n).detach().cpu().numpy(), g["aux." + n], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(pol.net.att_map_t_m.detach().cpu().numpy(), g["att_map_t_m"], atol=2e-6, rtol=2e-3)
+    np.testing.assert_allclose(pol.prog.detach().cpu().numpy(), g["prog"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(h0.detach().cpu().numpy(), g["h_out"], atol=1e-4, rtol=0)  # mutated in place
+    sd = pol.state_dict()
+    for k in g.files:
+        if k.startswith("bn."):
+            np.testing.assert_allclose(sd[k[3:]].cpu().numpy(), g[k], atol=2e-5, rtol=2e-5, err_msg=k)
+    assert int(sd["net.map_encoder.cnn.1.num_batches_tracked"]) == 1
+
+    # gradients: golden norms + samples for every tensor the reference gives a gradient
+    named = dict(pol.named_parameters(remove_duplicate=False))
+    bad = []
+    for i, n in enumerate(g["grad.names"]):
+        n = str(n)
+        if n in NULL_GRAD:
+            continue
+        gr = named[n].grad
+        assert gr is not None, f"no gradient for {n}"
+        gr = gr.detach().cpu().numpy().reshape(-1)
+        nr = float(np.sqrt((gr.astype(np.float64) ** 2).sum()))
+        ref = float(g["grad.norm"][i])
+        if abs(nr - ref) > 2e-3 * ref + 1e-7:
+            bad.append((n, nr, ref))
+    assert not bad, f"gradient norms off: {bad[:6]}"
+    for n in g["grad.none"]:
+        assert named[str(n)].grad is None, f"{n} must stay without gradient (unused in forward)"
+    AuxLosses.deactivate()
+
+
+def test_update_path_gradients_full_tensor_vs_oracle():
+    """every gradient tensor, element-wise, against the oracle run on this box's CPU."""
+    from wsmgmap.common.aux_losses import AuxLosses
+    Tn, N = 3, 2
+    obs_np, prev, masks, weights = cases.update_inputs(Tn, N, n_tok=(23, 61), tag="g3b")
+    # oracle
+    P = make_params()
+    P["net.instruction_encoder.embedding_layer.weight"].requires_grad_(False)
+    ref = policy_ref.PolicyRef(P, num_proc=2)
+    ref.aux_active = True
+    obs_c = {k: T(v) for k, v in obs_np.items()}
+    wc = T(weights).view(Tn, N)
+    pr, ar, _, sem_r = ref.forward(obs_c, torch.zeros(2, N, 512), T(prev), T(masks), wc)
+    lr, _ = policy_ref.dagger_loss(pr, ar, obs_c["waypoint"], wc)
+    lr.backward()
+    # HIP path
+    pol = build_policy()
+    pol.train()
+    pol.net.depth_encoder.eval()
+    pol.net.rgb_encoder.eval()
+    AuxLosses.activate()
+    AuxLosses.clear()
+    obs = cuda_obs(obs_np)
+    w = T(weights).cuda()
+    pred, aux = pol(obs, torch.zeros(2, N, 512, device="cuda"), T(prev).cuda(), T(masks).cuda(), w)
+    loss, _ = policy_ref.dagger_loss(pred, aux, obs["waypoint"], w.view(Tn, N))
+    loss.backward()
+    AuxLosses.deactivate()
+    assert np.abs(pred.detach().cpu().numpy() - pr.detach().numpy()).max() <= 1e-4
+    assert abs(float(loss) - float(lr)) <= 1e-4
+    named = dict(pol.named_parameters(remove_duplicate=False))
+    worst = []
+    for n, p in named.items():
+        if n in NULL_GRAD or P[n].grad is None:
+            continue
+        a, b = p.grad.detach().cpu().double(), P[n].grad.double()
+        scale = float(b.abs().max()) + 1e-12
+        e = float((a - b).abs().max()) / scale
+        if e > 5e-3:
+            worst.append((n, e))
+    assert not worst, f"gradients differ (max-abs / max-ref): {sorted(worst, key=lambda t: -t[1])[:8]}"
+
+
+@pytest.mark.parametrize("hw", [224, 256])
+def test_rollout_act_g4(hw):
+    from wsmgmap.common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    g = golden("g4_act.npz")
+    pol = build_policy(num_proc=2)
+    pol.eval()
+    h = torch.zeros(2, 2, 512, device="cuda")
+    prev = torch.zeros(2, 2, device="cuda")
+    with torch.no_grad():
+        for step in range(3):
+            obs_np, masks = cases.act_inputs(step, rgb_hw=hw)
+            obs = cuda_obs(obs_np)
+            p = f"r{hw}.s{step}"
+            if step == 1:
+                pol.update_map(obs, T(masks).cuda())
+            else:
+                value, action, logp, h = pol.act(obs, h, prev, T(masks).cuda(), deterministic=True)
+                prev = action
+                err = np.abs(action.cpu().numpy() - g[p + ".action"]).max()
+                assert err <= 1e-4, f"{p}: action differs by {err:.3e}"
+                np.testing.assert_allclose(value.cpu().numpy(), g[p + ".value"], atol=2e-4, rtol=0)
+                np.testing.assert_allclose(pol.prog.cpu().numpy(), g[p + ".prog"], atol=2e-4, rtol=0)
+                np.testing.assert_allclose(logp.cpu().numpy(), g[p + ".logp"], atol=1e-5, rtol=0)
+            ego = obs["rgb_ego_map"]
+            assert tuple(ego.shape) == (2, 64, 100, 100)
+            e = cases.summarize(ego.cpu().numpy())
+            np.testing.assert_allclose(e["sample"], g[p + ".ego.sample"], atol=2e-4, rtol=0)
+    gm = cases.summarize(pol.net.rgb_mapping_module.full_global_map.cpu().numpy())
+    np.testing.assert_allclose(gm["sample"], g[f"r{hw}.global.sample"], atol=2e-4, rtol=0)
+
+
+def test_hooks_and_state_surface():
+    """what the trainers reach into: hookable submodules, map state re-assignment."""
+    pol = build_policy(num_proc=2)
+    pol.eval()
+    seen = {}
+    hk = pol.net.rgb_mapping_module.register_forward_hook(lambda m, i, o: seen.setdefault("ego", o.cpu()))
+    hk2 = pol.net.rgb_encoder.base_model.layer4_1x1.register_forward_hook(lambda m, i, o: seen.setdefault("rgb", o.cpu()))
+    obs_np, masks = cases.act_inputs(0)
+    obs = cuda_obs(obs_np)
+    with torch.no_grad():
+        pol.update_map(obs, T(masks).cuda())
+    hk.remove()
+    hk2.remove()
+    assert tuple(seen["ego"].shape) == (2, 64, 100, 100) and tuple(seen["rgb"].shape) == (2, 512, 7, 7)
+    m = pol.net.rgb_mapping_module
+    m.full_global_map = m.full_global_map[[1]].contiguous()  # env 0 paused (common_trainer.py:171-172)
+    assert tuple(m.full_global_map.shape) == (1, 240, 240, 64)
+    assert pol.net.num_recurrent_layers == 2

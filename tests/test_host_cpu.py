@@ -1,0 +1,142 @@
+"""CPU: host logic and the C-ABI surface (no GPU compute)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases, policy_ref
+from util import T, make_params, state_dict_values, state_spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Box:
+    shape = (2,)
+
+
+def _policy(num_proc=2):
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.policy import BasePolicy, CMAPolicy
+    assert CMAPolicy is BasePolicy
+    return BasePolicy(None, _Box(), default_model_config(num_proc=num_proc))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from wsmgmap import _abi
+    header = open(os.path.join(ROOT, "include", "wsmgmap.h")).read()
+    declared = set(re.findall(r"\b(wsmg_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 26
+    L = _abi.lib()  # raises if the .so is missing: the HIP library is mandatory
+    for name in declared:
+        assert hasattr(L, name), f"libwsmgmap.so does not export {name}"
+    assert set(_abi.exported_names()) == declared
+    assert L.wsmg_abi_version() == 1
+    assert b"gfx950" in L.wsmg_build_info()
+
+
+def test_ops_refuse_cpu_tensors_no_fallback():
+    from wsmgmap import _abi, ops
+    x = torch.zeros(1, 4, 4, 32)
+    w = torch.zeros(32, 32, 1, 1)
+    with pytest.raises(_abi.WsmgError):
+        ops.conv2d(x, w, None, 1, 0)
+    with pytest.raises(_abi.WsmgError):
+        ops.attention(torch.zeros(1, 256), torch.zeros(1, 4, 256), torch.zeros(1, 4, 256))
+    with pytest.raises(_abi.WsmgError):
+        ops.bev_index(torch.zeros(1, 256, 256), 224, 224, 100)
+
+
+def test_state_dict_contract_matches_reference():
+    pol = _policy()
+    sd = pol.state_dict()
+    spec = state_spec()
+    assert set(sd) == set(spec)
+    for k, v in spec.items():
+        assert list(sd[k].shape) == v["shape"], k
+        assert str(sd[k].dtype).replace("torch.", "") == v["dtype"], k
+    req = {k: p.requires_grad for k, p in pol.named_parameters(remove_duplicate=False)}
+    for k, v in spec.items():
+        if v["param"] and k != "net.instruction_encoder.embedding_layer.weight":
+            assert req[k] == v["trainable"], k
+    pol.load_state_dict(state_dict_values(), strict=True)
+    assert sum(p.numel() for p in pol.parameters() if p.requires_grad) == 19762425
+    # aliases of the resnet18 stem are one tensor under two names, as in the reference
+    assert pol.net.map_decoder.layer0[0].weight is pol.net.map_decoder.base_model.conv1.weight
+
+
+def test_map_state_follows_module_moves_and_reassignment():
+    pol = _policy(num_proc=3)
+    m = pol.net.rgb_mapping_module
+    assert tuple(m.full_global_map.shape) == (3, 240, 240, 64)
+    assert "full_global_map" not in "".join(pol.state_dict().keys())
+    pol.double()
+    assert m.full_global_map.dtype == torch.float64
+    m.full_global_map = torch.zeros(2, 240, 240, 64)
+    assert pol.net.rgb_mapping_module.full_global_map.shape[0] == 2
+
+
+def test_aux_losses_registry_semantics():
+    from wsmgmap.common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    AuxLosses.clear()
+    with pytest.raises(AssertionError):
+        AuxLosses.register_loss("a", torch.ones(3))
+    AuxLosses.activate()
+    AuxLosses.register_loss("a", torch.tensor([1.0, 2.0, 3.0]), 0.5)
+    AuxLosses.register_loss("b", torch.tensor([4.0, 0.0, 2.0]))
+    with pytest.raises(AssertionError):
+        AuxLosses.register_loss("a", torch.ones(3))
+    total = AuxLosses.reduce(torch.tensor([True, False, True]))
+    assert abs(float(total) - (0.5 * 2.0 + 3.0)) < 1e-6
+    assert torch.equal(AuxLosses.get_loss("b"), torch.tensor([4.0, 0.0, 2.0]))
+    AuxLosses.clear()
+    AuxLosses.deactivate()
+
+
+def test_diag_gaussian_matches_oracle_head():
+    from wsmgmap.common.distributions import DiagGaussian
+    d = DiagGaussian(512, 2)
+    assert set(d.state_dict()) == {"fc_mean.weight", "fc_mean.bias", "logstd._bias"}
+    x = T(np.random.RandomState(0).randn(4, 512).astype(np.float32))
+    dist = d(x)
+    assert torch.equal(dist.mode(), dist.mean)
+    lp = dist.log_probs(dist.mean)
+    ref = torch.distributions.Normal(dist.mean, torch.ones_like(dist.mean)).log_prob(dist.mean).sum(-1)
+    assert torch.allclose(lp, ref)
+
+
+def test_masked_gru_matches_oracle_semantics():
+    """sequence form (split at restarts) == per-step h*mask form, incl. a mid-sequence restart."""
+    from wsmgmap.models.rnn_state_encoder import RNNStateEncoder
+    torch.manual_seed(0)
+    enc = RNNStateEncoder(16, 8)
+    Tn, N = 6, 3
+    x = torch.randn(Tn * N, 16)
+    masks = torch.ones(Tn, N)
+    masks[0] = 0
+    masks[3, 1] = 0
+    h0 = torch.randn(1, N, 8)
+    y, h = enc(x, h0, masks.view(-1, 1))
+    P = {"e.rnn." + k: v for k, v in enc.rnn.state_dict().items()}
+    yr, hr = policy_ref.masked_gru(P, "e", x, h0, masks.view(-1, 1))
+    assert torch.allclose(y, yr, atol=1e-6) and torch.allclose(h, hr, atol=1e-6)
+    assert RNNStateEncoder.restart_steps(masks.view(-1, 1), N) == [3]
+    y1, h1 = enc(x[:N], h0, masks[0].view(-1, 1))  # single-step form
+    assert torch.allclose(y1, y[:N], atol=1e-6)
+
+
+def test_instruction_encoder_dedup_matches_oracle():
+    pol = _policy()
+    pol.load_state_dict(state_dict_values(), strict=True)
+    enc = pol.net.instruction_encoder
+    obs_np, *_ = cases.update_inputs(4, 2)
+    instr = T(obs_np["instruction"])
+    hid, mask = enc({"instruction": instr})
+    P = make_params(grad=False)
+    hr, mr = policy_ref.instruction_encoder(P, instr)
+    assert hid.shape == hr.shape and torch.equal(mask, mr)
+    assert torch.allclose(hid, hr, atol=1e-6)
+    u, m, inv = enc.encode_unique(instr)
+    assert u.shape[0] == 2 and inv.shape[0] == 8

@@ -1,0 +1,166 @@
+// Cross-modal single-query attention (instruction tokens, then map cells), forward and
+// backward: MGMapNet._attn at mg_map_policy.py:173-178 and its two call sites :229-235.
+//
+//   logits[i] = sum_c q[c] k[i][c] - 1e8*mask[i];  attn = softmax(logits*scale);  out[c] = sum_i attn[i] v[i][c]
+//
+// One query per row makes both contractions GEMV-shaped (about 1 flop per byte of k / v), so
+// the kernel is HBM-bound by construction: one workgroup per row streams k and v exactly once
+// (token-major [I][256], one 1-KiB wave-wide float4 load per token), keeps the logits in LDS and
+// reduces with wavefront shuffles.  The matrix cores are used where the path has a real
+// contraction — the key projection (Conv1d k=1), which runs on the conv engine's MFMA GEMM.
+#include "wsmg_common.h"
+
+namespace {
+
+constexpr int AC = 256;       // channels (hidden_size/2)
+constexpr int AWAVES = 4;
+constexpr int AMAX_I = 1024;  // logits kept in LDS
+
+__device__ inline float block_reduce_max(float v, float* sh, int wave, int lane) {
+  v = wave_max(v);
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < AWAVES; ++w) r = fmaxf(r, sh[w]);
+  __syncthreads();
+  return r;
+}
+__device__ inline float block_reduce_sum(float v, float* sh, int wave, int lane) {
+  v = wave_sum(v);
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int w = 1; w < AWAVES; ++w) r += sh[w];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v,
+                                                       const uint8_t* __restrict__ mask, float scale, int I,
+                                                       float* __restrict__ out, float* __restrict__ attn) {
+  __shared__ float lg[AMAX_I];
+  __shared__ float red[AWAVES];
+  __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
+  const f32x4* kb = reinterpret_cast<const f32x4*>(k + (size_t)b * I * AC);
+  const f32x4* vb = reinterpret_cast<const f32x4*>(v + (size_t)b * I * AC);
+
+  // phase 1: logits (one wave per token; 64 lanes x float4 = the 256 channels)
+  for (int i = wave; i < I; i += AWAVES) {
+    f32x4 kv = kb[(size_t)i * (AC / 4) + lane];
+    float d = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+    d = wave_sum(d);
+    if (lane == 0) {
+      if (mask && mask[(size_t)b * I + i]) d = d - 1e8f;
+      lg[i] = d * scale;
+    }
+  }
+  __syncthreads();
+  // phase 2: softmax over the tokens
+  float mx = -INFINITY;
+  for (int i = tid; i < I; i += 256) mx = fmaxf(mx, lg[i]);
+  mx = block_reduce_max(mx, red, wave, lane);
+  float sm = 0.f;
+  for (int i = tid; i < I; i += 256) {
+    float e = expf(lg[i] - mx);
+    lg[i] = e;
+    sm += e;
+  }
+  sm = block_reduce_sum(sm, red, wave, lane);
+  const float inv = 1.f / sm;
+  for (int i = tid; i < I; i += 256) {
+    float a = lg[i] * inv;
+    lg[i] = a;
+    attn[(size_t)b * I + i] = a;
+  }
+  __syncthreads();
+  // phase 3: out = attn . v (each wave a token subset, combined through LDS)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < I; i += AWAVES) {
+    float a = lg[i];
+    f32x4 vv = vb[(size_t)i * (AC / 4) + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += a * vv[j];
+  }
+  reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
+  __syncthreads();
+  float o = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  out[(size_t)b * AC + tid] = o;
+}
+
+// backward: da = dout.v + dattn; s = sum attn*da; dl = attn*(da-s)*scale;
+//           dq = sum_i dl[i] k[i]; dk[i] = dl[i] q; dv[i] = attn[i] dout
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v,
+                                                       const float* __restrict__ attn,
+                                                       const float* __restrict__ dout,
+                                                       const float* __restrict__ dattn, float scale, int I,
+                                                       float* __restrict__ dq, float* __restrict__ dk,
+                                                       float* __restrict__ dv) {
+  __shared__ float da[AMAX_I];
+  __shared__ float red[AWAVES];
+  __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
+  const f32x4 gv = reinterpret_cast<const f32x4*>(dout + (size_t)b * AC)[lane];
+  const f32x4* kb = reinterpret_cast<const f32x4*>(k + (size_t)b * I * AC);
+  const f32x4* vb = reinterpret_cast<const f32x4*>(v + (size_t)b * I * AC);
+  f32x4* dkb = reinterpret_cast<f32x4*>(dk + (size_t)b * I * AC);
+  f32x4* dvb = reinterpret_cast<f32x4*>(dv + (size_t)b * I * AC);
+  const float* ab = attn + (size_t)b * I;
+
+  for (int i = wave; i < I; i += AWAVES) {
+    f32x4 vv = vb[(size_t)i * (AC / 4) + lane];
+    float d = gv[0] * vv[0] + gv[1] * vv[1] + gv[2] * vv[2] + gv[3] * vv[3];
+    d = wave_sum(d);
+    float a = ab[i];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
+    dvb[(size_t)i * (AC / 4) + lane] = o;
+    if (lane == 0) da[i] = d + (dattn ? dattn[(size_t)b * I + i] : 0.f);
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int i = tid; i < I; i += 256) s += ab[i] * da[i];
+  s = block_reduce_sum(s, red, wave, lane);
+  for (int i = tid; i < I; i += 256) da[i] = ab[i] * (da[i] - s) * scale;
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < I; i += AWAVES) {
+    float dl = da[i];
+    f32x4 kv = kb[(size_t)i * (AC / 4) + lane];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] += dl * kv[j];
+      o[j] = dl * qv[j];
+    }
+    dkb[(size_t)i * (AC / 4) + lane] = o;
+  }
+  reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
+  __syncthreads();
+  dq[(size_t)b * AC + tid] = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+}
+
+}  // namespace
+
+extern "C" int wsmg_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float scale, int B,
+                             int I, int C, float* out, float* attn, wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_attn_bwd(const float* q, const float* k, const float* v, const float* attn, const float* dout,
+                             const float* dattn, float scale, int B, int I, int C, float* dq, float* dk, float* dv,
+                             wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, attn, dout, dattn, scale, I, dq,
+                     dk, dv);
+  WSMG_RETURN_LAUNCH();
+}

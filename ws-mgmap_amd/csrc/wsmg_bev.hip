@@ -1,0 +1,381 @@
+// Operator 1: RGB-D -> egocentric bird's-eye-view map (rollout path, no backward).
+// Replaces, from common/rgb_mapping.py of the reference:
+//   ComputeSpatialLocs.forward :153-176, ProjectToGroundPlane.forward :184-232 (incl. the
+//   third-party torch_scatter.scatter_max CUDA kernel), RotateTensor.forward :239-250,
+//   to_grid.get_grid_coords :100-103, get_grid :106-139 and Mapping.project_feat_to_map :32-72.
+//
+// Integer part is bit-exact with the reference's float32 arithmetic: every operation below is
+// the same IEEE float32 operation in the same order, with FMA contraction disabled for this
+// file.  Sources the reference funnels to cell 0 with -1e16 (invalid depth / height filter /
+// out of range) are skipped instead, cells are initialised "empty" and emitted as 0 — the
+// same result without the cell-0 hot spot.
+//
+// HBM layout: features NCHW in (as the frozen UNet produces them), one E x E channel plane per
+// workgroup lives in LDS for the scatter; everything downstream of the first rotation is NHWC
+// (channel-contiguous, like the persistent global map [P][G][G][C]) so that the bilinear
+// gathers and the max-fuse read-modify-write are fully coalesced 256-B channel runs.
+#include "wsmg_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ----------------------------------------------------------------------------- index
+struct IndexArgs {
+  const float* depth;
+  int32_t* lin;
+  int B, Hd, Wd, Hf, Wf, E;
+  float depth_scale, local_scale, half, cx, cy, fx, fy, K;
+};
+
+__global__ void bev_index_kernel(IndexArgs a) {
+  int64_t n = (int64_t)a.B * a.Hf * a.Wf;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int wf = (int)(i % a.Wf);
+    int hf = (int)((i / a.Wf) % a.Hf);
+    int b = (int)(i / ((int64_t)a.Wf * a.Hf));
+    // (arange * K).long(): int64 * python float -> float32 product, truncated
+    int ih = (int)((float)hf * a.K);
+    int iw = (int)((float)wf * a.K);
+    float z = a.depth[((size_t)b * a.Hd + ih) * a.Wd + iw] * a.depth_scale;
+    float xx = ((float)iw - a.cx) / a.fx;
+    float yy = ((float)(a.Hd - ih) - a.cy) / a.fy;
+    float X = xx * z;
+    float Y = yy * z;
+    bool valid = (z != 0.f) && (Y > -1.5f) && (Y < 0.1f);
+    float xg = rintf(X / a.local_scale + a.half);
+    float yg = rintf(-(z / a.local_scale) + a.half);
+    float Ef = (float)a.E;
+    bool inr = (yg < Ef) && (yg >= 0.f) && (xg < Ef) && (xg >= 0.f);
+    a.lin[i] = (valid && inr) ? (int)yg * a.E + (int)xg : -1;
+  }
+}
+
+// ----------------------------------------------------------------------------- scatter-max
+__device__ __forceinline__ unsigned f2key(float v) {
+  unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// one workgroup = (sample, CG consecutive map channels); the CG E*E planes live in LDS
+__global__ __launch_bounds__(1024) void bev_scatter_kernel(const float* __restrict__ feat,
+                                                           const int32_t* __restrict__ lin, int Cf, int HW, int C,
+                                                           int E2, int CG, float* __restrict__ out) {
+  extern __shared__ unsigned tile[];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CG;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CG * E2; i += 1024) tile[i] = 0u;  // 0 = empty (below every float key)
+  __syncthreads();
+  const int32_t* lb = lin + (size_t)b * HW;
+  for (int g = 0; g < CG; ++g) {
+    int c = c0 + g;
+    if (c >= C) break;
+    // adaptive_max_pool1d window of output channel c over the Cf feature channels
+    int ws = (int)(((int64_t)c * Cf) / C);
+    int we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
+    const float* fb = feat + ((size_t)b * Cf + ws) * HW;
+    unsigned* tg = tile + (size_t)g * E2;
+    for (int s = tid; s < HW; s += 1024) {
+      int cell = lb[s];
+      if (cell < 0) continue;
+      float v = fb[s];
+      for (int w = 1; w < we - ws; ++w) v = fmaxf(v, fb[(size_t)w * HW + s]);
+      atomicMax(&tg[cell], f2key(v));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < CG * E2; i += 1024) {
+    int g = i / E2;
+    if (c0 + g >= C) break;
+    unsigned k = tile[i];
+    out[((size_t)b * C + c0) * E2 + i] = k ? key2f(k) + 0.0f : 0.0f;
+  }
+}
+
+// ----------------------------------------------------------------------------- sampling grid maths
+// affine_grid(align_corners=False) base coordinate: linspace(-1,1,W)[j] * (W-1) / W
+__device__ __forceinline__ float base_coord(int j, int W) {
+  float step = 2.0f / (float)(W - 1);
+  float v = (j < W / 2) ? -1.0f + step * (float)j : 1.0f - step * (float)(W - 1 - j);
+  return v * (float)(W - 1) / (float)W;
+}
+// grid_sample(align_corners=False) un-normalisation
+__device__ __forceinline__ float unnorm(float g, int W) { return ((g + 1.0f) * (float)W - 1.0f) / 2.0f; }
+
+struct Taps {
+  int x0, y0;          // north-west corner
+  float w00, w01, w10, w11;  // nw, ne, sw, se
+};
+__device__ __forceinline__ Taps make_taps(float ix, float iy) {
+  Taps t;
+  float fx0 = floorf(ix), fy0 = floorf(iy);
+  t.x0 = (int)fx0;
+  t.y0 = (int)fy0;
+  float x1 = fx0 + 1.0f, y1 = fy0 + 1.0f;
+  t.w00 = (x1 - ix) * (y1 - iy);
+  t.w01 = (ix - fx0) * (y1 - iy);
+  t.w10 = (x1 - ix) * (iy - fy0);
+  t.w11 = (ix - fx0) * (iy - fy0);
+  return t;
+}
+
+struct Rot { float c, s; };
+
+// rotation of an E x E map: gx = bx*c + by*s ; gy = -bx*s + by*c
+__device__ __forceinline__ Taps rot_taps(int x, int y, int E, Rot r) {
+  float bx = base_coord(x, E), by = base_coord(y, E);
+  float gx = bx * r.c + by * r.s;
+  float gy = bx * (-r.s) + by * r.c;
+  return make_taps(unnorm(gx, E), unnorm(gy, E));
+}
+
+// first rotation: NCHW planes in (scatter output), NHWC out through an LDS transpose
+__global__ __launch_bounds__(256) void rotate_nchw_to_nhwc_kernel(const float* __restrict__ in,
+                                                                  const float* __restrict__ heading, float sign,
+                                                                  int C, int E, float* __restrict__ out) {
+  __shared__ float sh[64 * 65];
+  const int b = blockIdx.y;
+  const int pix0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  const int pl = tid & 63, cq = tid >> 6;
+  const int E2 = E * E;
+  float t = sign * heading[b];
+  Rot r{cosf(t), sinf(t)};
+  int p = pix0 + pl;
+  bool pok = p < E2;
+  int y = pok ? p / E : 0, x = pok ? p - y * E : 0;
+  Taps tp = rot_taps(x, y, E, r);
+  bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
+  bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
+  for (int c = cq; c < C; c += 4) {
+    const float* pb = in + ((size_t)b * C + c) * E2;
+    float v = 0.f;
+    if (pok) {
+      if (y0ok && x0ok) v += pb[tp.y0 * E + tp.x0] * tp.w00;
+      if (y0ok && x1ok) v += pb[tp.y0 * E + tp.x0 + 1] * tp.w01;
+      if (y1ok && x0ok) v += pb[(tp.y0 + 1) * E + tp.x0] * tp.w10;
+      if (y1ok && x1ok) v += pb[(tp.y0 + 1) * E + tp.x0 + 1] * tp.w11;
+    }
+    sh[pl * 65 + c] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * C; i += 256) {
+    int q = i / C, c = i - q * C;
+    if (pix0 + q < E2) out[((size_t)b * E2 + pix0 + q) * C + c] = sh[q * 65 + c];
+  }
+}
+
+// final rotation: NHWC in, NHWC out (thread = (pixel, channel), channel fastest)
+__global__ __launch_bounds__(256) void rotate_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ heading,
+                                                          float sign, int C, int E, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int E2 = E * E;
+  float t = sign * heading[b];
+  Rot r{cosf(t), sinf(t)};
+  const float* ib = in + (size_t)b * E2 * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)E2 * C;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    int p = (int)(i / C);
+    int y = p / E, x = p - y * E;
+    Taps tp = rot_taps(x, y, E, r);
+    bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
+    bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
+    float v = 0.f;
+    if (y0ok && x0ok) v += ib[((size_t)tp.y0 * E + tp.x0) * C + c] * tp.w00;
+    if (y0ok && x1ok) v += ib[((size_t)tp.y0 * E + tp.x0 + 1) * C + c] * tp.w01;
+    if (y1ok && x0ok) v += ib[((size_t)(tp.y0 + 1) * E + tp.x0) * C + c] * tp.w10;
+    if (y1ok && x1ok) v += ib[((size_t)(tp.y0 + 1) * E + tp.x0 + 1) * C + c] * tp.w11;
+    out[(size_t)b * E2 * C + i] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------- global map
+struct Pose { float gx, gy; };  // integer-valued grid cell of the agent (to_grid.get_grid_coords)
+__device__ __forceinline__ Pose grid_cell(const float* gps, int b, int G, float cmax, float cmin, float gsz) {
+  Pose p;
+  p.gx = rintf((cmax - gps[b * 2 + 0]) / gsz);
+  p.gy = rintf((gps[b * 2 + 1] - cmin) / gsz);
+  return p;
+}
+
+// full_global_map[:bs] *= masks (episode reset).  Untouched when mask == 1.
+__global__ __launch_bounds__(256) void map_reset_kernel(float* gm, const float* masks, int64_t n4_per_env) {
+  const int b = blockIdx.y;
+  const float m = masks[b];
+  if (m == 1.0f) return;
+  f32x4* g = reinterpret_cast<f32x4*>(gm) + (size_t)b * n4_per_env;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4_per_env; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 v = g[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= m;
+    g[i] = v;
+  }
+}
+
+struct MapArgs {
+  int B, C, E, G, lo;
+  float cmax, cmin, gsz, halfG;
+};
+
+// paste (centre) + translate (bilinear) + max-fuse, restricted to the (E+4)^2 window the pasted
+// map can reach; outside it the translated view is exactly 0 and the map (>= 0) is unchanged.
+__global__ __launch_bounds__(256) void map_fuse_kernel(const float* __restrict__ ego, float* __restrict__ gm,
+                                                       const float* __restrict__ gps, MapArgs a) {
+  const int b = blockIdx.y;
+  const int WN = a.E + 4;
+  Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
+  const float tx = -(ps.gy - a.halfG) / a.halfG;
+  const float ty = -(ps.gx - a.halfG) / a.halfG;
+  const int wy0 = a.lo + (int)(ps.gx - a.halfG) - 2;
+  const int wx0 = a.lo + (int)(ps.gy - a.halfG) - 2;
+  const float* eb = ego + (size_t)b * a.E * a.E * a.C;
+  float* gb = gm + (size_t)b * a.G * a.G * a.C;
+  const int hi = a.lo + a.E;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)WN * WN * a.C;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % a.C);
+    int p = (int)(i / a.C);
+    int wy = p / WN, wx = p - wy * WN;
+    int Y = wy0 + wy, X = wx0 + wx;
+    if (Y < 0 || Y >= a.G || X < 0 || X >= a.G) continue;
+    float gx = base_coord(X, a.G) + tx;
+    float gy = base_coord(Y, a.G) + ty;
+    Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+      float w = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
+      // zero padding of grid_sample, then the zero border of the agent view around the paste
+      if (yy >= a.lo && yy < hi && xx >= a.lo && xx < hi && yy < a.G && xx < a.G)
+        v += eb[((size_t)(yy - a.lo) * a.E + (xx - a.lo)) * a.C + c] * w;
+    }
+    size_t o = ((size_t)Y * a.G + X) * a.C + c;
+    float g = gb[o];
+    gb[o] = v > g ? v : g;
+  }
+}
+
+// translate the global map back to the agent and crop the centre E x E (NHWC scratch)
+__global__ __launch_bounds__(256) void map_crop_kernel(const float* __restrict__ gm, const float* __restrict__ gps,
+                                                       MapArgs a, float* __restrict__ crop) {
+  const int b = blockIdx.y;
+  Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
+  const float tx = (ps.gy - a.halfG) / a.halfG;
+  const float ty = (ps.gx - a.halfG) / a.halfG;
+  const float* gb = gm + (size_t)b * a.G * a.G * a.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)a.E * a.E * a.C;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % a.C);
+    int p = (int)(i / a.C);
+    int y = p / a.E, x = p - y * a.E;
+    float gx = base_coord(a.lo + x, a.G) + tx;
+    float gy = base_coord(a.lo + y, a.G) + ty;
+    Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+      float w = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
+      if (yy >= 0 && yy < a.G && xx >= 0 && xx < a.G) v += gb[((size_t)yy * a.G + xx) * a.C + c] * w;
+    }
+    crop[(size_t)b * a.E * a.E * a.C + i] = v;
+  }
+}
+
+MapArgs map_args(int B, int C, int E, int G, float resolution) {
+  MapArgs a;
+  a.B = B; a.C = C; a.E = E; a.G = G;
+  a.lo = G / 2 - E / 2;  // G//2 - floor(E/2)
+  double cmin = -(double)G * (double)resolution / 2, cmax = (double)G * (double)resolution / 2;
+  a.cmax = (float)cmax;
+  a.cmin = (float)cmin;
+  a.gsz = (float)((cmax - cmin) / G);
+  a.halfG = (float)(G / 2);
+  return a;
+}
+
+int sgrid(int64_t n, int cap = 4096) {
+  int64_t g = wsmg_cdiv(n, 256);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int wsmg_bev_index(const float* depth, int B, int Hd, int Wd, float depth_scale, int Hf, int Wf, int E,
+                              float local_scale, int32_t* lin_idx, wsmg_stream_t stream) {
+  if (B <= 0 || Hd <= 0 || Wd <= 0 || Hf <= 0 || Wf <= 0 || E <= 0 || Hf > Hd || Wf > Wd) return WSMG_EINVAL;
+  IndexArgs a;
+  a.depth = depth; a.lin = lin_idx;
+  a.B = B; a.Hd = Hd; a.Wd = Wd; a.Hf = Hf; a.Wf = Wf; a.E = E;
+  a.depth_scale = depth_scale;
+  a.local_scale = local_scale;
+  a.half = (float)((E - 1) / 2.0);
+  // get_camera_matrix(imh, imw, 90): cx=imh/2, cy=imw/2, fx=(imh/2)/tan(45deg), fy=(imw/2)/tan(45deg) (float64 -> f32)
+  const double tn = tan(45.0 * 3.14159265358979323846 / 180.0);
+  a.cx = (float)(Hd / 2.0); a.cy = (float)(Wd / 2.0);
+  a.fx = (float)((Hd / 2.0) / tn); a.fy = (float)((Wd / 2.0) / tn);
+  a.K = (float)((double)Wd / (double)Wf);
+  hipLaunchKernelGGL(bev_index_kernel, dim3(sgrid((int64_t)B * Hf * Wf)), dim3(256), 0, wsmg_s(stream), a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bev_scatter_max(const float* feat, const int32_t* lin_idx, int B, int Cf, int Hf, int Wf, int C,
+                                    int E, float* out, wsmg_stream_t stream) {
+  if (B <= 0 || Cf <= 0 || C <= 0 || C > Cf || E <= 0 || B > 65535) return WSMG_EINVAL;
+  const int E2 = E * E;
+  const size_t plane = (size_t)E2 * sizeof(unsigned);
+  if (plane > 160 * 1024) return WSMG_EINVAL;
+  // two planes per workgroup when that still leaves >= 2 workgroups per CU's LDS and enough workgroups
+  int CG = (2 * plane <= 80 * 1024 && (int64_t)B * C >= 1024) ? 2 : 1;
+  size_t lds = plane * CG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bev_scatter_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)wsmg_cdiv(C, CG), (unsigned)B);
+  hipLaunchKernelGGL(bev_scatter_kernel, grid, dim3(1024), lds, wsmg_s(stream), feat, lin_idx, Cf, Hf * Wf, C, E2, CG,
+                     out);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bev_rotate(const float* in, const float* heading, float sign, int B, int C, int E, float* out,
+                               wsmg_stream_t stream) {
+  if (B <= 0 || C <= 0 || C > 64 || E <= 1 || B > 65535) return WSMG_EINVAL;
+  dim3 grid((unsigned)wsmg_cdiv(E * E, 64), (unsigned)B);
+  hipLaunchKernelGGL(rotate_nchw_to_nhwc_kernel, grid, dim3(256), 0, wsmg_s(stream), in, heading, sign, C, E, out);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_map_fuse(const float* ego_rot, float* global_map, const float* gps, const float* masks, int B,
+                             int C, int E, int G, float resolution, wsmg_stream_t stream) {
+  if (B <= 0 || C <= 0 || C % 4 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
+  MapArgs a = map_args(B, C, E, G, resolution);
+  int64_t n4 = (int64_t)G * G * C / 4;
+  hipLaunchKernelGGL(map_reset_kernel, dim3(sgrid(n4, 1024), B), dim3(256), 0, wsmg_s(stream), global_map, masks, n4);
+  int64_t n = (int64_t)(E + 4) * (E + 4) * C;
+  hipLaunchKernelGGL(map_fuse_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), ego_rot, global_map, gps, a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_map_retrieve(const float* global_map, const float* gps, const float* compass, int B, int C, int E,
+                                 int G, float resolution, float* scratch, float* out, wsmg_stream_t stream) {
+  if (B <= 0 || C <= 0 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
+  MapArgs a = map_args(B, C, E, G, resolution);
+  int64_t n = (int64_t)E * E * C;
+  hipLaunchKernelGGL(map_crop_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), global_map, gps, a, scratch);
+  hipLaunchKernelGGL(rotate_nhwc_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), scratch, compass, 1.0f, C, E,
+                     out);
+  WSMG_RETURN_LAUNCH();
+}

@@ -1,0 +1,324 @@
+// Map conv engine: implicit-GEMM convolution forward / backward-data / backward-weight for
+// NHWC float32 tensors on the gfx950 f32 matrix core (v_mfma_f32_32x32x2_f32: exact f32
+// products, k-ordered f32 accumulation — bitwise an fmaf chain).
+//
+// Replaces the cuDNN conv2d calls behind nn.Conv2d / nn.ConvTranspose2d / nn.Conv1d(k=1) at
+// map_encoder.py:19-29,94-112 and mg_map_policy.py:78-100,127,130 of the reference.
+//
+// GEMM view (forward):   Y[m][n] = sum_k A[m][k] * Wt[n][k]
+//     m = (b, oy, ox)   n = cout   k = (ky, kx, cin)   A[m][k] = X[b][oy*s-p+ky][ox*s-p+kx][cin]
+// The A tile is gathered straight from the NHWC tensor (one 128-B channel run per pixel and
+// tap); weights are OHWI so a Wt row is contiguous in k.  Backward-data is the same kernel
+// with the roles of the two pixel grids swapped and IHWO weights.  Backward-weight reduces
+// over pixels:  dW[co][(tap,ci)] = sum_px dY[px][co] * X[px@tap][ci], split over pixel
+// ranges (grid.z) and combined with float atomics.
+#include "wsmg_common.h"
+
+namespace {
+
+constexpr int BM = 128;   // pixels per workgroup tile
+constexpr int BN = 64;    // output channels per workgroup tile
+constexpr int BK = 32;    // channels per k-step
+constexpr int LDT = BK + 4;  // LDS row stride (floats): 144 B keeps ds_read_b128 conflict-free
+
+struct ConvArgs {
+  const float* src;   // [B][SH][SW][Kc]
+  const float* wt;    // [N][KH][KW][Kc]
+  const float* bias;  // [N] or null
+  float* dst;         // [B][TH][TW][N]
+  int B, SH, SW, Kc, TH, TW, N, KH, KW, stride, pad;
+  int M;              // B*TH*TW
+};
+
+// BWD=false: target pixel t reads source t*s - p + k.   BWD=true: source (t + p - k)/s if divisible.
+template <bool BWD>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int seg = tid & 7;          // 16-B segment inside a 128-B channel run
+  const int lrow = tid >> 3;        // 0..31
+
+  // the 4 A rows this thread stages (fixed over the k loop)
+  int pb[4], py[4], px[4];
+  bool pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + lrow + 32 * i;
+    pv[i] = m < a.M;
+    int mm = pv[i] ? m : 0;
+    int b = mm / (a.TH * a.TW);
+    int r = mm - b * (a.TH * a.TW);
+    int ty = r / a.TW, tx = r - ty * a.TW;
+    pb[i] = b * a.SH * a.SW;
+    py[i] = BWD ? ty + a.pad : ty * a.stride - a.pad;
+    px[i] = BWD ? tx + a.pad : tx * a.stride - a.pad;
+  }
+  const int kchunks = a.Kc / BK;
+  const int steps = a.KH * a.KW * kchunks;
+  const int taps = a.KH * a.KW;
+
+  f32x4 ra[4], rb[2];
+  auto gload = [&](int step) {
+    int tap = step / kchunks;
+    int c0 = (step - tap * kchunks) * BK + seg * 4;
+    int ky = tap / a.KW, kx = tap - ky * a.KW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int sy, sx;
+      bool ok = pv[i];
+      if (BWD) {
+        int ty = py[i] - ky, tx = px[i] - kx;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (a.stride == 2) {
+          ok = ok && ((ty | tx) & 1) == 0;
+          sy = ty >> 1; sx = tx >> 1;
+        } else {
+          sy = ty; sx = tx;
+        }
+        ok = ok && sy < a.SH && sx < a.SW;
+      } else {
+        sy = py[i] + ky; sx = px[i] + kx;
+        ok = ok && sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW;
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(a.src + ((size_t)(pb[i] + sy * a.SW + sx)) * a.Kc + c0);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int n = n0 + lrow + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < a.N) v = *reinterpret_cast<const f32x4*>(a.wt + ((size_t)n * taps + tap) * a.Kc + c0);
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDT + seg * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDT + seg * 4]) = rb[i];
+  };
+
+  // wave tile: 64 pixels x 32 channels = two 32x32 MFMA tiles
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const bool wave_live = (n0 + wn) < a.N;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int step = 0; step < steps; ++step) {
+    if (step + 1 < steps) gload(step + 1);
+    if (wave_live) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // lane half h supplies k = 8j + 4h + e of this k-step (same map for A and B)
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[(wm + r) * LDT + 8 * j + 4 * h]);
+        f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[(wm + 32 + r) * LDT + 8 * j + 4 * h]);
+        f32x4 bb = *reinterpret_cast<const f32x4*>(&Bs[(wn + r) * LDT + 8 * j + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], bb[e], acc1, 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    if (step + 1 < steps) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  if (!wave_live) return;
+  const int n = n0 + wn + r;
+  if (n >= a.N) return;
+  const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      int row = wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+      int m = m0 + row;
+      if (m < a.M) a.dst[(size_t)m * a.N + n] = (t == 0 ? acc0[g] : acc1[g]) + bv;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- backward weight
+constexpr int WPX = 32;   // pixels per k-step
+constexpr int WCO = 64;   // output channels per workgroup
+constexpr int WUN = 4;    // (tap, 32-channel chunk) units per workgroup = one per wave
+
+struct WgradArgs {
+  const float* x;    // [B][H][W][Cin]
+  const float* dy;   // [B][OH][OW][Cout]
+  float* dw;         // [Cout][KH][KW][Cin]
+  int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW;
+  int units;         // KH*KW*(Cin/32)
+  int64_t npix;      // B*OH*OW
+  int64_t chunk;     // pixels per grid.z slice (multiple of WPX)
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ds[WPX * WCO];
+  __shared__ __attribute__((aligned(16))) float Xs[WUN * WPX * 32];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * WUN;
+  const int co0 = blockIdx.y * WCO;
+  const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+  int64_t p_end = p_begin + a.chunk;
+  if (p_end > a.npix) p_end = a.npix;
+  const int cchunks = a.Cin / 32;
+  const int ohw = a.OH * a.OW;
+
+  // unit of each X staging slot (every thread stages one 16-B piece per unit and step)
+  int uky[WUN], ukx[WUN], uci[WUN];
+  bool uok[WUN];
+#pragma unroll
+  for (int u = 0; u < WUN; ++u) {
+    int uu = u0 + u;
+    uok[u] = uu < a.units;
+    int t = uok[u] ? uu / cchunks : 0;
+    uci[u] = uok[u] ? (uu - t * cchunks) * 32 : 0;
+    uky[u] = t / a.KW;
+    ukx[u] = t - uky[u] * a.KW;
+  }
+  const int xpx = tid >> 3, xseg = tid & 7;     // X staging: pixel 0..31, 16-B segment 0..7
+  const int dseg = tid & 15;                     // dY staging: 16 segments per 256-B row
+
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  f32x4 rd[2], rx[WUN];
+  auto gload = [&](int64_t p0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t p = p0 + (tid >> 4) + 16 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      int co = co0 + dseg * 4;
+      if (p < p_end && co < a.Cout) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.Cout + co);
+      rd[i] = v;
+    }
+    int64_t p = p0 + xpx;
+    bool pok = p < p_end;
+    int64_t pp = pok ? p : 0;
+    int b = (int)(pp / ohw);
+    int rem = (int)(pp - (int64_t)b * ohw);
+    int oy = rem / a.OW, ox = rem - oy * a.OW;
+#pragma unroll
+    for (int u = 0; u < WUN; ++u) {
+      int iy = oy * a.stride - a.pad + uky[u], ix = ox * a.stride - a.pad + ukx[u];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pok && uok[u] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)(b * a.H + iy) * a.W + ix) * a.Cin + uci[u] + xseg * 4);
+      rx[u] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Ds[((tid >> 4) + 16 * i) * WCO + dseg * 4]) = rd[i];
+#pragma unroll
+    for (int u = 0; u < WUN; ++u) *reinterpret_cast<f32x4*>(&Xs[(u * WPX + xpx) * 32 + xseg * 4]) = rx[u];
+  };
+
+  if (p_begin < p_end) {
+    gload(p_begin);
+    lstore();
+  }
+  __syncthreads();
+  const bool wave_live = (u0 + wave) < a.units;
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += WPX) {
+    bool more = p0 + WPX < p_end;
+    if (more) gload(p0 + WPX);
+    if (wave_live) {
+      const float* xs = &Xs[wave * WPX * 32];
+#pragma unroll
+      for (int s = 0; s < WPX / 2; ++s) {
+        float a0 = Ds[(2 * s + h) * WCO + r];
+        float a1 = Ds[(2 * s + h) * WCO + 32 + r];
+        float bb = xs[(2 * s + h) * 32 + r];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      lstore();
+      __syncthreads();
+    }
+  }
+  if (!wave_live) return;
+  const int uu = u0 + wave;
+  const int tap = uu / cchunks;
+  const int ci = (uu - tap * cchunks) * 32 + r;
+  const int taps = a.KH * a.KW;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      int co = co0 + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, t == 0 ? acc0[g] : acc1[g]);
+    }
+  }
+}
+
+int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return WSMG_EINVAL;
+  if (Cin % 32 || Cout % 32) return WSMG_EINVAL;
+  if (stride != 1 && stride != 2) return WSMG_EINVAL;
+  if (OH != (H + 2 * pad - KH) / stride + 1 || OW != (W + 2 * pad - KW) / stride + 1) return WSMG_EINVAL;
+  if ((int64_t)B * H * W >= (1ll << 31) || (int64_t)B * OH * OW >= (1ll << 31)) return WSMG_EINVAL;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int wsmg_conv2d_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int B, int H,
+                               int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                               wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  ConvArgs a{x, w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, B * OH * OW};
+  dim3 grid((unsigned)wsmg_cdiv(a.M, BM), (unsigned)wsmg_cdiv(Cout, BN));
+  hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_conv2d_bwd_data(const float* dy, const float* w_ihwo, float* dx, int B, int H, int W, int Cin,
+                                    int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                    wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  ConvArgs a{dy, w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, B * H * W};
+  dim3 grid((unsigned)wsmg_cdiv(a.M, BM), (unsigned)wsmg_cdiv(Cin, BN));
+  hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_conv2d_bwd_weight(const float* x, const float* dy, float* dw_ohwi, int B, int H, int W, int Cin,
+                                      int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                      wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  WgradArgs a{x, dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0};
+  a.units = KH * KW * (Cin / 32);
+  a.npix = (int64_t)B * OH * OW;
+  int gx = (int)wsmg_cdiv(a.units, WUN), gy = (int)wsmg_cdiv(Cout, WCO);
+  // split the pixel reduction so that ~2048 workgroups are in flight, >= 8 k-steps each
+  int64_t want = wsmg_cdiv(2048, (int64_t)gx * gy);
+  int64_t maxz = wsmg_cdiv(a.npix, WPX * 8);
+  int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);
+  if (gz < 1) gz = 1;
+  if (gz > 65535) gz = 65535;
+  a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WPX) * WPX;
+  gz = wsmg_cdiv(a.npix, a.chunk);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
+  WSMG_RETURN_LAUNCH();
+}

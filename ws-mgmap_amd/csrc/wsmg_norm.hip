@@ -1,0 +1,245 @@
+// BatchNorm2d (+residual, +ReLU) forward/backward and per-channel column sums for NHWC
+// float32 activations viewed as a [rows][C] matrix (rows = B*H*W, C in {32,64,128,256}).
+//
+// Replaces nn.BatchNorm2d / F.relu (cuDNN batch-norm + elementwise kernels) at
+// map_encoder.py:10-12,21-28,94-112, mg_map_policy.py:80-85 and the torchvision BasicBlock
+// tail (relu(bn2(conv2) + identity)).  Train-mode BN couples the whole T*N batch, so it is a
+// two-pass structure: (1) a chip-wide column reduction in float64 partials, (2) a streaming
+// normalise pass.  HBM-bound: pass 1 reads x once, pass 2 reads x (+res) and writes y.
+#include "wsmg_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+constexpr int RED_MAX_BLOCKS = 1024;
+
+__host__ __device__ inline int red_blocks(int64_t rows, int C) {
+  int rows_per_iter = RED_THREADS / C;
+  int64_t nb = (rows + (int64_t)rows_per_iter * 16 - 1) / ((int64_t)rows_per_iter * 16);
+  if (nb < 1) nb = 1;
+  if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
+  return (int)nb;
+}
+
+// MODE 0: sum(x)                      -> part[blk][0][c]
+// MODE 1: sum(x), sum(x*x)            -> part[blk][0..1][c]
+// MODE 2: sum(g), sum(g*xhat)  with g = dy * (relu ? y > 0 : 1), xhat = (x-mean)*invstd
+template <int MODE>
+__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ dy,
+                                                                 const float* __restrict__ y,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, int relu,
+                                                                 int64_t rows, int C, double* __restrict__ part) {
+  __shared__ double sh[2][RED_THREADS];
+  const int tid = threadIdx.x;
+  const int c = tid % C;
+  const int rl = tid / C;
+  const int rpi = RED_THREADS / C;
+  double s0 = 0.0, s1 = 0.0;
+  float mu = 0.f, is = 1.f;
+  if (MODE == 2) { mu = mean[c]; is = invstd[c]; }
+  for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
+    size_t o = (size_t)r * C + c;
+    if (MODE == 0) {
+      s0 += (double)x[o];
+    } else if (MODE == 1) {
+      float v = x[o];
+      s0 += (double)v;
+      s1 += (double)v * (double)v;
+    } else {
+      float g = dy[o];
+      if (relu && !(y[o] > 0.f)) g = 0.f;
+      float xh = (x[o] - mu) * is;
+      s0 += (double)g;
+      s1 += (double)g * (double)xh;
+    }
+  }
+  sh[0][tid] = s0;
+  sh[1][tid] = s1;
+  __syncthreads();
+  if (rl == 0) {
+    for (int j = 1; j < rpi; ++j) { s0 += sh[0][j * C + c]; s1 += sh[1][j * C + c]; }
+    part[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
+    part[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+  }
+}
+
+__global__ void sum_finalize_kernel(const double* part, int nblk, int C, float* out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += part[((size_t)b * 2) * C + c];
+  out[c] = (float)s;
+}
+
+__global__ void bn_stats_finalize_kernel(const double* part, int nblk, int C, int64_t rows, float momentum,
+                                         float eps, float* running_mean, float* running_var, float* save_mean,
+                                         float* save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += part[((size_t)b * 2 + 0) * C + c];
+    q += part[((size_t)b * 2 + 1) * C + c];
+  }
+  double n = (double)rows;
+  double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unb = rows > 1 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  }
+}
+
+__global__ void bn_eval_prepare_kernel(const float* running_mean, const float* running_var, float eps, int C,
+                                       float* save_mean, float* save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  save_mean[c] = running_mean[c];
+  save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// y = act((x - mean) * invstd * gamma + beta (+ res)); 4 channels per thread
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, int relu, int64_t n4,
+                                                       int C, float* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)((i * 4) % C);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+    f32x4 s = *reinterpret_cast<const f32x4*>(invstd + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (v[j] - m[j]) * s[j] * g[j] + b[j];
+    if (res) {
+      f32x4 rr = reinterpret_cast<const f32x4*>(res)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += rr[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(y)[i] = o;
+  }
+}
+
+// dgamma/dbeta from the reduction, then dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n)
+__global__ void bn_bwd_finalize_kernel(const double* part, int nblk, int C, float* dgamma, float* dbeta) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += part[((size_t)b * 2 + 0) * C + c];
+    q += part[((size_t)b * 2 + 1) * C + c];
+  }
+  dbeta[c] = (float)s;
+  dgamma[c] = (float)q;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ dgamma,
+                                                           const float* __restrict__ dbeta, int relu, float inv_n,
+                                                           int64_t n4, int C, float* __restrict__ dx,
+                                                           float* __restrict__ dres) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)((i * 4) % C);
+    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+    f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    if (relu) {
+      f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+    }
+    if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float is = invstd[c + j];
+      float xh = (xv[j] - mean[c + j]) * is;
+      o[j] = gamma[c + j] * is * (g[j] - dbeta[c + j] * inv_n - xh * dgamma[c + j] * inv_n);
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = o;
+  }
+}
+
+bool chan_ok(int C) { return C == 32 || C == 64 || C == 128 || C == 256; }
+
+int stream_grid(int64_t n4) {
+  int64_t g = wsmg_cdiv(n4, 256);
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int64_t wsmg_channel_reduce_workspace_bytes(int64_t rows, int C) {
+  if (!chan_ok(C)) return 0;
+  return (int64_t)red_blocks(rows, C) * 2 * C * (int64_t)sizeof(double);
+}
+
+extern "C" int wsmg_channel_sum(const float* x, int64_t rows, int C, float* out, double* workspace,
+                                int64_t workspace_bytes, wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
+  int nb = red_blocks(rows, C);
+  hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(RED_THREADS), 0, wsmg_s(stream), x, nullptr, nullptr,
+                     nullptr, nullptr, 0, rows, C, workspace);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, wsmg_s(stream), workspace, nb, C, out);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, int train,
+                               int relu, int64_t rows, int C, float* y, float* save_mean, float* save_invstd,
+                               double* workspace, int64_t workspace_bytes, wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  if (train) {
+    if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
+    int nb = red_blocks(rows, C);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(nb), dim3(RED_THREADS), 0, s, x, nullptr, nullptr, nullptr,
+                       nullptr, 0, rows, C, workspace);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(256), 0, s, workspace, nb, C, rows, momentum, eps,
+                       running_mean, running_var, save_mean, save_invstd);
+  } else {
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, running_mean, running_var, eps, C,
+                       save_mean, save_invstd);
+  }
+  int64_t n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, x, residual, gamma, beta, save_mean,
+                     save_invstd, relu, n4, C, y);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+                               const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
+                               float* dx, float* dresidual, float* dgamma, float* dbeta, double* workspace,
+                               int64_t workspace_bytes, wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
+  hipStream_t s = wsmg_s(stream);
+  int nb = red_blocks(rows, C);
+  hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd, relu,
+                     rows, C, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, workspace, nb, C, dgamma, dbeta);
+  int64_t n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, n4, C, dx, dresidual);
+  WSMG_RETURN_LAUNCH();
+}

@@ -1,0 +1,295 @@
+// Small NHWC float32 helpers of the UNet-style decoder: ReLU, MaxPool2d(3,2,1),
+// bilinear 2x upsample (align_corners=True), avg_pool2d(2), and the NCHW<->NHWC boundary
+// transposes.  Reference call sites: map_encoder.py:80,84,102,108; mg_map_policy.py:89-100,197.
+// All are streaming, HBM-bound kernels; backward passes are written as gathers so results
+// are deterministic (no atomics).
+#include "wsmg_common.h"
+
+namespace {
+
+int sgrid(int64_t n) {
+  int64_t g = wsmg_cdiv(n, 256);
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define GRID_STRIDE(i, n) \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void relu_fwd_kernel(const f32x4* x, f32x4* y, int64_t n4) {
+  GRID_STRIDE(i, n4) {
+    f32x4 v = x[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    y[i] = v;
+  }
+}
+__global__ void relu_bwd_kernel(const f32x4* dy, const f32x4* y, f32x4* dx, int64_t n4) {
+  GRID_STRIDE(i, n4) {
+    f32x4 g = dy[i], v = y[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? g[j] : 0.f;
+    dx[i] = g;
+  }
+}
+
+// ---- MaxPool2d(kernel 3, stride 2, pad 1): first maximum in (ky,kx) scan order wins ties (ATen)
+__global__ void maxpool_fwd_kernel(const float* x, float* y, int B, int H, int W, int C, int OH, int OW) {
+  int64_t n = (int64_t)B * OH * OW * C;
+  GRID_STRIDE(i, n) {
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ox = (int)(p % OW);
+    int oy = (int)((p / OW) % OH);
+    int b = (int)(p / ((int64_t)OW * OH));
+    float best = -INFINITY;
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float v = x[(((size_t)b * H + iy) * W + ix) * C + c];
+        if (v > best || v != v) best = v;
+      }
+    }
+    y[i] = best;
+  }
+}
+
+__device__ inline int maxpool_argmax(const float* x, int b, int oy, int ox, int c, int H, int W, int C) {
+  float best = -INFINITY;
+  int arg = -1;
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = oy * 2 - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = ox * 2 - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      float v = x[(((size_t)b * H + iy) * W + ix) * C + c];
+      if (v > best || v != v || arg < 0) { best = v; arg = iy * W + ix; }
+    }
+  }
+  return arg;
+}
+
+__global__ void maxpool_bwd_kernel(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH,
+                                   int OW) {
+  int64_t n = (int64_t)B * H * W * C;
+  GRID_STRIDE(i, n) {
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ix = (int)(p % W);
+    int iy = (int)((p / W) % H);
+    int b = (int)(p / ((int64_t)W * H));
+    float g = 0.f;
+    int oy0 = iy / 2, oy1 = (iy + 1) / 2;  // windows [2oy-1, 2oy+1] containing iy
+    int ox0 = ix / 2, ox1 = (ix + 1) / 2;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      if (oy >= OH) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        if (ox >= OW) continue;
+        if (maxpool_argmax(x, b, oy, ox, c, H, W, C) == iy * W + ix)
+          g += dy[(((size_t)b * OH + oy) * OW + ox) * C + c];
+      }
+    }
+    dx[i] = g;
+  }
+}
+
+// ---- bilinear x2, align_corners=True (ATen upsample_bilinear2d: src = dst * (in-1)/(out-1))
+__device__ inline void up_src(int o, int in, float scale, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * (float)o;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ void upsample_fwd_kernel(const float* x, float* y, int B, int H, int W, int C) {
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  int64_t n = (int64_t)B * OH * OW * C;
+  GRID_STRIDE(i, n) {
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ox = (int)(p % OW);
+    int oy = (int)((p / OW) % OH);
+    int b = (int)(p / ((int64_t)OW * OH));
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    up_src(oy, H, sh, y0, y1, hy0, hy1);
+    up_src(ox, W, sw, x0, x1, wx0, wx1);
+    const float* xb = x + (size_t)b * H * W * C + c;
+    float v00 = xb[((size_t)y0 * W + x0) * C], v01 = xb[((size_t)y0 * W + x1) * C];
+    float v10 = xb[((size_t)y1 * W + x0) * C], v11 = xb[((size_t)y1 * W + x1) * C];
+    y[i] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+  }
+}
+
+__global__ void upsample_bwd_kernel(const float* dy, float* dx, int B, int H, int W, int C) {
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  int64_t n = (int64_t)B * H * W * C;
+  GRID_STRIDE(i, n) {
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ix = (int)(p % W);
+    int iy = (int)((p / W) % H);
+    int b = (int)(p / ((int64_t)W * H));
+    float g = 0.f;
+    int oy_lo = 2 * iy - 2 < 0 ? 0 : 2 * iy - 2, oy_hi = 2 * iy + 3 > OH - 1 ? OH - 1 : 2 * iy + 3;
+    int ox_lo = 2 * ix - 2 < 0 ? 0 : 2 * ix - 2, ox_hi = 2 * ix + 3 > OW - 1 ? OW - 1 : 2 * ix + 3;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float hy0, hy1;
+      up_src(oy, H, sh, y0, y1, hy0, hy1);
+      float wy = (y0 == iy ? hy0 : 0.f) + (y1 == iy ? hy1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float wx0, wx1;
+        up_src(ox, W, sw, x0, x1, wx0, wx1);
+        float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+        if (wx == 0.f) continue;
+        g += wy * wx * dy[(((size_t)b * OH + oy) * OW + ox) * C + c];
+      }
+    }
+    dx[i] = g;
+  }
+}
+
+// ---- avg_pool2d(2,2), H and W even
+__global__ void avgpool_fwd_kernel(const float* x, float* y, int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  int64_t n = (int64_t)B * OH * OW * C;
+  GRID_STRIDE(i, n) {
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ox = (int)(p % OW);
+    int oy = (int)((p / OW) % OH);
+    int b = (int)(p / ((int64_t)OW * OH));
+    const float* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    y[i] = (xb[0] + xb[C] + xb[(size_t)W * C] + xb[(size_t)W * C + C]) * 0.25f;
+  }
+}
+__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  int64_t n = (int64_t)B * H * W * C;
+  GRID_STRIDE(i, n) {
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ix = (int)(p % W);
+    int iy = (int)((p / W) % H);
+    int b = (int)(p / ((int64_t)W * H));
+    dx[i] = dy[(((size_t)b * OH + iy / 2) * OW + ix / 2) * C + c] * 0.25f;
+  }
+}
+
+// ---- [B][R][S] -> [B][S][R'] transposes through a 32x33 LDS tile (coalesced both sides)
+// TO_NHWC: src rows = channels (R = C_src), cols = pixels;  dst [pixel][C_dst], zero-filled past C_src.
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y, int C_src, int HW, int C_dst) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (TO_NHWC) {
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int c = c0 + ty + 8 * j, p = p0 + tx;
+      tile[ty + 8 * j][tx] = (c < C_src && p < HW) ? x[((size_t)b * C_src + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int p = p0 + ty + 8 * j, c = c0 + tx;
+      if (p < HW && c < C_dst) y[((size_t)b * HW + p) * C_dst + c] = tile[tx][ty + 8 * j];
+    }
+  } else {
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int p = p0 + ty + 8 * j, c = c0 + tx;
+      tile[ty + 8 * j][tx] = (p < HW && c < C_src) ? x[((size_t)b * HW + p) * C_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int c = c0 + ty + 8 * j, p = p0 + tx;
+      if (c < C_dst && p < HW) y[((size_t)b * C_dst + c) * HW + p] = tile[tx][ty + 8 * j];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t stream) {
+  if (n <= 0 || n % 4) return WSMG_EINVAL;
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), (const f32x4*)x, (f32x4*)y,
+                     n / 4);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t stream) {
+  if (n <= 0 || n % 4) return WSMG_EINVAL;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), (const f32x4*)dy,
+                     (const f32x4*)y, (f32x4*)dx, n / 4);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW,
+                                     wsmg_stream_t stream) {
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0) return WSMG_EINVAL;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(sgrid((int64_t)B * OH * OW * C)), dim3(256), 0, wsmg_s(stream), x, y, B,
+                     H, W, C, OH, OW);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_maxpool3x3s2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH,
+                                     int OW, wsmg_stream_t stream) {
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0) return WSMG_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, x, dx,
+                     B, H, W, C, OH, OW);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(sgrid((int64_t)B * 4 * H * W * C)), dim3(256), 0, wsmg_s(stream), x, y,
+                     B, H, W, C);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
+                     H, W, C);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), x, y,
+                     B, H, W, C);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
+                     H, W, C);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_nchw_to_nhwc(const float* x, float* y, int B, int C_src, int H, int W, int C_dst,
+                                 wsmg_stream_t stream) {
+  if (B <= 0 || C_src <= 0 || C_dst <= 0 || H <= 0 || W <= 0 || B > 65535) return WSMG_EINVAL;
+  int HW = H * W;
+  dim3 grid((unsigned)wsmg_cdiv(HW, 32), (unsigned)wsmg_cdiv(C_dst, 32), (unsigned)B);
+  hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), x, y, C_src, HW, C_dst);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_nhwc_to_nchw(const float* x, float* y, int B, int C_src, int H, int W, int C_dst,
+                                 wsmg_stream_t stream) {
+  if (B <= 0 || C_src <= 0 || C_dst <= 0 || H <= 0 || W <= 0 || B > 65535) return WSMG_EINVAL;
+  int HW = H * W;
+  dim3 grid((unsigned)wsmg_cdiv(HW, 32), (unsigned)wsmg_cdiv(C_dst, 32), (unsigned)B);
+  hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), x, y, C_src, HW, C_dst);
+  WSMG_RETURN_LAUNCH();
+}

@@ -1,0 +1,89 @@
+"""ctypes binding of libwsmgmap.so (C ABI declared in include/wsmgmap.h).
+
+This is the only place the shared library is touched.  There is NO fallback: if the
+library is missing, or a call returns non-zero, a WsmgError is raised — the product path
+never silently degrades to PyTorch or CPU code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwsmgmap.so")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+
+
+class WsmgError(RuntimeError):
+    pass
+
+
+# name -> argtypes (all return int unless listed in _RESTYPE)
+_SIG = {
+    "wsmg_abi_version": [],
+    "wsmg_build_info": [],
+    "wsmg_bev_index": [c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_p, c_p],
+    "wsmg_bev_scatter_max": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "wsmg_bev_rotate": [c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p],
+    "wsmg_map_fuse": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
+    "wsmg_map_retrieve": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    "wsmg_conv2d_fwd": [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_p],
+    "wsmg_conv2d_bwd_data": [c_p, c_p, c_p] + [c_i] * 11 + [c_p],
+    "wsmg_conv2d_bwd_weight": [c_p, c_p, c_p] + [c_i] * 11 + [c_p],
+    "wsmg_channel_sum": [c_p, c_l, c_i, c_p, c_p, c_l, c_p],
+    "wsmg_channel_reduce_workspace_bytes": [c_l, c_i],
+    "wsmg_bn_act_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_p],
+    "wsmg_bn_act_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "wsmg_relu_fwd": [c_p, c_p, c_l, c_p],
+    "wsmg_relu_bwd": [c_p, c_p, c_p, c_l, c_p],
+    "wsmg_maxpool3x3s2_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_maxpool3x3s2_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_upsample2x_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_avgpool2_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_avgpool2_bwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_nchw_to_nhwc": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_nhwc_to_nchw": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p],
+    "wsmg_attn_fwd": [c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p],
+    "wsmg_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+}
+_RESTYPE = {"wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises WsmgError (never falls back) if it cannot be loaded."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WsmgError(
+                f"{LIB_PATH} not found: build it with `make -C ws-mgmap_amd/csrc` "
+                "(or __graft_entry__.build()). The HIP kernels are mandatory; there is no fallback path.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise WsmgError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, args in _SIG.items():
+            try:
+                fn = getattr(L, name)
+            except AttributeError as e:
+                raise WsmgError(f"{LIB_PATH} does not export {name}") from e
+            fn.argtypes = args
+            fn.restype = _RESTYPE.get(name, c_i)
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; non-zero is an error."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        kind = {-1: "WSMG_EINVAL (rejected arguments)", -2: "WSMG_ENOMEM (workspace too small)"}.get(rc, f"hipError_t {rc}")
+        raise WsmgError(f"{name} failed: {kind}")
+
+
+def exported_names():
+    return list(_SIG)

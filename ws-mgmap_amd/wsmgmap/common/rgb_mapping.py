@@ -1,0 +1,66 @@
+"""Operator 1 host side: RGB-D -> egocentric BEV map with a persistent global map.
+
+Interface of the reference's `RGBMapping` / `Mapping` (common/rgb_mapping.py:11-90):
+`forward(rgb_features, observations, masks)` writes `observations['rgb_ego_map']`, the
+persistent state lives in `self.full_global_map` [num_proc, G, G, C] (NHWC) which trainers
+read, slice and re-assign (dagger_trainer.py:668-678, common_trainer.py:266-267,429-435,473-476).
+`agent_view` is kept as an attribute for those call sites but never materialised per step:
+the gfx950 kernels paste/translate/fuse directly inside the (E+4)^2 window the view can reach.
+
+All arithmetic runs in libwsmgmap.so (wsmg_bev_index / _scatter_max / _rotate / wsmg_map_fuse /
+_retrieve); nothing here has a CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class Mapping(nn.Module):
+    def __init__(self, model_config):
+        super().__init__()
+        self.num_proc = model_config.num_proc
+        self.resolution = model_config.resolution
+        self.egocentric_map_size = model_config.egocentric_map_size
+        self.global_map_size = model_config.global_map_size
+        self.global_map_depth = model_config.map_depth
+        self._gpu_id = model_config.gpu_id
+        G, C = self.global_map_size, self.global_map_depth
+        # plain attributes (not buffers): they are rollout state, absent from the state_dict
+        self.full_global_map = torch.zeros(self.num_proc, G, G, C)
+        self.agent_view = torch.zeros(self.num_proc, C, 0, 0)
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self.full_global_map = fn(self.full_global_map)
+        self.agent_view = fn(self.agent_view)
+        return self
+
+    @torch.no_grad()
+    def project_feat_to_map(self, features, full_global_map, observations, masks):
+        """features [B,Cf,Hf,Wf] (NCHW).  Returns (ego map [B,C,E,E] as a channels-last view, global map)."""
+        E, C = self.egocentric_map_size, self.global_map_depth
+        bs, _, Hf, Wf = features.shape
+        depth = observations["depth"]
+        depth = depth.reshape(bs, depth.shape[1], depth.shape[2]).float().contiguous()
+        gm = full_global_map
+        if not gm.is_contiguous():
+            raise ops._abi.WsmgError("full_global_map must be a contiguous [num_proc,G,G,C] tensor")
+        local_scale = float(self.global_map_size * self.resolution) / float(self.global_map_size)
+        lin = ops.bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
+        planes = ops.bev_scatter_max(features.float().contiguous(), lin, C, E)
+        compass = observations["compass"].reshape(bs).float().contiguous()
+        gps = observations["gps"].reshape(bs, 2).float().contiguous()
+        rotated = ops.bev_rotate(planes, compass, -1.0)
+        ops.map_fuse(rotated, gm, gps, masks.reshape(bs).float().contiguous(), self.resolution)
+        ego_nhwc = ops.map_retrieve(gm, gps, compass, E, self.resolution)
+        return ego_nhwc.permute(0, 3, 1, 2), gm
+
+
+class RGBMapping(Mapping):
+    def forward(self, rgb_features, observations, masks):
+        if "rgb_ego_map" in observations:
+            return observations["rgb_ego_map"]
+        ego, self.full_global_map = self.project_feat_to_map(rgb_features, self.full_global_map, observations, masks)
+        observations["rgb_ego_map"] = ego
+        return ego

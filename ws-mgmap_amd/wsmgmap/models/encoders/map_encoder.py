@@ -1,0 +1,99 @@
+"""Map encoder (3 strided convs) and the UNet-style semantic-hallucination decoder over the
+24 x 24 encoded map — operator 2 of the hot path.
+
+Module / parameter names reproduce the reference's state_dict contract
+(vlnce_baselines/models/encoders/map_encoder.py:16-112); the arithmetic runs in the gfx950
+conv / batch-norm / pooling kernels of libwsmgmap.so on NHWC activations (wsmgmap.ops).
+The nn.Conv2d / nn.BatchNorm2d children are parameter containers only.
+"""
+import numpy as np
+import torch.nn as nn
+
+from ... import ops
+from .resnet18 import ResNet18
+
+
+def bump(bn: nn.BatchNorm2d, train: bool):
+    if train and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+
+
+def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
+    """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+    bump(bn, train)
+    return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
+
+
+def convrelu(in_channels, out_channels, kernel, padding):
+    return nn.Sequential(
+        nn.Conv2d(in_channels, out_channels, kernel, padding=padding),
+        nn.BatchNorm2d(num_features=out_channels),
+        nn.ReLU(inplace=True),
+    )
+
+
+def _out_dim(size, kernel, stride, padding):
+    return int(np.floor((size + 2 * padding - (kernel - 1) - 1) / stride + 1))
+
+
+class MapEncoder(nn.Module):
+    _layers = [(8, 2, 3), (5, 2, 1), (3, 1, 1)]  # (kernel, stride, padding)
+
+    def __init__(self, map_size, input_channel, output_channel):
+        super().__init__()
+        chans = [input_channel, 64, 128, output_channel]
+        mods = []
+        for (k, s, p), cin, cout in zip(self._layers, chans[:-1], chans[1:]):
+            mods += [nn.Conv2d(cin, cout, k, stride=s, padding=p), nn.BatchNorm2d(num_features=cout), nn.ReLU(inplace=True)]
+        self.cnn = nn.Sequential(*mods)
+        d = map_size
+        for k, s, p in self._layers:
+            d = _out_dim(d, k, s, p)
+        self.output_shape = [output_channel, d, d]
+
+    def forward(self, x_nhwc):
+        train = self.training
+        for i in (0, 3, 6):
+            x_nhwc = conv_bn_relu(x_nhwc, self.cnn[i], self.cnn[i + 1], train)
+        return x_nhwc
+
+
+class MapDecoder(nn.Module):
+    """2-level UNet on a resnet18 stem (conv1(256->64,k7,s2), bn1, maxpool, layer1)."""
+
+    def __init__(self, n_channel_in):
+        super().__init__()
+        self.base_model = ResNet18()
+        self.base_model.conv1 = nn.Conv2d(n_channel_in, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        children = list(self.base_model.children())
+        # same duplicate registrations as the reference => same state_dict keys
+        self.layer0 = nn.Sequential(*children[:3])
+        self.layer0_1x1 = convrelu(64, 64, 1, 0)
+        self.layer1 = nn.Sequential(*children[3:5])
+        self.layer1_1x1 = convrelu(64, 64, 1, 0)
+        self.upsample = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.conv_up0 = convrelu(64 + 64, 128, 3, 1)
+        self.conv_original_size0 = convrelu(n_channel_in, 64, 3, 1)
+        self.conv_original_size1 = convrelu(64, 64, 3, 1)
+        self.conv_original_size2 = convrelu(64 + 128, 64, 3, 1)
+        self.output_shape = [64, 100, 100]
+
+    def _block(self, x, blk, train):
+        y = conv_bn_relu(x, blk.conv1, blk.bn1, train)
+        return conv_bn_relu(y, blk.conv2, blk.bn2, train, relu=True, residual=x)
+
+    def forward(self, x):
+        import torch
+        train = self.training
+        cr = lambda t, seq: conv_bn_relu(t, seq[0], seq[1], train)  # noqa: E731
+        x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
+        stem = self.base_model
+        layer0 = conv_bn_relu(x, stem.conv1, stem.bn1, train)
+        layer1 = ops.maxpool3x3s2(layer0)
+        for blk in stem.layer1:
+            layer1 = self._block(layer1, blk, train)
+        up = ops.upsample2x(cr(layer1, self.layer1_1x1))
+        up = cr(torch.cat([up, cr(layer0, self.layer0_1x1)], dim=-1), self.conv_up0)
+        up = ops.upsample2x(up)
+        return cr(torch.cat([up, x_original], dim=-1), self.conv_original_size2)

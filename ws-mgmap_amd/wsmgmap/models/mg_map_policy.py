@@ -1,0 +1,188 @@
+"""MGMapNet: the multi-granularity-map policy network, host side.
+
+Attribute tree, state_dict keys and the in-place contract (writes `observations['rgb_ego_map']`,
+`rnn_hidden_states[...]`, `self.att_map_t_m`) follow the reference
+(vlnce_baselines/models/mg_map_policy.py:19-251).  The data path is re-designed for MI355X:
+
+  * the whole map stack (encoder, UNet decoder, classifier, the three map projections) runs
+    NHWC in the gfx950 conv / batch-norm / pooling kernels (operator 2);
+  * both cross-modal attentions run in the single-query attention kernel (operator 3) on
+    token-major keys/values; the k=1 Conv1d key projections are MFMA GEMMs of the conv engine;
+  * the BEV projection / scatter / global-map fuse run in the BEV kernels (operator 1);
+  * instruction encoding is de-duplicated over the time axis of a teacher-forcing batch;
+  * LSTM / GRU cells, Linear heads and losses stay stock PyTorch-ROCm.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..common.rgb_mapping import RGBMapping
+from .encoders.instruction_encoder import InstructionEncoder
+from .encoders.map_encoder import MapDecoder, MapEncoder
+from .encoders.resnet_encoders import VlnResnetDepthEncoder
+from .encoders.unet_encoder import UNet
+from .rnn_state_encoder import RNNStateEncoder
+
+SEM_CLASSES = 27
+SEM_PAD = 32  # channel padding of the 27-class tensors inside the NHWC engine
+
+
+class MGMapNet(nn.Module):
+    def __init__(self, observation_space, model_config):
+        super().__init__()
+        mc = model_config
+        self.model_config = mc
+        hid = mc.STATE_ENCODER.hidden_size
+        self._hidden_size = hid
+        self._inputs = list(mc.STATE_ENCODER.input_type)
+
+        self.instruction_encoder = InstructionEncoder(mc.INSTRUCTION_ENCODER)
+
+        self.rgb_encoder = UNet(mc)
+        for p in self.rgb_encoder.parameters():
+            p.requires_grad = False
+        self.rgb_linear = nn.Sequential(nn.AdaptiveAvgPool1d(1), nn.Flatten(),
+                                        nn.Linear(self.rgb_encoder.output_shape[0], mc.RGB_ENCODER.output_size), nn.ReLU(True))
+
+        self.depth_encoder = VlnResnetDepthEncoder(observation_space, output_size=mc.DEPTH_ENCODER.output_size,
+                                                   checkpoint=mc.DEPTH_ENCODER.ddppo_checkpoint,
+                                                   backbone=mc.DEPTH_ENCODER.backbone, spatial_output=True)
+        self.depth_linear = nn.Sequential(nn.Flatten(), nn.Linear(int(np.prod(self.depth_encoder.output_shape)),
+                                                                  mc.DEPTH_ENCODER.output_size), nn.ReLU(True))
+
+        self.rgb_mapping_module = RGBMapping(mc.RGBMAPPING)
+        map_channel = mc.RGBMAPPING.map_depth
+        self.map_encoder = MapEncoder(mc.MAP_ENCODER.ego_map_size, map_channel, mc.MAP_ENCODER.output_size)
+        self.map_decoder = MapDecoder(mc.MAP_ENCODER.output_size)
+        self.map_classfier = nn.Sequential(  # (sic) name is part of the checkpoint contract
+            nn.ConvTranspose2d(self.map_decoder.output_shape[0], 32, kernel_size=4, stride=2, padding=1, bias=False),
+            nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+            nn.Conv2d(32, 32, kernel_size=3, stride=1, padding=1, bias=False),
+            nn.BatchNorm2d(32), nn.ReLU(inplace=True),
+            nn.Conv2d(32, SEM_CLASSES, kernel_size=1, stride=1, padding=0, bias=True),
+        )
+        msz = mc.MAP_ENCODER.output_size
+        self.map_encoded_linear = nn.Sequential(nn.Conv2d(self.map_encoder.output_shape[0], 128, 3, stride=1, padding=1), nn.ReLU())
+        self.map_classified_linear = nn.Sequential(nn.Conv2d(SEM_CLASSES, 128, 3, stride=1, padding=1), nn.ReLU())
+        self.map_cated_linear = nn.Sequential(nn.Conv2d(128 * 2, msz, 3, stride=1, padding=1), nn.ReLU())
+        self.map_linear = nn.Sequential(nn.AdaptiveAvgPool1d(1), nn.Flatten(), nn.Linear(msz, msz), nn.ReLU(True))
+
+        first_in = ((mc.RGB_ENCODER.output_size if "rgb" in self._inputs else 0)
+                    + (mc.DEPTH_ENCODER.output_size if "depth" in self._inputs else 0)
+                    + (msz if "map" in self._inputs else 0))
+        self.state_encoder = RNNStateEncoder(first_in, hid, 1, mc.STATE_ENCODER.rnn_type)
+
+        self.state_text_q_layer = nn.Linear(hid, hid // 2)
+        self.state_text_k_layer = nn.Conv1d(self.instruction_encoder.output_size, hid // 2, 1)
+        self.text_map_q_layer = nn.Linear(self.instruction_encoder.output_size, hid // 2)
+        self.text_map_k_layer = nn.Conv1d(self.map_encoder.output_shape[0], hid // 2, 1)
+        self.register_buffer("_scale", torch.tensor(1.0 / ((hid // 2) ** 0.5)))
+        self._scale_f = 1.0 / ((hid // 2) ** 0.5)
+
+        second_in = hid + hid // 2 + (hid // 2 if "map" in self._inputs else 0)
+        self.second_state_compress = nn.Sequential(nn.Linear(second_in, hid), nn.ReLU(True))
+        self.second_state_encoder = RNNStateEncoder(hid, hid, 1, mc.STATE_ENCODER.rnn_type)
+        self._output_size = hid
+        self.att_map_t_m = None
+
+        self.train()
+        self.depth_encoder.eval()
+        self.rgb_encoder.eval()
+
+    # -- habitat `Net` properties ------------------------------------------------
+    @property
+    def output_size(self):
+        return self._output_size
+
+    @property
+    def is_blind(self):
+        return False
+
+    @property
+    def num_recurrent_layers(self):
+        return self.state_encoder.num_recurrent_layers + self.second_state_encoder.num_recurrent_layers
+
+    # -- operator 3 --------------------------------------------------------------
+    def _key_projection(self, conv1d: nn.Conv1d, tokens_tm):
+        """Conv1d(k=1) over a token-major [B, I, C] tensor = 1x1 conv of the NHWC engine."""
+        b, i, c = tokens_tm.shape
+        w = conv1d.weight.unsqueeze(-1)  # [O, C, 1, 1]
+        return ops.conv2d(tokens_tm.view(b, 1, i, c), w, conv1d.bias, 1, 0).view(b, i, -1)
+
+    def _attn(self, q, k, v, mask=None):
+        """q [B,C]; k, v [B,I,C] token-major -> (context [B,C], weights [B,I])."""
+        return ops.attention(q.contiguous(), k.contiguous(), v.contiguous(), mask, self._scale_f)
+
+    # -- operator 2 --------------------------------------------------------------
+    def _ego_to_nhwc(self, ego_map):
+        ego_map = ego_map.float()
+        nhwc_view = ego_map.permute(0, 2, 3, 1)
+        if nhwc_view.is_contiguous():  # channels-last storage (what our BEV kernels emit)
+            return nhwc_view
+        return ops.to_nhwc(ego_map.contiguous())
+
+    def map_stack(self, ego_map):
+        """ego map [B,C,E,E] -> (map tokens [B, S*S, 256] token-major, pred_sem_map [B,27,2S,2S])."""
+        train = self.training
+        x = self._ego_to_nhwc(ego_map)
+        enc = self.map_encoder(x)
+        conv = lambda t, seq, pad: ops.relu(ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad))  # noqa: E731
+        enc_proj = conv(enc, self.map_encoded_linear, 1)
+        dec = self.map_decoder(enc)
+        c = self.map_classfier
+        from .encoders.map_encoder import bump
+        y = ops.conv_transpose2d(dec, c[0].weight, 2, 1)
+        bump(c[1], train)
+        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps)
+        y = ops.conv2d(y, c[3].weight, None, 1, 1)
+        bump(c[4], train)
+        y = ops.bn_act(y, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var, train, True, None, c[4].momentum, c[4].eps)
+        pad_o = SEM_PAD - SEM_CLASSES
+        w6 = torch.nn.functional.pad(c[6].weight, (0, 0, 0, 0, 0, 0, 0, pad_o))   # [32,32,1,1]
+        b6 = torch.nn.functional.pad(c[6].bias, (0, pad_o))
+        sem = ops.conv2d(y, w6, b6, 1, 0)                                        # [B,2S,2S,32], channels 27.. are 0
+        pred_sem_map = ops.to_nchw(sem, SEM_CLASSES)
+        wcl = torch.nn.functional.pad(self.map_classified_linear[0].weight, (0, 0, 0, 0, 0, pad_o))  # [128,32,3,3]
+        cls_proj = ops.relu(ops.conv2d(ops.avgpool2(sem), wcl, self.map_classified_linear[0].bias, 1, 1))
+        emb = conv(torch.cat([enc_proj, cls_proj], dim=-1), self.map_cated_linear, 1)
+        b, s1, s2, ch = emb.shape
+        return emb.view(b, s1 * s2, ch), pred_sem_map
+
+    # -- forward -------------------------------------------------------------------
+    def forward(self, observations, rnn_hidden_states, prev_actions, masks):
+        instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"])
+        rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)
+        depth_embedding = self.depth_encoder(observations)
+
+        self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
+        map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
+
+        state_in = []
+        if "rgb" in self._inputs:
+            state_in.append(self.rgb_linear(torch.flatten(rgb_embedding.float(), 2)))
+        if "depth" in self._inputs:
+            state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
+        if "map" in self._inputs:
+            state_in.append(self.map_linear[3](self.map_linear[2](map_tokens.mean(dim=1))))
+        state_in = torch.cat(state_in, dim=1)
+
+        n1 = self.state_encoder.num_recurrent_layers
+        restarts = None
+        if state_in.size(0) != rnn_hidden_states.size(1):
+            restarts = RNNStateEncoder.restart_steps(masks, rnn_hidden_states.size(1))
+        state, rnn_hidden_states[0:n1] = self.state_encoder(state_in, rnn_hidden_states[0:n1], masks, restarts)
+
+        # instruction attention: keys projected once per unique instruction, gathered per row
+        text_k = self._key_projection(self.state_text_k_layer, instr_u)[inverse]
+        text_v = instr_u[inverse]
+        text_embedding, _ = self._attn(self.state_text_q_layer(state), text_k, text_v, mask_u[inverse].contiguous())
+
+        # map attention
+        map_k = self._key_projection(self.text_map_k_layer, map_tokens)
+        map_embedding, self.att_map_t_m = self._attn(self.text_map_q_layer(text_embedding), map_k, map_tokens, None)
+
+        parts = [state, text_embedding] + ([map_embedding] if "map" in self._inputs else [])
+        x = self.second_state_compress(torch.cat(parts, dim=1))
+        x, rnn_hidden_states[n1:] = self.second_state_encoder(x, rnn_hidden_states[n1:], masks, restarts)
+        return x, rnn_hidden_states, pred_sem_map

@@ -1,0 +1,87 @@
+"""Drop-in boundary: the policy object the reference's trainers construct and call
+(vlnce_baselines/models/policy.py:15-103 — constructed at common_trainer.py:55-59, called at
+dagger_trainer.py:430-439,522 and common_trainer.py:326-339).
+
+Same constructor, `forward` / `act` / `update_map` signatures, attribute tree
+(`.net`, `.action_distribution`, `.critic`, `.prog_pred`, `.prog`) and state_dict keys; the
+compute behind `self.net` runs in the gfx950 kernels of libwsmgmap.so.  `CMAPolicy` is an alias
+(BASELINE.json names the surface that way; the reference class is `BasePolicy`).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..common.aux_losses import AuxLosses
+from ..common.distributions import DiagGaussian
+from .mg_map_policy import MGMapNet
+
+
+class CriticHead(nn.Module):
+    """habitat-lab v0.1.5 CriticHead: Linear(input, 1), orthogonal init (state_dict: critic.fc.*)."""
+
+    def __init__(self, input_size):
+        super().__init__()
+        self.fc = nn.Linear(input_size, 1)
+        nn.init.orthogonal_(self.fc.weight)
+        nn.init.constant_(self.fc.bias, 0)
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class BasePolicy(nn.Module):
+    def __init__(self, observation_space, action_space, model_config):
+        super().__init__()
+        self.model_config = model_config
+        self.net = MGMapNet(observation_space, model_config)
+        self.action_distribution = DiagGaussian(self.net.output_size, action_space.shape[0])
+        self.critic = CriticHead(self.net.output_size)
+        self.prog_pred = nn.Linear(model_config.STATE_ENCODER.hidden_size, 1)
+        self.prog = None
+
+    # -- rollout -------------------------------------------------------------------
+    def update_map(self, observations, masks):
+        _, proj = self.net.rgb_encoder(observations)
+        self.net.rgb_mapping_module(proj, observations, masks)
+
+    def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False):
+        features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
+        self.aux_prediction(features, observations, pred_map)
+        distribution = self.action_distribution(features)
+        value = self.critic(features)
+        action = distribution.mode() if deterministic else distribution.sample()
+        return value, action, distribution.log_probs(action), rnn_hidden_states
+
+    # -- auxiliary heads -------------------------------------------------------------
+    def aux_prediction(self, features, observations, pred_map):
+        cfg = self.model_config
+        self.prog = torch.tanh(self.prog_pred(features))
+        if not AuxLosses.is_active():
+            return
+        if cfg.PREDICTION_MONITOR.use:
+            side = pred_map.shape[-1]
+            target = F.interpolate(observations["gt_semantic_map"].unsqueeze(1), size=(side, side)).squeeze(1).long()
+            loss = F.cross_entropy(pred_map, target, reduction="none").mean([1, 2])
+            AuxLosses.register_loss("prediction_monitor", loss, cfg.PREDICTION_MONITOR.alpha)
+        if cfg.CONTRASTIVE_MONITOR.use:
+            size = self.net.map_encoder.output_shape[-1]
+            dis = observations["gt_path"] if "gt_path" in observations.keys() else observations["waypoint_distribution"]
+            hi, lo = dis.max(), dis.min()  # batch-global normalisation, as the reference does
+            target = F.interpolate(((hi - dis) / (hi - lo)).unsqueeze(1), size=[size, size], mode="area").squeeze(1)
+            target = F.softmax(target.reshape(target.shape[0], -1) / cfg.CONTRASTIVE_MONITOR.target_tau, dim=1)
+            kl = F.kl_div(torch.log(self.net.att_map_t_m), target, reduction="none").mean(-1)
+            AuxLosses.register_loss("contrastive_monitor", kl, cfg.CONTRASTIVE_MONITOR.alpha)
+        if cfg.PROGRESS_MONITOR.use:
+            loss = F.mse_loss(self.prog, observations["progress"], reduction="none").mean(-1)
+            AuxLosses.register_loss("progress_monitor", loss, cfg.PROGRESS_MONITOR.alpha)
+
+    # -- teacher forcing / DAgger update ---------------------------------------------
+    def forward(self, observations, rnn_hidden_states, prev_actions, masks, weights):
+        features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
+        pred = self.action_distribution(features).mean
+        self.aux_prediction(features, observations, pred_map)
+        aux_loss = AuxLosses.reduce((weights > 0).view(-1))
+        return pred, aux_loss
+
+
+CMAPolicy = BasePolicy

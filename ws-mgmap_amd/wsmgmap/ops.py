@@ -1,0 +1,406 @@
+"""Host-side operators of the hot path: thin torch.autograd.Function wrappers around the
+C ABI of libwsmgmap.so.  PyTorch is used only for device memory, streams and the autograd
+tape; every FLOP of the three named operators runs in the hand-written gfx950 kernels.
+
+All tensors are float32, contiguous and resident on the GPU; anything else raises (there is
+no CPU or eager fallback).  Activations are NHWC ([B,H,W,C]).
+"""
+import ctypes
+
+import torch
+
+from . import _abi
+
+_ws_cache = {}
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _abi.WsmgError("wsmgmap operators need GPU tensors: the HIP path is the only path (no CPU fallback)")
+        if not t.is_contiguous():
+            raise _abi.WsmgError(f"non-contiguous tensor passed to a wsmgmap kernel: shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise _abi.WsmgError(f"wsmgmap kernels compute in float32, got {t.dtype}")
+
+
+def _workspace(device):
+    """float64 scratch for the chip-wide column reductions (4 MiB covers 1024 blocks x 2 x 256)."""
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(1024 * 2 * 256, dtype=torch.float64, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+# ----------------------------------------------------------------------------- convolution
+class _Conv2d(torch.autograd.Function):
+    """y = conv2d(x, w) + b on NHWC x / OHWI w (wsmg_conv2d_fwd / _bwd_data / _bwd_weight)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        _req(x, w, bias)
+        _f32(x, w, bias)
+        B, H, W, Cin = x.shape
+        Cout, KH, KW, Cin2 = w.shape
+        assert Cin == Cin2, (x.shape, w.shape)
+        OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
+        y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+            dx = torch.empty_like(x)
+            _abi.call("wsmg_conv2d_bwd_data", _p(dy), _p(w_ihwo), _p(dx), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            _abi.call("wsmg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+        if has_bias and ctx.needs_input_grad[2]:
+            db = channel_sum(dy.view(-1, Cout))
+        return dx, dw, db, None, None
+
+
+class _ConvT2d(torch.autograd.Function):
+    """ConvTranspose2d(k4,s2,p1) = backward-data of the adjoint convolution.  `w` is the adjoint
+    conv's OHWI weight: [Cin_t][KH][KW][Cout_t] for a transposed conv Cin_t -> Cout_t."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        _req(x, w)
+        _f32(x, w)
+        B, Hs, Ws, Ct_in = x.shape           # small grid (adjoint conv's output)
+        O, KH, KW, I = w.shape               # adjoint conv: I channels (big grid) -> O channels (small grid)
+        assert O == Ct_in
+        Hb, Wb = (Hs - 1) * stride - 2 * pad + KH, (Ws - 1) * stride - 2 * pad + KW
+        w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+        y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_conv2d_bwd_data", _p(x), _p(w_ihwo), _p(y), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws = ctx.cfg
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _abi.call("wsmg_conv2d_fwd", _p(dy), _p(w), None, _p(dx), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            _abi.call("wsmg_conv2d_bwd_weight", _p(dy), _p(x), _p(dw), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+        return dx, dw, None, None
+
+
+def conv2d(x, weight_oihw, bias, stride=1, pad=0):
+    """x NHWC; weight in the reference's OIHW parameter layout (re-laid out to OHWI on the fly,
+    inside the autograd graph so the parameter's .grad comes back OIHW)."""
+    return _Conv2d.apply(x, weight_oihw.permute(0, 2, 3, 1).contiguous(), bias, stride, pad)
+
+
+def conv_transpose2d(x, weight_iohw, stride=2, pad=1):
+    """nn.ConvTranspose2d weight is [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW."""
+    return _ConvT2d.apply(x, weight_iohw.permute(0, 2, 3, 1).contiguous(), stride, pad)
+
+
+def channel_sum(x2d):
+    _req(x2d)
+    rows, C = x2d.shape
+    out = torch.empty(C, device=x2d.device, dtype=torch.float32)
+    ws = _workspace(x2d.device)
+    _abi.call("wsmg_channel_sum", _p(x2d), rows, C, _p(out), _p(ws), ws.numel() * 8, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- batch norm (+res)(+relu)
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps):
+        _req(x, residual, gamma, beta, running_mean, running_var)
+        _f32(x, residual, gamma, beta, running_mean, running_var)
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = _workspace(x.device)
+        _abi.call("wsmg_bn_act_fwd", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                  float(momentum), float(eps), int(train), int(relu), rows, C, _p(y), _p(mean), _p(invstd),
+                  _p(ws), ws.numel() * 8, _stream())
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.cfg = (rows, C, int(relu), residual is not None, bool(train))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        rows, C, relu, has_res, train = ctx.cfg
+        if not train:
+            raise _abi.WsmgError("backward through eval-mode BatchNorm is not part of the reference's path")
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        ws = _workspace(x.device)
+        _abi.call("wsmg_bn_act_bwd", _p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), relu, rows, C,
+                  _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5):
+    return _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps)
+
+
+# ----------------------------------------------------------------------------- small NHWC ops
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req(x)
+        y = torch.empty_like(x)
+        _abi.call("wsmg_relu_fwd", _p(x), _p(y), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _abi.call("wsmg_relu_bwd", _p(dy), _p(y), _p(dx), y.numel(), _stream())
+        return dx
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req(x)
+        B, H, W, C = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, OH, OW, C, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_maxpool3x3s2_fwd", _p(x), _p(y), B, H, W, C, OH, OW, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        _abi.call("wsmg_maxpool3x3s2_bwd", _p(dy), _p(x), _p(dx), B, H, W, C, dy.shape[1], dy.shape[2], _stream())
+        return dx
+
+
+class _Up2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req(x)
+        B, H, W, C = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_upsample2x_fwd", _p(x), _p(y), B, H, W, C, _stream())
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
+        _abi.call("wsmg_upsample2x_bwd", _p(dy), _p(dx), B, H, W, C, _stream())
+        return dx
+
+
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req(x)
+        B, H, W, C = x.shape
+        y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_avgpool2_fwd", _p(x), _p(y), B, H, W, C, _stream())
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
+        _abi.call("wsmg_avgpool2_bwd", _p(dy), _p(dx), B, H, W, C, _stream())
+        return dx
+
+
+class _ToNHWC(torch.autograd.Function):
+    """[B,C,H,W] contiguous -> [B,H,W,c_dst] (zero-padded channels)."""
+
+    @staticmethod
+    def forward(ctx, x, c_dst):
+        _req(x)
+        _f32(x)
+        B, C, H, W = x.shape
+        y = torch.empty(B, H, W, c_dst, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_nchw_to_nhwc", _p(x), _p(y), B, C, H, W, c_dst, _stream())
+        ctx.shape = (B, C, H, W, c_dst)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, c_dst = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        _abi.call("wsmg_nhwc_to_nchw", _p(dy), _p(dx), B, c_dst, H, W, C, _stream())
+        return dx, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    """[B,H,W,C] -> [B,c_dst,H,W] contiguous (drops padded channels)."""
+
+    @staticmethod
+    def forward(ctx, x, c_dst):
+        _req(x)
+        B, H, W, C = x.shape
+        y = torch.empty(B, c_dst, H, W, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_nhwc_to_nchw", _p(x), _p(y), B, C, H, W, c_dst, _stream())
+        ctx.shape = (B, H, W, C, c_dst)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, c_dst = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
+        _abi.call("wsmg_nchw_to_nhwc", _p(dy), _p(dx), B, c_dst, H, W, C, _stream())
+        return dx, None
+
+
+relu = _Relu.apply
+maxpool3x3s2 = _MaxPool.apply
+upsample2x = _Up2.apply
+avgpool2 = _AvgPool2.apply
+
+
+def to_nhwc(x, c_dst=None):
+    return _ToNHWC.apply(x, x.shape[1] if c_dst is None else c_dst)
+
+
+def to_nchw(x, c_dst=None):
+    return _ToNCHW.apply(x, x.shape[-1] if c_dst is None else c_dst)
+
+
+# ----------------------------------------------------------------------------- attention
+class _Attn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale):
+        _req(q, k, v, mask)
+        _f32(q, k, v)
+        B, I, C = k.shape
+        if mask is not None and mask.dtype != torch.uint8:
+            raise _abi.WsmgError("attention mask must be uint8")
+        out = torch.empty(B, C, device=q.device, dtype=torch.float32)
+        attn = torch.empty(B, I, device=q.device, dtype=torch.float32)
+        _abi.call("wsmg_attn_fwd", _p(q), _p(k), _p(v), _p(mask), float(scale), B, I, C, _p(out), _p(attn), _stream())
+        ctx.save_for_backward(q, k, v, attn)
+        ctx.scale = float(scale)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        q, k, v, attn = ctx.saved_tensors
+        B, I, C = k.shape
+        dout = torch.zeros_like(q) if dout is None else dout.contiguous()
+        dattn = None if dattn is None else dattn.contiguous()
+        dq = torch.empty_like(q)
+        dk = torch.empty_like(k)
+        dv = torch.empty_like(v)
+        _abi.call("wsmg_attn_bwd", _p(q), _p(k), _p(v), _p(attn), _p(dout), _p(dattn), ctx.scale, B, I, C,
+                  _p(dq), _p(dk), _p(dv), _stream())
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, mask=None, scale=1.0 / 16):
+    """q [B,C]; k, v [B,I,C] token-major; mask [B,I] bool/uint8 (True = padded token)."""
+    if mask is not None and mask.dtype == torch.bool:
+        mask = mask.to(torch.uint8)
+    return _Attn.apply(q, k, v, mask, scale)
+
+
+# ----------------------------------------------------------------------------- BEV (no autograd: rollout only)
+@torch.no_grad()
+def bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=0.12):
+    """depth [B,Hd,Wd] -> lin_idx int32 [B,Hf*Wf] (-1 = invalid source)."""
+    _req(depth)
+    _f32(depth)
+    B, Hd, Wd = depth.shape
+    lin = torch.empty(B, Hf * Wf, device=depth.device, dtype=torch.int32)
+    _abi.call("wsmg_bev_index", _p(depth), B, Hd, Wd, float(depth_scale), Hf, Wf, E, float(local_scale), _p(lin), _stream())
+    return lin
+
+
+@torch.no_grad()
+def bev_scatter_max(feat, lin, C, E):
+    """feat [B,Cf,Hf,Wf] NCHW -> [B,C,E,E] NCHW planes."""
+    _req(feat, lin)
+    _f32(feat)
+    B, Cf, Hf, Wf = feat.shape
+    out = torch.empty(B, C, E, E, device=feat.device, dtype=torch.float32)
+    _abi.call("wsmg_bev_scatter_max", _p(feat), _p(lin), B, Cf, Hf, Wf, C, E, _p(out), _stream())
+    return out
+
+
+@torch.no_grad()
+def bev_rotate(planes, heading, sign):
+    """planes [B,C,E,E] -> rotated NHWC [B,E,E,C]."""
+    _req(planes, heading)
+    B, C, E, _ = planes.shape
+    out = torch.empty(B, E, E, C, device=planes.device, dtype=torch.float32)
+    _abi.call("wsmg_bev_rotate", _p(planes), _p(heading), float(sign), B, C, E, _p(out), _stream())
+    return out
+
+
+@torch.no_grad()
+def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12):
+    _req(ego_rot, global_map, gps, masks)
+    B, E, _, C = ego_rot.shape
+    G = global_map.shape[1]
+    _abi.call("wsmg_map_fuse", _p(ego_rot), _p(global_map), _p(gps), _p(masks), B, C, E, G, float(resolution), _stream())
+
+
+@torch.no_grad()
+def map_retrieve(global_map, gps, compass, E, resolution=0.12):
+    _req(global_map, gps, compass)
+    B = gps.shape[0]
+    G, C = global_map.shape[1], global_map.shape[3]
+    scratch = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
+    out = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
+    _abi.call("wsmg_map_retrieve", _p(global_map), _p(gps), _p(compass), B, C, E, G, float(resolution), _p(scratch), _p(out), _stream())
+    return out
