@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — policy steps/sec (fwd+bwd) of WS-MGMap's teacher-forcing update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" of this script = one policy UPDATE over a batch of T=64 x N=8 synthetic cached-
+feature trajectories per GPU (BASELINE.json configs[1] / SURVEY.md §8d cfg2): zero_grad +
+BasePolicy.forward + DAgger loss + backward (+ gradient all-reduce over RCCL for N>1) + Adam.
+`value` = policy steps (rows) per second over all ranks = T*N*world*K / t.  Inputs are
+device-resident before the timed region.  Prints ONE JSON line on rank 0.
+
+The line carries `roofline` for the dominant kernel (live HIP-event timing of the conv-engine
+launches inside the timed region) and `cpu_baseline` (the oracle — a PyTorch-CPU port of the
+reference's update step — timed on this box's host cores on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "ws-mgmap_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3      # MI355X f32 MFMA / vector peak (MI355X_MICROARCH.md)
+ALG_GFLOP_PER_STEP = 10.017  # 3.776 fwd + 6.241 bwd per policy step
+
+
+class _Box:
+    shape = (2,)
+
+
+def synth_batch(T, N, device, seed, E=100, C=64):
+    """cfg2 inputs, time-major rows (row = t*N + n)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    B = T * N
+    instr = torch.zeros(N, 200)
+    instr[:, :80] = torch.randint(1, 2504, (N, 80), generator=g).float()
+    obs = {
+        "instruction": instr.repeat(T, 1),
+        "rgb_features": torch.randn(B, 512, 7, 7, generator=g),
+        "depth_features": torch.randn(B, 128, 4, 4, generator=g),
+        "rgb_ego_map": torch.relu(torch.randn(B, C, E, E, generator=g)),
+        "gt_semantic_map": torch.randint(0, 27, (B, E, E), generator=g).float(),
+        "gt_path": torch.rand(B, E, E, generator=g) * 50.0,
+        "progress": torch.rand(B, 1, generator=g),
+        "waypoint": torch.rand(B, 3, generator=g) * 2 - 1,
+    }
+    masks = torch.ones(T, N)
+    masks[0] = 0
+    weights = torch.ones(T, N)
+    prev = torch.zeros(B, 2)
+    obs = {k: v.to(device) for k, v in obs.items()}
+    return obs, prev.to(device), masks.view(B, 1).to(device), weights.to(device)
+
+
+def dagger_loss(pred, aux_loss, waypoint, weights):
+    T, N = weights.shape
+    logits = torch.tanh(pred).view(T, N, -1)
+    al = F.mse_loss(logits, waypoint[:, :2].view(T, N, -1), reduction="none").sum(2)
+    al = ((weights * al).sum(0) / weights.sum(0)).mean()
+    return al + aux_loss
+
+
+def cpu_baseline(state, T_full, N, budget_s=20.0):
+    """The oracle's update step (fwd + loss + bwd + Adam, PyTorch CPU fp32) on the host cores.
+    Sample: the same workload at the largest T (<= T_full) expected to fit `budget_s`."""
+    from oracle import policy_ref
+    cores = torch.get_num_threads()
+
+    def make_P():
+        P = {}
+        for k, v in state.items():
+            t = v.detach().cpu().clone()
+            P[k] = t
+        return P
+
+    def run(T):
+        P = make_P()
+        leaves = {}
+        for k, t in P.items():
+            if t.is_floating_point() and not k.startswith(("net.rgb_encoder", "net.instruction_encoder.embedding")) \
+                    and "running_" not in k and k != "net._scale":
+                t.requires_grad_(True)
+                leaves[id(t)] = t
+        opt = torch.optim.Adam(list(leaves.values()), lr=2.5e-4)
+        ref = policy_ref.PolicyRef(P, num_proc=1)
+        ref.aux_active = True
+        obs, prev, masks, weights = synth_batch(T, N, "cpu", 1234)
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        pred, aux, _, _ = ref.forward(obs, torch.zeros(2, N, 512), prev, masks, weights)
+        loss, _ = policy_ref.dagger_loss(pred, aux, obs["waypoint"], weights)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    run(1)  # warm-up (thread pools, allocator)
+    t2 = run(2)
+    per_t = t2 / 2
+    T = int(max(2, min(T_full, budget_s / max(per_t, 1e-3))))
+    dt = run(T)
+    return dict(value=T * N / dt, unit="policy steps/s", cores=cores, kind="port",
+                sample=f"1 update of T={T} x N={N} ({T * N} policy steps, {dt:.1f} s) of the oracle (PyTorch-CPU fp32 port "
+                       f"of the reference update: fwd+loss+bwd+Adam), {cores} threads")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--T", type=int, default=64)
+    ap.add_argument("--N", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wsmgmap import ops
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.policy import BasePolicy
+    from wsmgmap.parallel import GradAllReducer
+
+    torch.manual_seed(0)
+    policy = BasePolicy(None, _Box(), default_model_config(num_proc=1, gpu_id=local))
+    policy.net.instruction_encoder.embedding_layer.weight.requires_grad_(False)  # reference default: frozen embeddings
+    state_cpu = {k: v.detach().clone() for k, v in policy.state_dict().items()} if rank == 0 else None
+    policy = policy.to(dev)
+    policy.train()
+    policy.net.depth_encoder.eval()
+    policy.net.rgb_encoder.eval()
+    opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
+    reducer = GradAllReducer(policy.parameters()) if world > 1 else None
+    if reducer:
+        reducer.broadcast_parameters(policy)
+
+    T, N = args.T, args.N
+    obs, prev, masks, weights = synth_batch(T, N, dev, 1000 + rank)
+    AuxLosses.activate()
+
+    def update():
+        opt.zero_grad(set_to_none=True)
+        AuxLosses.clear()
+        h0 = torch.zeros(policy.net.num_recurrent_layers, N, 512, device=dev)
+        o = dict(obs)  # forward mutates the dict (rgb_ego_map key) like the reference
+        pred, aux = policy(o, h0, prev, masks, weights)
+        loss = dagger_loss(pred, aux, o["waypoint"], weights)
+        loss.backward()
+        if reducer:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        update()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = update()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_end()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        steps_per_s = T * N * world * args.steps / dt
+        kernels = {}
+        for name, r in prof.items():
+            avg_ms = r["ms_total"] / max(r["launches"], 1)
+            kernels[name] = dict(launches=r["launches"], avg_ms=avg_ms, ms_per_update=r["ms_total"] / args.steps,
+                                 tflops=r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12 if r["ms_total"] > 0 else 0.0)
+        dom = max(kernels, key=lambda k: kernels[k]["ms_per_update"]) if kernels else None
+        roofline = None
+        if dom:
+            r = prof[dom]
+            ach = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=None,
+                            avg_launch_ms=round(r["ms_total"] / r["launches"], 4), launches=r["launches"],
+                            alg_gflop_per_launch=round(r["flops_total"] / r["launches"] / 1e9, 3))
+        out = {
+            "metric": "policy steps/sec (fwd+bwd), CMA batch=8 seq=64",
+            "value": round(steps_per_s, 2),
+            "unit": "policy steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"teacher-forcing update fwd+bwd+Adam, T={T} x N={N} rows/GPU (B={T * N}), E=100 C=64 "
+                                   f"80-token instructions, cached rgb/depth/ego-map features (BASELINE configs[1])",
+                       "T": T, "N_per_gpu": N, "parallelism": f"dp{world}"},
+            "whole_update_tflops": round(ALG_GFLOP_PER_STEP * steps_per_s / 1e3 / world, 2),
+            "loss": round(final_loss, 5),
+            "roofline": roofline,
+            "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(state_cpu, T, N, args.cpu_budget)
+            out["gpu_over_cpu"] = round(steps_per_s / out["cpu_baseline"]["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

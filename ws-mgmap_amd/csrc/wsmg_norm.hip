@@ -65,24 +65,34 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float* __
   }
 }
 
-__global__ void sum_finalize_kernel(const double* part, int nblk, int C, float* out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += part[((size_t)b * 2) * C + c];
-  out[c] = (float)s;
-}
-
-__global__ void bn_stats_finalize_kernel(const double* part, int nblk, int C, int64_t rows, float momentum,
-                                         float eps, float* running_mean, float* running_var, float* save_mean,
-                                         float* save_invstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+// finalize kernels: one wave per channel sums the per-block float64 partials (lane-strided, then
+// a shuffle reduction) — a few microseconds instead of a 1024-iteration serial loop.
+__device__ __forceinline__ void reduce_partials(const double* part, int nblk, int C, int c, double& s, double& q) {
+  s = 0.0;
+  q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += WSMG_WAVE) {
     s += part[((size_t)b * 2 + 0) * C + c];
     q += part[((size_t)b * 2 + 1) * C + c];
   }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+}
+
+__global__ __launch_bounds__(64) void sum_finalize_kernel(const double* part, int nblk, int C, float* out) {
+  const int c = blockIdx.x;
+  double s, q;
+  reduce_partials(part, nblk, C, c, s, q);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* part, int nblk, int C, int64_t rows,
+                                                               float momentum, float eps, float* running_mean,
+                                                               float* running_var, float* save_mean,
+                                                               float* save_invstd) {
+  const int c = blockIdx.x;
+  double s, q;
+  reduce_partials(part, nblk, C, c, s, q);
+  if (threadIdx.x != 0) return;
   double n = (double)rows;
   double mean = s / n;
   double var = q / n - mean * mean;
@@ -135,16 +145,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // dgamma/dbeta from the reduction, then dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n)
-__global__ void bn_bwd_finalize_kernel(const double* part, int nblk, int C, float* dgamma, float* dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += part[((size_t)b * 2 + 0) * C + c];
-    q += part[((size_t)b * 2 + 1) * C + c];
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* part, int nblk, int C, float* dgamma,
+                                                             float* dbeta) {
+  const int c = blockIdx.x;
+  double s, q;
+  reduce_partials(part, nblk, C, c, s, q);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
   }
-  dbeta[c] = (float)s;
-  dgamma[c] = (float)q;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -200,7 +209,7 @@ extern "C" int wsmg_channel_sum(const float* x, int64_t rows, int C, float* out,
   int nb = red_blocks(rows, C);
   hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(RED_THREADS), 0, wsmg_s(stream), x, nullptr, nullptr,
                      nullptr, nullptr, 0, rows, C, workspace);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(1), dim3(256), 0, wsmg_s(stream), workspace, nb, C, out);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(64), 0, wsmg_s(stream), workspace, nb, C, out);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -215,7 +224,7 @@ extern "C" int wsmg_bn_act_fwd(const float* x, const float* residual, const floa
     int nb = red_blocks(rows, C);
     hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(nb), dim3(RED_THREADS), 0, s, x, nullptr, nullptr, nullptr,
                        nullptr, 0, rows, C, workspace);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(256), 0, s, workspace, nb, C, rows, momentum, eps,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, rows, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd);
   } else {
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, running_mean, running_var, eps, C,
@@ -237,7 +246,7 @@ extern "C" int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, 
   int nb = red_blocks(rows, C);
   hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd, relu,
                      rows, C, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, workspace, nb, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
   int64_t n4 = rows * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
                      save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, n4, C, dx, dresidual);

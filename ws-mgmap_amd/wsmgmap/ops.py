@@ -52,6 +52,46 @@ def _conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
 
+# ----------------------------------------------------------------------------- live kernel timing
+# bench.py brackets the conv-engine launches with HIP events on the launch stream (torch's
+# current stream IS the stream handed to the C ABI) to report per-kernel roofline figures.
+_prof = None
+
+KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trace names it)
+    "wsmg_conv2d_fwd": "conv_igemm_kernel<false>",
+    "wsmg_conv2d_bwd_data": "conv_igemm_kernel<true>",
+    "wsmg_conv2d_bwd_weight": "conv_wgrad_kernel",
+}
+
+
+def profile_begin():
+    global _prof
+    _prof = {}
+
+
+def profile_end():
+    """-> {kernel: dict(launches, ms_total, flops_total)}; synchronises."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, items in (rec or {}).items():
+        ms = sum(s.elapsed_time(e) for s, e, _ in items)
+        out[KERNEL_OF[name]] = dict(launches=len(items), ms_total=ms, flops_total=float(sum(f for _, _, f in items)))
+    return out
+
+
+def _launch(name, flops, *args):
+    if _prof is None:
+        _abi.call(name, *args)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    _abi.call(name, *args)
+    e.record()
+    _prof.setdefault(name, []).append((s, e, flops))
+
+
 # ----------------------------------------------------------------------------- convolution
 class _Conv2d(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC x / OHWI w (wsmg_conv2d_fwd / _bwd_data / _bwd_weight)."""
@@ -65,7 +105,8 @@ class _Conv2d(torch.autograd.Function):
         assert Cin == Cin2, (x.shape, w.shape)
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
         y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_conv2d_fwd", _p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+        fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
+        _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, bias is not None)
         return y
@@ -76,13 +117,14 @@ class _Conv2d(torch.autograd.Function):
         B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, has_bias = ctx.cfg
         dy = dy.contiguous()
         dx = dw = db = None
+        fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         if ctx.needs_input_grad[0]:
             w_ihwo = w.permute(3, 1, 2, 0).contiguous()
             dx = torch.empty_like(x)
-            _abi.call("wsmg_conv2d_bwd_data", _p(dy), _p(w_ihwo), _p(dx), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+            _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
-            _abi.call("wsmg_conv2d_bwd_weight", _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+            _launch("wsmg_conv2d_bwd_weight", fl, _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
         if has_bias and ctx.needs_input_grad[2]:
             db = channel_sum(dy.view(-1, Cout))
         return dx, dw, db, None, None
@@ -102,7 +144,8 @@ class _ConvT2d(torch.autograd.Function):
         Hb, Wb = (Hs - 1) * stride - 2 * pad + KH, (Ws - 1) * stride - 2 * pad + KW
         w_ihwo = w.permute(3, 1, 2, 0).contiguous()
         y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_conv2d_bwd_data", _p(x), _p(w_ihwo), _p(y), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+        fl = 2.0 * B * Hs * Ws * O * I * KH * KW
+        _launch("wsmg_conv2d_bwd_data", fl, _p(x), _p(w_ihwo), _p(y), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = (B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws)
         return y
@@ -113,12 +156,13 @@ class _ConvT2d(torch.autograd.Function):
         B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws = ctx.cfg
         dy = dy.contiguous()
         dx = dw = None
+        fl = 2.0 * B * Hs * Ws * O * I * KH * KW
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _abi.call("wsmg_conv2d_fwd", _p(dy), _p(w), None, _p(dx), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+            _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
         if ctx.needs_input_grad[1]:
             dw = torch.zeros_like(w)
-            _abi.call("wsmg_conv2d_bwd_weight", _p(dy), _p(x), _p(dw), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+            _launch("wsmg_conv2d_bwd_weight", fl, _p(dy), _p(x), _p(dw), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
         return dx, dw, None, None
 
 
