@@ -27,19 +27,45 @@ struct ConvArgs {
   const float* bias;  // [N] or null
   float* dst;         // [B][TH][TW][N]
   int B, SH, SW, Kc, TH, TW, N, KH, KW, stride, pad;
-  int M;              // B*TH*TW
+  int mtiles;         // pixel tiles per parity class (grid.x = mtiles * ntiles)
+  int ntiles;
 };
 
-// BWD=false: target pixel t reads source t*s - p + k.   BWD=true: source (t + p - k)/s if divisible.
+// XCD-aware, bijective remap of a 1-D block id: the dispatcher deals blocks round-robin over the
+// 8 XCDs, so give each XCD one contiguous run of logical tiles (tiles that share input windows /
+// the same A rows then share one L2).  Speed only — any placement is correct.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, x = bid & 7;
+  return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
+// BWD=false: target pixel t reads source t*s - p + k.
+// BWD=true : source (t + p - k)/s where divisible.  For s == 2 the target pixels are split into
+//            the 4 parity classes (blockIdx.y) so that every tap a class visits is valid:
+//            class (cy,cx) owns targets with (t+p)&1 == c and taps k = c + 2a, source = (t+p-c)/2 - a.
 template <bool BWD>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+  __shared__ int dpix[BM];  // destination pixel index of each tile row (-1 = none)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int logical = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (logical / a.ntiles) * BM, n0 = (logical % a.ntiles) * BN;
   const int seg = tid & 7;          // 16-B segment inside a 128-B channel run
   const int lrow = tid >> 3;        // 0..31
+
+  // parity class geometry (identity unless BWD && stride == 2)
+  int cy = 0, cx = 0, ty0 = 0, tx0 = 0, tstep = 1, THc = a.TH, TWc = a.TW, KHc = a.KH, KWc = a.KW;
+  if (BWD && a.stride == 2) {
+    cy = blockIdx.y >> 1; cx = blockIdx.y & 1;
+    ty0 = (cy + a.pad) & 1; tx0 = (cx + a.pad) & 1;   // first target row/col with (t + pad) & 1 == c
+    tstep = 2;
+    THc = (a.TH - ty0 + 1) >> 1; TWc = (a.TW - tx0 + 1) >> 1;
+    KHc = (a.KH - cy + 1) >> 1; KWc = (a.KW - cx + 1) >> 1;
+  }
+  const int Mc = a.B * THc * TWc;
+  if (m0 >= Mc) return;  // uniform per workgroup (classes differ in size)
 
   // the 4 A rows this thread stages (fixed over the k loop)
   int pb[4], py[4], px[4];
@@ -47,42 +73,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = m0 + lrow + 32 * i;
-    pv[i] = m < a.M;
+    pv[i] = m < Mc;
     int mm = pv[i] ? m : 0;
-    int b = mm / (a.TH * a.TW);
-    int r = mm - b * (a.TH * a.TW);
-    int ty = r / a.TW, tx = r - ty * a.TW;
+    int b = mm / (THc * TWc);
+    int r = mm - b * (THc * TWc);
+    int iy = r / TWc, ix = r - iy * TWc;
+    int ty = ty0 + iy * tstep, tx = tx0 + ix * tstep;
     pb[i] = b * a.SH * a.SW;
-    py[i] = BWD ? ty + a.pad : ty * a.stride - a.pad;
-    px[i] = BWD ? tx + a.pad : tx * a.stride - a.pad;
+    if (BWD) {
+      py[i] = (a.stride == 2) ? ((ty + a.pad - cy) >> 1) : ty + a.pad;
+      px[i] = (a.stride == 2) ? ((tx + a.pad - cx) >> 1) : tx + a.pad;
+    } else {
+      py[i] = ty * a.stride - a.pad;
+      px[i] = tx * a.stride - a.pad;
+    }
+    if (seg == 0) dpix[lrow + 32 * i] = pv[i] ? (b * a.TH + ty) * a.TW + tx : -1;
   }
   const int kchunks = a.Kc / BK;
-  const int steps = a.KH * a.KW * kchunks;
+  const int taps_c = KHc * KWc;
+  const int steps = taps_c * kchunks;
   const int taps = a.KH * a.KW;
 
   f32x4 ra[4], rb[2];
   auto gload = [&](int step) {
-    int tap = step / kchunks;
-    int c0 = (step - tap * kchunks) * BK + seg * 4;
-    int ky = tap / a.KW, kx = tap - ky * a.KW;
+    int tc = step / kchunks;
+    int c0 = (step - tc * kchunks) * BK + seg * 4;
+    int ay = tc / KWc, ax = tc - ay * KWc;
+    int ky = BWD ? cy + ay * tstep : ay, kx = BWD ? cx + ax * tstep : ax;
+    int tap = ky * a.KW + kx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int sy, sx;
-      bool ok = pv[i];
-      if (BWD) {
-        int ty = py[i] - ky, tx = px[i] - kx;
-        ok = ok && ty >= 0 && tx >= 0;
-        if (a.stride == 2) {
-          ok = ok && ((ty | tx) & 1) == 0;
-          sy = ty >> 1; sx = tx >> 1;
-        } else {
-          sy = ty; sx = tx;
-        }
-        ok = ok && sy < a.SH && sx < a.SW;
-      } else {
-        sy = py[i] + ky; sx = px[i] + kx;
-        ok = ok && sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW;
-      }
+      int sy = BWD ? py[i] - ((a.stride == 2) ? ay : ky) : py[i] + ky;
+      int sx = BWD ? px[i] - ((a.stride == 2) ? ax : kx) : px[i] + kx;
+      bool ok = pv[i] && sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) v = *reinterpret_cast<const f32x4*>(a.src + ((size_t)(pb[i] + sy * a.SW + sx)) * a.Kc + c0);
       ra[i] = v;
@@ -95,11 +118,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       rb[i] = v;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDT + seg * 4]) = ra[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * i) * LDT + seg * 4]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDT + seg * 4]) = rb[i];
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * i) * LDT + seg * 4]) = rb[i];
   };
 
   // wave tile: 64 pixels x 32 channels = two 32x32 MFMA tiles
@@ -110,18 +133,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
 
+  // two LDS buffers, ONE barrier per k-step: while buffer `cur` feeds the MFMAs, the registers
+  // prefetched during the previous step are written to the other buffer and the step after
+  // that is requested from memory.
   gload(0);
-  lstore();
+  lstore(0);
+  if (steps > 1) gload(1);
   __syncthreads();
   for (int step = 0; step < steps; ++step) {
-    if (step + 1 < steps) gload(step + 1);
+    const int cur = step & 1;
+    if (step + 1 < steps) lstore(cur ^ 1);
+    if (step + 2 < steps) gload(step + 2);
     if (wave_live) {
+      const float* Ab = As[cur];
+      const float* Bb = Bs[cur];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // lane half h supplies k = 8j + 4h + e of this k-step (same map for A and B)
-        f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[(wm + r) * LDT + 8 * j + 4 * h]);
-        f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[(wm + 32 + r) * LDT + 8 * j + 4 * h]);
-        f32x4 bb = *reinterpret_cast<const f32x4*>(&Bs[(wn + r) * LDT + 8 * j + 4 * h]);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(&Ab[(wm + r) * LDT + 8 * j + 4 * h]);
+        f32x4 a1 = *reinterpret_cast<const f32x4*>(&Ab[(wm + 32 + r) * LDT + 8 * j + 4 * h]);
+        f32x4 bb = *reinterpret_cast<const f32x4*>(&Bb[(wn + r) * LDT + 8 * j + 4 * h]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], bb[e], acc0, 0, 0, 0);
@@ -130,10 +161,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     }
     __syncthreads();
-    if (step + 1 < steps) {
-      lstore();
-      __syncthreads();
-    }
   }
 
   if (!wave_live) return;
@@ -145,8 +172,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       int row = wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-      int m = m0 + row;
-      if (m < a.M) a.dst[(size_t)m * a.N + n] = (t == 0 ? acc0[g] : acc1[g]) + bv;
+      int dp = dpix[row];
+      if (dp >= 0) a.dst[(size_t)dp * a.N + n] = (t == 0 ? acc0[g] : acc1[g]) + bv;
     }
   }
 }
@@ -167,8 +194,8 @@ struct WgradArgs {
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ds[WPX * WCO];
-  __shared__ __attribute__((aligned(16))) float Xs[WUN * WPX * 32];
+  __shared__ __attribute__((aligned(16))) float Ds[2][WPX * WCO];
+  __shared__ __attribute__((aligned(16))) float Xs[2][WUN * WPX * 32];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * WUN;
@@ -224,38 +251,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       rx[u] = v;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Ds[((tid >> 4) + 16 * i) * WCO + dseg * 4]) = rd[i];
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Ds[buf][((tid >> 4) + 16 * i) * WCO + dseg * 4]) = rd[i];
 #pragma unroll
-    for (int u = 0; u < WUN; ++u) *reinterpret_cast<f32x4*>(&Xs[(u * WPX + xpx) * 32 + xseg * 4]) = rx[u];
+    for (int u = 0; u < WUN; ++u) *reinterpret_cast<f32x4*>(&Xs[buf][(u * WPX + xpx) * 32 + xseg * 4]) = rx[u];
   };
 
+  // two LDS buffers, one barrier per 32-pixel step (same pipeline as conv_igemm_kernel)
   if (p_begin < p_end) {
     gload(p_begin);
-    lstore();
+    lstore(0);
+    if (p_begin + WPX < p_end) gload(p_begin + WPX);
   }
   __syncthreads();
   const bool wave_live = (u0 + wave) < a.units;
-  for (int64_t p0 = p_begin; p0 < p_end; p0 += WPX) {
-    bool more = p0 + WPX < p_end;
-    if (more) gload(p0 + WPX);
+  int cur = 0;
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += WPX, cur ^= 1) {
+    if (p0 + WPX < p_end) lstore(cur ^ 1);
+    if (p0 + 2 * WPX < p_end) gload(p0 + 2 * WPX);
     if (wave_live) {
-      const float* xs = &Xs[wave * WPX * 32];
+      const float* ds = Ds[cur];
+      const float* xs = &Xs[cur][wave * WPX * 32];
 #pragma unroll
       for (int s = 0; s < WPX / 2; ++s) {
-        float a0 = Ds[(2 * s + h) * WCO + r];
-        float a1 = Ds[(2 * s + h) * WCO + 32 + r];
+        float a0 = ds[(2 * s + h) * WCO + r];
+        float a1 = ds[(2 * s + h) * WCO + 32 + r];
         float bb = xs[(2 * s + h) * 32 + r];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb, acc1, 0, 0, 0);
       }
     }
     __syncthreads();
-    if (more) {
-      lstore();
-      __syncthreads();
-    }
   }
   if (!wave_live) return;
   const int uu = u0 + wave;
@@ -287,8 +314,10 @@ extern "C" int wsmg_conv2d_fwd(const float* x, const float* w_ohwi, const float*
                                int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  ConvArgs a{x, w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, B * OH * OW};
-  dim3 grid((unsigned)wsmg_cdiv(a.M, BM), (unsigned)wsmg_cdiv(Cout, BN));
+  ConvArgs a{x, w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0};
+  a.mtiles = (int)wsmg_cdiv((int64_t)B * OH * OW, BM);
+  a.ntiles = (int)wsmg_cdiv(Cout, BN);
+  dim3 grid((unsigned)(a.mtiles * a.ntiles));
   hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
@@ -297,8 +326,16 @@ extern "C" int wsmg_conv2d_bwd_data(const float* dy, const float* w_ihwo, float*
                                     int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  ConvArgs a{dy, w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, B * H * W};
-  dim3 grid((unsigned)wsmg_cdiv(a.M, BM), (unsigned)wsmg_cdiv(Cin, BN));
+  ConvArgs a{dy, w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0};
+  a.ntiles = (int)wsmg_cdiv(Cin, BN);
+  int classes = 1;
+  int64_t mmax = (int64_t)B * H * W;
+  if (stride == 2) {  // largest parity class: ceil(H/2) x ceil(W/2) target pixels per image
+    classes = 4;
+    mmax = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  }
+  a.mtiles = (int)wsmg_cdiv(mmax, BM);
+  dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)classes);
   hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
