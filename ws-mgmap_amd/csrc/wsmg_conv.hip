@@ -12,6 +12,8 @@
 // with the roles of the two pixel grids swapped and IHWO weights.  Backward-weight reduces
 // over pixels:  dW[co][(tap,ci)] = sum_px dY[px][co] * X[px@tap][ci], split over pixel
 // ranges (grid.z) and combined with float atomics.
+#include <stdlib.h>
+
 #include "wsmg_common.h"
 
 namespace {
@@ -43,10 +45,12 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
 // BWD=true : source (t + p - k)/s where divisible.  For s == 2 the target pixels are split into
 //            the 4 parity classes (blockIdx.y) so that every tap a class visits is valid:
 //            class (cy,cx) owns targets with (t+p)&1 == c and taps k = c + 2a, source = (t+p-c)/2 - a.
-template <bool BWD>
+// DB=true : two LDS buffers, one barrier per k-step (2 workgroups per CU by LDS);
+// DB=false: one LDS buffer, two barriers per k-step (3 workgroups per CU).
+template <bool BWD, bool DB>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+  __shared__ __attribute__((aligned(16))) float As[DB ? 2 : 1][BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[DB ? 2 : 1][BN * LDT];
   __shared__ int dpix[BM];  // destination pixel index of each tile row (-1 = none)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -138,12 +142,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // that is requested from memory.
   gload(0);
   lstore(0);
-  if (steps > 1) gload(1);
+  if (DB && steps > 1) gload(1);
   __syncthreads();
   for (int step = 0; step < steps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < steps) lstore(cur ^ 1);
-    if (step + 2 < steps) gload(step + 2);
+    const int cur = DB ? (step & 1) : 0;
+    if (DB) {
+      if (step + 1 < steps) lstore(cur ^ 1);
+      if (step + 2 < steps) gload(step + 2);
+    } else {
+      if (step + 1 < steps) gload(step + 1);
+    }
     if (wave_live) {
       const float* Ab = As[cur];
       const float* Bb = Bs[cur];
@@ -161,6 +169,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     }
     __syncthreads();
+    if (!DB && step + 1 < steps) {
+      lstore(0);
+      __syncthreads();
+    }
   }
 
   if (!wave_live) return;
@@ -193,9 +205,10 @@ struct WgradArgs {
   int64_t chunk;     // pixels per grid.z slice (multiple of WPX)
 };
 
+template <bool DB>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ds[2][WPX * WCO];
-  __shared__ __attribute__((aligned(16))) float Xs[2][WUN * WPX * 32];
+  __shared__ __attribute__((aligned(16))) float Ds[DB ? 2 : 1][WPX * WCO];
+  __shared__ __attribute__((aligned(16))) float Xs[DB ? 2 : 1][WUN * WPX * 32];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * WUN;
@@ -258,18 +271,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int u = 0; u < WUN; ++u) *reinterpret_cast<f32x4*>(&Xs[buf][(u * WPX + xpx) * 32 + xseg * 4]) = rx[u];
   };
 
-  // two LDS buffers, one barrier per 32-pixel step (same pipeline as conv_igemm_kernel)
+  // same pipeline choice as conv_igemm_kernel (DB: two LDS buffers, one barrier per step)
   if (p_begin < p_end) {
     gload(p_begin);
     lstore(0);
-    if (p_begin + WPX < p_end) gload(p_begin + WPX);
+    if (DB && p_begin + WPX < p_end) gload(p_begin + WPX);
   }
   __syncthreads();
   const bool wave_live = (u0 + wave) < a.units;
   int cur = 0;
-  for (int64_t p0 = p_begin; p0 < p_end; p0 += WPX, cur ^= 1) {
-    if (p0 + WPX < p_end) lstore(cur ^ 1);
-    if (p0 + 2 * WPX < p_end) gload(p0 + 2 * WPX);
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += WPX, cur ^= (DB ? 1 : 0)) {
+    if (DB) {
+      if (p0 + WPX < p_end) lstore(cur ^ 1);
+      if (p0 + 2 * WPX < p_end) gload(p0 + 2 * WPX);
+    } else {
+      if (p0 + WPX < p_end) gload(p0 + WPX);
+    }
     if (wave_live) {
       const float* ds = Ds[cur];
       const float* xs = &Xs[cur][wave * WPX * 32];
@@ -283,6 +300,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
     __syncthreads();
+    if (!DB && p0 + WPX < p_end) {
+      lstore(0);
+      __syncthreads();
+    }
   }
   if (!wave_live) return;
   const int uu = u0 + wave;
@@ -297,6 +318,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, t == 0 ? acc0[g] : acc1[g]);
     }
   }
+}
+
+// pipeline variant: WSMG_CONV_DB=0/1 (tuning knob; default set from measurements)
+bool conv_double_buffer() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WSMG_CONV_DB");
+    v = e ? (atoi(e) != 0) : 0;
+  }
+  return v != 0;
 }
 
 int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
@@ -318,7 +349,10 @@ extern "C" int wsmg_conv2d_fwd(const float* x, const float* w_ohwi, const float*
   a.mtiles = (int)wsmg_cdiv((int64_t)B * OH * OW, BM);
   a.ntiles = (int)wsmg_cdiv(Cout, BN);
   dim3 grid((unsigned)(a.mtiles * a.ntiles));
-  hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), a);
+  if (conv_double_buffer())
+    hipLaunchKernelGGL((conv_igemm_kernel<false, true>), grid, dim3(256), 0, wsmg_s(stream), a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<false, false>), grid, dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -336,7 +370,10 @@ extern "C" int wsmg_conv2d_bwd_data(const float* dy, const float* w_ihwo, float*
   }
   a.mtiles = (int)wsmg_cdiv(mmax, BM);
   dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)classes);
-  hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), a);
+  if (conv_double_buffer())
+    hipLaunchKernelGGL((conv_igemm_kernel<true, true>), grid, dim3(256), 0, wsmg_s(stream), a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<true, false>), grid, dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -356,6 +393,9 @@ extern "C" int wsmg_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   if (gz > 65535) gz = 65535;
   a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WPX) * WPX;
   gz = wsmg_cdiv(a.npix, a.chunk);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
+  if (conv_double_buffer())
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }

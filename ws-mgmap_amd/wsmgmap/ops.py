@@ -58,9 +58,9 @@ def _conv_out(h, k, s, p):
 _prof = None
 
 KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trace names it)
-    "wsmg_conv2d_fwd": "conv_igemm_kernel<false>",
-    "wsmg_conv2d_bwd_data": "conv_igemm_kernel<true>",
-    "wsmg_conv2d_bwd_weight": "conv_wgrad_kernel",
+    "wsmg_conv2d_fwd": "conv_igemm_kernel<false, false>",
+    "wsmg_conv2d_bwd_data": "conv_igemm_kernel<true, false>",
+    "wsmg_conv2d_bwd_weight": "conv_wgrad_kernel<false>",
 }
 
 
