@@ -150,6 +150,53 @@ int wsmg_attn_bwd(const float* q, const float* k, const float* v, const float* a
                   const float* dattn, float scale, int B, int I, int C, float* dq, float* dk, float* dv,
                   wsmg_stream_t stream);
 
+/* ============================ bf16 storage variants (BASELINE configs[1]: bf16) ============================ */
+/* Same operators with activations (x, y, dy, dx, residual, k, v) stored as bf16 in HBM (`void*` = bf16
+ * elements), float32 arithmetic / accumulation, float32 parameters, statistics and weight gradients.
+ * Convolutions take bf16 weights (the host casts the float32 master weights once per update) and run on
+ * v_mfma_f32_32x32x16_bf16; backward-weight reads its pixel-major tiles with ds_read_b64_tr_b16.
+ * `out_f32` != 0 makes the conv write float32 instead of bf16. */
+int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, int B, int H,
+                         int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                         wsmg_stream_t stream);
+int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
+                              int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                              wsmg_stream_t stream);
+int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin,
+                                int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                wsmg_stream_t stream);
+int wsmg_channel_sum_bf16(const void* x, int64_t rows, int C, float* out, double* workspace,
+                          int64_t workspace_bytes, wsmg_stream_t stream);
+int wsmg_bn_act_fwd_bf16(const void* x, const void* residual, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, int train,
+                         int relu, int64_t rows, int C, void* y, float* save_mean, float* save_invstd,
+                         double* workspace, int64_t workspace_bytes, wsmg_stream_t stream);
+int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const float* gamma,
+                         const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
+                         void* dx, void* dresidual, float* dgamma, float* dbeta, double* workspace,
+                         int64_t workspace_bytes, wsmg_stream_t stream);
+int wsmg_relu_fwd_bf16(const void* x, void* y, int64_t n, wsmg_stream_t stream);
+int wsmg_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, wsmg_stream_t stream);
+int wsmg_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW,
+                               wsmg_stream_t stream);
+int wsmg_maxpool3x3s2_bwd_bf16(const void* dy, const void* x, void* dx, int B, int H, int W, int C, int OH,
+                               int OW, wsmg_stream_t stream);
+int wsmg_upsample2x_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_upsample2x_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_avgpool2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_avgpool2_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, wsmg_stream_t stream);
+/* float32 NCHW -> bf16 NHWC (ego map in; gradient of pred_sem_map) and bf16 NHWC -> float32 NCHW */
+int wsmg_nchw_to_nhwc_bf16(const float* x, void* y, int B, int C_src, int H, int W, int C_dst,
+                           wsmg_stream_t stream);
+int wsmg_nhwc_to_nchw_bf16(const void* x, float* y, int B, int C_src, int H, int W, int C_dst,
+                           wsmg_stream_t stream);
+/* attention with bf16 keys / values (q, out, attn, dq float32; dk, dv bf16) */
+int wsmg_attn_fwd_bf16(const float* q, const void* k, const void* v, const uint8_t* mask, float scale, int B,
+                       int I, int C, float* out, float* attn, wsmg_stream_t stream);
+int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, const float* attn, const float* dout,
+                       const float* dattn, float scale, int B, int I, int C, float* dq, void* dk, void* dv,
+                       wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -283,3 +283,135 @@ def test_map_sequence_vs_oracle(ops):
         close(f"s{s}.global", gm, ref.full_global_map, 0, 2e-4)
         close(f"s{s}.ego", ego, ego_ref, 0, 2e-4)
         np.testing.assert_allclose(ego[:, ::16, 40:56, 44:60].cpu().numpy(), g[f"s{s}.ego_patch"], atol=2e-4, rtol=0)
+
+
+# ----------------------------------------------------------------------------- bf16 storage mode
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+BF16_EPS = 2.0 ** -8  # one bf16 ulp at 1.0 is 2^-7; round-to-nearest error <= 2^-8 relative
+
+
+@pytest.mark.parametrize("cfg", CONVS, ids=[c[0] for c in CONVS])
+def test_conv2d_bf16_fwd_bwd(ops, cfg):
+    """bf16 engine against a float64 convolution of the SAME bf16-rounded operands: what is left
+    is float32 accumulation order plus one bf16 rounding of each output (<= 2^-8 relative)."""
+    name, B, Cin, Cout, k, s, p, H = cfg
+    x = bf(T(df.uniform(f"conv.{name}.x", (B, Cin, H, H), 2.0)))
+    w = T(df.uniform(f"conv.{name}.w", (Cout, Cin, k, k), float(np.sqrt(12.0 / (Cin * k * k)))))
+    b = T(df.uniform(f"conv.{name}.b", (Cout,), 0.5))
+    xr = x.double().requires_grad_(True)
+    wr = bf(w).double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    gy = bf(T(df.uniform(f"conv.{name}.gy", tuple(yr.shape), 2.0)))
+    yr.backward(gy.double())
+
+    xg = nhwc(x).cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    bg = b.cuda().requires_grad_(True)
+    y = ops.conv2d(xg, wg, bg, s, p)
+    assert y.dtype == torch.bfloat16
+    y.backward(nhwc(gy).cuda())
+    assert wg.grad.dtype == torch.float32 and xg.grad.dtype == torch.bfloat16
+    close(name + ".y", nchw(y.float()), yr, BF16_EPS, 1e-3)
+    close(name + ".dx", nchw(xg.grad.float()), xr.grad, BF16_EPS, 1e-3)
+    close(name + ".dw", wg.grad, wr.grad, 1e-4, 3e-4 * float(wr.grad.abs().max()) + 1e-6)
+    close(name + ".db", bg.grad, br.grad, 1e-4, 3e-4 * float(br.grad.abs().max()) + 1e-6)
+
+
+def test_conv_transpose2d_bf16(ops):
+    B, Ci, Co, H = 2, 64, 32, 24
+    x = bf(T(df.uniform("convt.x", (B, Ci, H, H), 2.0)))
+    w = T(df.uniform("convt.w", (Ci, Co, 4, 4), 0.2))
+    xr, wr = x.double().requires_grad_(True), bf(w).double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, stride=2, padding=1)
+    gy = bf(T(df.uniform("convt.gy", tuple(yr.shape), 2.0)))
+    yr.backward(gy.double())
+    xg = nhwc(x).cuda().requires_grad_(True)
+    wg = w.cuda().requires_grad_(True)
+    y = ops.conv_transpose2d(xg, wg, 2, 1)
+    y.backward(nhwc(gy).cuda())
+    close("convt16.y", nchw(y.float()), yr, BF16_EPS, 1e-3)
+    close("convt16.dx", nchw(xg.grad.float()), xr.grad, BF16_EPS, 1e-3)
+    close("convt16.dw", wg.grad, wr.grad, 1e-4, 3e-4 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("C,H,B,res", [(64, 50, 3, False), (256, 24, 2, False), (64, 6, 5, True)])
+def test_bn_act_bf16(ops, C, H, B, res):
+    x = bf(T(df.uniform(f"bn.x.{C}.{H}", (B, C, H, H), 3.0)) + T(df.uniform(f"bn.off.{C}", (1, C, 1, 1), 2.0)))
+    r = bf(T(df.uniform(f"bn.r.{C}.{H}", (B, C, H, H), 2.0))) if res else None
+    g, bt = T(df.positive(f"bn.g.{C}", (C,))), T(df.uniform(f"bn.b.{C}", (C,), 0.5))
+    rm, rv = T(df.uniform(f"bn.rm.{C}", (C,), 0.2)), T(df.positive(f"bn.rv.{C}", (C,)))
+    xr, gr, br = x.double().requires_grad_(True), g.double().requires_grad_(True), bt.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True) if res else None
+    rmr, rvr = rm.double().clone(), rv.double().clone()
+    yr = F.batch_norm(xr, rmr, rvr, gr, br, training=True, momentum=0.1, eps=1e-5)
+    yr = F.relu(yr + rr if res else yr)
+    # the kernel masks the gradient with the bf16-ROUNDED output: feed the reference the same mask
+    gy = bf(T(df.uniform(f"bn.gy.{C}.{H}", tuple(yr.shape), 2.0)))
+    xg = nhwc(x).cuda().requires_grad_(True)
+    gg, bg = g.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
+    rg = nhwc(r).cuda().requires_grad_(True) if res else None
+    rmg, rvg = rm.cuda(), rv.cuda()
+    y = ops.bn_act(xg, gg, bg, rmg, rvg, True, True, rg, 0.1, 1e-5)
+    assert y.dtype == torch.bfloat16
+    close("bn16.y", nchw(y.float()), yr, BF16_EPS, 1e-6)
+    close("bn16.running_mean", rmg, rmr, 1e-6, 1e-6)
+    close("bn16.running_var", rvg, rvr, 1e-5, 1e-6)
+    mask = (nchw(y.float()).cpu() > 0).double()
+    # reference backward with the kernel's own mask (elements that rounded to 0 carry no gradient)
+    pre = F.batch_norm(xr, rm.double().clone(), rv.double().clone(), gr, br, training=True, momentum=0.1, eps=1e-5)
+    pre = pre + rr if res else pre
+    (pre * mask * gy.double()).sum().backward()
+    y.backward(nhwc(gy).cuda())
+    scale = float(xr.grad.abs().max())
+    close("bn16.dx", nchw(xg.grad.float()), xr.grad, BF16_EPS, 2e-3 * scale)
+    close("bn16.dgamma", gg.grad, gr.grad, 1e-4, 1e-4 * float(gr.grad.abs().max()))
+    close("bn16.dbeta", bg.grad, br.grad, 1e-4, 1e-4 * float(br.grad.abs().max()))
+
+
+def test_small_ops_and_layout_bf16(ops):
+    B, C, H = 3, 64, 12
+    x = bf(torch.relu(T(df.uniform("pool.x", (B, C, H, H), 2.0))))
+    for nm, fn_ref, fn in [
+        ("maxpool", lambda t: F.max_pool2d(t, 3, 2, 1), ops.maxpool3x3s2),
+        ("upsample", lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x),
+        ("avgpool", lambda t: F.avg_pool2d(t, 2, 2), ops.avgpool2),
+        ("relu", lambda t: F.relu(t), ops.relu),
+    ]:
+        xr = x.double().requires_grad_(True)
+        yr = fn_ref(xr)
+        gy = bf(T(df.uniform(f"pool.gy.{nm}", tuple(yr.shape), 2.0)))
+        yr.backward(gy.double())
+        xg = nhwc(x).cuda().requires_grad_(True)
+        y = fn(xg)
+        assert y.dtype == torch.bfloat16
+        y.backward(nhwc(gy).cuda())
+        close(nm + "16.y", nchw(y.float()), yr, BF16_EPS, 1e-6)
+        close(nm + "16.dx", nchw(xg.grad.float()), xr.grad, BF16_EPS, 1e-6)
+    e = T(df.uniform("lay.e", (2, 64, 100, 100), 2.0)).cuda()
+    assert torch.equal(ops.to_nhwc(e, dtype=torch.bfloat16), bf(e.permute(0, 2, 3, 1)))
+    s27 = bf(T(df.uniform("lay.s", (2, 48, 48, 32), 2.0))).cuda().requires_grad_(True)
+    z = ops.to_nchw(s27, 27)
+    assert z.dtype == torch.float32 and torch.equal(z, s27.detach().float().permute(0, 3, 1, 2)[:, :27])
+    z.backward(torch.ones_like(z))
+    assert float(s27.grad[..., :27].float().min()) == 1.0 and float(s27.grad[..., 27:].float().abs().max()) == 0.0
+
+
+def test_attention_bf16(ops):
+    q = T(df.uniform("attn2.q", (9, 256), 6.0))
+    kv = bf(T(df.uniform("attn2.kv", (9, 576, 256), 3.0)))
+    qr, kr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    o_ref, a_ref = policy_ref.attn(qr, kr.permute(0, 2, 1), kr.permute(0, 2, 1))
+    go, ga = T(df.uniform("attn.go16", (9, 256), 2.0)), T(df.uniform("attn.ga16", (9, 576), 2.0))
+    ((o_ref * go.double()).sum() + (a_ref * ga.double()).sum()).backward()
+    qg = q.cuda().requires_grad_(True)
+    kg = kv.cuda().requires_grad_(True)
+    o, a = ops.attention(qg, kg, kg, None, 1.0 / 16)
+    ((o * go.cuda()).sum() + (a * ga.cuda()).sum()).backward()
+    close("attn16.out", o, o_ref, 1e-5, 1e-6)
+    close("attn16.attn", a, a_ref, 1e-5, 1e-8)
+    close("attn16.dq", qg.grad, qr.grad, 1e-4, 1e-6)
+    close("attn16.dkv", kg.grad.float(), kr.grad, 2 * BF16_EPS, 1e-7)

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default=None)
     ap.add_argument("--B", type=int, default=512)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
     B = a.B
     st = ops._stream
@@ -50,19 +51,25 @@ def main():
     for name, Cin, Cout, k, s, p, H, need_dx in LAYERS:
         if a.only and a.only not in name: continue
         OH = (H + 2 * p - k) // s + 1
-        x = torch.randn(B, H, H, Cin, device="cuda")
-        w = torch.randn(Cout, k, k, Cin, device="cuda") * 0.05
+        dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+        x = torch.randn(B, H, H, Cin, device="cuda").to(dt)
+        w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).to(dt)
         wi = w.permute(3, 1, 2, 0).contiguous()
-        y = torch.empty(B, OH, OH, Cout, device="cuda")
-        dy = torch.randn(B, OH, OH, Cout, device="cuda")
+        y = torch.empty(B, OH, OH, Cout, device="cuda", dtype=dt)
+        dy = torch.randn(B, OH, OH, Cout, device="cuda").to(dt)
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
+        dw = torch.zeros(Cout, k, k, Cin, device="cuda")
         P = ops._p
         gf = 2.0 * B * OH * OH * Cout * Cin * k * k / 1e9
         args = (B, H, H, Cin, Cout, k, k, s, p, OH, OH)
-        t_f = timeit(lambda: _abi.call("wsmg_conv2d_fwd", P(x), P(w), None, P(y), *args, st()), a.reps)
-        t_d = timeit(lambda: _abi.call("wsmg_conv2d_bwd_data", P(dy), P(wi), P(dx), *args, st()), a.reps) if need_dx else 0.0
-        t_w = timeit(lambda: _abi.call("wsmg_conv2d_bwd_weight", P(x), P(dy), P(dw), *args, st()), a.reps)
+        if a.dtype == "bf16":
+            t_f = timeit(lambda: _abi.call("wsmg_conv2d_fwd_bf16", P(x), P(w), None, P(y), 0, *args, st()), a.reps)
+            t_d = timeit(lambda: _abi.call("wsmg_conv2d_bwd_data_bf16", P(dy), P(wi), P(dx), 0, *args, st()), a.reps) if need_dx else 0.0
+            t_w = timeit(lambda: _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(dy), P(dw), *args, st()), a.reps)
+        else:
+            t_f = timeit(lambda: _abi.call("wsmg_conv2d_fwd", P(x), P(w), None, P(y), *args, st()), a.reps)
+            t_d = timeit(lambda: _abi.call("wsmg_conv2d_bwd_data", P(dy), P(wi), P(dx), *args, st()), a.reps) if need_dx else 0.0
+            t_w = timeit(lambda: _abi.call("wsmg_conv2d_bwd_weight", P(x), P(dy), P(dw), *args, st()), a.reps)
         tot["fwd"] += t_f; tot["bwdD"] += t_d; tot["wgrad"] += t_w
         tf = lambda t: gf / t if t > 0 else 0.0
         print(f"{name:18s} {gf:8.1f} | {t_f:8.3f} {tf(t_f):6.1f} | {t_d:8.3f} {tf(t_d):6.1f} | {t_w:8.3f} {tf(t_w):6.1f}")

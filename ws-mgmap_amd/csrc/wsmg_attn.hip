@@ -35,8 +35,9 @@ __device__ inline float block_reduce_sum(float v, float* sh, int wave, int lane)
   return r;
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v,
+template <class T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ v,
                                                        const uint8_t* __restrict__ mask, float scale, int I,
                                                        float* __restrict__ out, float* __restrict__ attn) {
   __shared__ float lg[AMAX_I];
@@ -45,12 +46,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
-  const f32x4* kb = reinterpret_cast<const f32x4*>(k + (size_t)b * I * AC);
-  const f32x4* vb = reinterpret_cast<const f32x4*>(v + (size_t)b * I * AC);
+  const T* kb = k + (size_t)b * I * AC + lane * 4;
+  const T* vb = v + (size_t)b * I * AC + lane * 4;
 
   // phase 1: logits (one wave per token; 64 lanes x float4 = the 256 channels)
   for (int i = wave; i < I; i += AWAVES) {
-    f32x4 kv = kb[(size_t)i * (AC / 4) + lane];
+    f32x4 kv = ld4(kb + (size_t)i * AC);
     float d = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
     d = wave_sum(d);
     if (lane == 0) {
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int i = wave; i < I; i += AWAVES) {
     float a = lg[i];
-    f32x4 vv = vb[(size_t)i * (AC / 4) + lane];
+    f32x4 vv = ld4(vb + (size_t)i * AC);
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] += a * vv[j];
   }
@@ -93,13 +94,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
 // backward: da = dout.v + dattn; s = sum attn*da; dl = attn*(da-s)*scale;
 //           dq = sum_i dl[i] k[i]; dk[i] = dl[i] q; dv[i] = attn[i] dout
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                       const float* __restrict__ v,
+template <class T>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
+                                                       const T* __restrict__ v,
                                                        const float* __restrict__ attn,
                                                        const float* __restrict__ dout,
                                                        const float* __restrict__ dattn, float scale, int I,
-                                                       float* __restrict__ dq, float* __restrict__ dk,
-                                                       float* __restrict__ dv) {
+                                                       float* __restrict__ dq, T* __restrict__ dk,
+                                                       T* __restrict__ dv) {
   __shared__ float da[AMAX_I];
   __shared__ float red[AWAVES];
   __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
@@ -107,21 +109,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
   const f32x4 gv = reinterpret_cast<const f32x4*>(dout + (size_t)b * AC)[lane];
-  const f32x4* kb = reinterpret_cast<const f32x4*>(k + (size_t)b * I * AC);
-  const f32x4* vb = reinterpret_cast<const f32x4*>(v + (size_t)b * I * AC);
-  f32x4* dkb = reinterpret_cast<f32x4*>(dk + (size_t)b * I * AC);
-  f32x4* dvb = reinterpret_cast<f32x4*>(dv + (size_t)b * I * AC);
+  const T* kb = k + (size_t)b * I * AC + lane * 4;
+  const T* vb = v + (size_t)b * I * AC + lane * 4;
+  T* dkb = dk + (size_t)b * I * AC + lane * 4;
+  T* dvb = dv + (size_t)b * I * AC + lane * 4;
   const float* ab = attn + (size_t)b * I;
 
   for (int i = wave; i < I; i += AWAVES) {
-    f32x4 vv = vb[(size_t)i * (AC / 4) + lane];
+    f32x4 vv = ld4(vb + (size_t)i * AC);
     float d = gv[0] * vv[0] + gv[1] * vv[1] + gv[2] * vv[2] + gv[3] * vv[3];
     d = wave_sum(d);
     float a = ab[i];
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
-    dvb[(size_t)i * (AC / 4) + lane] = o;
+    st4(dvb + (size_t)i * AC, o);
     if (lane == 0) da[i] = d + (dattn ? dattn[(size_t)b * I + i] : 0.f);
   }
   __syncthreads();
@@ -133,14 +135,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int i = wave; i < I; i += AWAVES) {
     float dl = da[i];
-    f32x4 kv = kb[(size_t)i * (AC / 4) + lane];
+    f32x4 kv = ld4(kb + (size_t)i * AC);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       acc[j] += dl * kv[j];
       o[j] = dl * qv[j];
     }
-    dkb[(size_t)i * (AC / 4) + lane] = o;
+    st4(dkb + (size_t)i * AC, o);
   }
   reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
   __syncthreads();
@@ -152,7 +154,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 extern "C" int wsmg_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float scale, int B,
                              int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn);
+  hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_attn_fwd_bf16(const float* q, const void* k, const void* v, const uint8_t* mask, float scale, int B,
+                                  int I, int C, float* out, float* attn, wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
+                     (const bf16_t*)v, mask, scale, I, out, attn);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -160,7 +170,16 @@ extern "C" int wsmg_attn_bwd(const float* q, const float* k, const float* v, con
                              const float* dattn, float scale, int B, int I, int C, float* dq, float* dk, float* dv,
                              wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, attn, dout, dattn, scale, I, dq,
-                     dk, dv);
+  hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, attn, dout, dattn, scale,
+                     I, dq, dk, dv);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, const float* attn, const float* dout,
+                                  const float* dattn, float scale, int B, int I, int C, float* dq, void* dk, void* dv,
+                                  wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
+                     (const bf16_t*)v, attn, dout, dattn, scale, I, dq, (bf16_t*)dk, (bf16_t*)dv);
   WSMG_RETURN_LAUNCH();
 }

@@ -8,7 +8,34 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16_t;
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
 #define WSMG_WAVE 64
+
+// storage-type helpers: activations are float32 or bf16 in HBM, arithmetic is float32
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+  u16x4 u = *reinterpret_cast<const u16x4*>(p);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(((unsigned)u[j]) << 16);
+  return o;
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+  u16x4 u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bf16_t b = (bf16_t)v[j];
+    u[j] = __builtin_bit_cast(unsigned short, b);
+  }
+  *reinterpret_cast<u16x4*>(p) = u;
+}
 
 // after a kernel launch: report launch-time errors through the C ABI's int return
 #define WSMG_RETURN_LAUNCH()                      \

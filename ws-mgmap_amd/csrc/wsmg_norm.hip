@@ -24,10 +24,10 @@ __host__ __device__ inline int red_blocks(int64_t rows, int C) {
 // MODE 0: sum(x)                      -> part[blk][0][c]
 // MODE 1: sum(x), sum(x*x)            -> part[blk][0..1][c]
 // MODE 2: sum(g), sum(g*xhat)  with g = dy * (relu ? y > 0 : 1), xhat = (x-mean)*invstd
-template <int MODE>
-__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float* __restrict__ x,
-                                                                 const float* __restrict__ dy,
-                                                                 const float* __restrict__ y,
+template <int MODE, class T>
+__global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __restrict__ x,
+                                                                 const T* __restrict__ dy,
+                                                                 const T* __restrict__ y,
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, int relu,
                                                                  int64_t rows, int C, double* __restrict__ part) {
@@ -42,15 +42,15 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const float* __
   for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
     size_t o = (size_t)r * C + c;
     if (MODE == 0) {
-      s0 += (double)x[o];
+      s0 += (double)ldf(x + o);
     } else if (MODE == 1) {
-      float v = x[o];
+      float v = ldf(x + o);
       s0 += (double)v;
       s1 += (double)v * (double)v;
     } else {
-      float g = dy[o];
-      if (relu && !(y[o] > 0.f)) g = 0.f;
-      float xh = (x[o] - mu) * is;
+      float g = ldf(dy + o);
+      if (relu && !(ldf(y + o) > 0.f)) g = 0.f;
+      float xh = (ldf(x + o) - mu) * is;
       s0 += (double)g;
       s1 += (double)g * (double)xh;
     }
@@ -115,15 +115,16 @@ __global__ void bn_eval_prepare_kernel(const float* running_mean, const float* r
 }
 
 // y = act((x - mean) * invstd * gamma + beta (+ res)); 4 channels per thread
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, int relu, int64_t n4,
-                                                       int C, float* __restrict__ y) {
+                                                       int C, T* __restrict__ y) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)((i * 4) % C);
-    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 v = ld4(x + i * 4);
     f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
     f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
     f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (v[j] - m[j]) * s[j] * g[j] + b[j];
     if (res) {
-      f32x4 rr = reinterpret_cast<const f32x4*>(res)[i];
+      f32x4 rr = ld4(res + i * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] += rr[j];
     }
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
     }
-    reinterpret_cast<f32x4*>(y)[i] = o;
+    st4(y + i * 4, o);
   }
 }
 
@@ -156,25 +157,26 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* part,
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ y,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, int relu, float inv_n,
-                                                           int64_t n4, int C, float* __restrict__ dx,
-                                                           float* __restrict__ dres) {
+                                                           int64_t n4, int C, T* __restrict__ dx,
+                                                           T* __restrict__ dres) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)((i * 4) % C);
-    f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
-    f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 g = ld4(dy + i * 4);
+    f32x4 xv = ld4(x + i * 4);
     if (relu) {
-      f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+      f32x4 yv = ld4(y + i * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
     }
-    if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+    if (dres) st4(dres + i * 4, g);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       float xh = (xv[j] - mean[c + j]) * is;
       o[j] = gamma[c + j] * is * (g[j] - dbeta[c + j] * inv_n - xh * dgamma[c + j] * inv_n);
     }
-    reinterpret_cast<f32x4*>(dx)[i] = o;
+    st4(dx + i * 4, o);
   }
 }
 
@@ -195,6 +197,59 @@ int stream_grid(int64_t n4) {
   return (int)g;
 }
 
+template <class T>
+int channel_sum_t(const T* x, int64_t rows, int C, float* out, double* workspace, int64_t workspace_bytes,
+                  wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
+  int nb = red_blocks(rows, C);
+  hipLaunchKernelGGL((col_reduce_kernel<0, T>), dim3(nb), dim3(RED_THREADS), 0, wsmg_s(stream), x, (const T*)nullptr,
+                     (const T*)nullptr, nullptr, nullptr, 0, rows, C, workspace);
+  hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(64), 0, wsmg_s(stream), workspace, nb, C, out);
+  WSMG_RETURN_LAUNCH();
+}
+
+template <class T>
+int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float* beta, float* running_mean,
+                 float* running_var, float momentum, float eps, int train, int relu, int64_t rows, int C, T* y,
+                 float* save_mean, float* save_invstd, double* workspace, int64_t workspace_bytes,
+                 wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  if (train) {
+    if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
+    int nb = red_blocks(rows, C);
+    hipLaunchKernelGGL((col_reduce_kernel<1, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, 0, rows, C, workspace);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, rows, momentum, eps,
+                       running_mean, running_var, save_mean, save_invstd);
+  } else {
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, running_mean, running_var, eps, C,
+                       save_mean, save_invstd);
+  }
+  int64_t n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(n4)), dim3(256), 0, s, x, residual, gamma, beta, save_mean,
+                     save_invstd, relu, n4, C, y);
+  WSMG_RETURN_LAUNCH();
+}
+
+template <class T>
+int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const float* save_mean,
+                 const float* save_invstd, int relu, int64_t rows, int C, T* dx, T* dresidual, float* dgamma,
+                 float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
+  hipStream_t s = wsmg_s(stream);
+  int nb = red_blocks(rows, C);
+  hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
+                     relu, rows, C, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
+  int64_t n4 = rows * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(n4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, n4, C, dx, dresidual);
+  WSMG_RETURN_LAUNCH();
+}
+
 }  // namespace
 
 extern "C" int64_t wsmg_channel_reduce_workspace_bytes(int64_t rows, int C) {
@@ -204,51 +259,40 @@ extern "C" int64_t wsmg_channel_reduce_workspace_bytes(int64_t rows, int C) {
 
 extern "C" int wsmg_channel_sum(const float* x, int64_t rows, int C, float* out, double* workspace,
                                 int64_t workspace_bytes, wsmg_stream_t stream) {
-  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
-  if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
-  int nb = red_blocks(rows, C);
-  hipLaunchKernelGGL(col_reduce_kernel<0>, dim3(nb), dim3(RED_THREADS), 0, wsmg_s(stream), x, nullptr, nullptr,
-                     nullptr, nullptr, 0, rows, C, workspace);
-  hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(64), 0, wsmg_s(stream), workspace, nb, C, out);
-  WSMG_RETURN_LAUNCH();
+  return channel_sum_t<float>(x, rows, C, out, workspace, workspace_bytes, stream);
+}
+extern "C" int wsmg_channel_sum_bf16(const void* x, int64_t rows, int C, float* out, double* workspace,
+                                     int64_t workspace_bytes, wsmg_stream_t stream) {
+  return channel_sum_t<bf16_t>((const bf16_t*)x, rows, C, out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int wsmg_bn_act_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, int train,
                                int relu, int64_t rows, int C, float* y, float* save_mean, float* save_invstd,
                                double* workspace, int64_t workspace_bytes, wsmg_stream_t stream) {
-  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
-  hipStream_t s = wsmg_s(stream);
-  if (train) {
-    if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
-    int nb = red_blocks(rows, C);
-    hipLaunchKernelGGL(col_reduce_kernel<1>, dim3(nb), dim3(RED_THREADS), 0, s, x, nullptr, nullptr, nullptr,
-                       nullptr, 0, rows, C, workspace);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, rows, momentum, eps,
-                       running_mean, running_var, save_mean, save_invstd);
-  } else {
-    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, running_mean, running_var, eps, C,
-                       save_mean, save_invstd);
-  }
-  int64_t n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, x, residual, gamma, beta, save_mean,
-                     save_invstd, relu, n4, C, y);
-  WSMG_RETURN_LAUNCH();
+  return bn_act_fwd_t<float>(x, residual, gamma, beta, running_mean, running_var, momentum, eps, train, relu, rows, C, y,
+                             save_mean, save_invstd, workspace, workspace_bytes, stream);
+}
+extern "C" int wsmg_bn_act_fwd_bf16(const void* x, const void* residual, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, int train,
+                                    int relu, int64_t rows, int C, void* y, float* save_mean, float* save_invstd,
+                                    double* workspace, int64_t workspace_bytes, wsmg_stream_t stream) {
+  return bn_act_fwd_t<bf16_t>((const bf16_t*)x, (const bf16_t*)residual, gamma, beta, running_mean, running_var, momentum,
+                              eps, train, relu, rows, C, (bf16_t*)y, save_mean, save_invstd, workspace, workspace_bytes,
+                              stream);
 }
 
 extern "C" int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma,
                                const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
                                float* dx, float* dresidual, float* dgamma, float* dbeta, double* workspace,
                                int64_t workspace_bytes, wsmg_stream_t stream) {
-  if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
-  if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
-  hipStream_t s = wsmg_s(stream);
-  int nb = red_blocks(rows, C);
-  hipLaunchKernelGGL(col_reduce_kernel<2>, dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd, relu,
-                     rows, C, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
-  int64_t n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
-                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, n4, C, dx, dresidual);
-  WSMG_RETURN_LAUNCH();
+  return bn_act_bwd_t<float>(dy, x, y, gamma, save_mean, save_invstd, relu, rows, C, dx, dresidual, dgamma, dbeta,
+                             workspace, workspace_bytes, stream);
+}
+extern "C" int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const float* gamma,
+                                    const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
+                                    void* dx, void* dresidual, float* dgamma, float* dbeta, double* workspace,
+                                    int64_t workspace_bytes, wsmg_stream_t stream) {
+  return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, save_mean, save_invstd, relu,
+                              rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream);
 }

@@ -17,25 +17,28 @@ int sgrid(int64_t n) {
 #define GRID_STRIDE(i, n) \
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
-__global__ void relu_fwd_kernel(const f32x4* x, f32x4* y, int64_t n4) {
+template <class T>
+__global__ void relu_fwd_kernel(const T* x, T* y, int64_t n4) {
   GRID_STRIDE(i, n4) {
-    f32x4 v = x[i];
+    f32x4 v = ld4(x + i * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-    y[i] = v;
+    st4(y + i * 4, v);
   }
 }
-__global__ void relu_bwd_kernel(const f32x4* dy, const f32x4* y, f32x4* dx, int64_t n4) {
+template <class T>
+__global__ void relu_bwd_kernel(const T* dy, const T* y, T* dx, int64_t n4) {
   GRID_STRIDE(i, n4) {
-    f32x4 g = dy[i], v = y[i];
+    f32x4 g = ld4(dy + i * 4), v = ld4(y + i * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? g[j] : 0.f;
-    dx[i] = g;
+    st4(dx + i * 4, g);
   }
 }
 
 // ---- MaxPool2d(kernel 3, stride 2, pad 1): first maximum in (ky,kx) scan order wins ties (ATen)
-__global__ void maxpool_fwd_kernel(const float* x, float* y, int B, int H, int W, int C, int OH, int OW) {
+template <class T>
+__global__ void maxpool_fwd_kernel(const T* x, T* y, int B, int H, int W, int C, int OH, int OW) {
   int64_t n = (int64_t)B * OH * OW * C;
   GRID_STRIDE(i, n) {
     int c = (int)(i % C);
@@ -50,15 +53,16 @@ __global__ void maxpool_fwd_kernel(const float* x, float* y, int B, int H, int W
       for (int kx = 0; kx < 3; ++kx) {
         int ix = ox * 2 - 1 + kx;
         if (ix < 0 || ix >= W) continue;
-        float v = x[(((size_t)b * H + iy) * W + ix) * C + c];
+        float v = ldf(x + (((size_t)b * H + iy) * W + ix) * C + c);
         if (v > best || v != v) best = v;
       }
     }
-    y[i] = best;
+    stf(y + i, best);
   }
 }
 
-__device__ inline int maxpool_argmax(const float* x, int b, int oy, int ox, int c, int H, int W, int C) {
+template <class T>
+__device__ inline int maxpool_argmax(const T* x, int b, int oy, int ox, int c, int H, int W, int C) {
   float best = -INFINITY;
   int arg = -1;
   for (int ky = 0; ky < 3; ++ky) {
@@ -67,14 +71,15 @@ __device__ inline int maxpool_argmax(const float* x, int b, int oy, int ox, int 
     for (int kx = 0; kx < 3; ++kx) {
       int ix = ox * 2 - 1 + kx;
       if (ix < 0 || ix >= W) continue;
-      float v = x[(((size_t)b * H + iy) * W + ix) * C + c];
+      float v = ldf(x + (((size_t)b * H + iy) * W + ix) * C + c);
       if (v > best || v != v || arg < 0) { best = v; arg = iy * W + ix; }
     }
   }
   return arg;
 }
 
-__global__ void maxpool_bwd_kernel(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH,
+template <class T>
+__global__ void maxpool_bwd_kernel(const T* dy, const T* x, T* dx, int B, int H, int W, int C, int OH,
                                    int OW) {
   int64_t n = (int64_t)B * H * W * C;
   GRID_STRIDE(i, n) {
@@ -91,10 +96,10 @@ __global__ void maxpool_bwd_kernel(const float* dy, const float* x, float* dx, i
       for (int ox = ox0; ox <= ox1; ++ox) {
         if (ox >= OW) continue;
         if (maxpool_argmax(x, b, oy, ox, c, H, W, C) == iy * W + ix)
-          g += dy[(((size_t)b * OH + oy) * OW + ox) * C + c];
+          g += ldf(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
       }
     }
-    dx[i] = g;
+    stf(dx + i, g);
   }
 }
 
@@ -107,7 +112,8 @@ __device__ inline void up_src(int o, int in, float scale, int& i0, int& i1, floa
   l0 = 1.f - l1;
 }
 
-__global__ void upsample_fwd_kernel(const float* x, float* y, int B, int H, int W, int C) {
+template <class T>
+__global__ void upsample_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
   const int OH = 2 * H, OW = 2 * W;
   const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
@@ -122,14 +128,15 @@ __global__ void upsample_fwd_kernel(const float* x, float* y, int B, int H, int 
     float hy0, hy1, wx0, wx1;
     up_src(oy, H, sh, y0, y1, hy0, hy1);
     up_src(ox, W, sw, x0, x1, wx0, wx1);
-    const float* xb = x + (size_t)b * H * W * C + c;
-    float v00 = xb[((size_t)y0 * W + x0) * C], v01 = xb[((size_t)y0 * W + x1) * C];
-    float v10 = xb[((size_t)y1 * W + x0) * C], v11 = xb[((size_t)y1 * W + x1) * C];
-    y[i] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    const T* xb = x + (size_t)b * H * W * C + c;
+    float v00 = ldf(xb + ((size_t)y0 * W + x0) * C), v01 = ldf(xb + ((size_t)y0 * W + x1) * C);
+    float v10 = ldf(xb + ((size_t)y1 * W + x0) * C), v11 = ldf(xb + ((size_t)y1 * W + x1) * C);
+    stf(y + i, hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11));
   }
 }
 
-__global__ void upsample_bwd_kernel(const float* dy, float* dx, int B, int H, int W, int C) {
+template <class T>
+__global__ void upsample_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int C) {
   const int OH = 2 * H, OW = 2 * W;
   const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
@@ -155,15 +162,16 @@ __global__ void upsample_bwd_kernel(const float* dy, float* dx, int B, int H, in
         up_src(ox, W, sw, x0, x1, wx0, wx1);
         float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
         if (wx == 0.f) continue;
-        g += wy * wx * dy[(((size_t)b * OH + oy) * OW + ox) * C + c];
+        g += wy * wx * ldf(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
       }
     }
-    dx[i] = g;
+    stf(dx + i, g);
   }
 }
 
 // ---- avg_pool2d(2,2), H and W even
-__global__ void avgpool_fwd_kernel(const float* x, float* y, int B, int H, int W, int C) {
+template <class T>
+__global__ void avgpool_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
   const int OH = H / 2, OW = W / 2;
   int64_t n = (int64_t)B * OH * OW * C;
   GRID_STRIDE(i, n) {
@@ -172,11 +180,12 @@ __global__ void avgpool_fwd_kernel(const float* x, float* y, int B, int H, int W
     int ox = (int)(p % OW);
     int oy = (int)((p / OW) % OH);
     int b = (int)(p / ((int64_t)OW * OH));
-    const float* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
-    y[i] = (xb[0] + xb[C] + xb[(size_t)W * C] + xb[(size_t)W * C + C]) * 0.25f;
+    const T* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    stf(y + i, (ldf(xb) + ldf(xb + C) + ldf(xb + (size_t)W * C) + ldf(xb + (size_t)W * C + C)) * 0.25f);
   }
 }
-__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int B, int H, int W, int C) {
+template <class T>
+__global__ void avgpool_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int C) {
   const int OH = H / 2, OW = W / 2;
   int64_t n = (int64_t)B * H * W * C;
   GRID_STRIDE(i, n) {
@@ -185,14 +194,14 @@ __global__ void avgpool_bwd_kernel(const float* dy, float* dx, int B, int H, int
     int ix = (int)(p % W);
     int iy = (int)((p / W) % H);
     int b = (int)(p / ((int64_t)W * H));
-    dx[i] = dy[(((size_t)b * OH + iy / 2) * OW + ix / 2) * C + c] * 0.25f;
+    stf(dx + i, ldf(dy + (((size_t)b * OH + iy / 2) * OW + ix / 2) * C + c) * 0.25f);
   }
 }
 
 // ---- [B][R][S] -> [B][S][R'] transposes through a 32x33 LDS tile (coalesced both sides)
 // TO_NHWC: src rows = channels (R = C_src), cols = pixels;  dst [pixel][C_dst], zero-filled past C_src.
-template <bool TO_NHWC>
-__global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y, int C_src, int HW, int C_dst) {
+template <bool TO_NHWC, class TI, class TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* x, TO* y, int C_src, int HW, int C_dst) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -201,95 +210,114 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* x, float* y
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int c = c0 + ty + 8 * j, p = p0 + tx;
-      tile[ty + 8 * j][tx] = (c < C_src && p < HW) ? x[((size_t)b * C_src + c) * HW + p] : 0.f;
+      tile[ty + 8 * j][tx] = (c < C_src && p < HW) ? ldf(x + ((size_t)b * C_src + c) * HW + p) : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int p = p0 + ty + 8 * j, c = c0 + tx;
-      if (p < HW && c < C_dst) y[((size_t)b * HW + p) * C_dst + c] = tile[tx][ty + 8 * j];
+      if (p < HW && c < C_dst) stf(y + ((size_t)b * HW + p) * C_dst + c, tile[tx][ty + 8 * j]);
     }
   } else {
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int p = p0 + ty + 8 * j, c = c0 + tx;
-      tile[ty + 8 * j][tx] = (p < HW && c < C_src) ? x[((size_t)b * HW + p) * C_src + c] : 0.f;
+      tile[ty + 8 * j][tx] = (p < HW && c < C_src) ? ldf(x + ((size_t)b * HW + p) * C_src + c) : 0.f;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int c = c0 + ty + 8 * j, p = p0 + tx;
-      if (c < C_dst && p < HW) y[((size_t)b * C_dst + c) * HW + p] = tile[tx][ty + 8 * j];
+      if (c < C_dst && p < HW) stf(y + ((size_t)b * C_dst + c) * HW + p, tile[tx][ty + 8 * j]);
     }
   }
 }
 
-}  // namespace
-
-extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t stream) {
+template <class T>
+int relu_fwd_t(const T* x, T* y, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
-  hipLaunchKernelGGL(relu_fwd_kernel, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), (const f32x4*)x, (f32x4*)y,
-                     n / 4);
+  hipLaunchKernelGGL(relu_fwd_kernel<T>, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), x, y, n / 4);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t stream) {
+template <class T>
+int relu_bwd_t(const T* dy, const T* y, T* dx, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), (const f32x4*)dy,
-                     (const f32x4*)y, (f32x4*)dx, n / 4);
+  hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), dy, y, dx, n / 4);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW,
-                                     wsmg_stream_t stream) {
+template <class T>
+int maxpool_fwd_t(const T* x, T* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t stream) {
   if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(sgrid((int64_t)B * OH * OW * C)), dim3(256), 0, wsmg_s(stream), x, y, B,
+  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(sgrid((int64_t)B * OH * OW * C)), dim3(256), 0, wsmg_s(stream), x, y, B,
                      H, W, C, OH, OW);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_maxpool3x3s2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH,
-                                     int OW, wsmg_stream_t stream) {
+template <class T>
+int maxpool_bwd_t(const T* dy, const T* x, T* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t stream) {
   if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, x, dx,
+  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, x, dx,
                      B, H, W, C, OH, OW);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t stream) {
+template <class T>
+int upsample_fwd_t(const T* x, T* y, int B, int H, int W, int C, wsmg_stream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(sgrid((int64_t)B * 4 * H * W * C)), dim3(256), 0, wsmg_s(stream), x, y,
+  hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(sgrid((int64_t)B * 4 * H * W * C)), dim3(256), 0, wsmg_s(stream), x,
+                     y, B, H, W, C);
+  WSMG_RETURN_LAUNCH();
+}
+template <class T>
+int upsample_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
+  hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx,
                      B, H, W, C);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
-                     H, W, C);
-  WSMG_RETURN_LAUNCH();
-}
-extern "C" int wsmg_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t stream) {
+template <class T>
+int avgpool_fwd_t(const T* x, T* y, int B, int H, int W, int C, wsmg_stream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return WSMG_EINVAL;
-  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), x, y,
+  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), x, y,
                      B, H, W, C);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
+template <class T>
+int avgpool_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return WSMG_EINVAL;
-  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
+  hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
                      H, W, C);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_nchw_to_nhwc(const float* x, float* y, int B, int C_src, int H, int W, int C_dst,
-                                 wsmg_stream_t stream) {
+template <bool TO_NHWC, class TI, class TO>
+int transpose_t(const TI* x, TO* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t stream) {
   if (B <= 0 || C_src <= 0 || C_dst <= 0 || H <= 0 || W <= 0 || B > 65535) return WSMG_EINVAL;
   int HW = H * W;
-  dim3 grid((unsigned)wsmg_cdiv(HW, 32), (unsigned)wsmg_cdiv(C_dst, 32), (unsigned)B);
-  hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), x, y, C_src, HW, C_dst);
+  dim3 grid((unsigned)wsmg_cdiv(HW, 32), (unsigned)wsmg_cdiv(TO_NHWC ? C_dst : (C_dst > C_src ? C_dst : C_src), 32), (unsigned)B);
+  hipLaunchKernelGGL((transpose_kernel<TO_NHWC, TI, TO>), grid, dim3(256), 0, wsmg_s(stream), x, y, C_src, HW, C_dst);
   WSMG_RETURN_LAUNCH();
 }
-extern "C" int wsmg_nhwc_to_nchw(const float* x, float* y, int B, int C_src, int H, int W, int C_dst,
-                                 wsmg_stream_t stream) {
-  if (B <= 0 || C_src <= 0 || C_dst <= 0 || H <= 0 || W <= 0 || B > 65535) return WSMG_EINVAL;
-  int HW = H * W;
-  dim3 grid((unsigned)wsmg_cdiv(HW, 32), (unsigned)wsmg_cdiv(C_dst, 32), (unsigned)B);
-  hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), x, y, C_src, HW, C_dst);
-  WSMG_RETURN_LAUNCH();
-}
+
+}  // namespace
+
+#define B16(p) ((bf16_t*)(p))
+#define CB16(p) ((const bf16_t*)(p))
+extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<float>(x, y, n, s); }
+extern "C" int wsmg_relu_fwd_bf16(const void* x, void* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<bf16_t>(CB16(x), B16(y), n, s); }
+extern "C" int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<float>(dy, y, dx, n, s); }
+extern "C" int wsmg_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<bf16_t>(CB16(dy), CB16(y), B16(dx), n, s); }
+extern "C" int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<float>(x, y, B, H, W, C, OH, OW, s); }
+extern "C" int wsmg_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, OH, OW, s); }
+extern "C" int wsmg_maxpool3x3s2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_bwd_t<float>(dy, x, dx, B, H, W, C, OH, OW, s); }
+extern "C" int wsmg_maxpool3x3s2_bwd_bf16(const void* dy, const void* x, void* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_bwd_t<bf16_t>(CB16(dy), CB16(x), B16(dx), B, H, W, C, OH, OW, s); }
+extern "C" int wsmg_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_fwd_t<float>(x, y, B, H, W, C, s); }
+extern "C" int wsmg_upsample2x_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, s); }
+extern "C" int wsmg_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_bwd_t<float>(dy, dx, B, H, W, C, s); }
+extern "C" int wsmg_upsample2x_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_bwd_t<bf16_t>(CB16(dy), B16(dx), B, H, W, C, s); }
+extern "C" int wsmg_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_fwd_t<float>(x, y, B, H, W, C, s); }
+extern "C" int wsmg_avgpool2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, s); }
+extern "C" int wsmg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_bwd_t<float>(dy, dx, B, H, W, C, s); }
+extern "C" int wsmg_avgpool2_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_bwd_t<bf16_t>(CB16(dy), B16(dx), B, H, W, C, s); }
+extern "C" int wsmg_nchw_to_nhwc(const float* x, float* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<true, float, float>(x, y, B, C_src, H, W, C_dst, s); }
+extern "C" int wsmg_nchw_to_nhwc_bf16(const float* x, void* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<true, float, bf16_t>(x, B16(y), B, C_src, H, W, C_dst, s); }
+extern "C" int wsmg_nhwc_to_nchw(const float* x, float* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<false, float, float>(x, y, B, C_src, H, W, C_dst, s); }
+extern "C" int wsmg_nhwc_to_nchw_bf16(const void* x, float* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<false, bf16_t, float>(CB16(x), y, B, C_src, H, W, C_dst, s); }

@@ -49,6 +49,14 @@ _SIG = {
     "wsmg_attn_fwd": [c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p],
     "wsmg_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
 }
+# bf16 storage variants: identical argument lists except the convs' extra `out_f32` int
+for _n in ["wsmg_channel_sum", "wsmg_bn_act_fwd", "wsmg_bn_act_bwd", "wsmg_relu_fwd", "wsmg_relu_bwd",
+           "wsmg_maxpool3x3s2_fwd", "wsmg_maxpool3x3s2_bwd", "wsmg_upsample2x_fwd", "wsmg_upsample2x_bwd",
+           "wsmg_avgpool2_fwd", "wsmg_avgpool2_bwd", "wsmg_nchw_to_nhwc", "wsmg_nhwc_to_nchw", "wsmg_attn_fwd",
+           "wsmg_attn_bwd", "wsmg_conv2d_bwd_weight"]:
+    _SIG[_n + "_bf16"] = list(_SIG[_n])
+_SIG["wsmg_conv2d_fwd_bf16"] = [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
+_SIG["wsmg_conv2d_bwd_data_bf16"] = [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
 _RESTYPE = {"wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l}
 
 _lib = None

@@ -15,8 +15,10 @@ class Cfg(dict):
         self[k] = v
 
 
-def default_model_config(num_proc=1, gpu_id=0, ego_map_size=100, map_depth=64, global_map_size=240):
+def default_model_config(num_proc=1, gpu_id=0, ego_map_size=100, map_depth=64, global_map_size=240,
+                         compute_dtype="f32"):
     return Cfg(
+        COMPUTE_DTYPE=compute_dtype,  # "f32" (parity mode) or "bf16" — not a reference field
         INSTRUCTION_ENCODER=Cfg(vocab_size=2504, max_length=200, embedding_size=50, hidden_size=128, rnn_type="LSTM",
                                 final_state_only=False, bidirectional=True, use_pretrained_embeddings=False,
                                 embedding_file="", fine_tune_embeddings=False),

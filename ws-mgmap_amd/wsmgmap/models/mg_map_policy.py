@@ -85,6 +85,10 @@ class MGMapNet(nn.Module):
         self.second_state_encoder = RNNStateEncoder(hid, hid, 1, mc.STATE_ENCODER.rnn_type)
         self._output_size = hid
         self.att_map_t_m = None
+        # storage type of the map-stack activations: float32 (parity mode, f32 MFMA) or bfloat16
+        # (BASELINE configs[1]; bf16 MFMA, float32 accumulation, float32 master weights)
+        self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16}.get(
+            str(getattr(mc, "COMPUTE_DTYPE", "f32")).lower(), torch.float32)
 
         self.train()
         self.depth_encoder.eval()
@@ -119,8 +123,8 @@ class MGMapNet(nn.Module):
         ego_map = ego_map.float()
         nhwc_view = ego_map.permute(0, 2, 3, 1)
         if nhwc_view.is_contiguous():  # channels-last storage (what our BEV kernels emit)
-            return nhwc_view
-        return ops.to_nhwc(ego_map.contiguous())
+            return nhwc_view.to(self.compute_dtype)
+        return ops.to_nhwc(ego_map.contiguous(), dtype=self.compute_dtype)
 
     def map_stack(self, ego_map):
         """ego map [B,C,E,E] -> (map tokens [B, S*S, 256] token-major, pred_sem_map [B,27,2S,2S])."""
@@ -164,7 +168,7 @@ class MGMapNet(nn.Module):
         if "depth" in self._inputs:
             state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
         if "map" in self._inputs:
-            state_in.append(self.map_linear[3](self.map_linear[2](map_tokens.mean(dim=1))))
+            state_in.append(self.map_linear[3](self.map_linear[2](map_tokens.mean(dim=1, dtype=torch.float32))))
         state_in = torch.cat(state_in, dim=1)
 
         n1 = self.state_encoder.num_recurrent_layers

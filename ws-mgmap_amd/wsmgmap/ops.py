@@ -2,8 +2,10 @@
 C ABI of libwsmgmap.so.  PyTorch is used only for device memory, streams and the autograd
 tape; every FLOP of the three named operators runs in the hand-written gfx950 kernels.
 
-All tensors are float32, contiguous and resident on the GPU; anything else raises (there is
-no CPU or eager fallback).  Activations are NHWC ([B,H,W,C]).
+All tensors are contiguous and resident on the GPU; anything else raises (there is no CPU or
+eager fallback).  Activations are NHWC ([B,H,W,C]) stored float32 (parity mode: f32 MFMA, exact
+float32 products) or bf16 (BASELINE configs[1]: bf16 MFMA, float32 accumulation); parameters,
+statistics and weight gradients are always float32.
 """
 import ctypes
 
@@ -35,7 +37,16 @@ def _req(*ts):
 def _f32(*ts):
     for t in ts:
         if t is not None and t.dtype != torch.float32:
-            raise _abi.WsmgError(f"wsmgmap kernels compute in float32, got {t.dtype}")
+            raise _abi.WsmgError(f"this wsmgmap argument must be float32, got {t.dtype}")
+
+
+def _sfx(t):
+    """C-ABI suffix for the storage type of an activation tensor (float32 or bf16)."""
+    if t.dtype == torch.float32:
+        return ""
+    if t.dtype == torch.bfloat16:
+        return "_bf16"
+    raise _abi.WsmgError(f"wsmgmap activations are float32 or bfloat16, got {t.dtype}")
 
 
 def _workspace(device):
@@ -61,6 +72,9 @@ KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trac
     "wsmg_conv2d_fwd": "conv_igemm_kernel<false, false>",
     "wsmg_conv2d_bwd_data": "conv_igemm_kernel<true, false>",
     "wsmg_conv2d_bwd_weight": "conv_wgrad_kernel<false>",
+    "wsmg_conv2d_fwd_bf16": "conv_igemm_bf16_kernel<false, *>",
+    "wsmg_conv2d_bwd_data_bf16": "conv_igemm_bf16_kernel<true, *>",
+    "wsmg_conv2d_bwd_weight_bf16": "conv_wgrad_bf16_kernel",
 }
 
 
@@ -94,37 +108,48 @@ def _launch(name, flops, *args):
 
 # ----------------------------------------------------------------------------- convolution
 class _Conv2d(torch.autograd.Function):
-    """y = conv2d(x, w) + b on NHWC x / OHWI w (wsmg_conv2d_fwd / _bwd_data / _bwd_weight)."""
+    """y = conv2d(x, w) + b on NHWC x / OHWI float32 master weight.  x float32 -> f32 MFMA engine;
+    x bf16 -> the weight is cast to bf16 for the MFMA, dW comes back float32."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad):
         _req(x, w, bias)
-        _f32(x, w, bias)
+        _f32(w, bias)
+        sfx = _sfx(x)
         B, H, W, Cin = x.shape
         Cout, KH, KW, Cin2 = w.shape
         assert Cin == Cin2, (x.shape, w.shape)
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
-        y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32)
+        y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
-        _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+        dims = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)
+        if sfx:
+            w = w.to(torch.bfloat16)
+            _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias), _p(y), 0, *dims, _stream())
+        else:
+            _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), *dims, _stream())
         ctx.save_for_backward(x, w)
-        ctx.cfg = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, bias is not None)
+        ctx.cfg = dims + (bias is not None, sfx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, has_bias = ctx.cfg
+        *dims, has_bias, sfx = ctx.cfg
+        B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
         dy = dy.contiguous()
         dx = dw = db = None
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         if ctx.needs_input_grad[0]:
             w_ihwo = w.permute(3, 1, 2, 0).contiguous()
             dx = torch.empty_like(x)
-            _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+            if sfx:
+                _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
+            else:
+                _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            _launch("wsmg_conv2d_bwd_weight", fl, _p(x), _p(dy), _p(dw), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+            dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
+            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw), *dims, _stream())
         if has_bias and ctx.needs_input_grad[2]:
             db = channel_sum(dy.view(-1, Cout))
         return dx, dw, db, None, None
@@ -132,37 +157,48 @@ class _Conv2d(torch.autograd.Function):
 
 class _ConvT2d(torch.autograd.Function):
     """ConvTranspose2d(k4,s2,p1) = backward-data of the adjoint convolution.  `w` is the adjoint
-    conv's OHWI weight: [Cin_t][KH][KW][Cout_t] for a transposed conv Cin_t -> Cout_t."""
+    conv's OHWI float32 weight: [Cin_t][KH][KW][Cout_t] for a transposed conv Cin_t -> Cout_t."""
 
     @staticmethod
     def forward(ctx, x, w, stride, pad):
         _req(x, w)
-        _f32(x, w)
+        _f32(w)
+        sfx = _sfx(x)
         B, Hs, Ws, Ct_in = x.shape           # small grid (adjoint conv's output)
         O, KH, KW, I = w.shape               # adjoint conv: I channels (big grid) -> O channels (small grid)
         assert O == Ct_in
         Hb, Wb = (Hs - 1) * stride - 2 * pad + KH, (Ws - 1) * stride - 2 * pad + KW
+        if sfx:
+            w = w.to(torch.bfloat16)
         w_ihwo = w.permute(3, 1, 2, 0).contiguous()
-        y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=torch.float32)
+        y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * Hs * Ws * O * I * KH * KW
-        _launch("wsmg_conv2d_bwd_data", fl, _p(x), _p(w_ihwo), _p(y), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+        dims = (B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws)
+        if sfx:
+            _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(x), _p(w_ihwo), _p(y), 0, *dims, _stream())
+        else:
+            _launch("wsmg_conv2d_bwd_data", fl, _p(x), _p(w_ihwo), _p(y), *dims, _stream())
         ctx.save_for_backward(x, w)
-        ctx.cfg = (B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws)
+        ctx.cfg = dims + (sfx,)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws = ctx.cfg
+        *dims, sfx = ctx.cfg
+        B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws = dims
         dy = dy.contiguous()
         dx = dw = None
         fl = 2.0 * B * Hs * Ws * O * I * KH * KW
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+            if sfx:
+                _launch("wsmg_conv2d_fwd_bf16", fl, _p(dy), _p(w), None, _p(dx), 0, *dims, _stream())
+            else:
+                _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            _launch("wsmg_conv2d_bwd_weight", fl, _p(dy), _p(x), _p(dw), B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+            dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
+            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(dy), _p(x), _p(dw), *dims, _stream())
         return dx, dw, None, None
 
 
@@ -182,7 +218,7 @@ def channel_sum(x2d):
     rows, C = x2d.shape
     out = torch.empty(C, device=x2d.device, dtype=torch.float32)
     ws = _workspace(x2d.device)
-    _abi.call("wsmg_channel_sum", _p(x2d), rows, C, _p(out), _p(ws), ws.numel() * 8, _stream())
+    _abi.call("wsmg_channel_sum" + _sfx(x2d), _p(x2d), rows, C, _p(out), _p(ws), ws.numel() * 8, _stream())
     return out
 
 
@@ -191,24 +227,27 @@ class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps):
         _req(x, residual, gamma, beta, running_mean, running_var)
-        _f32(x, residual, gamma, beta, running_mean, running_var)
+        _f32(gamma, beta, running_mean, running_var)
+        sfx = _sfx(x)
+        if residual is not None and residual.dtype != x.dtype:
+            raise _abi.WsmgError("residual must have the activation dtype")
         C = x.shape[-1]
         rows = x.numel() // C
         y = torch.empty_like(x)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
         ws = _workspace(x.device)
-        _abi.call("wsmg_bn_act_fwd", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+        _abi.call("wsmg_bn_act_fwd" + sfx, _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                   float(momentum), float(eps), int(train), int(relu), rows, C, _p(y), _p(mean), _p(invstd),
                   _p(ws), ws.numel() * 8, _stream())
         ctx.save_for_backward(x, y, gamma, mean, invstd)
-        ctx.cfg = (rows, C, int(relu), residual is not None, bool(train))
+        ctx.cfg = (rows, C, int(relu), residual is not None, bool(train), sfx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y, gamma, mean, invstd = ctx.saved_tensors
-        rows, C, relu, has_res, train = ctx.cfg
+        rows, C, relu, has_res, train, sfx = ctx.cfg
         if not train:
             raise _abi.WsmgError("backward through eval-mode BatchNorm is not part of the reference's path")
         dy = dy.contiguous()
@@ -217,7 +256,7 @@ class _BnAct(torch.autograd.Function):
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         ws = _workspace(x.device)
-        _abi.call("wsmg_bn_act_bwd", _p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), relu, rows, C,
+        _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), relu, rows, C,
                   _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
@@ -232,7 +271,7 @@ class _Relu(torch.autograd.Function):
     def forward(ctx, x):
         _req(x)
         y = torch.empty_like(x)
-        _abi.call("wsmg_relu_fwd", _p(x), _p(y), x.numel(), _stream())
+        _abi.call("wsmg_relu_fwd" + _sfx(x), _p(x), _p(y), x.numel(), _stream())
         ctx.save_for_backward(y)
         return y
 
@@ -241,7 +280,7 @@ class _Relu(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         dy = dy.contiguous()
         dx = torch.empty_like(y)
-        _abi.call("wsmg_relu_bwd", _p(dy), _p(y), _p(dx), y.numel(), _stream())
+        _abi.call("wsmg_relu_bwd" + _sfx(y), _p(dy), _p(y), _p(dx), y.numel(), _stream())
         return dx
 
 
@@ -251,8 +290,8 @@ class _MaxPool(torch.autograd.Function):
         _req(x)
         B, H, W, C = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty(B, OH, OW, C, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_maxpool3x3s2_fwd", _p(x), _p(y), B, H, W, C, OH, OW, _stream())
+        y = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
+        _abi.call("wsmg_maxpool3x3s2_fwd" + _sfx(x), _p(x), _p(y), B, H, W, C, OH, OW, _stream())
         ctx.save_for_backward(x)
         return y
 
@@ -262,7 +301,7 @@ class _MaxPool(torch.autograd.Function):
         B, H, W, C = x.shape
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        _abi.call("wsmg_maxpool3x3s2_bwd", _p(dy), _p(x), _p(dx), B, H, W, C, dy.shape[1], dy.shape[2], _stream())
+        _abi.call("wsmg_maxpool3x3s2_bwd" + _sfx(x), _p(dy), _p(x), _p(dx), B, H, W, C, dy.shape[1], dy.shape[2], _stream())
         return dx
 
 
@@ -271,8 +310,8 @@ class _Up2(torch.autograd.Function):
     def forward(ctx, x):
         _req(x)
         B, H, W, C = x.shape
-        y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_upsample2x_fwd", _p(x), _p(y), B, H, W, C, _stream())
+        y = torch.empty(B, 2 * H, 2 * W, C, device=x.device, dtype=x.dtype)
+        _abi.call("wsmg_upsample2x_fwd" + _sfx(x), _p(x), _p(y), B, H, W, C, _stream())
         ctx.shape = (B, H, W, C)
         return y
 
@@ -280,8 +319,8 @@ class _Up2(torch.autograd.Function):
     def backward(ctx, dy):
         B, H, W, C = ctx.shape
         dy = dy.contiguous()
-        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
-        _abi.call("wsmg_upsample2x_bwd", _p(dy), _p(dx), B, H, W, C, _stream())
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=dy.dtype)
+        _abi.call("wsmg_upsample2x_bwd" + _sfx(dy), _p(dy), _p(dx), B, H, W, C, _stream())
         return dx
 
 
@@ -290,8 +329,8 @@ class _AvgPool2(torch.autograd.Function):
     def forward(ctx, x):
         _req(x)
         B, H, W, C = x.shape
-        y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_avgpool2_fwd", _p(x), _p(y), B, H, W, C, _stream())
+        y = torch.empty(B, H // 2, W // 2, C, device=x.device, dtype=x.dtype)
+        _abi.call("wsmg_avgpool2_fwd" + _sfx(x), _p(x), _p(y), B, H, W, C, _stream())
         ctx.shape = (B, H, W, C)
         return y
 
@@ -299,21 +338,21 @@ class _AvgPool2(torch.autograd.Function):
     def backward(ctx, dy):
         B, H, W, C = ctx.shape
         dy = dy.contiguous()
-        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
-        _abi.call("wsmg_avgpool2_bwd", _p(dy), _p(dx), B, H, W, C, _stream())
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=dy.dtype)
+        _abi.call("wsmg_avgpool2_bwd" + _sfx(dy), _p(dy), _p(dx), B, H, W, C, _stream())
         return dx
 
 
 class _ToNHWC(torch.autograd.Function):
-    """[B,C,H,W] contiguous -> [B,H,W,c_dst] (zero-padded channels)."""
+    """float32 [B,C,H,W] contiguous -> [B,H,W,c_dst] (zero-padded channels) in float32 or bf16."""
 
     @staticmethod
-    def forward(ctx, x, c_dst):
+    def forward(ctx, x, c_dst, dtype):
         _req(x)
         _f32(x)
         B, C, H, W = x.shape
-        y = torch.empty(B, H, W, c_dst, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_nchw_to_nhwc", _p(x), _p(y), B, C, H, W, c_dst, _stream())
+        y = torch.empty(B, H, W, c_dst, device=x.device, dtype=dtype)
+        _abi.call("wsmg_nchw_to_nhwc" + _sfx(y), _p(x), _p(y), B, C, H, W, c_dst, _stream())
         ctx.shape = (B, C, H, W, c_dst)
         return y
 
@@ -322,28 +361,28 @@ class _ToNHWC(torch.autograd.Function):
         B, C, H, W, c_dst = ctx.shape
         dy = dy.contiguous()
         dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
-        _abi.call("wsmg_nhwc_to_nchw", _p(dy), _p(dx), B, c_dst, H, W, C, _stream())
-        return dx, None
+        _abi.call("wsmg_nhwc_to_nchw" + _sfx(dy), _p(dy), _p(dx), B, c_dst, H, W, C, _stream())
+        return dx, None, None
 
 
 class _ToNCHW(torch.autograd.Function):
-    """[B,H,W,C] -> [B,c_dst,H,W] contiguous (drops padded channels)."""
+    """[B,H,W,C] float32 or bf16 -> float32 [B,c_dst,H,W] contiguous (drops padded channels)."""
 
     @staticmethod
     def forward(ctx, x, c_dst):
         _req(x)
         B, H, W, C = x.shape
         y = torch.empty(B, c_dst, H, W, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_nhwc_to_nchw", _p(x), _p(y), B, C, H, W, c_dst, _stream())
-        ctx.shape = (B, H, W, C, c_dst)
+        _abi.call("wsmg_nhwc_to_nchw" + _sfx(x), _p(x), _p(y), B, C, H, W, c_dst, _stream())
+        ctx.shape = (B, H, W, C, c_dst, x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, H, W, C, c_dst = ctx.shape
-        dy = dy.contiguous()
-        dx = torch.empty(B, H, W, C, device=dy.device, dtype=torch.float32)
-        _abi.call("wsmg_nchw_to_nhwc", _p(dy), _p(dx), B, c_dst, H, W, C, _stream())
+        B, H, W, C, c_dst, dtype = ctx.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=dtype)
+        _abi.call("wsmg_nchw_to_nhwc" + _sfx(dx), _p(dy), _p(dx), B, c_dst, H, W, C, _stream())
         return dx, None
 
 
@@ -353,8 +392,8 @@ upsample2x = _Up2.apply
 avgpool2 = _AvgPool2.apply
 
 
-def to_nhwc(x, c_dst=None):
-    return _ToNHWC.apply(x, x.shape[1] if c_dst is None else c_dst)
+def to_nhwc(x, c_dst=None, dtype=torch.float32):
+    return _ToNHWC.apply(x, x.shape[1] if c_dst is None else c_dst, dtype)
 
 
 def to_nchw(x, c_dst=None):
@@ -366,13 +405,16 @@ class _Attn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, scale):
         _req(q, k, v, mask)
-        _f32(q, k, v)
+        _f32(q)
+        sfx = _sfx(k)
+        if v.dtype != k.dtype:
+            raise _abi.WsmgError("attention keys and values must share a dtype")
         B, I, C = k.shape
         if mask is not None and mask.dtype != torch.uint8:
             raise _abi.WsmgError("attention mask must be uint8")
         out = torch.empty(B, C, device=q.device, dtype=torch.float32)
         attn = torch.empty(B, I, device=q.device, dtype=torch.float32)
-        _abi.call("wsmg_attn_fwd", _p(q), _p(k), _p(v), _p(mask), float(scale), B, I, C, _p(out), _p(attn), _stream())
+        _abi.call("wsmg_attn_fwd" + sfx, _p(q), _p(k), _p(v), _p(mask), float(scale), B, I, C, _p(out), _p(attn), _stream())
         ctx.save_for_backward(q, k, v, attn)
         ctx.scale = float(scale)
         return out, attn
@@ -381,12 +423,12 @@ class _Attn(torch.autograd.Function):
     def backward(ctx, dout, dattn):
         q, k, v, attn = ctx.saved_tensors
         B, I, C = k.shape
-        dout = torch.zeros_like(q) if dout is None else dout.contiguous()
-        dattn = None if dattn is None else dattn.contiguous()
+        dout = torch.zeros_like(q) if dout is None else dout.contiguous().float()
+        dattn = None if dattn is None else dattn.contiguous().float()
         dq = torch.empty_like(q)
         dk = torch.empty_like(k)
         dv = torch.empty_like(v)
-        _abi.call("wsmg_attn_bwd", _p(q), _p(k), _p(v), _p(attn), _p(dout), _p(dattn), ctx.scale, B, I, C,
+        _abi.call("wsmg_attn_bwd" + _sfx(k), _p(q), _p(k), _p(v), _p(attn), _p(dout), _p(dattn), ctx.scale, B, I, C,
                   _p(dq), _p(dk), _p(dv), _stream())
         return dq, dk, dv, None, None
 
