@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3      # MI355X f32 MFMA / vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF figure is 2:1 sparse)
 ALG_GFLOP_PER_STEP = 10.017  # 3.776 fwd + 6.241 bwd per policy step
 
 
@@ -119,6 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--T", type=int, default=64)
     ap.add_argument("--N", type=int, default=8)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage/MFMA type of the map stack: f32 = parity mode (1e-4 vs reference), bf16 = BASELINE configs[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -141,7 +144,7 @@ def main():
     from wsmgmap.parallel import GradAllReducer
 
     torch.manual_seed(0)
-    policy = BasePolicy(None, _Box(), default_model_config(num_proc=1, gpu_id=local))
+    policy = BasePolicy(None, _Box(), default_model_config(num_proc=1, gpu_id=local, compute_dtype=args.dtype))
     policy.net.instruction_encoder.embedding_layer.weight.requires_grad_(False)  # reference default: frozen embeddings
     state_cpu = {k: v.detach().clone() for k, v in policy.state_dict().items()} if rank == 0 else None
     policy = policy.to(dev)
@@ -203,8 +206,9 @@ def main():
         if dom:
             r = prof[dom]
             ach = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
-            roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=PEAK_F32_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / PEAK_F32_TFLOPS, 4), traffic=None,
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            roofline = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 4), traffic=None,
                             avg_launch_ms=round(r["ms_total"] / r["launches"], 4), launches=r["launches"],
                             alg_gflop_per_launch=round(r["flops_total"] / r["launches"] / 1e9, 3))
         out = {
@@ -218,7 +222,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"teacher-forcing update fwd+bwd+Adam, T={T} x N={N} rows/GPU (B={T * N}), E=100 C=64 "
                                    f"80-token instructions, cached rgb/depth/ego-map features (BASELINE configs[1])",

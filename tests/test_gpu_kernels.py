@@ -414,4 +414,5 @@ def test_attention_bf16(ops):
     close("attn16.out", o, o_ref, 1e-5, 1e-6)
     close("attn16.attn", a, a_ref, 1e-5, 1e-8)
     close("attn16.dq", qg.grad, qr.grad, 1e-4, 1e-6)
-    close("attn16.dkv", kg.grad.float(), kr.grad, 2 * BF16_EPS, 1e-7)
+    # k and v are the same tensor here: dk and dv are each rounded to bf16 and then summed in bf16
+    close("attn16.dkv", kg.grad.float(), kr.grad, 4 * BF16_EPS, 1e-4 * float(kr.grad.abs().max()))
