@@ -415,4 +415,4 @@ def test_attention_bf16(ops):
     close("attn16.attn", a, a_ref, 1e-5, 1e-8)
     close("attn16.dq", qg.grad, qr.grad, 1e-4, 1e-6)
     # k and v are the same tensor here: dk and dv are each rounded to bf16 and then summed in bf16
-    close("attn16.dkv", kg.grad.float(), kr.grad, 4 * BF16_EPS, 1e-4 * float(kr.grad.abs().max()))
+    close("attn16.dkv", kg.grad.float(), kr.grad, 4 * BF16_EPS, 2 * BF16_EPS * float(kr.grad.abs().max()))
