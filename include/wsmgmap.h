@@ -197,6 +197,25 @@ int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, const float
                        const float* dattn, float scale, int B, int I, int C, float* dq, void* dk, void* dv,
                        wsmg_stream_t stream);
 
+/* ============================ persistent masked-GRU state encoders ============================ */
+/* habitat-lab RNNStateEncoder (GRU, hidden 512) as used at mg_map_policy.py:118-123,147-152,220-227,242-249:
+ * h_{t-1} is multiplied by masks[t] before every step (episode restarts), gate order r,z,n.
+ * One launch runs all T steps (32 cooperating workgroups, W_hh in registers, one bounded-spin grid
+ * barrier per step).  gi = x W_ih^T + b_ih [T][N][3H] is computed by the caller; N <= 8.
+ * sync_ws: wsmg_gru_sync_bytes() bytes of device scratch (zeroed by the call; word 1 != 0 afterwards
+ * means a barrier timed out).  save_*: [T][N][H] each, consumed by wsmg_gru_bwd. */
+int64_t wsmg_gru_sync_bytes(void);
+int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                 int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                 float* save_ghn, void* sync_ws, wsmg_stream_t stream);
+/* backward through time: dy [T][N][H] (gradient of every h_t), dhT [N][H] or NULL; writes dgi, dgh
+ * [T][N][3H] (gradients of the input / hidden pre-activations) and dh0 [N][H].  The caller forms
+ * dW_hh = dgh^T (mask * h_prev), db_hh = sum dgh, and back-propagates dgi through its input GEMM. */
+int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                 const float* y, const float* save_r, const float* save_z, const float* save_n,
+                 const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
+                 void* sync_ws, wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

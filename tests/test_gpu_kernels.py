@@ -416,3 +416,45 @@ def test_attention_bf16(ops):
     close("attn16.dq", qg.grad, qr.grad, 1e-4, 1e-6)
     # k and v are the same tensor here: dk and dv are each rounded to bf16 and then summed in bf16
     close("attn16.dkv", kg.grad.float(), kr.grad, 4 * BF16_EPS, 2 * BF16_EPS * float(kr.grad.abs().max()))
+
+
+# ----------------------------------------------------------------------------- persistent masked GRU
+@pytest.mark.parametrize("Tn,N", [(1, 3), (6, 3), (64, 8), (9, 11)])
+def test_masked_gru_persistent_kernel(Tn, N):
+    """whole-sequence HIP GRU (forward + BPTT) vs the oracle's per-step masked GRU in float64,
+    with episode restarts in the middle of the sequence."""
+    from wsmgmap.models.rnn_state_encoder import RNNStateEncoder
+    In, Hd = 640, 512
+    enc = RNNStateEncoder(In, Hd)
+    sd = {k: T(df.uniform(f"gru.{k}", tuple(v.shape), 0.2 if "bias" in k else float(np.sqrt(12.0 / v.shape[1]))))
+          for k, v in enc.rnn.state_dict().items()}
+    enc.rnn.load_state_dict(sd)
+    x = T(df.uniform(f"gru.x.{Tn}.{N}", (Tn * N, In), 2.0))
+    h0 = T(df.uniform(f"gru.h0.{N}", (1, N, Hd), 1.0))
+    masks = torch.ones(Tn, N)
+    masks[0, : max(1, N // 2)] = 0
+    if Tn > 3:
+        masks[3, 1] = 0
+        masks[Tn - 1, 0] = 0
+    gy = T(df.uniform(f"gru.gy.{Tn}.{N}", (Tn * N, Hd), 2.0))
+    # float64 truth
+    P = {"e.rnn." + k: v.double().requires_grad_(True) for k, v in sd.items()}
+    xr, hr = x.double().requires_grad_(True), h0.double().requires_grad_(True)
+    torch.set_default_dtype(torch.float64)
+    try:
+        yr, hTr = policy_ref.masked_gru(P, "e", xr, hr, masks.double().view(-1, 1))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    (yr * gy.double()).sum().backward()
+    # HIP
+    enc = enc.cuda()
+    xg, hg = x.cuda().requires_grad_(True), h0.cuda().requires_grad_(True)
+    y, hT = enc(xg, hg, masks.view(-1, 1).cuda())
+    (y * gy.cuda()).sum().backward()
+    close("gru.y", y, yr, 1e-5, 2e-6)
+    close("gru.hT", hT, hTr, 1e-5, 2e-6)
+    close("gru.dx", xg.grad, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()))
+    close("gru.dh0", hg.grad, hr.grad, 1e-4, 1e-5 * float(hr.grad.abs().max()) + 1e-9)
+    for k in sd:
+        ref = P["e.rnn." + k].grad
+        close("gru.d" + k, getattr(enc.rnn, k).grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)

@@ -108,7 +108,7 @@ def test_diag_gaussian_matches_oracle_head():
 
 
 def test_masked_gru_matches_oracle_semantics():
-    """sequence form (split at restarts) == per-step h*mask form, incl. a mid-sequence restart."""
+    """stock sequence form (split at restarts) == per-step h*mask form, incl. a mid-sequence restart."""
     from wsmgmap.models.rnn_state_encoder import RNNStateEncoder
     torch.manual_seed(0)
     enc = RNNStateEncoder(16, 8)
@@ -118,13 +118,16 @@ def test_masked_gru_matches_oracle_semantics():
     masks[0] = 0
     masks[3, 1] = 0
     h0 = torch.randn(1, N, 8)
-    y, h = enc(x, h0, masks.view(-1, 1))
+    y, h = enc.forward_stock(x, h0, masks.view(-1, 1))
     P = {"e.rnn." + k: v for k, v in enc.rnn.state_dict().items()}
     yr, hr = policy_ref.masked_gru(P, "e", x, h0, masks.view(-1, 1))
     assert torch.allclose(y, yr, atol=1e-6) and torch.allclose(h, hr, atol=1e-6)
     assert RNNStateEncoder.restart_steps(masks.view(-1, 1), N) == [3]
-    y1, h1 = enc(x[:N], h0, masks[0].view(-1, 1))  # single-step form
+    y1, h1 = enc.forward_stock(x[:N], h0, masks[0].view(-1, 1))  # single-step form
     assert torch.allclose(y1, y[:N], atol=1e-6)
+    from wsmgmap import _abi
+    with pytest.raises(_abi.WsmgError):  # the product forward is the HIP kernel: no CPU path
+        enc(x, h0, masks.view(-1, 1))
 
 
 def test_instruction_encoder_dedup_matches_oracle():

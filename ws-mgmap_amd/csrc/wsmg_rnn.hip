@@ -1,0 +1,290 @@
+// Persistent masked-GRU sequence kernels (forward + backward-through-time) for the two state
+// encoders of the policy (hidden 512, batch N <= 8 per step, T <= 200 steps).
+//
+// Replaces the per-time-step cuDNN/MIOpen GRU launches behind habitat-lab's RNNStateEncoder
+// (reference call sites mg_map_policy.py:220-227,242-249).  At N = 8 the recurrence is a chain of
+// T dependent [8 x 512] x [512 x 1536] products: latency-, not FLOP-bound (about 4000 tiny
+// launches per update in MIOpen).  Here ONE launch runs the whole sequence:
+//   * 32 workgroups x 4 waves; each wave owns 4 hidden units (12 gate rows of W_hh, or 4 columns
+//     for backward) and keeps them in REGISTERS for all T steps — no LDS or HBM weight traffic
+//     inside the loop;
+//   * the K = 512 (1536) reduction is split across the 64 lanes; partial sums are combined with a
+//     halving butterfly (each shuffle halves the live values), so lane l ends up with its own
+//     (unit, batch) outputs;
+//   * h_t (resp. dGH_t) is exchanged through HBM with ONE grid-wide barrier per step: plain
+//     stores -> vmcnt(0) -> workgroup barrier -> agent-scope release -> counter add; consumers
+//     poll relaxed, then one agent-scope acquire (cdna_hip_programming.md Guideline 16).  Spins
+//     are bounded: on timeout an error word is set and every workgroup exits (no GPU hang).
+// Episode restarts are handled in-kernel: h_{t-1} is multiplied by masks[t] before every step,
+// which is what the reference's split-at-zeros sequence form computes — so no host sync is needed.
+// Input projections (x W_ih^T + b_ih for all T*N rows) and the weight gradients are single large
+// GEMMs done by the caller.  Gate order r, z, n (PyTorch nn.GRU).
+#include "wsmg_common.h"
+
+namespace {
+
+constexpr int H = 512;
+constexpr int NB = 8;            // batch slots per step
+constexpr int UNITS_WAVE = 4;
+constexpr int WAVES = 4;
+constexpr int UNITS_WG = UNITS_WAVE * WAVES;   // 16
+constexpr int NWG = H / UNITS_WG;              // 32
+constexpr unsigned SPIN_LIMIT = 1u << 20;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// one-per-step grid barrier among NWG co-resident workgroups; returns false on timeout
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int tid, int* ok_lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned n = 0;
+    int good = 1;
+    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++n > SPIN_LIMIT || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *ok_lds = good;
+  }
+  __syncthreads();
+  return *ok_lds != 0;
+}
+
+// halving butterfly: C live values per lane, xor distance D; afterwards C/2 live values
+template <int C, int D, int NV>
+__device__ __forceinline__ void halve(float (&v)[NV], int lane) {
+  const bool up = (lane & D) != 0;
+#pragma unroll
+  for (int i = 0; i < C / 2; ++i) {
+    float keep = up ? v[i + C / 2] : v[i];
+    float send = up ? v[i] : v[i + C / 2];
+    v[i] = keep + __shfl_xor(send, D, 64);
+  }
+}
+
+struct GruFwdArgs {
+  const float* gi;     // [T][N][3H]  x W_ih^T + b_ih
+  const float* whh;    // [3H][H]
+  const float* bhh;    // [3H]
+  const float* h0;     // [N][H]
+  const float* masks;  // [T][N]
+  float* y;            // [T][N][H]   h_t
+  float* sr;           // saved gates for backward, each [T][N][H]
+  float* sz;
+  float* sn;
+  float* sghn;         // W_hn h + b_hn
+  unsigned* sync;      // [0] arrival counter, [1] error word (zeroed by the launcher)
+  int T, N;
+};
+
+__global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
+  __shared__ int ok_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
+  // W_hh rows of this wave in registers: row r = gate*4 + unit, k = 4*lane + e (+256 for e >= 4)
+  float w[12][8];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int row = (r >> 2) * H + u0 + (r & 3);
+    f32x4 lo = *reinterpret_cast<const f32x4*>(a.whh + (size_t)row * H + 4 * lane);
+    f32x4 hi = *reinterpret_cast<const f32x4*>(a.whh + (size_t)row * H + 256 + 4 * lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { w[r][e] = lo[e]; w[r][4 + e] = hi[e]; }
+  }
+  // after the butterfly lane l (< 48) holds row_local = l/4 (gate = l/16, unit = (l/4)&3), batches 2*(l&3)+{0,1}
+  const int my_unit = u0 + ((lane >> 2) & 3);
+  const int my_b0 = 2 * (lane & 3);
+  float br = 0.f, bz = 0.f, bn = 0.f;
+  if (lane < 16) { br = a.bhh[my_unit]; bz = a.bhh[H + my_unit]; bn = a.bhh[2 * H + my_unit]; }
+
+  for (int t = 0; t < a.T; ++t) {
+    const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
+    float hp[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      float m = 0.f;
+      if (b < a.N) {
+        m = a.masks[t * a.N + b];
+        lo = *reinterpret_cast<const f32x4*>(hsrc + (size_t)b * H + 4 * lane);
+        hi = *reinterpret_cast<const f32x4*>(hsrc + (size_t)b * H + 256 + 4 * lane);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { hp[b][e] = lo[e] * m; hp[b][4 + e] = hi[e] * m; }
+    }
+    float acc[128];
+#pragma unroll
+    for (int i = 96; i < 128; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(w[r][e], hp[b][e], s);
+        acc[r * 8 + b] = s;
+      }
+    }
+    halve<128, 32>(acc, lane);
+    halve<64, 16>(acc, lane);
+    halve<32, 8>(acc, lane);
+    halve<16, 4>(acc, lane);
+    halve<8, 2>(acc, lane);
+    halve<4, 1>(acc, lane);
+    // acc[0], acc[1]: row_local = lane/4, batch = my_b0 + {0,1}.  Bring z (lanes 16..31) and n (32..47) to lanes 0..15.
+    float z0 = __shfl(acc[0], lane + 16, 64), z1 = __shfl(acc[1], lane + 16, 64);
+    float n0 = __shfl(acc[0], lane + 32, 64), n1 = __shfl(acc[1], lane + 32, 64);
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int b = my_b0 + i;
+        if (b < a.N) {
+          const size_t row = (size_t)t * a.N + b;
+          const float* g = a.gi + row * 3 * H;
+          float ghr = (i ? acc[1] : acc[0]) + br;
+          float ghz = (i ? z1 : z0) + bz;
+          float ghn = (i ? n1 : n0) + bn;
+          float r = sigmoidf_(g[my_unit] + ghr);
+          float z = sigmoidf_(g[H + my_unit] + ghz);
+          float nn = tanhf(g[2 * H + my_unit] + r * ghn);
+          float hprev = hsrc[(size_t)b * H + my_unit] * a.masks[t * a.N + b];
+          float h = (1.0f - z) * nn + z * hprev;
+          a.y[row * H + my_unit] = h;
+          a.sr[row * H + my_unit] = r;
+          a.sz[row * H + my_unit] = z;
+          a.sn[row * H + my_unit] = nn;
+          a.sghn[row * H + my_unit] = ghn;
+        }
+      }
+    }
+    if (t + 1 < a.T) {
+      if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(t + 1), tid, &ok_lds)) return;
+    }
+  }
+}
+
+struct GruBwdArgs {
+  const float* dy;     // [T][N][H]   gradient w.r.t. every h_t
+  const float* dhT;    // [N][H] gradient w.r.t. the final hidden state, or null
+  const float* whh;    // [3H][H]
+  const float* h0;     // [N][H]
+  const float* masks;  // [T][N]
+  const float* y;      // [T][N][H]
+  const float* sr;
+  const float* sz;
+  const float* sn;
+  const float* sghn;
+  float* dgi;          // [T][N][3H]
+  float* dgh;          // [T][N][3H]
+  float* dh0;          // [N][H]
+  unsigned* sync;
+  int T, N;
+};
+
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
+  __shared__ int ok_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
+  // columns u0..u0+3 of W_hh over all 3H rows: k = 256*q + 4*lane + e, q = 0..5
+  float wt[4][24];
+#pragma unroll
+  for (int q = 0; q < 6; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 256 * q + 4 * lane + e;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wt[u][q * 4 + e] = a.whh[(size_t)row * H + u0 + u];
+    }
+  // after the reduction lane l holds (unit = l/16, batch = (l>>1)&7); even lanes do the element-wise work
+  const int my_unit = u0 + (lane >> 4);
+  const int my_b = (lane >> 1) & 7;
+  const bool worker = ((lane & 1) == 0) && (my_b < a.N);
+  float carry = 0.f;
+  if (worker && a.dhT) carry = a.dhT[(size_t)my_b * H + my_unit];
+
+  for (int t = a.T - 1; t >= 0; --t) {
+    float dh_direct = 0.f, mk = 0.f;
+    if (worker) {
+      const size_t row = (size_t)t * a.N + my_b;
+      const size_t o = row * H + my_unit;
+      mk = a.masks[t * a.N + my_b];
+      const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
+      float hprev = hsrc[(size_t)my_b * H + my_unit] * mk;
+      float dh = a.dy[o] + carry;
+      float r = a.sr[o], z = a.sz[o], nn = a.sn[o], ghn = a.sghn[o];
+      float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
+      float dz_pre = dh * (hprev - nn) * z * (1.0f - z);
+      float dr_pre = dn_pre * ghn * r * (1.0f - r);
+      float* gi = a.dgi + row * 3 * H;
+      float* gh = a.dgh + row * 3 * H;
+      gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
+      gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dn_pre * r;
+      dh_direct = dh * z;
+    }
+    if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
+    // dh_{t-1}[b][u] = mask * (dh*z + sum_k dgh[b][k] * W_hh[k][u])
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+    const float* gsrc = a.dgh + (size_t)t * a.N * 3 * H;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < a.N) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + (size_t)b * 3 * H + 256 * q + 4 * lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u * 8 + b] = fmaf(wt[u][q * 4 + e], g[e], acc[u * 8 + b]);
+        }
+      }
+    }
+    halve<32, 32>(acc, lane);
+    halve<16, 16>(acc, lane);
+    halve<8, 8>(acc, lane);
+    halve<4, 4>(acc, lane);
+    halve<2, 2>(acc, lane);
+    float s = acc[0] + __shfl_xor(acc[0], 1, 64);
+    carry = (dh_direct + s) * mk;
+  }
+  if (worker) a.dh0[(size_t)my_b * H + my_unit] = carry;
+}
+
+}  // namespace
+
+extern "C" int64_t wsmg_gru_sync_bytes(void) { return 64; }
+
+extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                            int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                            float* save_ghn, void* sync_ws, wsmg_stream_t stream) {
+  if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
+  if (e != hipSuccess) return (int)e;
+  GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws, T, N};
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                            const float* y, const float* save_r, const float* save_z, const float* save_n,
+                            const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
+                            void* sync_ws, wsmg_stream_t stream) {
+  if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
+  if (e != hipSuccess) return (int)e;
+  GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws, T, N};
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  WSMG_RETURN_LAUNCH();
+}

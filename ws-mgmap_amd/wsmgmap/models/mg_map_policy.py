@@ -10,7 +10,8 @@ Attribute tree, state_dict keys and the in-place contract (writes `observations[
     token-major keys/values; the k=1 Conv1d key projections are MFMA GEMMs of the conv engine;
   * the BEV projection / scatter / global-map fuse run in the BEV kernels (operator 1);
   * instruction encoding is de-duplicated over the time axis of a teacher-forcing batch;
-  * LSTM / GRU cells, Linear heads and losses stay stock PyTorch-ROCm.
+  * the two GRU state encoders run as persistent whole-sequence kernels (csrc/wsmg_rnn.hip);
+  * the instruction LSTM cell, Linear heads and losses stay stock PyTorch-ROCm.
 """
 import numpy as np
 import torch
@@ -172,10 +173,7 @@ class MGMapNet(nn.Module):
         state_in = torch.cat(state_in, dim=1)
 
         n1 = self.state_encoder.num_recurrent_layers
-        restarts = None
-        if state_in.size(0) != rnn_hidden_states.size(1):
-            restarts = RNNStateEncoder.restart_steps(masks, rnn_hidden_states.size(1))
-        state, rnn_hidden_states[0:n1] = self.state_encoder(state_in, rnn_hidden_states[0:n1], masks, restarts)
+        state, rnn_hidden_states[0:n1] = self.state_encoder(state_in, rnn_hidden_states[0:n1], masks)
 
         # instruction attention: keys projected once per unique instruction, gathered per row
         text_k = self._key_projection(self.state_text_k_layer, instr_u)[inverse]
@@ -188,5 +186,5 @@ class MGMapNet(nn.Module):
 
         parts = [state, text_embedding] + ([map_embedding] if "map" in self._inputs else [])
         x = self.second_state_compress(torch.cat(parts, dim=1))
-        x, rnn_hidden_states[n1:] = self.second_state_encoder(x, rnn_hidden_states[n1:], masks, restarts)
+        x, rnn_hidden_states[n1:] = self.second_state_encoder(x, rnn_hidden_states[n1:], masks)
         return x, rnn_hidden_states, pred_sem_map

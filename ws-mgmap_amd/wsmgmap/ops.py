@@ -440,6 +440,50 @@ def attention(q, k, v, mask=None, scale=1.0 / 16):
     return _Attn.apply(q, k, v, mask, scale)
 
 
+# ----------------------------------------------------------------------------- persistent masked GRU
+class _MaskedGRU(torch.autograd.Function):
+    """gi [T,N,3H] (input projections), w_hh [3H,H], b_hh [3H], h0 [N,H], masks [T,N] -> y [T,N,H]."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0, masks):
+        _req(gi, w_hh, b_hh, h0, masks)
+        _f32(gi, w_hh, b_hh, h0, masks)
+        T, N, H3 = gi.shape
+        H = H3 // 3
+        dev = gi.device
+        y = torch.empty(T, N, H, device=dev, dtype=torch.float32)
+        saves = [torch.empty(T, N, H, device=dev, dtype=torch.float32) for _ in range(4)]
+        sync = torch.empty(16, device=dev, dtype=torch.int32)
+        _abi.call("wsmg_gru_fwd", _p(gi), _p(w_hh), _p(b_hh), _p(h0), _p(masks), T, N, H, _p(y),
+                  *[_p(s) for s in saves], _p(sync), _stream())
+        ctx.save_for_backward(w_hh, h0, masks, y, *saves)
+        ctx.sync = sync
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        w_hh, h0, masks, y, sr, sz, sn, sghn = ctx.saved_tensors
+        T, N, H = y.shape
+        dev = y.device
+        dy = dy.contiguous()
+        dgi = torch.empty(T, N, 3 * H, device=dev, dtype=torch.float32)
+        dgh = torch.empty(T, N, 3 * H, device=dev, dtype=torch.float32)
+        dh0 = torch.empty(N, H, device=dev, dtype=torch.float32)
+        sync = torch.empty(16, device=dev, dtype=torch.int32)
+        _abi.call("wsmg_gru_bwd", _p(dy), None, _p(w_hh), _p(h0), _p(masks), _p(y), _p(sr), _p(sz), _p(sn), _p(sghn),
+                  T, N, H, _p(dgi), _p(dgh), _p(dh0), _p(sync), _stream())
+        hprev = torch.cat([h0.unsqueeze(0), y[:-1]], dim=0) * masks.unsqueeze(-1)
+        g2 = dgh.view(T * N, 3 * H)
+        dw_hh = g2.t() @ hprev.view(T * N, H)
+        db_hh = g2.sum(dim=0)
+        return dgi, dw_hh, db_hh, dh0, None
+
+
+def masked_gru(gi, w_hh, b_hh, h0, masks):
+    """Whole-sequence masked GRU in one persistent launch.  Returns y [T,N,H]; final state = y[-1]."""
+    return _MaskedGRU.apply(gi.contiguous(), w_hh.contiguous(), b_hh.contiguous(), h0.contiguous(), masks.contiguous())
+
+
 # ----------------------------------------------------------------------------- BEV (no autograd: rollout only)
 @torch.no_grad()
 def bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=0.12):
