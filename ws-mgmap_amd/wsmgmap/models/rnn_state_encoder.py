@@ -41,7 +41,7 @@ class RNNStateEncoder(nn.Module):
         t = x.size(0) // n
         gi = torch.addmm(r.bias_ih_l0, x, r.weight_ih_l0.t()).view(t, n, -1)
         m = masks.reshape(t, n).float()
-        h0 = hidden_states[0]
+        h0 = hidden_states[0].clone()  # the caller overwrites hidden_states in place (reference contract)
         if n <= MAX_BATCH:
             y = ops.masked_gru(gi, r.weight_hh_l0, r.bias_hh_l0, h0, m)
         else:
