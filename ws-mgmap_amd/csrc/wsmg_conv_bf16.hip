@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
 // ----------------------------------------------------------------------------- backward weight
 constexpr int WKP = 64;          // pixels per k-step
 constexpr int WCO = 64;          // output channels per workgroup
-constexpr int WUN = 4;           // (tap, 32-channel) units per workgroup, one per wave
+constexpr int WUW = 2;           // (tap, 32-channel) units per wave (dY fragments reused across them)
+constexpr int WUN = 4 * WUW;     // units per workgroup
 constexpr int D_LD = 192;        // dY tile row stride (bytes): 128 B data + 64 B pad -> tr reads conflict-free
 constexpr int X_LD = 64;         // X tile row stride (bytes): 32 bf16, rows land 16 banks apart
 
@@ -239,9 +240,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const int dpx = tid >> 3, dseg = tid & 7;   // + 32 rows on the second pass
   const int xpx = tid >> 2, xseg = tid & 3;
 
-  f32x16 acc0, acc1;
+  f32x16 acc[2][WUW];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < WUW; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
   u32x4 rd[2], rx[WUN];
   auto gload = [&](int64_t p0) {
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const int h = lane >> 5;             // k half: pixels 8h .. 8h+7 of a 16-pixel MFMA step
   const unsigned char* a_base0 = &Ds[(8 * h + q) * D_LD + (half16 * 16 + p4 * 4) * 2];        // co 0..31
   const unsigned char* a_base1 = a_base0 + 64;                                                 // co 32..63
-  const unsigned char* b_base = &Xs[(wave * WKP + 8 * h + q) * X_LD + (half16 * 16 + p4 * 4) * 2];
+  const unsigned char* b_base = &Xs[(wave * WUW * WKP + 8 * h + q) * X_LD + (half16 * 16 + p4 * 4) * 2];
 
   if (p_begin < p_end) {
     gload(p_begin);
@@ -295,12 +300,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
     for (int ks = 0; ks < WKP / 16; ++ks) {
       bf16x4 a0l = tr_read(a_base0 + (16 * ks) * D_LD), a0h = tr_read(a_base0 + (16 * ks + 4) * D_LD);
       bf16x4 a1l = tr_read(a_base1 + (16 * ks) * D_LD), a1h = tr_read(a_base1 + (16 * ks + 4) * D_LD);
-      bf16x4 bl = tr_read(b_base + (16 * ks) * X_LD), bh = tr_read(b_base + (16 * ks + 4) * X_LD);
       bf16x8 a0 = __builtin_shufflevector(a0l, a0h, 0, 1, 2, 3, 4, 5, 6, 7);
       bf16x8 a1 = __builtin_shufflevector(a1l, a1h, 0, 1, 2, 3, 4, 5, 6, 7);
-      bf16x8 bb = __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc1, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < WUW; ++u) {
+        const unsigned char* bp = b_base + u * WKP * X_LD;
+        bf16x4 bl = tr_read(bp + (16 * ks) * X_LD), bh = tr_read(bp + (16 * ks + 4) * X_LD);
+        bf16x8 bb = __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][u], 0, 0, 0);
+        acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][u], 0, 0, 0);
+      }
     }
     __syncthreads();
     if (more) {
@@ -308,18 +317,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
       __syncthreads();
     }
   }
-  const int uu = u0 + wave;
-  if (uu >= a.units) return;
   const int r = lane & 31;
-  const int tap = uu / cchunks;
-  const int ci = (uu - tap * cchunks) * 32 + r;
   const int taps = a.KH * a.KW;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int u = 0; u < WUW; ++u) {
+    const int uu = u0 + wave * WUW + u;
+    if (uu >= a.units) continue;
+    const int tap = uu / cchunks;
+    const int ci = (uu - tap * cchunks) * 32 + r;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      int co = co0 + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, t == 0 ? acc0[g] : acc1[g]);
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        int co = co0 + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+        if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, acc[t][u][g]);
+      }
     }
   }
 }

@@ -14,13 +14,15 @@ constexpr int RED_THREADS = 256;
 constexpr int RED_MAX_BLOCKS = 1024;
 
 __host__ __device__ inline int red_blocks(int64_t rows, int C) {
-  int rows_per_iter = RED_THREADS / C;
-  int64_t nb = (rows + (int64_t)rows_per_iter * 16 - 1) / ((int64_t)rows_per_iter * 16);
+  int rows_per_iter = RED_THREADS / (C / 4);
+  int64_t nb = (rows + (int64_t)rows_per_iter * 8 - 1) / ((int64_t)rows_per_iter * 8);
   if (nb < 1) nb = 1;
   if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
   return (int)nb;
 }
 
+// Column reductions over a [rows][C] matrix; each thread owns 4 adjacent channels (one 8/16-B load
+// per tensor and row) and walks rows with a grid stride; float64 accumulation.
 // MODE 0: sum(x)                      -> part[blk][0][c]
 // MODE 1: sum(x), sum(x*x)            -> part[blk][0..1][c]
 // MODE 2: sum(g), sum(g*xhat)  with g = dy * (relu ? y > 0 : 1), xhat = (x-mean)*invstd
@@ -31,37 +33,52 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
                                                                  const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, int relu,
                                                                  int64_t rows, int C, double* __restrict__ part) {
-  __shared__ double sh[2][RED_THREADS];
+  __shared__ double sh[2][4][RED_THREADS];
   const int tid = threadIdx.x;
-  const int c = tid % C;
-  const int rl = tid / C;
-  const int rpi = RED_THREADS / C;
-  double s0 = 0.0, s1 = 0.0;
-  float mu = 0.f, is = 1.f;
-  if (MODE == 2) { mu = mean[c]; is = invstd[c]; }
+  const int C4 = C >> 2;
+  const int c = (tid % C4) * 4;
+  const int rl = tid / C4;
+  const int rpi = RED_THREADS / C4;
+  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == 2) { mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c); }
   for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
     size_t o = (size_t)r * C + c;
     if (MODE == 0) {
-      s0 += (double)ldf(x + o);
+      f32x4 v = ld4(x + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s0[j] += (double)v[j];
     } else if (MODE == 1) {
-      float v = ldf(x + o);
-      s0 += (double)v;
-      s1 += (double)v * (double)v;
+      f32x4 v = ld4(x + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] += (double)v[j]; s1[j] += (double)v[j] * (double)v[j]; }
     } else {
-      float g = ldf(dy + o);
-      if (relu && !(ldf(y + o) > 0.f)) g = 0.f;
-      float xh = (ldf(x + o) - mu) * is;
-      s0 += (double)g;
-      s1 += (double)g * (double)xh;
+      f32x4 g = ld4(dy + o), xv = ld4(x + o);
+      if (relu) {
+        f32x4 yv = ld4(y + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float xh = (xv[j] - mu[j]) * is[j];
+        s0[j] += (double)g[j];
+        s1[j] += (double)g[j] * (double)xh;
+      }
     }
   }
-  sh[0][tid] = s0;
-  sh[1][tid] = s1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[0][j][tid] = s0[j]; sh[1][j][tid] = s1[j]; }
   __syncthreads();
   if (rl == 0) {
-    for (int j = 1; j < rpi; ++j) { s0 += sh[0][j * C + c]; s1 += sh[1][j * C + c]; }
-    part[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
-    part[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    for (int k = 1; k < rpi; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] += sh[0][j][k * C4 + tid]; s1[j] += sh[1][j][k * C4 + tid]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      part[((size_t)blockIdx.x * 2 + 0) * C + c + j] = s0[j];
+      part[((size_t)blockIdx.x * 2 + 1) * C + c + j] = s1[j];
+    }
   }
 }
 

@@ -34,13 +34,33 @@ class InstructionEncoder(nn.Module):
     def output_size(self):
         return self.config.hidden_size * (2 if self.bidir else 1)
 
+    @staticmethod
+    def _dedup(tokens):
+        """Unique rows of a [B, L] token matrix without a row-wise sort: a 64-bit polynomial hash per
+        row, a 1-D unique over the B hashes, and an exact on-device check (a hash collision falls back
+        to torch.unique(dim=0)).  Returns (unique rows [U, L], inverse [B], lengths on the host)."""
+        B, L = tokens.shape
+        mult = (torch.arange(1, L + 1, device=tokens.device, dtype=torch.int64) * 0x9E3779B97F4A7C15) | 1
+        h = (tokens * mult).sum(dim=1)
+        _, inverse = torch.unique(h, return_inverse=True)
+        U = int(inverse.max()) + 1 if B else 0  # host sync (the packed LSTM needs host lengths anyway)
+        rep = torch.full((U,), B, device=tokens.device, dtype=torch.int64)
+        rep.scatter_reduce_(0, inverse, torch.arange(B, device=tokens.device), reduce="amin")
+        uniq = tokens[rep]
+        lengths = (uniq != 0).long().sum(dim=1)
+        exact = (uniq[inverse] == tokens).all().view(1).long()
+        host = torch.cat([exact, lengths]).cpu()
+        if int(host[0]) != 1:  # hash collision: exact path
+            uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
+            return uniq, inverse, (uniq != 0).long().sum(dim=1).cpu()
+        return uniq, inverse, host[1:]
+
     def encode_unique(self, instruction):
         """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows."""
         tokens = instruction.long()
-        uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
-        lengths = (uniq != 0).long().sum(dim=1)
+        uniq, inverse, lengths = self._dedup(tokens)
         embedded = self.embedding_layer(uniq)
-        packed = nn.utils.rnn.pack_padded_sequence(embedded, lengths.cpu(), batch_first=True, enforce_sorted=False)
+        packed = nn.utils.rnn.pack_padded_sequence(embedded, lengths, batch_first=True, enforce_sorted=False)
         output, _ = self.encoder_rnn(packed)
         hidden = nn.utils.rnn.pad_packed_sequence(output, batch_first=True)[0]  # [U, L, D]
         mask = (hidden == 0.0).all(dim=2)
