@@ -113,30 +113,8 @@ def cpu_baseline(state, T_full, N, budget_s=20.0):
                        f"of the reference update: fwd+loss+bwd+Adam), {cores} threads")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--T", type=int, default=64)
-    ap.add_argument("--N", type=int, default=8)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="storage/MFMA type of the map stack: f32 = parity mode (1e-4 vs reference), bf16 = BASELINE configs[1]")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
+def measure(args, dtype, steps, warmup, rank, world, local, dev):
+    """Build the policy in `dtype` mode and time `steps` updates; returns (dt, prof, loss, state_cpu)."""
     from wsmgmap import ops
     from wsmgmap.common.aux_losses import AuxLosses
     from wsmgmap.config import default_model_config
@@ -144,7 +122,7 @@ def main():
     from wsmgmap.parallel import GradAllReducer
 
     torch.manual_seed(0)
-    policy = BasePolicy(None, _Box(), default_model_config(num_proc=1, gpu_id=local, compute_dtype=args.dtype))
+    policy = BasePolicy(None, _Box(), default_model_config(num_proc=1, gpu_id=local, compute_dtype=dtype))
     policy.net.instruction_encoder.embedding_layer.weight.requires_grad_(False)  # reference default: frozen embeddings
     state_cpu = {k: v.detach().clone() for k, v in policy.state_dict().items()} if rank == 0 else None
     policy = policy.to(dev)
@@ -173,14 +151,14 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         update()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = update()
     torch.cuda.synchronize()
     if world > 1:
@@ -193,6 +171,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    del policy, opt, obs
+    torch.cuda.empty_cache()
+    return dt, prof, final_loss, state_cpu
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--T", type=int, default=64)
+    ap.add_argument("--N", type=int, default=8)
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="storage/MFMA type of the map stack: bf16 = BASELINE configs[1] (default); f32 = parity mode (1e-4 vs reference)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the extra float32 parity-mode measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    T, N = args.T, args.N
+    dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)
+    parity = None
+    if args.dtype == "bf16" and not args.no_f32:
+        k32 = max(2, args.steps // 2)
+        dt32, _, loss32, _ = measure(args, "f32", k32, 2, rank, world, local, dev)
+        parity = dict(dtype="f32", value=round(T * N * world * k32 / dt32, 2), unit="policy steps/s",
+                      ms_per_step=round(dt32 / k32 * 1e3, 3), steps=k32, loss=round(loss32, 5),
+                      note="same workload in the float32 parity mode (f32 MFMA; logits within 1e-4 of the reference)")
 
     if rank == 0:
         steps_per_s = T * N * world * args.steps / dt
@@ -229,6 +246,7 @@ def main():
                        "T": T, "N_per_gpu": N, "parallelism": f"dp{world}"},
             "whole_update_tflops": round(ALG_GFLOP_PER_STEP * steps_per_s / 1e3 / world, 2),
             "loss": round(final_loss, 5),
+            "f32_parity_mode": parity,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
         }

@@ -216,6 +216,23 @@ int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const flo
                  const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
                  void* sync_ws, wsmg_stream_t stream);
 
+/* ============================ persistent packed bidirectional LSTM ============================ */
+/* nn.LSTM(50 -> 128, bidirectional) over packed instructions (instruction_encoder.py:80-92): row b is
+ * active at token t iff t < lengths[b]; inactive positions emit 0.  Both directions run concurrently
+ * in one launch (8 cooperating workgroups each, W_hh in registers, one bounded barrier per token).
+ * gi [U][L][2][4H] = x W_ih^T + b_ih for (forward, reverse); w_hh [2][4H][H]; b_hh [2][4H]; U <= 8.
+ * out [U][L][2H] (forward | reverse); save_gates [2][U][L][4][H], save_c [2][U][L][H] feed the backward.
+ * state_ws: wsmg_lstm_state_bytes() bytes of device scratch. */
+int64_t wsmg_lstm_state_bytes(void);
+int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int U, int L,
+                  int hidden, float* out, float* save_gates, float* save_c, void* state_ws,
+                  wsmg_stream_t stream);
+/* backward through time: dout [U][L][2H] -> dgates [U][L][2][4H] (gradient of the gate pre-activations,
+ * i.e. of gi and of W_hh h + b_hh); the caller forms dW_hh, db_hh and back-propagates through its GEMM. */
+int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t* lengths, const float* save_gates,
+                  const float* save_c, int U, int L, int hidden, float* dgates, void* state_ws,
+                  wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

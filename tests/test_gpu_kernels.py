@@ -458,3 +458,39 @@ def test_masked_gru_persistent_kernel(Tn, N):
     for k in sd:
         ref = P["e.rnn." + k].grad
         close("gru.d" + k, getattr(enc.rnn, k).grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)
+
+
+# ----------------------------------------------------------------------------- persistent packed bi-LSTM
+@pytest.mark.parametrize("lens", [[80, 37], [5, 1, 200, 64, 64, 199, 3, 120], [10] * 11])
+def test_bilstm_persistent_kernel(lens):
+    """HIP packed bi-LSTM (forward + BPTT) behind InstructionEncoder vs the oracle's packed nn.LSTM in
+    float64: outputs, pad mask, and the gradients of every LSTM parameter."""
+    from util import make_params
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.encoders.instruction_encoder import InstructionEncoder
+    cfg = default_model_config().INSTRUCTION_ENCODER
+    enc = InstructionEncoder(cfg)
+    P0 = make_params(grad=False)
+    pre = "net.instruction_encoder."
+    enc.load_state_dict({k[len(pre):]: v for k, v in P0.items() if k.startswith(pre)})
+    instr = T(df.tokens(f"lstm.tok.{len(lens)}", len(lens), lens).astype(np.float32))
+    # float64 truth
+    P = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in P0.items() if k.startswith(pre)}
+    torch.set_default_dtype(torch.float64)
+    try:
+        hr, mr = policy_ref.instruction_encoder(P, instr)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    gy = T(df.uniform(f"lstm.gy.{len(lens)}", tuple(hr.shape), 2.0))
+    (hr * gy.double()).sum().backward()
+    enc = enc.cuda()
+    hid, mask = enc({"instruction": instr.cuda()})
+    assert hid.shape == hr.shape and torch.equal(mask.cpu(), mr)
+    (hid * gy.cuda()).sum().backward()
+    close("lstm.out", hid, hr, 1e-5, 2e-6)
+    for k in ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0", "weight_ih_l0_reverse", "weight_hh_l0_reverse",
+              "bias_ih_l0_reverse", "bias_hh_l0_reverse"]:
+        ref = P[pre + "encoder_rnn." + k].grad
+        close("lstm.d" + k, getattr(enc.encoder_rnn, k).grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)
+    ref = P[pre + "embedding_layer.weight"].grad
+    close("lstm.demb", enc.embedding_layer.weight.grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)

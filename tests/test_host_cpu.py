@@ -141,5 +141,5 @@ def test_instruction_encoder_dedup_matches_oracle():
     hr, mr = policy_ref.instruction_encoder(P, instr)
     assert hid.shape == hr.shape and torch.equal(mask, mr)
     assert torch.allclose(hid, hr, atol=1e-6)
-    u, m, inv = enc.encode_unique(instr)
+    u, m, inv = enc.encode_unique(instr, stock=True)
     assert u.shape[0] == 2 and inv.shape[0] == 8

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
 // ----------------------------------------------------------------------------- backward weight
 constexpr int WKP = 64;          // pixels per k-step
 constexpr int WCO = 64;          // output channels per workgroup
-constexpr int WUW = 2;           // (tap, 32-channel) units per wave (dY fragments reused across them)
+constexpr int WUW = 1;           // (tap, 32-channel) units per wave (dY fragments reused across them)
 constexpr int WUN = 4 * WUW;     // units per workgroup
 constexpr int D_LD = 192;        // dY tile row stride (bytes): 128 B data + 64 B pad -> tr reads conflict-free
 constexpr int X_LD = 64;         // X tile row stride (bytes): 32 bf16, rows land 16 banks apart

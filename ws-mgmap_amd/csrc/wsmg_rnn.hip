@@ -288,3 +288,237 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
+
+// =================================================================================================
+// Persistent packed bidirectional LSTM (instruction encoder, hidden 128 per direction, U <= 8 unique
+// instructions per launch).  Replaces the cuDNN/MIOpen packed-sequence LSTM behind nn.LSTM at
+// instruction_encoder.py:80-92 (about 10 tiny launches per token step and direction in MIOpen).
+// Same structure as the GRU kernels: per direction 8 workgroups x 4 waves, each wave keeps the
+// 16 gate rows (i,f,g,o of 4 hidden units) of W_hh in registers, lanes split K = 128, one bounded
+// grid barrier per token step per direction; both directions run concurrently in one launch.
+// Packed-sequence semantics: row b is active at step t iff t < len[b]; inactive steps freeze the
+// state and emit 0 (forward direction: after the end; reverse direction: before its first token).
+// Gate order i, f, g, o (PyTorch nn.LSTM).  gi = x W_ih^T + b_ih for both directions is one GEMM
+// done by the caller; so are dW_hh / dW_ih.
+namespace {
+
+constexpr int LH = 128;            // hidden per direction
+constexpr int L_NWG = LH / UNITS_WG;   // 8 workgroups per direction
+
+struct LstmFwdArgs {
+  const float* gi;     // [U][L][2][4*LH]
+  const float* whh;    // [2][4*LH][LH]
+  const float* bhh;    // [2][4*LH]
+  const int* len;      // [U]
+  float* out;          // [U][L][2*LH]
+  float* hs;           // [2 dir][2 ping-pong][NB][LH] recurrent state exchange (zeroed by the launcher)
+  float* sg;           // [2][U][L][4][LH] saved gates i,f,g,o
+  float* sc;           // [2][U][L][LH]    saved cell state c_t
+  unsigned* sync;      // per direction 16 words: [0] counter, [1] error
+  int U, L;
+};
+
+__global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
+  __shared__ int ok_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dir = blockIdx.x / L_NWG;
+  const int u0 = (blockIdx.x % L_NWG) * UNITS_WG + wave * UNITS_WAVE;
+  const float* whh = a.whh + (size_t)dir * 4 * LH * LH;
+  const float* bhh = a.bhh + dir * 4 * LH;
+  unsigned* sync = a.sync + dir * 16;
+  // rows r = gate*4 + unit; k = 2*lane + e
+  float w[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r >> 2) * LH + u0 + (r & 3);
+    w[r][0] = whh[(size_t)row * LH + 2 * lane];
+    w[r][1] = whh[(size_t)row * LH + 2 * lane + 1];
+  }
+  const int my_unit = u0 + ((lane >> 2) & 3);
+  const int my_b0 = 2 * (lane & 3);
+  float bi = 0.f, bf = 0.f, bg = 0.f, bo = 0.f;
+  if (lane < 16) { bi = bhh[my_unit]; bf = bhh[LH + my_unit]; bg = bhh[2 * LH + my_unit]; bo = bhh[3 * LH + my_unit]; }
+  int mylen[2] = {0, 0};
+  if (lane < 16) {
+    if (my_b0 < a.U) mylen[0] = a.len[my_b0];
+    if (my_b0 + 1 < a.U) mylen[1] = a.len[my_b0 + 1];
+  }
+  float c[2] = {0.f, 0.f};
+  float* hs = a.hs + (size_t)dir * 2 * NB * LH;
+
+  for (int s = 0; s < a.L; ++s) {
+    const int t = dir == 0 ? s : a.L - 1 - s;
+    const float* hprev = hs + (size_t)(s & 1) * NB * LH;
+    float* hnext = hs + (size_t)((s + 1) & 1) * NB * LH;
+    float hp[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      hp[b][0] = hprev[b * LH + 2 * lane];
+      hp[b][1] = hprev[b * LH + 2 * lane + 1];
+    }
+    float acc[128];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[r * 8 + b] = fmaf(w[r][1], hp[b][1], w[r][0] * hp[b][0]);
+    halve<128, 32>(acc, lane);
+    halve<64, 16>(acc, lane);
+    halve<32, 8>(acc, lane);
+    halve<16, 4>(acc, lane);
+    halve<8, 2>(acc, lane);
+    halve<4, 1>(acc, lane);
+    float f0 = __shfl(acc[0], lane + 16, 64), f1 = __shfl(acc[1], lane + 16, 64);
+    float g0 = __shfl(acc[0], lane + 32, 64), g1 = __shfl(acc[1], lane + 32, 64);
+    float o0 = __shfl(acc[0], lane + 48, 64), o1 = __shfl(acc[1], lane + 48, 64);
+    if (lane < 16) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int b = my_b0 + i;
+        if (b < a.U) {
+          const float hold = hprev[b * LH + my_unit];
+          const bool active = t < mylen[i];
+          float hnew = hold;
+          float outv = 0.f;
+          if (active) {
+            const float* g = a.gi + (((size_t)b * a.L + t) * 2 + dir) * 4 * LH;
+            float gi_ = sigmoidf_(g[my_unit] + (i ? acc[1] : acc[0]) + bi);
+            float gf_ = sigmoidf_(g[LH + my_unit] + (i ? f1 : f0) + bf);
+            float gg_ = tanhf(g[2 * LH + my_unit] + (i ? g1 : g0) + bg);
+            float go_ = sigmoidf_(g[3 * LH + my_unit] + (i ? o1 : o0) + bo);
+            c[i] = gf_ * c[i] + gi_ * gg_;
+            hnew = go_ * tanhf(c[i]);
+            outv = hnew;
+            float* sgp = a.sg + ((((size_t)dir * a.U + b) * a.L + t) * 4) * LH + my_unit;
+            sgp[0] = gi_; sgp[LH] = gf_; sgp[2 * LH] = gg_; sgp[3 * LH] = go_;
+            a.sc[(((size_t)dir * a.U + b) * a.L + t) * LH + my_unit] = c[i];
+          }
+          hnext[b * LH + my_unit] = hnew;
+          a.out[((size_t)b * a.L + t) * 2 * LH + dir * LH + my_unit] = outv;
+        }
+      }
+    }
+    if (s + 1 < a.L) {
+      if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds)) return;
+    }
+  }
+}
+
+struct LstmBwdArgs {
+  const float* dout;   // [U][L][2*LH]
+  const float* whh;    // [2][4*LH][LH]
+  const int* len;      // [U]
+  const float* sg;     // [2][U][L][4][LH]
+  const float* sc;     // [2][U][L][LH]
+  float* dg;           // [U][L][2][4*LH]  gradient of the gate pre-activations (= d gi = d gh)
+  unsigned* sync;
+  int U, L;
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
+  __shared__ int ok_lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int dir = blockIdx.x / L_NWG;
+  const int u0 = (blockIdx.x % L_NWG) * UNITS_WG + wave * UNITS_WAVE;
+  const float* whh = a.whh + (size_t)dir * 4 * LH * LH;
+  unsigned* sync = a.sync + dir * 16;
+  // columns u0..u0+3 of W_hh over the 4*LH gate rows: k = 256*q + 4*lane + e
+  float wt[4][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = 256 * q + 4 * lane + e;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wt[u][q * 4 + e] = whh[(size_t)row * LH + u0 + u];
+    }
+  const int my_unit = u0 + (lane >> 4);
+  const int my_b = (lane >> 1) & 7;
+  const bool worker = ((lane & 1) == 0) && (my_b < a.U);
+  const int mylen = worker ? a.len[my_b] : 0;
+  float carry_h = 0.f, carry_c = 0.f;
+
+  for (int s = a.L - 1; s >= 0; --s) {
+    const int t = dir == 0 ? s : a.L - 1 - s;
+    float dh_direct = 0.f;
+    if (worker) {
+      float* dgp = a.dg + (((size_t)my_b * a.L + t) * 2 + dir) * 4 * LH + my_unit;
+      if (t < mylen) {
+        const size_t o = (((size_t)dir * a.U + my_b) * a.L + t);
+        const float* sgp = a.sg + o * 4 * LH + my_unit;
+        float gi_ = sgp[0], gf_ = sgp[LH], gg_ = sgp[2 * LH], go_ = sgp[3 * LH];
+        float cn = a.sc[o * LH + my_unit];
+        // previous cell state in processing order (0 at the first active step)
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        float cp = (tp >= 0 && tp < mylen) ? a.sc[((((size_t)dir * a.U + my_b) * a.L + tp)) * LH + my_unit] : 0.f;
+        float dh = a.dout[((size_t)my_b * a.L + t) * 2 * LH + dir * LH + my_unit] + carry_h;
+        float tc = tanhf(cn);
+        float do_pre = dh * tc * go_ * (1.0f - go_);
+        float dc = dh * go_ * (1.0f - tc * tc) + carry_c;
+        float di_pre = dc * gg_ * gi_ * (1.0f - gi_);
+        float df_pre = dc * cp * gf_ * (1.0f - gf_);
+        float dg_pre = dc * gi_ * (1.0f - gg_ * gg_);
+        carry_c = dc * gf_;
+        dgp[0] = di_pre; dgp[LH] = df_pre; dgp[2 * LH] = dg_pre; dgp[3 * LH] = do_pre;
+      } else {
+        dgp[0] = 0.f; dgp[LH] = 0.f; dgp[2 * LH] = 0.f; dgp[3 * LH] = 0.f;
+        dh_direct = carry_h;  // frozen state: gradient passes straight through
+      }
+    }
+    if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds)) return;
+    float acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < a.U) {
+        const float* gsrc = a.dg + (((size_t)b * a.L + t) * 2 + dir) * 4 * LH;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 256 * q + 4 * lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u * 8 + b] = fmaf(wt[u][q * 4 + e], g[e], acc[u * 8 + b]);
+        }
+      }
+    }
+    halve<32, 32>(acc, lane);
+    halve<16, 16>(acc, lane);
+    halve<8, 8>(acc, lane);
+    halve<4, 4>(acc, lane);
+    halve<2, 2>(acc, lane);
+    float sum = acc[0] + __shfl_xor(acc[0], 1, 64);
+    carry_h = dh_direct + sum;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t wsmg_lstm_state_bytes(void) { return (int64_t)2 * 2 * NB * LH * sizeof(float) + 256; }
+
+extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int U, int L,
+                             int hidden, float* out, float* save_gates, float* save_c, void* state_ws,
+                             wsmg_stream_t stream) {
+  if (hidden != LH || U <= 0 || U > NB || L <= 0) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  const size_t hs_bytes = (size_t)2 * 2 * NB * LH * sizeof(float);
+  hipError_t e = hipMemsetAsync(state_ws, 0, hs_bytes + 256, s);
+  if (e != hipSuccess) return (int)e;
+  LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)state_ws, save_gates, save_c,
+                (unsigned*)((char*)state_ws + hs_bytes), U, L};
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t* lengths, const float* save_gates,
+                             const float* save_c, int U, int L, int hidden, float* dgates, void* state_ws,
+                             wsmg_stream_t stream) {
+  if (hidden != LH || U <= 0 || U > NB || L <= 0) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  const size_t hs_bytes = (size_t)2 * 2 * NB * LH * sizeof(float);
+  hipError_t e = hipMemsetAsync((char*)state_ws + hs_bytes, 0, 256, s);
+  if (e != hipSuccess) return (int)e;
+  LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)((char*)state_ws + hs_bytes), U, L};
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  WSMG_RETURN_LAUNCH();
+}

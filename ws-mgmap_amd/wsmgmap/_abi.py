@@ -60,7 +60,10 @@ _SIG["wsmg_conv2d_bwd_data_bf16"] = [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
 _SIG["wsmg_gru_sync_bytes"] = []
 _SIG["wsmg_gru_fwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_p]
 _SIG["wsmg_gru_bwd"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_p]
-_RESTYPE = {"wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_sync_bytes": c_l}
+_SIG["wsmg_lstm_state_bytes"] = []
+_SIG["wsmg_lstm_fwd"] = [c_p] * 4 + [c_i] * 3 + [c_p] * 4 + [c_p]
+_SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
+_RESTYPE = {"wsmg_lstm_state_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_sync_bytes": c_l}
 
 _lib = None
 

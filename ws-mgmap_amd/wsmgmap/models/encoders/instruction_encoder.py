@@ -1,6 +1,6 @@
 """Instruction encoder: embedding + packed bidirectional LSTM.  State_dict keys and config
-fields follow the reference (instruction_encoder.py:10-93).  The recurrent cell itself is the
-stock PyTorch-ROCm (MIOpen) LSTM — it is not one of the three hand-written operators.
+fields follow the reference (instruction_encoder.py:10-93).  On the GPU the recurrence runs as one
+persistent packed bi-LSTM launch (csrc/wsmg_rnn.hip) instead of ~10 MIOpen launches per token.
 
 Differences in data flow (results identical):
   * output is token-major [B, L, 256] (what the attention kernel streams), the reference's
@@ -38,7 +38,7 @@ class InstructionEncoder(nn.Module):
     def _dedup(tokens):
         """Unique rows of a [B, L] token matrix without a row-wise sort: a 64-bit polynomial hash per
         row, a 1-D unique over the B hashes, and an exact on-device check (a hash collision falls back
-        to torch.unique(dim=0)).  Returns (unique rows [U, L], inverse [B], lengths on the host)."""
+        to torch.unique(dim=0)).  Returns (unique rows [U, L], inverse [B], lengths on host, on device)."""
         B, L = tokens.shape
         mult = (torch.arange(1, L + 1, device=tokens.device, dtype=torch.int64) * 0x9E3779B97F4A7C15) | 1
         h = (tokens * mult).sum(dim=1)
@@ -52,21 +52,39 @@ class InstructionEncoder(nn.Module):
         host = torch.cat([exact, lengths]).cpu()
         if int(host[0]) != 1:  # hash collision: exact path
             uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
-            return uniq, inverse, (uniq != 0).long().sum(dim=1).cpu()
-        return uniq, inverse, host[1:]
+            lengths = (uniq != 0).long().sum(dim=1)
+            return uniq, inverse, lengths.cpu(), lengths
+        return uniq, inverse, host[1:], lengths
 
-    def encode_unique(self, instruction):
-        """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows."""
+    def encode_unique(self, instruction, stock=False):
+        """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows.
+        stock=False: persistent HIP bi-LSTM (csrc/wsmg_rnn.hip); stock=True: nn.LSTM on a packed
+        sequence (MIOpen / CPU), kept for comparison in tests."""
         tokens = instruction.long()
-        uniq, inverse, lengths = self._dedup(tokens)
-        embedded = self.embedding_layer(uniq)
-        packed = nn.utils.rnn.pack_padded_sequence(embedded, lengths, batch_first=True, enforce_sorted=False)
-        output, _ = self.encoder_rnn(packed)
-        hidden = nn.utils.rnn.pad_packed_sequence(output, batch_first=True)[0]  # [U, L, D]
+        uniq, inverse, len_host, len_dev = self._dedup(tokens)
+        if stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
+            embedded = self.embedding_layer(uniq)
+            packed = nn.utils.rnn.pack_padded_sequence(embedded, len_host, batch_first=True, enforce_sorted=False)
+            output, _ = self.encoder_rnn(packed)
+            hidden = nn.utils.rnn.pad_packed_sequence(output, batch_first=True)[0]  # [U, L, D]
+        else:
+            from ... import ops
+            r = self.encoder_rnn
+            lmax = int(len_host.max())
+            embedded = self.embedding_layer(uniq[:, :lmax])                     # [U, L, E]
+            w_ih = torch.cat([r.weight_ih_l0, r.weight_ih_l0_reverse], dim=0)   # [2*4H, E]
+            b_ih = torch.cat([r.bias_ih_l0, r.bias_ih_l0_reverse], dim=0)
+            U = uniq.shape[0]
+            gi = torch.addmm(b_ih, embedded.reshape(U * lmax, -1), w_ih.t()).view(U, lmax, 2, -1)
+            w_hh = torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse])
+            b_hh = torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse])
+            lens = len_dev.to(torch.int32)
+            parts = [ops.bilstm(gi[c:c + 8], w_hh, b_hh, lens[c:c + 8]) for c in range(0, U, 8)]
+            hidden = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         mask = (hidden == 0.0).all(dim=2)
         return hidden.contiguous(), mask, inverse
 
     def forward(self, observations):
         """Reference-shaped result: ([B, D, L], mask [B, L])."""
-        hidden, mask, inverse = self.encode_unique(observations["instruction"])
+        hidden, mask, inverse = self.encode_unique(observations["instruction"], stock=not observations["instruction"].is_cuda)
         return hidden[inverse].permute(0, 2, 1), mask[inverse]

@@ -484,6 +484,49 @@ def masked_gru(gi, w_hh, b_hh, h0, masks):
     return _MaskedGRU.apply(gi.contiguous(), w_hh.contiguous(), b_hh.contiguous(), h0.contiguous(), masks.contiguous())
 
 
+# ----------------------------------------------------------------------------- persistent packed bi-LSTM
+class _BiLSTM(torch.autograd.Function):
+    """gi [U,L,2,4H], w_hh [2,4H,H], b_hh [2,4H], lengths int32 [U] -> out [U,L,2H]."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, lengths):
+        _req(gi, w_hh, b_hh, lengths)
+        _f32(gi, w_hh, b_hh)
+        U, L, _, H4 = gi.shape
+        H = H4 // 4
+        dev = gi.device
+        out = torch.empty(U, L, 2 * H, device=dev, dtype=torch.float32)
+        sg = torch.zeros(2, U, L, 4, H, device=dev, dtype=torch.float32)
+        sc = torch.zeros(2, U, L, H, device=dev, dtype=torch.float32)
+        ws = torch.empty(int(_abi.lib().wsmg_lstm_state_bytes()) // 4, device=dev, dtype=torch.int32)
+        _abi.call("wsmg_lstm_fwd", _p(gi), _p(w_hh), _p(b_hh), _p(lengths), U, L, H, _p(out), _p(sg), _p(sc), _p(ws), _stream())
+        ctx.save_for_backward(w_hh, lengths, out, sg, sc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w_hh, lengths, out, sg, sc = ctx.saved_tensors
+        U, L, H2 = out.shape
+        H = H2 // 2
+        dev = out.device
+        dout = dout.contiguous()
+        dg = torch.empty(U, L, 2, 4 * H, device=dev, dtype=torch.float32)
+        ws = torch.empty(int(_abi.lib().wsmg_lstm_state_bytes()) // 4, device=dev, dtype=torch.int32)
+        _abi.call("wsmg_lstm_bwd", _p(dout), _p(w_hh), _p(lengths), _p(sg), _p(sc), U, L, H, _p(dg), _p(ws), _stream())
+        zero = torch.zeros(U, 1, H, device=dev, dtype=torch.float32)
+        hprev_f = torch.cat([zero, out[:, :-1, :H]], dim=1)       # state before step t (forward direction)
+        hprev_r = torch.cat([out[:, 1:, H:], zero], dim=1)        # state before step t (reverse direction)
+        dw = torch.stack([dg[:, :, 0].reshape(U * L, 4 * H).t() @ hprev_f.reshape(U * L, H),
+                          dg[:, :, 1].reshape(U * L, 4 * H).t() @ hprev_r.reshape(U * L, H)])
+        db = dg.sum(dim=(0, 1))
+        return dg, dw, db, None
+
+
+def bilstm(gi, w_hh, b_hh, lengths):
+    """Packed bidirectional LSTM over <= 8 sequences in one persistent launch."""
+    return _BiLSTM.apply(gi.contiguous(), w_hh.contiguous(), b_hh.contiguous(), lengths.contiguous())
+
+
 # ----------------------------------------------------------------------------- BEV (no autograd: rollout only)
 @torch.no_grad()
 def bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=0.12):
