@@ -42,9 +42,12 @@ struct ConvArgsB {
   int B, SH, SW, Kc, TH, TW, N, KH, KW, stride, pad;
   int mtiles, ntiles;
   int out_f32;
+  int tap_inner;   // 1: k-steps walk the taps of one channel chunk back to back (shifted re-reads hit L1)
 };
 
-template <bool BWD, int BN, int BK>
+// PF = k-steps of global loads kept in flight in registers (a bf16 k-step is only 256-512 MFMA
+// cycles, far less than the L2/HBM latency, so one step of look-ahead leaves the loads exposed).
+template <bool BWD, int BN, int BK, int PF>
 __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   constexpr int LDB = BK * 2 + 16;           // LDS row stride in bytes
   constexpr int SEGS = BK / 8;               // 16-B segments per row (8 bf16 each)
@@ -98,10 +101,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   const int steps = KHc * KWc * kchunks;
   const int taps = a.KH * a.KW;
 
-  u32x4 ra[APASS], rb[BPASS];
-  auto gload = [&](int step) {
-    int tc = step / kchunks;
-    int c0 = (step - tc * kchunks) * BK + seg * 8;
+  u32x4 ra[PF][APASS], rb[PF][BPASS];
+  const int ntap_c = KHc * KWc;
+  auto gload = [&](int step, u32x4 (&ra)[APASS], u32x4 (&rb)[BPASS]) {
+    int tc, ch;
+    if (a.tap_inner) { ch = step / ntap_c; tc = step - ch * ntap_c; }
+    else { tc = step / kchunks; ch = step - tc * kchunks; }
+    int c0 = ch * BK + seg * 8;
     int ay = tc / KWc, ax = tc - ay * KWc;
     int ky = BWD ? cy + ay * tstep : ay, kx = BWD ? cx + ax * tstep : ax;
     int tap = ky * a.KW + kx;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
       rb[i] = v;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const u32x4 (&ra)[APASS], const u32x4 (&rb)[BPASS]) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) *reinterpret_cast<u32x4*>(&As[(lrow + RPP * i) * LDB + seg * 16]) = ra[i];
 #pragma unroll
@@ -140,31 +146,41 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  gload(0);
-  lstore();
+  // register set j holds the k-step with (step % PF == j); LDS holds the current step
+  gload(0, ra[0], rb[0]);
+  lstore(ra[0], rb[0]);
   __syncthreads();
-  for (int step = 0; step < steps; ++step) {
-    if (step + 1 < steps) gload(step + 1);
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      // lane (r, h) holds k = 16*ks + 8h .. +7 of its row: one 16-B LDS read per operand
-      bf16x8 af[2], bf[NT];
+  for (int j = 1; j < PF; ++j)
+    if (j < steps) gload(j, ra[j], rb[j]);
+  for (int step0 = 0; step0 < steps; step0 += PF) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        af[t] = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 * t + r) * LDB + ks * 32 + h * 16]);
+    for (int j = 0; j < PF; ++j) {
+      const int step = step0 + j;
+      if (step < steps) {
+        if (step + PF < steps) gload(step + PF, ra[j], rb[j]);  // set j is free: its step is in LDS
 #pragma unroll
-      for (int u = 0; u < NT; ++u)
-        bf[u] = *reinterpret_cast<const bf16x8*>(&Bs[(wn + 32 * u + r) * LDB + ks * 32 + h * 16]);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          // lane (r, h) holds k = 16*ks + 8h .. +7 of its row: one 16-B LDS read per operand
+          bf16x8 af[2], bf[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
+            af[t] = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 * t + r) * LDB + ks * 32 + h * 16]);
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bf[u], acc[t][u], 0, 0, 0);
-    }
-    __syncthreads();
-    if (step + 1 < steps) {
-      lstore();
-      __syncthreads();
+          for (int u = 0; u < NT; ++u)
+            bf[u] = *reinterpret_cast<const bf16x8*>(&Bs[(wn + 32 * u + r) * LDB + ks * 32 + h * 16]);
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+              acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bf[u], acc[t][u], 0, 0, 0);
+        }
+        __syncthreads();
+        if (step + 1 < steps) {
+          lstore(ra[(j + 1) % PF], rb[(j + 1) % PF]);
+          __syncthreads();
+        }
+      }
     }
   }
 
@@ -211,6 +227,7 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)(p));
 }
 
+template <int PF>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   __shared__ __attribute__((aligned(16))) unsigned char Ds[WKP * D_LD];
   __shared__ __attribute__((aligned(16))) unsigned char Xs[WUN * WKP * X_LD];
@@ -248,8 +265,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  u32x4 rd[2], rx[WUN];
-  auto gload = [&](int64_t p0) {
+  u32x4 rd[PF][2], rx[PF][WUN];
+  auto gload = [&](int64_t p0, u32x4 (&rd)[2], u32x4 (&rx)[WUN]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int64_t p = p0 + dpx + 32 * i;
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
       rx[u] = v;
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](const u32x4 (&rd)[2], const u32x4 (&rx)[WUN]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Ds[(dpx + 32 * i) * D_LD + dseg * 16]) = rd[i];
 #pragma unroll
@@ -289,13 +306,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const unsigned char* b_base = &Xs[(wave * WUW * WKP + 8 * h + q) * X_LD + (half16 * 16 + p4 * 4) * 2];
 
   if (p_begin < p_end) {
-    gload(p_begin);
-    lstore();
+    gload(p_begin, rd[0], rx[0]);
+    lstore(rd[0], rx[0]);
   }
   __syncthreads();
-  for (int64_t p0 = p_begin; p0 < p_end; p0 += WKP) {
+#pragma unroll
+  for (int j = 1; j < PF; ++j)
+    if (p_begin + (int64_t)j * WKP < p_end) gload(p_begin + (int64_t)j * WKP, rd[j], rx[j]);
+  for (int64_t pb = p_begin; pb < p_end; pb += (int64_t)PF * WKP) {
+#pragma unroll
+   for (int j = 0; j < PF; ++j) {
+    const int64_t p0 = pb + (int64_t)j * WKP;
+    if (p0 >= p_end) break;
     bool more = p0 + WKP < p_end;
-    if (more) gload(p0 + WKP);
+    if (p0 + (int64_t)PF * WKP < p_end) gload(p0 + (int64_t)PF * WKP, rd[j], rx[j]);
 #pragma unroll
     for (int ks = 0; ks < WKP / 16; ++ks) {
       bf16x4 a0l = tr_read(a_base0 + (16 * ks) * D_LD), a0h = tr_read(a_base0 + (16 * ks + 4) * D_LD);
@@ -313,9 +337,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
     }
     __syncthreads();
     if (more) {
-      lstore();
+      lstore(rd[(j + 1) % PF], rx[(j + 1) % PF]);
       __syncthreads();
     }
+   }
   }
   const int r = lane & 31;
   const int taps = a.KH * a.KW;
@@ -345,22 +370,54 @@ int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int strid
   return 0;
 }
 
+int conv_tap_inner() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WSMG_CONV_TAP_INNER");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v;
+}
+
+// register prefetch depth (k-steps in flight).  Measured on MI355X (tools/bench_conv.py): the igemm
+// kernels are fastest at 1 (deeper costs a wave of occupancy), backward-weight at 2.
+int conv_prefetch(int dflt) {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("WSMG_CONV_PF");
+    v = e ? atoi(e) : -1;
+    if (v < 1 || v > 3) v = -1;
+  }
+  return v > 0 ? v : dflt;
+}
+
+template <bool BWD, int PF>
+void launch_igemm_pf(ConvArgsB& a, dim3 grid, bool bk64, bool bn128, hipStream_t s) {
+  if (bk64 && bn128)
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 128, 64, PF>), grid, dim3(256), 0, s, a);
+  else if (bk64)
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 64, 64, PF>), grid, dim3(256), 0, s, a);
+  else if (bn128)
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 128, 32, PF>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 64, 32, PF>), grid, dim3(256), 0, s, a);
+}
+
 template <bool BWD>
 void launch_igemm(ConvArgsB& a, int64_t mrows, int classes, hipStream_t s) {
+  a.tap_inner = conv_tap_inner();
   const bool bk64 = (a.Kc % 64) == 0;
   const bool bn128 = a.N >= 128;
   const int bn = bn128 ? 128 : 64;
   a.mtiles = (int)wsmg_cdiv(mrows, BM);
   a.ntiles = (int)wsmg_cdiv(a.N, bn);
   dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)classes);
-  if (bk64 && bn128)
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 128, 64>), grid, dim3(256), 0, s, a);
-  else if (bk64)
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 64, 64>), grid, dim3(256), 0, s, a);
-  else if (bn128)
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 128, 32>), grid, dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((conv_igemm_bf16_kernel<BWD, 64, 32>), grid, dim3(256), 0, s, a);
+  switch (conv_prefetch(1)) {
+    case 1: launch_igemm_pf<BWD, 1>(a, grid, bk64, bn128, s); break;
+    case 3: launch_igemm_pf<BWD, 3>(a, grid, bk64, bn128, s); break;
+    case 2: launch_igemm_pf<BWD, 2>(a, grid, bk64, bn128, s); break;
+    default: launch_igemm_pf<BWD, 1>(a, grid, bk64, bn128, s); break;
+  }
 }
 
 }  // namespace
@@ -369,7 +426,7 @@ extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const flo
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
                                     int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32};
+  ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32, 0};
   launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream));
   WSMG_RETURN_LAUNCH();
 }
@@ -378,7 +435,7 @@ extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, voi
                                          int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                          wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32};
+  ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32, 0};
   int classes = 1;
   int64_t mmax = (int64_t)B * H * W;
   if (stride == 2) {
@@ -404,6 +461,10 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
   if (gz > 65535) gz = 65535;
   a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WKP) * WKP;
   gz = wsmg_cdiv(a.npix, a.chunk);
-  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
+  switch (conv_prefetch(2)) {
+    case 1: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a); break;
+    case 3: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a); break;
+    default: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a); break;
+  }
   WSMG_RETURN_LAUNCH();
 }

@@ -131,34 +131,39 @@ __global__ void bn_eval_prepare_kernel(const float* running_mean, const float* r
   save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-// y = act((x - mean) * invstd * gamma + beta (+ res)); 4 channels per thread
+// y = act((x - mean) * invstd * gamma + beta (+ res)).  Each thread owns ONE channel quad for the
+// whole launch (per-channel constants live in registers) and walks rows with a grid stride.
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, int relu, int64_t n4,
+                                                       const float* __restrict__ invstd, int relu, int64_t rows,
                                                        int C, T* __restrict__ y) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)((i * 4) % C);
-    f32x4 v = ld4(x + i * 4);
-    f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-    f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-    f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
-    f32x4 s = *reinterpret_cast<const f32x4*>(invstd + c);
-    f32x4 o;
+  const int C4 = C >> 2;
+  const int c = (threadIdx.x % C4) * 4;
+  const int rl = threadIdx.x / C4;
+  const int rpi = 256 / C4;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+  const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+  const f32x4 s = *reinterpret_cast<const f32x4*>(invstd + c);
+  for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
+    const size_t o = (size_t)r * C + c;
+    f32x4 v = ld4(x + o);
+    f32x4 out;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (v[j] - m[j]) * s[j] * g[j] + b[j];
+    for (int j = 0; j < 4; ++j) out[j] = (v[j] - m[j]) * s[j] * g[j] + b[j];
     if (res) {
-      f32x4 rr = ld4(res + i * 4);
+      f32x4 rr = ld4(res + o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += rr[j];
+      for (int j = 0; j < 4; ++j) out[j] += rr[j];
     }
     if (relu) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = o[j] > 0.f ? o[j] : 0.f;
+      for (int j = 0; j < 4; ++j) out[j] = out[j] > 0.f ? out[j] : 0.f;
     }
-    st4(y + i * 4, o);
+    st4(y + o, out);
   }
 }
 
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* part,
   }
 }
 
+// dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n), g = dy masked by the ReLU; fixed channel quad per thread
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y,
@@ -182,34 +188,46 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, int relu, float inv_n,
-                                                           int64_t n4, int C, T* __restrict__ dx,
+                                                           int64_t rows, int C, T* __restrict__ dx,
                                                            T* __restrict__ dres) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)((i * 4) % C);
-    f32x4 g = ld4(dy + i * 4);
-    f32x4 xv = ld4(x + i * 4);
+  const int C4 = C >> 2;
+  const int c = (threadIdx.x % C4) * 4;
+  const int rl = threadIdx.x / C4;
+  const int rpi = 256 / C4;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+  const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+  const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c);
+  const f32x4 db = *reinterpret_cast<const f32x4*>(dbeta + c);
+  f32x4 k0, k1, k2;  // dx = k0 * (g - k1 - xhat * k2)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { k0[j] = gm[j] * is[j]; k1[j] = db[j] * inv_n; k2[j] = dg[j] * inv_n; }
+  for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
+    const size_t o = (size_t)r * C + c;
+    f32x4 g = ld4(dy + o);
+    f32x4 xv = ld4(x + o);
     if (relu) {
-      f32x4 yv = ld4(y + i * 4);
+      f32x4 yv = ld4(y + o);
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
     }
-    if (dres) st4(dres + i * 4, g);
-    f32x4 o;
+    if (dres) st4(dres + o, g);
+    f32x4 out;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float is = invstd[c + j];
-      float xh = (xv[j] - mean[c + j]) * is;
-      o[j] = gamma[c + j] * is * (g[j] - dbeta[c + j] * inv_n - xh * dgamma[c + j] * inv_n);
+      float xh = (xv[j] - mu[j]) * is[j];
+      out[j] = k0[j] * (g[j] - k1[j] - xh * k2[j]);
     }
-    st4(dx + i * 4, o);
+    st4(dx + o, out);
   }
 }
 
 bool chan_ok(int C) { return C == 32 || C == 64 || C == 128 || C == 256; }
 
-int stream_grid(int64_t n4) {
-  int64_t g = wsmg_cdiv(n4, 256);
-  if (g > 8192) g = 8192;
+int stream_grid(int64_t rows, int C) {
+  int64_t rpi = 256 / (C / 4);
+  int64_t g = wsmg_cdiv(rows, rpi * 4);   // >= 4 rows per thread
+  if (g > 4096) g = 4096;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -244,9 +262,8 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, running_mean, running_var, eps, C,
                        save_mean, save_invstd);
   }
-  int64_t n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(n4)), dim3(256), 0, s, x, residual, gamma, beta, save_mean,
-                     save_invstd, relu, n4, C, y);
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, x, residual, gamma, beta,
+                     save_mean, save_invstd, relu, rows, C, y);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -261,9 +278,8 @@ int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const 
   hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
                      relu, rows, C, workspace);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
-  int64_t n4 = rows * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(n4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
-                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, n4, C, dx, dresidual);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
+                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual);
   WSMG_RETURN_LAUNCH();
 }
 
