@@ -34,6 +34,14 @@ __device__ __forceinline__ unsigned short f2bf_bits(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// raw buffer resource over a tensor: 32-bit byte offsets, out-of-range lanes read 0 (no branches)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
 struct ConvArgsB {
   const bf16_t* src;  // [B][SH][SW][Kc]
   const bf16_t* wt;   // [N][KH][KW][Kc]
@@ -42,7 +50,7 @@ struct ConvArgsB {
   int B, SH, SW, Kc, TH, TW, N, KH, KW, stride, pad;
   int mtiles, ntiles;
   int out_f32;
-  int tap_inner;   // 1: k-steps walk the taps of one channel chunk back to back (shifted re-reads hit L1)
+  unsigned src_bytes, wt_bytes;
 };
 
 // PF = k-steps of global loads kept in flight in registers (a bf16 k-step is only 256-512 MFMA
@@ -76,57 +84,67 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   const int Mc = a.B * THc * TWc;
   if (m0 >= Mc) return;
 
-  int pb[APASS], py[APASS], px[APASS];
-  bool pv[APASS];
+  // Address generation is kept off the critical path (the kernel is instruction-issue bound once the
+  // MFMAs are bf16): per staged row ONE 32-bit base offset and two validity bitmasks (bit t = class tap
+  // t in range) are computed once; per k-step the uniform tap/chunk iterator contributes one scalar
+  // delta; invalid rows get offset -1 and the buffer load returns zeros.
+  // Source coordinate of class tap (ay, ax): sy = py + sg*ay, sx = px + sg*ax  (sg = +1 fwd, -1 bwd).
+  const int sg = BWD ? -1 : 1;
+  int roff[APASS];
+  unsigned ymask[APASS], xmask[APASS];
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     int m = m0 + lrow + RPP * i;
-    pv[i] = m < Mc;
-    int mm = pv[i] ? m : 0;
+    bool pv = m < Mc;
+    int mm = pv ? m : 0;
     int b = mm / (THc * TWc);
     int r = mm - b * (THc * TWc);
     int iy = r / TWc, ix = r - iy * TWc;
     int ty = ty0 + iy * tstep, tx = tx0 + ix * tstep;
-    pb[i] = b * a.SH * a.SW;
+    int py, px;
     if (BWD) {
-      py[i] = (a.stride == 2) ? ((ty + a.pad - cy) >> 1) : ty + a.pad;
-      px[i] = (a.stride == 2) ? ((tx + a.pad - cx) >> 1) : tx + a.pad;
+      py = (a.stride == 2) ? ((ty + a.pad - cy) >> 1) : ty + a.pad;
+      px = (a.stride == 2) ? ((tx + a.pad - cx) >> 1) : tx + a.pad;
     } else {
-      py[i] = ty * a.stride - a.pad;
-      px[i] = tx * a.stride - a.pad;
+      py = ty * a.stride - a.pad;
+      px = tx * a.stride - a.pad;
     }
-    if (seg == 0) dpix[lrow + RPP * i] = pv[i] ? (b * a.TH + ty) * a.TW + tx : -1;
+    unsigned ym = 0, xm = 0;
+    for (int t = 0; t < KHc; ++t) { int sy = py + sg * t; if (sy >= 0 && sy < a.SH) ym |= 1u << t; }
+    for (int t = 0; t < KWc; ++t) { int sx = px + sg * t; if (sx >= 0 && sx < a.SW) xm |= 1u << t; }
+    ymask[i] = pv ? ym : 0u;
+    xmask[i] = xm;
+    roff[i] = ((b * a.SH + py) * a.SW + px) * a.Kc + seg * 8;
+    if (seg == 0) dpix[lrow + RPP * i] = pv ? (b * a.TH + ty) * a.TW + tx : -1;
+  }
+  const int taps = a.KH * a.KW;
+  int woff[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    int n = n0 + lrow + RPP * i;
+    woff[i] = n < a.N ? n * taps * a.Kc + seg * 8 : -0x40000000;  // far out of range -> zeros
   }
   const int kchunks = a.Kc / BK;
   const int steps = KHc * KWc * kchunks;
-  const int taps = a.KH * a.KW;
+  const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(a.src, a.src_bytes);
+  const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt, a.wt_bytes);
 
+  // uniform k-step iterator: channel chunk outermost, taps innermost (consecutive steps re-read the
+  // same pixels shifted by one tap: L1-friendly); advanced once per gload call, never divided.
+  int it_ch = 0, it_ay = 0, it_ax = 0;
   u32x4 ra[PF][APASS], rb[PF][BPASS];
-  const int ntap_c = KHc * KWc;
-  auto gload = [&](int step, u32x4 (&ra)[APASS], u32x4 (&rb)[BPASS]) {
-    int tc, ch;
-    if (a.tap_inner) { ch = step / ntap_c; tc = step - ch * ntap_c; }
-    else { tc = step / kchunks; ch = step - tc * kchunks; }
-    int c0 = ch * BK + seg * 8;
-    int ay = tc / KWc, ax = tc - ay * KWc;
-    int ky = BWD ? cy + ay * tstep : ay, kx = BWD ? cx + ax * tstep : ax;
-    int tap = ky * a.KW + kx;
+  auto gload = [&](u32x4 (&ra)[APASS], u32x4 (&rb)[BPASS]) {
+    const int ky = BWD ? cy + it_ay * tstep : it_ay, kx = BWD ? cx + it_ax * tstep : it_ax;
+    const int sdelta = sg * (it_ay * a.SW + it_ax) * a.Kc + it_ch * BK;
+    const int wdelta = (ky * a.KW + kx) * a.Kc + it_ch * BK;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      int sy = BWD ? py[i] - ((a.stride == 2) ? ay : ky) : py[i] + ky;
-      int sx = BWD ? px[i] - ((a.stride == 2) ? ax : kx) : px[i] + kx;
-      bool ok = pv[i] && sy >= 0 && sy < a.SH && sx >= 0 && sx < a.SW;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const u32x4*>(a.src + ((size_t)(pb[i] + sy * a.SW + sx)) * a.Kc + c0);
-      ra[i] = v;
+      bool ok = ((ymask[i] >> it_ay) & (xmask[i] >> it_ax) & 1u) != 0;
+      ra[i] = buf_load16(rs_src, ok ? (roff[i] + sdelta) * 2 : -1);
     }
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      int n = n0 + lrow + RPP * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < a.N) v = *reinterpret_cast<const u32x4*>(a.wt + ((size_t)n * taps + tap) * a.Kc + c0);
-      rb[i] = v;
-    }
+    for (int i = 0; i < BPASS; ++i) rb[i] = buf_load16(rs_wt, (woff[i] + wdelta) * 2);
+    if (++it_ax == KWc) { it_ax = 0; if (++it_ay == KHc) { it_ay = 0; ++it_ch; } }
   };
   auto lstore = [&](const u32x4 (&ra)[APASS], const u32x4 (&rb)[BPASS]) {
 #pragma unroll
@@ -147,18 +165,18 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
   // register set j holds the k-step with (step % PF == j); LDS holds the current step
-  gload(0, ra[0], rb[0]);
+  gload(ra[0], rb[0]);
   lstore(ra[0], rb[0]);
   __syncthreads();
 #pragma unroll
   for (int j = 1; j < PF; ++j)
-    if (j < steps) gload(j, ra[j], rb[j]);
+    if (j < steps) gload(ra[j], rb[j]);
   for (int step0 = 0; step0 < steps; step0 += PF) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
       const int step = step0 + j;
       if (step < steps) {
-        if (step + PF < steps) gload(step + PF, ra[j], rb[j]);  // set j is free: its step is in LDS
+        if (step + PF < steps) gload(ra[j], rb[j]);  // set j is free: its step is in LDS
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
           // lane (r, h) holds k = 16*ks + 8h .. +7 of its row: one 16-B LDS read per operand
@@ -221,6 +239,7 @@ struct WgradArgsB {
   int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW;
   int units;
   int64_t npix, chunk;
+  unsigned x_bytes, dy_bytes;
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
@@ -265,30 +284,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
+  // Address generation without per-step divisions or branches (the kernel is issue-bound): each thread
+  // keeps the (image, oy, ox) of the pixel it stages and advances it by WKP pixels per k-step; unit
+  // offsets are thread-invariant; invalid pieces get offset -1 and the buffer load returns zeros.
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(a.dy, a.dy_bytes);
+  const bool co_ok = (co0 + dseg * 8) < a.Cout;
+  int udelta[WUN];
+#pragma unroll
+  for (int u = 0; u < WUN; ++u) udelta[u] = (uky[u] * a.W + ukx[u]) * a.Cin + uci[u] + xseg * 8;
+  // pixel iterator of the X staging row (pixel p_begin + xpx + k*WKP)
+  int it_b, it_oy, it_ox;
+  {
+    int64_t p = p_begin + xpx;
+    if (p >= a.npix) p = a.npix - 1;
+    it_b = (int)(p / ohw);
+    int rem = (int)(p - (int64_t)it_b * ohw);
+    it_oy = rem / a.OW;
+    it_ox = rem - it_oy * a.OW;
+  }
+  const int adv_b = WKP / ohw, adv_rem = WKP - adv_b * ohw;
+  const int adv_oy = adv_rem / a.OW, adv_ox = adv_rem - adv_oy * a.OW;
+  int it_p = (int)p_begin;  // first pixel of the k-step about to be loaded
+  const int pend = (int)p_end;
   u32x4 rd[PF][2], rx[PF][WUN];
-  auto gload = [&](int64_t p0, u32x4 (&rd)[2], u32x4 (&rx)[WUN]) {
+  auto gload = [&](u32x4 (&rd)[2], u32x4 (&rx)[WUN]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int64_t p = p0 + dpx + 32 * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      int co = co0 + dseg * 8;
-      if (p < p_end && co < a.Cout) v = *reinterpret_cast<const u32x4*>(a.dy + (size_t)p * a.Cout + co);
-      rd[i] = v;
+      int p = it_p + dpx + 32 * i;
+      bool ok = co_ok && p < pend;
+      rd[i] = buf_load16(rs_dy, ok ? (p * a.Cout + co0 + dseg * 8) * 2 : -1);
     }
-    int64_t p = p0 + xpx;
-    bool pok = p < p_end;
-    int64_t pp = pok ? p : 0;
-    int b = (int)(pp / ohw);
-    int rem = (int)(pp - (int64_t)b * ohw);
-    int oy = rem / a.OW, ox = rem - oy * a.OW;
+    const bool pok = (it_p + xpx) < pend;
+    const int y0 = it_oy * a.stride - a.pad, x0 = it_ox * a.stride - a.pad;
+    const int base = ((it_b * a.H + y0) * a.W + x0) * a.Cin;
 #pragma unroll
     for (int u = 0; u < WUN; ++u) {
-      int iy = oy * a.stride - a.pad + uky[u], ix = ox * a.stride - a.pad + ukx[u];
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pok && uok[u] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-        v = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(b * a.H + iy) * a.W + ix) * a.Cin + uci[u] + xseg * 8);
-      rx[u] = v;
+      bool ok = pok && uok[u] && (unsigned)(y0 + uky[u]) < (unsigned)a.H && (unsigned)(x0 + ukx[u]) < (unsigned)a.W;
+      rx[u] = buf_load16(rs_x, ok ? (base + udelta[u]) * 2 : -1);
     }
+    // advance by WKP pixels
+    it_p += WKP;
+    it_ox += adv_ox;
+    if (it_ox >= a.OW) { it_ox -= a.OW; ++it_oy; }
+    it_oy += adv_oy;
+    if (it_oy >= a.OH) { it_oy -= a.OH; ++it_b; }
+    it_b += adv_b;
   };
   auto lstore = [&](const u32x4 (&rd)[2], const u32x4 (&rx)[WUN]) {
 #pragma unroll
@@ -306,20 +347,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const unsigned char* b_base = &Xs[(wave * WUW * WKP + 8 * h + q) * X_LD + (half16 * 16 + p4 * 4) * 2];
 
   if (p_begin < p_end) {
-    gload(p_begin, rd[0], rx[0]);
+    gload(rd[0], rx[0]);
     lstore(rd[0], rx[0]);
   }
   __syncthreads();
 #pragma unroll
   for (int j = 1; j < PF; ++j)
-    if (p_begin + (int64_t)j * WKP < p_end) gload(p_begin + (int64_t)j * WKP, rd[j], rx[j]);
+    if (p_begin + (int64_t)j * WKP < p_end) gload(rd[j], rx[j]);
   for (int64_t pb = p_begin; pb < p_end; pb += (int64_t)PF * WKP) {
 #pragma unroll
    for (int j = 0; j < PF; ++j) {
     const int64_t p0 = pb + (int64_t)j * WKP;
     if (p0 >= p_end) break;
     bool more = p0 + WKP < p_end;
-    if (p0 + (int64_t)PF * WKP < p_end) gload(p0 + (int64_t)PF * WKP, rd[j], rx[j]);
+    if (p0 + (int64_t)PF * WKP < p_end) gload(rd[j], rx[j]);
 #pragma unroll
     for (int ks = 0; ks < WKP / 16; ++ks) {
       bf16x4 a0l = tr_read(a_base0 + (16 * ks) * D_LD), a0h = tr_read(a_base0 + (16 * ks + 4) * D_LD);
@@ -370,15 +411,6 @@ int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int strid
   return 0;
 }
 
-int conv_tap_inner() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WSMG_CONV_TAP_INNER");
-    v = e ? (atoi(e) != 0) : 1;
-  }
-  return v;
-}
-
 // register prefetch depth (k-steps in flight).  Measured on MI355X (tools/bench_conv.py): the igemm
 // kernels are fastest at 1 (deeper costs a wave of occupancy), backward-weight at 2.
 int conv_prefetch(int dflt) {
@@ -405,7 +437,6 @@ void launch_igemm_pf(ConvArgsB& a, dim3 grid, bool bk64, bool bn128, hipStream_t
 
 template <bool BWD>
 void launch_igemm(ConvArgsB& a, int64_t mrows, int classes, hipStream_t s) {
-  a.tap_inner = conv_tap_inner();
   const bool bk64 = (a.Kc % 64) == 0;
   const bool bn128 = a.N >= 128;
   const int bn = bn128 ? 128 : 64;
@@ -426,7 +457,8 @@ extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const flo
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
                                     int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32, 0};
+  ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32,
+              (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2)};
   launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream));
   WSMG_RETURN_LAUNCH();
 }
@@ -435,7 +467,8 @@ extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, voi
                                          int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                          wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32, 0};
+  ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32,
+              (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2)};
   int classes = 1;
   int64_t mmax = (int64_t)B * H * W;
   if (stride == 2) {
@@ -450,7 +483,8 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
                                            int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                            wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0};
+  WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
+               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2)};
   a.units = KH * KW * (Cin / 32);
   a.npix = (int64_t)B * OH * OW;
   int gx = (int)wsmg_cdiv(a.units, WUN), gy = (int)wsmg_cdiv(Cout, WCO);
