@@ -195,11 +195,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    local = local % max(1, torch.cuda.device_count()) if os.environ.get("WSMG_BENCH_SHARE_GPU") else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("WSMG_BENCH_BACKEND", "nccl")  # "gloo": functional test of the DP path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     T, N = args.T, args.N
     dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)

@@ -270,3 +270,25 @@ def test_bf16_mode_forward_on_golden_inputs():
     AuxLosses.deactivate()
     assert np.abs(pred.detach().float().cpu().numpy() - g["pred"]).max() <= 3e-2
     assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-2 * float(g["loss"])
+
+
+def test_cfg4_map_encoder_c40_e200():
+    """BASELINE configs[3] geometry (E=200, 40 map channels): the conv engine pads 40 -> 64 channels
+    with zeros; MapEncoder output [B,256,49,49] against the oracle (the decoder is undefined at this
+    size in the reference itself)."""
+    from wsmgmap.models.encoders.map_encoder import MapEncoder
+    from oracle import detfill as df
+    enc = MapEncoder(200, 40, 256)
+    assert enc.output_shape == [256, 49, 49]
+    sd = {k: T(df.state_value("net.map_encoder." + k, tuple(v.shape))).to(v.dtype) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    ego = torch.relu(T(df.uniform("cfg4.ego", (2, 40, 200, 200), 3.0)))
+    P = {"net.map_encoder." + k: v.clone() for k, v in sd.items()}
+    ref = policy_ref.map_encoder(P, ego, True)
+    enc = enc.cuda().train()
+    from wsmgmap import ops
+    x = ops.to_nhwc(ego.cuda(), 64)
+    y = enc(x).permute(0, 3, 1, 2)
+    assert tuple(y.shape) == (2, 256, 49, 49)
+    err = float((y.cpu() - ref).abs().max())
+    assert err <= 2e-4, err

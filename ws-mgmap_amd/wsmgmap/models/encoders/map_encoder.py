@@ -7,6 +7,7 @@ conv / batch-norm / pooling kernels of libwsmgmap.so on NHWC activations (wsmgma
 The nn.Conv2d / nn.BatchNorm2d children are parameter containers only.
 """
 import numpy as np
+import torch
 import torch.nn as nn
 
 from ... import ops
@@ -20,7 +21,10 @@ def bump(bn: nn.BatchNorm2d, train: bool):
 
 def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
     """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
-    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0])
+    w = conv.weight
+    if x.shape[-1] != w.shape[1]:  # input channels were zero-padded to a multiple of 32: pad the weight too
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, x.shape[-1] - w.shape[1]))
+    y = ops.conv2d(x, w, conv.bias, conv.stride[0], conv.padding[0])
     bump(bn, train)
     return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
 

@@ -122,10 +122,12 @@ class MGMapNet(nn.Module):
     # -- operator 2 --------------------------------------------------------------
     def _ego_to_nhwc(self, ego_map):
         ego_map = ego_map.float()
+        c = ego_map.shape[1]
+        cpad = (c + 31) // 32 * 32   # the conv engine works on multiples of 32 channels (cfg4: 40 -> 64)
         nhwc_view = ego_map.permute(0, 2, 3, 1)
-        if nhwc_view.is_contiguous():  # channels-last storage (what our BEV kernels emit)
+        if nhwc_view.is_contiguous() and cpad == c:  # channels-last storage (what our BEV kernels emit)
             return nhwc_view.to(self.compute_dtype)
-        return ops.to_nhwc(ego_map.contiguous(), dtype=self.compute_dtype)
+        return ops.to_nhwc(ego_map.contiguous(), cpad, dtype=self.compute_dtype)
 
     def map_stack(self, ego_map):
         """ego map [B,C,E,E] -> (map tokens [B, S*S, 256] token-major, pred_sem_map [B,27,2S,2S])."""
