@@ -202,7 +202,8 @@ struct WgradArgs {
   int B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW;
   int units;         // KH*KW*(Cin/32)
   int64_t npix;      // B*OH*OW
-  int64_t chunk;     // pixels per grid.z slice (multiple of WPX)
+  int64_t chunk;     // pixels per pixel-range slice (multiple of WPX)
+  int gx, gy;        // unit tiles, co tiles (1-D grid of gx*gy*gz blocks, XCD-swizzled)
 };
 
 template <bool DB>
@@ -211,9 +212,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[DB ? 2 : 1][WUN * WPX * 32];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int u0 = blockIdx.x * WUN;
-  const int co0 = blockIdx.y * WCO;
-  const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+  // all tiles of one pixel slice are consecutive logical blocks => one XCD / one L2 per slice
+  const int logical = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int gxy = a.gx * a.gy;
+  const int bz = logical / gxy, bxy = logical - bz * gxy;
+  const int u0 = (bxy % a.gx) * WUN;
+  const int co0 = (bxy / a.gx) * WCO;
+  const int64_t p_begin = (int64_t)bz * a.chunk;
   int64_t p_end = p_begin + a.chunk;
   if (p_end > a.npix) p_end = a.npix;
   const int cchunks = a.Cin / 32;
@@ -381,7 +386,7 @@ extern "C" int wsmg_conv2d_bwd_weight(const float* x, const float* dy, float* dw
                                       int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                       wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  WgradArgs a{x, dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0};
+  WgradArgs a{x, dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0, 0, 0};
   a.units = KH * KW * (Cin / 32);
   a.npix = (int64_t)B * OH * OW;
   int gx = (int)wsmg_cdiv(a.units, WUN), gy = (int)wsmg_cdiv(Cout, WCO);
@@ -393,9 +398,12 @@ extern "C" int wsmg_conv2d_bwd_weight(const float* x, const float* dy, float* dw
   if (gz > 65535) gz = 65535;
   a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WPX) * WPX;
   gz = wsmg_cdiv(a.npix, a.chunk);
+  a.gx = gx;
+  a.gy = gy;
+  dim3 grid((unsigned)((int64_t)gx * gy * gz));
   if (conv_double_buffer())
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), a);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }

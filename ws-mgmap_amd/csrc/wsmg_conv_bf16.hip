@@ -240,6 +240,7 @@ struct WgradArgsB {
   int units;
   int64_t npix, chunk;
   unsigned x_bytes, dy_bytes;
+  int gx, gy;   // unit tiles, co tiles (1-D grid of gx*gy*gz blocks, XCD-swizzled)
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
@@ -252,9 +253,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   __shared__ __attribute__((aligned(16))) unsigned char Xs[WUN * WKP * X_LD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int u0 = blockIdx.x * WUN;
-  const int co0 = blockIdx.y * WCO;
-  const int64_t p_begin = (int64_t)blockIdx.z * a.chunk;
+  // all (unit, co) tiles of one pixel chunk are consecutive logical blocks => same XCD => the chunk's
+  // dY / X slices are fetched into ONE L2 instead of eight
+  const int logical = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int gxy = a.gx * a.gy;
+  const int bz = logical / gxy, bxy = logical - bz * gxy;
+  const int u0 = (bxy % a.gx) * WUN;
+  const int co0 = (bxy / a.gx) * WCO;
+  const int64_t p_begin = (int64_t)bz * a.chunk;
   int64_t p_end = p_begin + a.chunk;
   if (p_end > a.npix) p_end = a.npix;
   const int cchunks = a.Cin / 32;
@@ -484,7 +490,7 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
                                            wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
   WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
-               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2)};
+               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0};
   a.units = KH * KW * (Cin / 32);
   a.npix = (int64_t)B * OH * OW;
   int gx = (int)wsmg_cdiv(a.units, WUN), gy = (int)wsmg_cdiv(Cout, WCO);
@@ -495,10 +501,13 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
   if (gz > 65535) gz = 65535;
   a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WKP) * WKP;
   gz = wsmg_cdiv(a.npix, a.chunk);
+  a.gx = gx;
+  a.gy = gy;
+  dim3 grid((unsigned)((int64_t)gx * gy * gz));
   switch (conv_prefetch(2)) {
-    case 1: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a); break;
-    case 3: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a); break;
-    default: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, dim3(gx, gy, (unsigned)gz), dim3(256), 0, wsmg_s(stream), a); break;
+    case 1: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, wsmg_s(stream), a); break;
+    case 3: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, grid, dim3(256), 0, wsmg_s(stream), a); break;
+    default: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, wsmg_s(stream), a); break;
   }
   WSMG_RETURN_LAUNCH();
 }
