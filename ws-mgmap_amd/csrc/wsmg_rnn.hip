@@ -19,6 +19,8 @@
 // which is what the reference's split-at-zeros sequence form computes — so no host sync is needed.
 // Input projections (x W_ih^T + b_ih for all T*N rows) and the weight gradients are single large
 // GEMMs done by the caller.  Gate order r, z, n (PyTorch nn.GRU).
+#include <stdlib.h>
+
 #include "wsmg_common.h"
 
 namespace {
@@ -33,13 +35,49 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Exchange-buffer accessors.  SC1 = true: every byte that crosses workgroups inside the launch is
+// stored write-through (`sc1`) and loaded with L1-bypassing `sc1` loads, which replaces the agent-scope
+// release / acquire fences of the barrier (MI355X_MICROARCH.md "Valid forms", table row 1: one lane per
+// workgroup adds to the counter after every storing wave's vmcnt(0) + workgroup barrier; the poller
+// reads the counter with sc1 loads; the other waves load after a workgroup barrier).
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+template <bool SC1>
+__device__ __forceinline__ f32x4 xld4(__amdgpu_buffer_rsrc_t r, int elem) {
+  u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 4, 0, SC1 ? 16 : 0);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(v[j]);
+  return o;
+}
+template <bool SC1>
+__device__ __forceinline__ void xld2(__amdgpu_buffer_rsrc_t r, int elem, float& a, float& b) {
+  u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(r, elem * 4, 0, SC1 ? 16 : 0);
+  a = __uint_as_float(v[0]);
+  b = __uint_as_float(v[1]);
+}
+template <bool SC1>
+__device__ __forceinline__ float xld1(__amdgpu_buffer_rsrc_t r, int elem) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4, 0, SC1 ? 16 : 0));
+}
+template <bool SC1>
+__device__ __forceinline__ void xst1(__amdgpu_buffer_rsrc_t r, int elem, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, elem * 4, 0, SC1 ? 16 : 0);
+}
+
 // one-per-step grid barrier among NWG co-resident workgroups; returns false on timeout
+template <bool SC1>
 __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int tid, int* ok_lds) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!SC1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned n = 0;
     int good = 1;
@@ -51,8 +89,10 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, in
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!SC1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     *ok_lds = good;
   }
   __syncthreads();
@@ -86,8 +126,11 @@ struct GruFwdArgs {
   int T, N;
 };
 
+template <bool SC1>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
   __shared__ int ok_lds;
+  const __amdgpu_buffer_rsrc_t rs_y = rsrc_of(a.y, (size_t)a.T * a.N * H * 4);
+  const __amdgpu_buffer_rsrc_t rs_h0 = rsrc_of(a.h0, (size_t)a.N * H * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
   // W_hh rows of this wave in registers: row r = gate*4 + unit, k = 4*lane + e (+256 for e >= 4)
@@ -107,7 +150,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
   if (lane < 16) { br = a.bhh[my_unit]; bz = a.bhh[H + my_unit]; bn = a.bhh[2 * H + my_unit]; }
 
   for (int t = 0; t < a.T; ++t) {
-    const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
+    const __amdgpu_buffer_rsrc_t rs_prev = (t == 0) ? rs_h0 : rs_y;
+    const int prev0 = (t == 0) ? 0 : (t - 1) * a.N * H;   // element offset of h_{t-1}[0][0]
     float hp[NB][8];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -115,8 +159,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
       float m = 0.f;
       if (b < a.N) {
         m = a.masks[t * a.N + b];
-        lo = *reinterpret_cast<const f32x4*>(hsrc + (size_t)b * H + 4 * lane);
-        hi = *reinterpret_cast<const f32x4*>(hsrc + (size_t)b * H + 256 + 4 * lane);
+        lo = xld4<SC1>(rs_prev, prev0 + b * H + 4 * lane);
+        hi = xld4<SC1>(rs_prev, prev0 + b * H + 256 + 4 * lane);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { hp[b][e] = lo[e] * m; hp[b][4 + e] = hi[e] * m; }
@@ -156,9 +200,9 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
           float r = sigmoidf_(g[my_unit] + ghr);
           float z = sigmoidf_(g[H + my_unit] + ghz);
           float nn = tanhf(g[2 * H + my_unit] + r * ghn);
-          float hprev = hsrc[(size_t)b * H + my_unit] * a.masks[t * a.N + b];
+          float hprev = xld1<SC1>(rs_prev, prev0 + b * H + my_unit) * a.masks[t * a.N + b];
           float h = (1.0f - z) * nn + z * hprev;
-          a.y[row * H + my_unit] = h;
+          xst1<SC1>(rs_y, (int)(row * H + my_unit), h);
           a.sr[row * H + my_unit] = r;
           a.sz[row * H + my_unit] = z;
           a.sn[row * H + my_unit] = nn;
@@ -167,7 +211,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
       }
     }
     if (t + 1 < a.T) {
-      if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(t + 1), tid, &ok_lds)) return;
+      if (!grid_barrier<SC1>(a.sync, (unsigned)NWG * (unsigned)(t + 1), tid, &ok_lds)) return;
     }
   }
 }
@@ -190,8 +234,10 @@ struct GruBwdArgs {
   int T, N;
 };
 
+template <bool SC1>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
   __shared__ int ok_lds;
+  const __amdgpu_buffer_rsrc_t rs_gh = rsrc_of(a.dgh, (size_t)a.T * a.N * 3 * H * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
   // columns u0..u0+3 of W_hh over all 3H rows: k = 256*q + 4*lane + e, q = 0..5
@@ -225,23 +271,25 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
       float dz_pre = dh * (hprev - nn) * z * (1.0f - z);
       float dr_pre = dn_pre * ghn * r * (1.0f - r);
       float* gi = a.dgi + row * 3 * H;
-      float* gh = a.dgh + row * 3 * H;
+      const int gh0 = (int)(row * 3 * H) + my_unit;
       gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
-      gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dn_pre * r;
+      xst1<SC1>(rs_gh, gh0, dr_pre);
+      xst1<SC1>(rs_gh, gh0 + H, dz_pre);
+      xst1<SC1>(rs_gh, gh0 + 2 * H, dn_pre * r);
       dh_direct = dh * z;
     }
-    if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
+    if (!grid_barrier<SC1>(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
     // dh_{t-1}[b][u] = mask * (dh*z + sum_k dgh[b][k] * W_hh[k][u])
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-    const float* gsrc = a.dgh + (size_t)t * a.N * 3 * H;
+    const int gsrc = t * a.N * 3 * H;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < a.N) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + (size_t)b * 3 * H + 256 * q + 4 * lane);
+          f32x4 g = xld4<SC1>(rs_gh, gsrc + b * 3 * H + 256 * q + 4 * lane);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -262,6 +310,16 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
 
 }  // namespace
 
+// hand-off variant: WSMG_RNN_SC1=1 -> sc1 stores/loads, no fences; 0 -> plain accesses + agent fences
+static bool rnn_sc1() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WSMG_RNN_SC1");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+
 extern "C" int64_t wsmg_gru_sync_bytes(void) { return 64; }
 
 extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
@@ -272,7 +330,8 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
   if (e != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws, T, N};
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  if (rnn_sc1()) hipLaunchKernelGGL(gru_fwd_kernel<true>, dim3(NWG), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gru_fwd_kernel<false>, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -285,7 +344,8 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
   if (e != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws, T, N};
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  if (rnn_sc1()) hipLaunchKernelGGL(gru_bwd_kernel<true>, dim3(NWG), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gru_bwd_kernel<false>, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -318,8 +378,10 @@ struct LstmFwdArgs {
   int U, L;
 };
 
+template <bool SC1>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
   __shared__ int ok_lds;
+  const __amdgpu_buffer_rsrc_t rs_hs = rsrc_of(a.hs, (size_t)2 * 2 * NB * LH * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dir = blockIdx.x / L_NWG;
   const int u0 = (blockIdx.x % L_NWG) * UNITS_WG + wave * UNITS_WAVE;
@@ -344,18 +406,15 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     if (my_b0 + 1 < a.U) mylen[1] = a.len[my_b0 + 1];
   }
   float c[2] = {0.f, 0.f};
-  float* hs = a.hs + (size_t)dir * 2 * NB * LH;
+  const int hs0 = dir * 2 * NB * LH;
 
   for (int s = 0; s < a.L; ++s) {
     const int t = dir == 0 ? s : a.L - 1 - s;
-    const float* hprev = hs + (size_t)(s & 1) * NB * LH;
-    float* hnext = hs + (size_t)((s + 1) & 1) * NB * LH;
+    const int hprev = hs0 + (s & 1) * NB * LH;
+    const int hnext = hs0 + ((s + 1) & 1) * NB * LH;
     float hp[NB][2];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      hp[b][0] = hprev[b * LH + 2 * lane];
-      hp[b][1] = hprev[b * LH + 2 * lane + 1];
-    }
+    for (int b = 0; b < NB; ++b) xld2<SC1>(rs_hs, hprev + b * LH + 2 * lane, hp[b][0], hp[b][1]);
     float acc[128];
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -375,7 +434,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int i = 0; i < 2; ++i) {
         const int b = my_b0 + i;
         if (b < a.U) {
-          const float hold = hprev[b * LH + my_unit];
+          const float hold = xld1<SC1>(rs_hs, hprev + b * LH + my_unit);
           const bool active = t < mylen[i];
           float hnew = hold;
           float outv = 0.f;
@@ -392,13 +451,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
             sgp[0] = gi_; sgp[LH] = gf_; sgp[2 * LH] = gg_; sgp[3 * LH] = go_;
             a.sc[(((size_t)dir * a.U + b) * a.L + t) * LH + my_unit] = c[i];
           }
-          hnext[b * LH + my_unit] = hnew;
+          xst1<SC1>(rs_hs, hnext + b * LH + my_unit, hnew);
           a.out[((size_t)b * a.L + t) * 2 * LH + dir * LH + my_unit] = outv;
         }
       }
     }
     if (s + 1 < a.L) {
-      if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds)) return;
+      if (!grid_barrier<SC1>(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds)) return;
     }
   }
 }
@@ -414,8 +473,10 @@ struct LstmBwdArgs {
   int U, L;
 };
 
+template <bool SC1>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   __shared__ int ok_lds;
+  const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg, (size_t)a.U * a.L * 2 * 4 * LH * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dir = blockIdx.x / L_NWG;
   const int u0 = (blockIdx.x % L_NWG) * UNITS_WG + wave * UNITS_WAVE;
@@ -441,7 +502,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
     const int t = dir == 0 ? s : a.L - 1 - s;
     float dh_direct = 0.f;
     if (worker) {
-      float* dgp = a.dg + (((size_t)my_b * a.L + t) * 2 + dir) * 4 * LH + my_unit;
+      const int dgp = ((my_b * a.L + t) * 2 + dir) * 4 * LH + my_unit;
       if (t < mylen) {
         const size_t o = (((size_t)dir * a.U + my_b) * a.L + t);
         const float* sgp = a.sg + o * 4 * LH + my_unit;
@@ -458,23 +519,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
         float df_pre = dc * cp * gf_ * (1.0f - gf_);
         float dg_pre = dc * gi_ * (1.0f - gg_ * gg_);
         carry_c = dc * gf_;
-        dgp[0] = di_pre; dgp[LH] = df_pre; dgp[2 * LH] = dg_pre; dgp[3 * LH] = do_pre;
+        xst1<SC1>(rs_dg, dgp, di_pre); xst1<SC1>(rs_dg, dgp + LH, df_pre);
+        xst1<SC1>(rs_dg, dgp + 2 * LH, dg_pre); xst1<SC1>(rs_dg, dgp + 3 * LH, do_pre);
       } else {
-        dgp[0] = 0.f; dgp[LH] = 0.f; dgp[2 * LH] = 0.f; dgp[3 * LH] = 0.f;
+        xst1<SC1>(rs_dg, dgp, 0.f); xst1<SC1>(rs_dg, dgp + LH, 0.f);
+        xst1<SC1>(rs_dg, dgp + 2 * LH, 0.f); xst1<SC1>(rs_dg, dgp + 3 * LH, 0.f);
         dh_direct = carry_h;  // frozen state: gradient passes straight through
       }
     }
-    if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds)) return;
+    if (!grid_barrier<SC1>(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds)) return;
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < a.U) {
-        const float* gsrc = a.dg + (((size_t)b * a.L + t) * 2 + dir) * 4 * LH;
+        const int gsrc = ((b * a.L + t) * 2 + dir) * 4 * LH;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 256 * q + 4 * lane);
+          f32x4 g = xld4<SC1>(rs_dg, gsrc + 256 * q + 4 * lane);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -506,7 +569,8 @@ extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_
   if (e != hipSuccess) return (int)e;
   LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)state_ws, save_gates, save_c,
                 (unsigned*)((char*)state_ws + hs_bytes), U, L};
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  if (rnn_sc1()) hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(2 * L_NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -519,6 +583,7 @@ extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t
   hipError_t e = hipMemsetAsync((char*)state_ws + hs_bytes, 0, 256, s);
   if (e != hipSuccess) return (int)e;
   LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)((char*)state_ws + hs_bytes), U, L};
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  if (rnn_sc1()) hipLaunchKernelGGL(lstm_bwd_kernel<true>, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(lstm_bwd_kernel<false>, dim3(2 * L_NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }

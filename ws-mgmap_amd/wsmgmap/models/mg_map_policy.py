@@ -86,6 +86,7 @@ class MGMapNet(nn.Module):
         self.second_state_encoder = RNNStateEncoder(hid, hid, 1, mc.STATE_ENCODER.rnn_type)
         self._output_size = hid
         self.att_map_t_m = None
+        self._side_stream = None
         # storage type of the map-stack activations: float32 (parity mode, f32 MFMA) or bfloat16
         # (BASELINE configs[1]; bf16 MFMA, float32 accumulation, float32 master weights)
         self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16}.get(
@@ -157,8 +158,26 @@ class MGMapNet(nn.Module):
         return emb.view(b, s1 * s2, ch), pred_sem_map
 
     # -- forward -------------------------------------------------------------------
+    def _encode_instruction(self, observations):
+        """Instruction branch (dedup + packed bi-LSTM + key projection) on a side stream: it is
+        independent of the map stack, its persistent 16-workgroup kernels leave 94 % of the CUs free,
+        and autograd replays its backward on the same stream — so it overlaps the convolutions in
+        both directions.  Joined (event wait) right before the text attention."""
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"])
+            text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
+            text_k = text_k_u.index_select(0, inverse)
+            text_v = instr_u.index_select(0, inverse)
+            text_mask = mask_u.index_select(0, inverse).contiguous()
+        return (text_k, text_v, text_mask), side
+
     def forward(self, observations, rnn_hidden_states, prev_actions, masks):
-        instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"])
+        text, side = self._encode_instruction(observations)
         rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)
         depth_embedding = self.depth_encoder(observations)
 
@@ -178,9 +197,11 @@ class MGMapNet(nn.Module):
         state, rnn_hidden_states[0:n1] = self.state_encoder(state_in, rnn_hidden_states[0:n1], masks)
 
         # instruction attention: keys projected once per unique instruction, gathered per row
-        text_k = self._key_projection(self.state_text_k_layer, instr_u)[inverse]
-        text_v = instr_u[inverse]
-        text_embedding, _ = self._attn(self.state_text_q_layer(state), text_k, text_v, mask_u[inverse].contiguous())
+        torch.cuda.current_stream().wait_stream(side)
+        text_k, text_v, text_mask = text
+        for t in text:
+            t.record_stream(torch.cuda.current_stream())
+        text_embedding, _ = self._attn(self.state_text_q_layer(state), text_k, text_v, text_mask)
 
         # map attention
         map_k = self._key_projection(self.text_map_k_layer, map_tokens)
