@@ -32,6 +32,7 @@ def run():
     (o * lgy).sum().backward()
     return [y.detach(), g.grad, w.grad, o.detach(), lg.grad, lww.grad]
 
+NAMES = ["gru.y", "gru.dgi", "gru.dw_hh(torch GEMM)", "lstm.out", "lstm.dgi", "lstm.dw_hh(torch GEMM)"]
 ref = run()
 torch.cuda.synchronize()
 # background load on another stream
@@ -45,9 +46,12 @@ for i in range(reps):
         for _ in range(4):
             ops.conv2d(x, wconv, None, 1, 1)
     out = run()
-    for a, b in zip(ref, out):
+    for j, (a, b) in enumerate(zip(ref, out)):
         if not torch.equal(a, b):
             bad += 1
+            d = (a - b).abs()
+            nz = int((d > 0).sum())
+            print(f"  repeat {i}: tensor {NAMES[j]} differs in {nz} elements, max abs {float(d.max()):.3e} (ref max {float(a.abs().max()):.3e})")
 torch.cuda.synchronize()
 print("SC1 =", os.environ.get("WSMG_RNN_SC1", "default"), "| mismatching tensors over", reps, "stressed repeats:", bad)
 # timing (idle chip)

@@ -19,8 +19,6 @@
 // which is what the reference's split-at-zeros sequence form computes — so no host sync is needed.
 // Input projections (x W_ih^T + b_ih for all T*N rows) and the weight gradients are single large
 // GEMMs done by the caller.  Gate order r, z, n (PyTorch nn.GRU).
-#include <stdlib.h>
-
 #include "wsmg_common.h"
 
 namespace {
@@ -35,49 +33,13 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Exchange-buffer accessors.  SC1 = true: every byte that crosses workgroups inside the launch is
-// stored write-through (`sc1`) and loaded with L1-bypassing `sc1` loads, which replaces the agent-scope
-// release / acquire fences of the barrier (MI355X_MICROARCH.md "Valid forms", table row 1: one lane per
-// workgroup adds to the counter after every storing wave's vmcnt(0) + workgroup barrier; the poller
-// reads the counter with sc1 loads; the other waves load after a workgroup barrier).
-typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, size_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-template <bool SC1>
-__device__ __forceinline__ f32x4 xld4(__amdgpu_buffer_rsrc_t r, int elem) {
-  u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(r, elem * 4, 0, SC1 ? 16 : 0);
-  f32x4 o;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(v[j]);
-  return o;
-}
-template <bool SC1>
-__device__ __forceinline__ void xld2(__amdgpu_buffer_rsrc_t r, int elem, float& a, float& b) {
-  u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(r, elem * 4, 0, SC1 ? 16 : 0);
-  a = __uint_as_float(v[0]);
-  b = __uint_as_float(v[1]);
-}
-template <bool SC1>
-__device__ __forceinline__ float xld1(__amdgpu_buffer_rsrc_t r, int elem) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, elem * 4, 0, SC1 ? 16 : 0));
-}
-template <bool SC1>
-__device__ __forceinline__ void xst1(__amdgpu_buffer_rsrc_t r, int elem, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, elem * 4, 0, SC1 ? 16 : 0);
-}
-
 // one-per-step grid barrier among NWG co-resident workgroups; returns false on timeout
-template <bool SC1>
 __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int tid, int* ok_lds) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    if (!SC1) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned n = 0;
     int good = 1;
@@ -89,10 +51,8 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, in
         break;
       }
     }
-    if (!SC1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     *ok_lds = good;
   }
   __syncthreads();
@@ -123,14 +83,12 @@ struct GruFwdArgs {
   float* sn;
   float* sghn;         // W_hn h + b_hn
   unsigned* sync;      // [0] arrival counter, [1] error word (zeroed by the launcher)
+  float* xh;           // exchange [2][NWG][NB][UNITS_WG]: every 128-B line has ONE writing workgroup
   int T, N;
 };
 
-template <bool SC1>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
   __shared__ int ok_lds;
-  const __amdgpu_buffer_rsrc_t rs_y = rsrc_of(a.y, (size_t)a.T * a.N * H * 4);
-  const __amdgpu_buffer_rsrc_t rs_h0 = rsrc_of(a.h0, (size_t)a.N * H * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
   // W_hh rows of this wave in registers: row r = gate*4 + unit, k = 4*lane + e (+256 for e >= 4)
@@ -149,9 +107,14 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
   float br = 0.f, bz = 0.f, bn = 0.f;
   if (lane < 16) { br = a.bhh[my_unit]; bz = a.bhh[H + my_unit]; bn = a.bhh[2 * H + my_unit]; }
 
+  // element (b, k) of the exchange image: [(k / 16) workgroup][b][k % 16]
+  const int xk_lo = ((4 * lane) >> 4) * NB * UNITS_WG + ((4 * lane) & 15);
+  const int xk_hi = ((256 + 4 * lane) >> 4) * NB * UNITS_WG + ((4 * lane) & 15);
+  const int xw = (blockIdx.x * NB) * UNITS_WG + wave * UNITS_WAVE + ((lane >> 2) & 3);  // + b*16: this lane's slot
   for (int t = 0; t < a.T; ++t) {
-    const __amdgpu_buffer_rsrc_t rs_prev = (t == 0) ? rs_h0 : rs_y;
-    const int prev0 = (t == 0) ? 0 : (t - 1) * a.N * H;   // element offset of h_{t-1}[0][0]
+    const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;   // own previous value only
+    const float* xprev = a.xh + (size_t)((t + 1) & 1) * NWG * NB * UNITS_WG;  // written in step t-1
+    float* xnext = a.xh + (size_t)(t & 1) * NWG * NB * UNITS_WG;
     float hp[NB][8];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -159,8 +122,13 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
       float m = 0.f;
       if (b < a.N) {
         m = a.masks[t * a.N + b];
-        lo = xld4<SC1>(rs_prev, prev0 + b * H + 4 * lane);
-        hi = xld4<SC1>(rs_prev, prev0 + b * H + 256 + 4 * lane);
+        if (t == 0) {
+          lo = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * H + 4 * lane);
+          hi = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * H + 256 + 4 * lane);
+        } else {
+          lo = *reinterpret_cast<const f32x4*>(xprev + xk_lo + b * UNITS_WG);
+          hi = *reinterpret_cast<const f32x4*>(xprev + xk_hi + b * UNITS_WG);
+        }
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { hp[b][e] = lo[e] * m; hp[b][4 + e] = hi[e] * m; }
@@ -200,9 +168,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
           float r = sigmoidf_(g[my_unit] + ghr);
           float z = sigmoidf_(g[H + my_unit] + ghz);
           float nn = tanhf(g[2 * H + my_unit] + r * ghn);
-          float hprev = xld1<SC1>(rs_prev, prev0 + b * H + my_unit) * a.masks[t * a.N + b];
+          float hprev = hsrc[(size_t)b * H + my_unit] * a.masks[t * a.N + b];
           float h = (1.0f - z) * nn + z * hprev;
-          xst1<SC1>(rs_y, (int)(row * H + my_unit), h);
+          a.y[row * H + my_unit] = h;
+          xnext[xw + b * UNITS_WG] = h;
           a.sr[row * H + my_unit] = r;
           a.sz[row * H + my_unit] = z;
           a.sn[row * H + my_unit] = nn;
@@ -211,7 +180,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
       }
     }
     if (t + 1 < a.T) {
-      if (!grid_barrier<SC1>(a.sync, (unsigned)NWG * (unsigned)(t + 1), tid, &ok_lds)) return;
+      if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(t + 1), tid, &ok_lds)) return;
     }
   }
 }
@@ -231,13 +200,12 @@ struct GruBwdArgs {
   float* dgh;          // [T][N][3H]
   float* dh0;          // [N][H]
   unsigned* sync;
+  float* xg;           // exchange [2][NWG][NB][3][UNITS_WG]: one writing workgroup per 128-B line
   int T, N;
 };
 
-template <bool SC1>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
   __shared__ int ok_lds;
-  const __amdgpu_buffer_rsrc_t rs_gh = rsrc_of(a.dgh, (size_t)a.T * a.N * 3 * H * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
   // columns u0..u0+3 of W_hh over all 3H rows: k = 256*q + 4*lane + e, q = 0..5
@@ -257,7 +225,10 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
   float carry = 0.f;
   if (worker && a.dhT) carry = a.dhT[(size_t)my_b * H + my_unit];
 
+  constexpr int XG_WG = NB * 3 * UNITS_WG;   // floats per workgroup per step
+  const int xgw = blockIdx.x * XG_WG + my_b * 3 * UNITS_WG + wave * UNITS_WAVE + (lane >> 4);  // + gate*16
   for (int t = a.T - 1; t >= 0; --t) {
+    float* xcur = a.xg + (size_t)(t & 1) * NWG * XG_WG;
     float dh_direct = 0.f, mk = 0.f;
     if (worker) {
       const size_t row = (size_t)t * a.N + my_b;
@@ -271,25 +242,26 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
       float dz_pre = dh * (hprev - nn) * z * (1.0f - z);
       float dr_pre = dn_pre * ghn * r * (1.0f - r);
       float* gi = a.dgi + row * 3 * H;
-      const int gh0 = (int)(row * 3 * H) + my_unit;
+      float* gh = a.dgh + row * 3 * H;
       gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
-      xst1<SC1>(rs_gh, gh0, dr_pre);
-      xst1<SC1>(rs_gh, gh0 + H, dz_pre);
-      xst1<SC1>(rs_gh, gh0 + 2 * H, dn_pre * r);
+      gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dn_pre * r;
+      xcur[xgw] = dr_pre; xcur[xgw + UNITS_WG] = dz_pre; xcur[xgw + 2 * UNITS_WG] = dn_pre * r;
       dh_direct = dh * z;
     }
-    if (!grid_barrier<SC1>(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
+    if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
     // dh_{t-1}[b][u] = mask * (dh*z + sum_k dgh[b][k] * W_hh[k][u])
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-    const int gsrc = t * a.N * 3 * H;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < a.N) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          f32x4 g = xld4<SC1>(rs_gh, gsrc + b * 3 * H + 256 * q + 4 * lane);
+          // gate row k = 256q + 4 lane + e  ->  gate k/512, unit k%512 -> [unit/16 workgroup][b][gate][unit%16]
+          const int k = 256 * q + 4 * lane;
+          const int gate = k >> 9, unit = k & 511;
+          f32x4 g = *reinterpret_cast<const f32x4*>(xcur + (unit >> 4) * XG_WG + b * 3 * UNITS_WG + gate * UNITS_WG + (unit & 15));
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -310,28 +282,23 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
 
 }  // namespace
 
-// hand-off variant: WSMG_RNN_SC1=1 -> sc1 stores/loads, no fences; 0 -> plain accesses + agent fences
-static bool rnn_sc1() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WSMG_RNN_SC1");
-    v = e ? (atoi(e) != 0) : 1;
-  }
-  return v != 0;
-}
-
-extern "C" int64_t wsmg_gru_sync_bytes(void) { return 64; }
+// workspace layout: [0, 256) barrier words (zeroed per call) | [256, ...) exchange image (128-B aligned
+// when the workspace is; rows of one workgroup never share a cache line with another workgroup's)
+// forward image: 2*NWG*NB*UNITS_WG floats (32 KB); backward image (below) is the larger one
+constexpr int64_t GRU_XG_BYTES = (int64_t)2 * NWG * NB * 3 * UNITS_WG * 4;    // backward
+extern "C" int64_t wsmg_gru_sync_bytes(void) { return 256 + GRU_XG_BYTES; }
 
 extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
                             int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
                             float* save_ghn, void* sync_ws, wsmg_stream_t stream) {
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
+  if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
-  GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws, T, N};
-  if (rnn_sc1()) hipLaunchKernelGGL(gru_fwd_kernel<true>, dim3(NWG), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gru_fwd_kernel<false>, dim3(NWG), dim3(256), 0, s, a);
+  GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
+               (float*)((char*)sync_ws + 256), T, N};
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -341,11 +308,12 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
                             void* sync_ws, wsmg_stream_t stream) {
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
+  if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
-  GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws, T, N};
-  if (rnn_sc1()) hipLaunchKernelGGL(gru_bwd_kernel<true>, dim3(NWG), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gru_bwd_kernel<false>, dim3(NWG), dim3(256), 0, s, a);
+  GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
+               (float*)((char*)sync_ws + 256), T, N};
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -378,10 +346,8 @@ struct LstmFwdArgs {
   int U, L;
 };
 
-template <bool SC1>
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
   __shared__ int ok_lds;
-  const __amdgpu_buffer_rsrc_t rs_hs = rsrc_of(a.hs, (size_t)2 * 2 * NB * LH * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dir = blockIdx.x / L_NWG;
   const int u0 = (blockIdx.x % L_NWG) * UNITS_WG + wave * UNITS_WAVE;
@@ -406,15 +372,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     if (my_b0 + 1 < a.U) mylen[1] = a.len[my_b0 + 1];
   }
   float c[2] = {0.f, 0.f};
-  const int hs0 = dir * 2 * NB * LH;
+  float* hs = a.hs + (size_t)dir * 2 * NB * LH;   // image [2][L_NWG][NB][UNITS_WG]: one writer per line
+  const int wgi = blockIdx.x % L_NWG;
+  const int xk = ((2 * lane) >> 4) * NB * UNITS_WG + ((2 * lane) & 15);          // + b*16
+  const int xw = wgi * NB * UNITS_WG + wave * UNITS_WAVE + ((lane >> 2) & 3);    // + b*16
 
   for (int s = 0; s < a.L; ++s) {
     const int t = dir == 0 ? s : a.L - 1 - s;
-    const int hprev = hs0 + (s & 1) * NB * LH;
-    const int hnext = hs0 + ((s + 1) & 1) * NB * LH;
+    const float* hprev = hs + (size_t)(s & 1) * NB * LH;
+    float* hnext = hs + (size_t)((s + 1) & 1) * NB * LH;
     float hp[NB][2];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) xld2<SC1>(rs_hs, hprev + b * LH + 2 * lane, hp[b][0], hp[b][1]);
+    for (int b = 0; b < NB; ++b) {
+      hp[b][0] = hprev[xk + b * UNITS_WG];
+      hp[b][1] = hprev[xk + b * UNITS_WG + 1];
+    }
     float acc[128];
 #pragma unroll
     for (int r = 0; r < 16; ++r)
@@ -434,7 +406,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int i = 0; i < 2; ++i) {
         const int b = my_b0 + i;
         if (b < a.U) {
-          const float hold = xld1<SC1>(rs_hs, hprev + b * LH + my_unit);
+          const float hold = hprev[xw + b * UNITS_WG];
           const bool active = t < mylen[i];
           float hnew = hold;
           float outv = 0.f;
@@ -451,13 +423,13 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
             sgp[0] = gi_; sgp[LH] = gf_; sgp[2 * LH] = gg_; sgp[3 * LH] = go_;
             a.sc[(((size_t)dir * a.U + b) * a.L + t) * LH + my_unit] = c[i];
           }
-          xst1<SC1>(rs_hs, hnext + b * LH + my_unit, hnew);
+          hnext[xw + b * UNITS_WG] = hnew;
           a.out[((size_t)b * a.L + t) * 2 * LH + dir * LH + my_unit] = outv;
         }
       }
     }
     if (s + 1 < a.L) {
-      if (!grid_barrier<SC1>(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds)) return;
+      if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds)) return;
     }
   }
 }
@@ -470,13 +442,12 @@ struct LstmBwdArgs {
   const float* sc;     // [2][U][L][LH]
   float* dg;           // [U][L][2][4*LH]  gradient of the gate pre-activations (= d gi = d gh)
   unsigned* sync;
+  float* xg;           // exchange [2 dir][2][L_NWG][NB][4][UNITS_WG]
   int U, L;
 };
 
-template <bool SC1>
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   __shared__ int ok_lds;
-  const __amdgpu_buffer_rsrc_t rs_dg = rsrc_of(a.dg, (size_t)a.U * a.L * 2 * 4 * LH * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int dir = blockIdx.x / L_NWG;
   const int u0 = (blockIdx.x % L_NWG) * UNITS_WG + wave * UNITS_WAVE;
@@ -497,12 +468,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
   const bool worker = ((lane & 1) == 0) && (my_b < a.U);
   const int mylen = worker ? a.len[my_b] : 0;
   float carry_h = 0.f, carry_c = 0.f;
+  constexpr int LXG_WG = NB * 4 * UNITS_WG;
+  const int wgi = blockIdx.x % L_NWG;
+  const int xgw = wgi * LXG_WG + my_b * 4 * UNITS_WG + wave * UNITS_WAVE + (lane >> 4);   // + gate*16
 
   for (int s = a.L - 1; s >= 0; --s) {
     const int t = dir == 0 ? s : a.L - 1 - s;
+    float* xcur = a.xg + ((size_t)dir * 2 + (s & 1)) * L_NWG * LXG_WG;
     float dh_direct = 0.f;
     if (worker) {
-      const int dgp = ((my_b * a.L + t) * 2 + dir) * 4 * LH + my_unit;
+      float* dgp = a.dg + (((size_t)my_b * a.L + t) * 2 + dir) * 4 * LH + my_unit;
       if (t < mylen) {
         const size_t o = (((size_t)dir * a.U + my_b) * a.L + t);
         const float* sgp = a.sg + o * 4 * LH + my_unit;
@@ -519,25 +494,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
         float df_pre = dc * cp * gf_ * (1.0f - gf_);
         float dg_pre = dc * gi_ * (1.0f - gg_ * gg_);
         carry_c = dc * gf_;
-        xst1<SC1>(rs_dg, dgp, di_pre); xst1<SC1>(rs_dg, dgp + LH, df_pre);
-        xst1<SC1>(rs_dg, dgp + 2 * LH, dg_pre); xst1<SC1>(rs_dg, dgp + 3 * LH, do_pre);
+        dgp[0] = di_pre; dgp[LH] = df_pre; dgp[2 * LH] = dg_pre; dgp[3 * LH] = do_pre;
+        xcur[xgw] = di_pre; xcur[xgw + UNITS_WG] = df_pre; xcur[xgw + 2 * UNITS_WG] = dg_pre; xcur[xgw + 3 * UNITS_WG] = do_pre;
       } else {
-        xst1<SC1>(rs_dg, dgp, 0.f); xst1<SC1>(rs_dg, dgp + LH, 0.f);
-        xst1<SC1>(rs_dg, dgp + 2 * LH, 0.f); xst1<SC1>(rs_dg, dgp + 3 * LH, 0.f);
+        dgp[0] = 0.f; dgp[LH] = 0.f; dgp[2 * LH] = 0.f; dgp[3 * LH] = 0.f;
+        xcur[xgw] = 0.f; xcur[xgw + UNITS_WG] = 0.f; xcur[xgw + 2 * UNITS_WG] = 0.f; xcur[xgw + 3 * UNITS_WG] = 0.f;
         dh_direct = carry_h;  // frozen state: gradient passes straight through
       }
     }
-    if (!grid_barrier<SC1>(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds)) return;
+    if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds)) return;
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (b < a.U) {
-        const int gsrc = ((b * a.L + t) * 2 + dir) * 4 * LH;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          f32x4 g = xld4<SC1>(rs_dg, gsrc + 256 * q + 4 * lane);
+          const int k = 256 * q + 4 * lane;          // gate row -> gate k/128, unit k%128
+          const int gate = k >> 7, unit = k & 127;
+          f32x4 g = *reinterpret_cast<const f32x4*>(xcur + (unit >> 4) * LXG_WG + b * 4 * UNITS_WG + gate * UNITS_WG + (unit & 15));
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -557,20 +533,21 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 
 }  // namespace
 
-extern "C" int64_t wsmg_lstm_state_bytes(void) { return (int64_t)2 * 2 * NB * LH * sizeof(float) + 256; }
+constexpr int64_t LSTM_HS_BYTES = (int64_t)2 * 2 * NB * LH * 4;                          // forward state image
+constexpr int64_t LSTM_XG_BYTES = (int64_t)2 * 2 * L_NWG * NB * 4 * UNITS_WG * 4;        // backward gate image
+extern "C" int64_t wsmg_lstm_state_bytes(void) { return 256 + LSTM_XG_BYTES; }
 
 extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int U, int L,
                              int hidden, float* out, float* save_gates, float* save_c, void* state_ws,
                              wsmg_stream_t stream) {
   if (hidden != LH || U <= 0 || U > NB || L <= 0) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
-  const size_t hs_bytes = (size_t)2 * 2 * NB * LH * sizeof(float);
-  hipError_t e = hipMemsetAsync(state_ws, 0, hs_bytes + 256, s);
+  if (((uintptr_t)state_ws & 127) != 0) return WSMG_EINVAL;
+  hipError_t e = hipMemsetAsync(state_ws, 0, 256 + LSTM_HS_BYTES, s);   // barrier words + zero initial state
   if (e != hipSuccess) return (int)e;
-  LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)state_ws, save_gates, save_c,
-                (unsigned*)((char*)state_ws + hs_bytes), U, L};
-  if (rnn_sc1()) hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3(2 * L_NWG), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)((char*)state_ws + 256), save_gates, save_c,
+                (unsigned*)state_ws, U, L};
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -579,11 +556,10 @@ extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t
                              wsmg_stream_t stream) {
   if (hidden != LH || U <= 0 || U > NB || L <= 0) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
-  const size_t hs_bytes = (size_t)2 * 2 * NB * LH * sizeof(float);
-  hipError_t e = hipMemsetAsync((char*)state_ws + hs_bytes, 0, 256, s);
+  if (((uintptr_t)state_ws & 127) != 0) return WSMG_EINVAL;
+  hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
-  LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)((char*)state_ws + hs_bytes), U, L};
-  if (rnn_sc1()) hipLaunchKernelGGL(lstm_bwd_kernel<true>, dim3(2 * L_NWG), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(lstm_bwd_kernel<false>, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)state_ws, (float*)((char*)state_ws + 256), U, L};
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
