@@ -494,3 +494,55 @@ def test_bilstm_persistent_kernel(lens):
         close("lstm.d" + k, getattr(enc.encoder_rnn, k).grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)
     ref = P[pre + "embedding_layer.weight"].grad
     close("lstm.demb", enc.embedding_layer.weight.grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)
+
+
+def test_rnn_handoff_under_concurrent_load(ops):
+    """The persistent GRU/LSTM kernels exchange h_t between workgroups on different XCDs inside one
+    launch.  Run them repeatedly while a second stream saturates the chip, with the exchange images
+    poisoned with NaN before every launch: any stale or missed hand-off would surface as a NaN or as
+    a bitwise difference from the first (unloaded) run."""
+    torch.manual_seed(0)
+    Tn, N, Hd = 48, 8, 512
+    gi = torch.randn(Tn, N, 3 * Hd, device="cuda")
+    whh = torch.randn(3 * Hd, Hd, device="cuda") * 0.04
+    bhh = torch.randn(3 * Hd, device="cuda") * 0.1
+    h0 = torch.randn(N, Hd, device="cuda")
+    masks = torch.ones(Tn, N, device="cuda")
+    masks[0] = 0
+    masks[17, 3] = 0
+    gy = torch.randn(Tn, N, Hd, device="cuda")
+    U, L = 8, 60
+    lgi = torch.randn(U, L, 2, 512, device="cuda")
+    lw = torch.randn(2, 512, 128, device="cuda") * 0.08
+    lb = torch.randn(2, 512, device="cuda") * 0.1
+    lens = torch.tensor([60, 37, 1, 44, 60, 12, 55, 59], device="cuda", dtype=torch.int32)
+    lgy = torch.randn(U, L, 256, device="cuda")
+
+    def run():
+        g = gi.clone().requires_grad_(True)
+        y = ops.masked_gru(g, whh, bhh, h0, masks)
+        (y * gy).sum().backward()
+        lg = lgi.clone().requires_grad_(True)
+        o = ops.bilstm(lg, lw, lb, lens)
+        (o * lgy).sum().backward()
+        return [y.detach(), g.grad, o.detach(), lg.grad]
+
+    ref = run()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(t).all()) for t in ref)
+    old = ops._POISON
+    ops._POISON = True
+    try:
+        side = torch.cuda.Stream()
+        x = torch.randn(256, 24, 24, 256, device="cuda").to(torch.bfloat16)
+        wconv = torch.randn(256, 256, 3, 3, device="cuda") * 0.02
+        for i in range(80):
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    ops.conv2d(x, wconv, None, 1, 1)
+            out = run()
+            for name, a, b in zip(["gru.y", "gru.dgi", "lstm.out", "lstm.dgi"], ref, out):
+                assert torch.equal(a, b), f"repeat {i}: {name} differs under load (max {float((a - b).abs().max()):.3e})"
+        torch.cuda.synchronize()
+    finally:
+        ops._POISON = old
