@@ -202,9 +202,11 @@ int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, const float
  * h_{t-1} is multiplied by masks[t] before every step (episode restarts), gate order r,z,n.
  * One launch runs all T steps (32 cooperating workgroups, W_hh in registers, one bounded-spin grid
  * barrier per step).  gi = x W_ih^T + b_ih [T][N][3H] is computed by the caller; N <= 8.
- * sync_ws: wsmg_gru_sync_bytes() bytes of device scratch (zeroed by the call; word 1 != 0 afterwards
- * means a barrier timed out).  save_*: [T][N][H] each, consumed by wsmg_gru_bwd. */
-int64_t wsmg_gru_sync_bytes(void);
+ * sync_ws: wsmg_gru_workspace_bytes(T) bytes of 128-B-aligned device scratch: barrier words (zeroed by the
+ * call; word 1 != 0 afterwards means a barrier timed out) + the step-indexed exchange image through which
+ * h_t crosses workgroups (each 128-B line written once by one workgroup and never re-used in the launch).
+ * save_*: [T][N][H] each, consumed by wsmg_gru_bwd. */
+int64_t wsmg_gru_workspace_bytes(int T);
 int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
                  int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
                  float* save_ghn, void* sync_ws, wsmg_stream_t stream);
@@ -222,8 +224,8 @@ int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const flo
  * in one launch (8 cooperating workgroups each, W_hh in registers, one bounded barrier per token).
  * gi [U][L][2][4H] = x W_ih^T + b_ih for (forward, reverse); w_hh [2][4H][H]; b_hh [2][4H]; U <= 8.
  * out [U][L][2H] (forward | reverse); save_gates [2][U][L][4][H], save_c [2][U][L][H] feed the backward.
- * state_ws: wsmg_lstm_state_bytes() bytes of device scratch. */
-int64_t wsmg_lstm_state_bytes(void);
+ * state_ws: wsmg_lstm_workspace_bytes(L) bytes of 128-B-aligned device scratch (barrier words + exchange image). */
+int64_t wsmg_lstm_workspace_bytes(int L);
 int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int U, int L,
                   int hidden, float* out, float* save_gates, float* save_c, void* state_ws,
                   wsmg_stream_t stream);

@@ -83,7 +83,7 @@ struct GruFwdArgs {
   float* sn;
   float* sghn;         // W_hn h + b_hn
   unsigned* sync;      // [0] arrival counter, [1] error word (zeroed by the launcher)
-  float* xh;           // exchange [2][NWG][NB][UNITS_WG]: every 128-B line has ONE writing workgroup
+  float* xh;           // exchange [T][NWG][NB][UNITS_WG]: every 128-B line is written ONCE, by ONE workgroup
   int T, N;
 };
 
@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
   const int xw = (blockIdx.x * NB) * UNITS_WG + wave * UNITS_WAVE + ((lane >> 2) & 3);  // + b*16: this lane's slot
   for (int t = 0; t < a.T; ++t) {
     const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;   // own previous value only
-    const float* xprev = a.xh + (size_t)((t + 1) & 1) * NWG * NB * UNITS_WG;  // written in step t-1
-    float* xnext = a.xh + (size_t)(t & 1) * NWG * NB * UNITS_WG;
+    // step-indexed slots: a line is never re-used inside the launch, so no XCD's L2 can hold an
+    // older copy of it (the agent-scope acquire only invalidates the reader's L1)
+    const float* xprev = a.xh + (size_t)(t > 0 ? t - 1 : 0) * NWG * NB * UNITS_WG;  // written in step t-1
+    float* xnext = a.xh + (size_t)t * NWG * NB * UNITS_WG;
     float hp[NB][8];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -200,7 +202,7 @@ struct GruBwdArgs {
   float* dgh;          // [T][N][3H]
   float* dh0;          // [N][H]
   unsigned* sync;
-  float* xg;           // exchange [2][NWG][NB][3][UNITS_WG]: one writing workgroup per 128-B line
+  float* xg;           // exchange [T][NWG][NB][3][UNITS_WG]: each 128-B line written once by one workgroup
   int T, N;
 };
 
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
   constexpr int XG_WG = NB * 3 * UNITS_WG;   // floats per workgroup per step
   const int xgw = blockIdx.x * XG_WG + my_b * 3 * UNITS_WG + wave * UNITS_WAVE + (lane >> 4);  // + gate*16
   for (int t = a.T - 1; t >= 0; --t) {
-    float* xcur = a.xg + (size_t)(t & 1) * NWG * XG_WG;
+    float* xcur = a.xg + (size_t)t * NWG * XG_WG;
     float dh_direct = 0.f, mk = 0.f;
     if (worker) {
       const size_t row = (size_t)t * a.N + my_b;
@@ -284,9 +286,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
 
 // workspace layout: [0, 256) barrier words (zeroed per call) | [256, ...) exchange image (128-B aligned
 // when the workspace is; rows of one workgroup never share a cache line with another workgroup's)
-// forward image: 2*NWG*NB*UNITS_WG floats (32 KB); backward image (below) is the larger one
-constexpr int64_t GRU_XG_BYTES = (int64_t)2 * NWG * NB * 3 * UNITS_WG * 4;    // backward
-extern "C" int64_t wsmg_gru_sync_bytes(void) { return 256 + GRU_XG_BYTES; }
+// per step: forward image NWG*NB*UNITS_WG floats (16 KB), backward image 3x that (48 KB)
+extern "C" int64_t wsmg_gru_workspace_bytes(int T) { return 256 + (int64_t)T * NWG * NB * 3 * UNITS_WG * 4; }
 
 extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
                             int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
@@ -339,7 +340,7 @@ struct LstmFwdArgs {
   const float* bhh;    // [2][4*LH]
   const int* len;      // [U]
   float* out;          // [U][L][2*LH]
-  float* hs;           // [2 dir][2 ping-pong][NB][LH] recurrent state exchange (zeroed by the launcher)
+  float* hs;           // exchange [2 dir][L][L_NWG][NB][UNITS_WG]: each line written once by one workgroup
   float* sg;           // [2][U][L][4][LH] saved gates i,f,g,o
   float* sc;           // [2][U][L][LH]    saved cell state c_t
   unsigned* sync;      // per direction 16 words: [0] counter, [1] error
@@ -372,20 +373,20 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
     if (my_b0 + 1 < a.U) mylen[1] = a.len[my_b0 + 1];
   }
   float c[2] = {0.f, 0.f};
-  float* hs = a.hs + (size_t)dir * 2 * NB * LH;   // image [2][L_NWG][NB][UNITS_WG]: one writer per line
+  float* hs = a.hs + (size_t)dir * a.L * NB * LH;  // step-indexed image [L][L_NWG][NB][UNITS_WG]
   const int wgi = blockIdx.x % L_NWG;
   const int xk = ((2 * lane) >> 4) * NB * UNITS_WG + ((2 * lane) & 15);          // + b*16
   const int xw = wgi * NB * UNITS_WG + wave * UNITS_WAVE + ((lane >> 2) & 3);    // + b*16
 
   for (int s = 0; s < a.L; ++s) {
     const int t = dir == 0 ? s : a.L - 1 - s;
-    const float* hprev = hs + (size_t)(s & 1) * NB * LH;
-    float* hnext = hs + (size_t)((s + 1) & 1) * NB * LH;
+    const float* hprev = hs + (size_t)(s > 0 ? s - 1 : 0) * NB * LH;   // slot written in step s-1
+    float* hnext = hs + (size_t)s * NB * LH;
     float hp[NB][2];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      hp[b][0] = hprev[xk + b * UNITS_WG];
-      hp[b][1] = hprev[xk + b * UNITS_WG + 1];
+      hp[b][0] = s > 0 ? hprev[xk + b * UNITS_WG] : 0.f;       // initial state is zero
+      hp[b][1] = s > 0 ? hprev[xk + b * UNITS_WG + 1] : 0.f;
     }
     float acc[128];
 #pragma unroll
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       for (int i = 0; i < 2; ++i) {
         const int b = my_b0 + i;
         if (b < a.U) {
-          const float hold = hprev[xw + b * UNITS_WG];
+          const float hold = s > 0 ? hprev[xw + b * UNITS_WG] : 0.f;
           const bool active = t < mylen[i];
           float hnew = hold;
           float outv = 0.f;
@@ -442,7 +443,7 @@ struct LstmBwdArgs {
   const float* sc;     // [2][U][L][LH]
   float* dg;           // [U][L][2][4*LH]  gradient of the gate pre-activations (= d gi = d gh)
   unsigned* sync;
-  float* xg;           // exchange [2 dir][2][L_NWG][NB][4][UNITS_WG]
+  float* xg;           // exchange [2 dir][L][L_NWG][NB][4][UNITS_WG]: each line written once
   int U, L;
 };
 
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 
   for (int s = a.L - 1; s >= 0; --s) {
     const int t = dir == 0 ? s : a.L - 1 - s;
-    float* xcur = a.xg + ((size_t)dir * 2 + (s & 1)) * L_NWG * LXG_WG;
+    float* xcur = a.xg + ((size_t)dir * a.L + s) * L_NWG * LXG_WG;
     float dh_direct = 0.f;
     if (worker) {
       float* dgp = a.dg + (((size_t)my_b * a.L + t) * 2 + dir) * 4 * LH + my_unit;
@@ -533,9 +534,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
 
 }  // namespace
 
-constexpr int64_t LSTM_HS_BYTES = (int64_t)2 * 2 * NB * LH * 4;                          // forward state image
-constexpr int64_t LSTM_XG_BYTES = (int64_t)2 * 2 * L_NWG * NB * 4 * UNITS_WG * 4;        // backward gate image
-extern "C" int64_t wsmg_lstm_state_bytes(void) { return 256 + LSTM_XG_BYTES; }
+// per token and direction: forward image NB*LH floats (4 KB), backward image 4x that (16 KB)
+extern "C" int64_t wsmg_lstm_workspace_bytes(int L) { return 256 + (int64_t)2 * L * L_NWG * NB * 4 * UNITS_WG * 4; }
 
 extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_hh, const int32_t* lengths, int U, int L,
                              int hidden, float* out, float* save_gates, float* save_c, void* state_ws,
@@ -543,7 +543,7 @@ extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_
   if (hidden != LH || U <= 0 || U > NB || L <= 0) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
   if (((uintptr_t)state_ws & 127) != 0) return WSMG_EINVAL;
-  hipError_t e = hipMemsetAsync(state_ws, 0, 256 + LSTM_HS_BYTES, s);   // barrier words + zero initial state
+  hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);   // barrier words
   if (e != hipSuccess) return (int)e;
   LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)((char*)state_ws + 256), save_gates, save_c,
                 (unsigned*)state_ws, U, L};

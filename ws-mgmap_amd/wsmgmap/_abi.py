@@ -57,13 +57,13 @@ for _n in ["wsmg_channel_sum", "wsmg_bn_act_fwd", "wsmg_bn_act_bwd", "wsmg_relu_
     _SIG[_n + "_bf16"] = list(_SIG[_n])
 _SIG["wsmg_conv2d_fwd_bf16"] = [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
 _SIG["wsmg_conv2d_bwd_data_bf16"] = [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
-_SIG["wsmg_gru_sync_bytes"] = []
+_SIG["wsmg_gru_workspace_bytes"] = [c_i]
 _SIG["wsmg_gru_fwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_p]
 _SIG["wsmg_gru_bwd"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_p]
-_SIG["wsmg_lstm_state_bytes"] = []
+_SIG["wsmg_lstm_workspace_bytes"] = [c_i]
 _SIG["wsmg_lstm_fwd"] = [c_p] * 4 + [c_i] * 3 + [c_p] * 4 + [c_p]
 _SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
-_RESTYPE = {"wsmg_lstm_state_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_sync_bytes": c_l}
+_RESTYPE = {"wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
 
 _lib = None
 

@@ -466,7 +466,7 @@ class _MaskedGRU(torch.autograd.Function):
         dev = gi.device
         y = torch.empty(T, N, H, device=dev, dtype=torch.float32)
         saves = [torch.empty(T, N, H, device=dev, dtype=torch.float32) for _ in range(4)]
-        sync = _rnn_workspace(_abi.lib().wsmg_gru_sync_bytes(), dev)
+        sync = _rnn_workspace(_abi.lib().wsmg_gru_workspace_bytes(T), dev)
         _abi.call("wsmg_gru_fwd", _p(gi), _p(w_hh), _p(b_hh), _p(h0), _p(masks), T, N, H, _p(y),
                   *[_p(s) for s in saves], _p(sync), _stream())
         ctx.save_for_backward(w_hh, h0, masks, y, *saves)
@@ -482,7 +482,7 @@ class _MaskedGRU(torch.autograd.Function):
         dgi = torch.empty(T, N, 3 * H, device=dev, dtype=torch.float32)
         dgh = torch.empty(T, N, 3 * H, device=dev, dtype=torch.float32)
         dh0 = torch.empty(N, H, device=dev, dtype=torch.float32)
-        sync = _rnn_workspace(_abi.lib().wsmg_gru_sync_bytes(), dev)
+        sync = _rnn_workspace(_abi.lib().wsmg_gru_workspace_bytes(T), dev)
         _abi.call("wsmg_gru_bwd", _p(dy), None, _p(w_hh), _p(h0), _p(masks), _p(y), _p(sr), _p(sz), _p(sn), _p(sghn),
                   T, N, H, _p(dgi), _p(dgh), _p(dh0), _p(sync), _stream())
         hprev = torch.cat([h0.unsqueeze(0), y[:-1]], dim=0) * masks.unsqueeze(-1)
@@ -511,7 +511,7 @@ class _BiLSTM(torch.autograd.Function):
         out = torch.empty(U, L, 2 * H, device=dev, dtype=torch.float32)
         sg = torch.zeros(2, U, L, 4, H, device=dev, dtype=torch.float32)
         sc = torch.zeros(2, U, L, H, device=dev, dtype=torch.float32)
-        ws = _rnn_workspace(_abi.lib().wsmg_lstm_state_bytes(), dev)
+        ws = _rnn_workspace(_abi.lib().wsmg_lstm_workspace_bytes(L), dev)
         _abi.call("wsmg_lstm_fwd", _p(gi), _p(w_hh), _p(b_hh), _p(lengths), U, L, H, _p(out), _p(sg), _p(sc), _p(ws), _stream())
         ctx.save_for_backward(w_hh, lengths, out, sg, sc)
         return out
@@ -524,7 +524,7 @@ class _BiLSTM(torch.autograd.Function):
         dev = out.device
         dout = dout.contiguous()
         dg = torch.empty(U, L, 2, 4 * H, device=dev, dtype=torch.float32)
-        ws = _rnn_workspace(_abi.lib().wsmg_lstm_state_bytes(), dev)
+        ws = _rnn_workspace(_abi.lib().wsmg_lstm_workspace_bytes(L), dev)
         _abi.call("wsmg_lstm_bwd", _p(dout), _p(w_hh), _p(lengths), _p(sg), _p(sc), U, L, H, _p(dg), _p(ws), _stream())
         zero = torch.zeros(U, 1, H, device=dev, dtype=torch.float32)
         hprev_f = torch.cat([zero, out[:, :-1, :H]], dim=1)       # state before step t (forward direction)
