@@ -496,20 +496,22 @@ def test_bilstm_persistent_kernel(lens):
     close("lstm.demb", enc.embedding_layer.weight.grad, ref, 1e-4, 2e-5 * float(ref.abs().max()) + 1e-9)
 
 
-def test_rnn_handoff_under_concurrent_load(ops):
+@pytest.mark.parametrize("Tn", [33, 64])
+def test_rnn_handoff_under_concurrent_load(ops, Tn):
     """The persistent GRU/LSTM kernels exchange h_t between workgroups on different XCDs inside one
-    launch.  Run them repeatedly while a second stream saturates the chip, with the exchange images
-    poisoned with NaN before every launch: any stale or missed hand-off would surface as a NaN or as
-    a bitwise difference from the first (unloaded) run."""
+    launch.  Run them repeatedly while a second stream saturates the chip with bf16 MFMA convs, with the
+    exchange images poisoned with NaN before every launch: a stale or missed hand-off, or the wrong
+    partial sums these kernels produced when a conv workgroup shared their CU (they now own the CU, see
+    wsmg_rnn.hip "CU ownership"), surface as a NaN or a bitwise difference from the first, unloaded run."""
     torch.manual_seed(0)
-    Tn, N, Hd = 48, 8, 512
+    N, Hd = 8, 512
     gi = torch.randn(Tn, N, 3 * Hd, device="cuda")
     whh = torch.randn(3 * Hd, Hd, device="cuda") * 0.04
     bhh = torch.randn(3 * Hd, device="cuda") * 0.1
     h0 = torch.randn(N, Hd, device="cuda")
     masks = torch.ones(Tn, N, device="cuda")
     masks[0] = 0
-    masks[17, 3] = 0
+    masks[Tn // 2, 3] = 0
     gy = torch.randn(Tn, N, Hd, device="cuda")
     U, L = 8, 60
     lgi = torch.randn(U, L, 2, 512, device="cuda")
@@ -536,7 +538,7 @@ def test_rnn_handoff_under_concurrent_load(ops):
         side = torch.cuda.Stream()
         x = torch.randn(256, 24, 24, 256, device="cuda").to(torch.bfloat16)
         wconv = torch.randn(256, 256, 3, 3, device="cuda") * 0.02
-        for i in range(80):
+        for i in range(40):
             with torch.cuda.stream(side):
                 for _ in range(4):
                     ops.conv2d(x, wconv, None, 1, 1)

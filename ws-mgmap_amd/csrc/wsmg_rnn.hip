@@ -19,6 +19,8 @@
 // which is what the reference's split-at-zeros sequence form computes — so no host sync is needed.
 // Input projections (x W_ih^T + b_ih for all T*N rows) and the weight gradients are single large
 // GEMMs done by the caller.  Gate order r, z, n (PyTorch nn.GRU).
+#include <stdlib.h>
+
 #include "wsmg_common.h"
 
 namespace {
@@ -206,6 +208,38 @@ struct GruBwdArgs {
   int T, N;
 };
 
+// partial sums of W_hh^T dgh over this lane's K slice: acc[u*8+b], u = 0..3 units of the wave
+__device__ __forceinline__ void gru_bwd_partials(const float* xcur, const float (&wt)[4][24], int N, int lane,
+                                                 float (&acc)[32]) {
+  constexpr int XG_WG = NB * 3 * UNITS_WG;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b < N) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        // gate row k = 256q + 4 lane + e  ->  gate k/512, unit k%512 -> [unit/16 workgroup][b][gate][unit%16]
+        const int k = 256 * q + 4 * lane;
+        const int gate = k >> 9, unit = k & 511;
+        f32x4 g = *reinterpret_cast<const f32x4*>(xcur + (unit >> 4) * XG_WG + b * 3 * UNITS_WG + gate * UNITS_WG + (unit & 15));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[u * 8 + b] = fmaf(wt[u][q * 4 + e], g[e], acc[u * 8 + b]);
+      }
+    }
+  }
+}
+__device__ __forceinline__ float reduce32(float (&acc)[32], int lane) {
+  halve<32, 32>(acc, lane);
+  halve<16, 16>(acc, lane);
+  halve<8, 8>(acc, lane);
+  halve<4, 4>(acc, lane);
+  halve<2, 2>(acc, lane);
+  return acc[0] + __shfl_xor(acc[0], 1, 64);
+}
+
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
   __shared__ int ok_lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,30 +287,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
     if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
     // dh_{t-1}[b][u] = mask * (dh*z + sum_k dgh[b][k] * W_hh[k][u])
     float acc[32];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < a.N) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          // gate row k = 256q + 4 lane + e  ->  gate k/512, unit k%512 -> [unit/16 workgroup][b][gate][unit%16]
-          const int k = 256 * q + 4 * lane;
-          const int gate = k >> 9, unit = k & 511;
-          f32x4 g = *reinterpret_cast<const f32x4*>(xcur + (unit >> 4) * XG_WG + b * 3 * UNITS_WG + gate * UNITS_WG + (unit & 15));
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u * 8 + b] = fmaf(wt[u][q * 4 + e], g[e], acc[u * 8 + b]);
-        }
-      }
-    }
-    halve<32, 32>(acc, lane);
-    halve<16, 16>(acc, lane);
-    halve<8, 8>(acc, lane);
-    halve<4, 4>(acc, lane);
-    halve<2, 2>(acc, lane);
-    float s = acc[0] + __shfl_xor(acc[0], 1, 64);
+    gru_bwd_partials(xcur, wt, a.N, lane, acc);
+    const float s = reduce32(acc, lane);
     carry = (dh_direct + s) * mk;
   }
   if (worker) a.dh0[(size_t)my_b * H + my_unit] = carry;
@@ -286,6 +298,28 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
 
 // workspace layout: [0, 256) barrier words (zeroed per call) | [256, ...) exchange image (128-B aligned
 // when the workspace is; rows of one workgroup never share a cache line with another workgroup's)
+// CU ownership.  These persistent kernels must not share a CU with workgroups of other kernels: with a
+// bf16 implicit-GEMM conv (MFMA) workgroup co-resident on the same SIMDs, gru_bwd_kernel returned wrong
+// partial sums in isolated lanes (low half of v_pk_fma_f32 pairs; memory contents and the shuffle
+// reduction were verified identical) on every run, and never when it owned the CU.  The cause below the
+// ISA level is not established; the measured facts are in DESIGN.md ("RNN kernels: CU ownership").
+// Requesting (almost) the CU's whole 160 KiB LDS makes co-residency with any LDS-using workgroup, and
+// of two of these workgroups, impossible.  WSMG_RNN_EXCL=0 disables, any other value is KiB (debug).
+constexpr unsigned EXCL_LDS_BYTES = 159 * 1024;
+static unsigned rnn_excl_lds() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WSMG_RNN_EXCL");
+    v = e ? atoi(e) : 1;
+  }
+  return v == 0 ? 0u : (v == 1 ? EXCL_LDS_BYTES : (unsigned)v * 1024u);
+}
+template <class K>
+static hipError_t allow_big_lds(K kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)(160 * 1024 - 64));
+}
+
 // per step: forward image NWG*NB*UNITS_WG floats (16 KB), backward image 3x that (48 KB)
 extern "C" int64_t wsmg_gru_workspace_bytes(int T) { return 256 + (int64_t)T * NWG * NB * 3 * UNITS_WG * 4; }
 
@@ -299,7 +333,8 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   if (e != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
                (float*)((char*)sync_ws + 256), T, N};
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  if ((e = allow_big_lds(gru_fwd_kernel)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), rnn_excl_lds(), s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -314,7 +349,8 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   if (e != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
                (float*)((char*)sync_ws + 256), T, N};
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  if ((e = allow_big_lds(gru_bwd_kernel)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), rnn_excl_lds(), s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -547,7 +583,8 @@ extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_
   if (e != hipSuccess) return (int)e;
   LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)((char*)state_ws + 256), save_gates, save_c,
                 (unsigned*)state_ws, U, L};
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  if ((e = allow_big_lds(lstm_fwd_kernel)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), rnn_excl_lds(), s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -560,6 +597,7 @@ extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t
   hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
   LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)state_ws, (float*)((char*)state_ws + 256), U, L};
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
+  if ((e = allow_big_lds(lstm_bwd_kernel)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), rnn_excl_lds(), s, a);
   WSMG_RETURN_LAUNCH();
 }
