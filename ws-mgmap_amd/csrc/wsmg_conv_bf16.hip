@@ -136,10 +136,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   auto gload = [&](u32x4 (&ra)[APASS], u32x4 (&rb)[BPASS]) {
     const int ky = BWD ? cy + it_ay * tstep : it_ay, kx = BWD ? cx + it_ax * tstep : it_ax;
     const int sdelta = sg * (it_ay * a.SW + it_ax) * a.Kc + it_ch * BK;
-    const int wdelta = (ky * a.KW + kx) * a.Kc + it_ch * BK;
+    // past the last k-step (the loop runs a multiple of PF steps) every piece is out of range -> zeros
+    const int wdelta = it_ch < kchunks ? (ky * a.KW + kx) * a.Kc + it_ch * BK : -0x20000000;
+    const unsigned live = it_ch < kchunks ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      bool ok = ((ymask[i] >> it_ay) & (xmask[i] >> it_ax) & 1u) != 0;
+      bool ok = ((ymask[i] >> it_ay) & (xmask[i] >> it_ax) & live) != 0;
       ra[i] = buf_load16(rs_src, ok ? (roff[i] + sdelta) * 2 : -1);
     }
 #pragma unroll
@@ -164,41 +166,38 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  // register set j holds the k-step with (step % PF == j); LDS holds the current step
+  // register set j holds the k-step with (step % PF == j); LDS holds the current step.  The loop body is
+  // branch-free and runs a multiple of PF steps (the surplus steps load zeros): with conditional steps
+  // the compiler routes the loop-carried accumulators through VGPR copies (64-128 v_accvgpr moves per
+  // iteration), which costs more than the padding.
   gload(ra[0], rb[0]);
   lstore(ra[0], rb[0]);
   __syncthreads();
 #pragma unroll
-  for (int j = 1; j < PF; ++j)
-    if (j < steps) gload(ra[j], rb[j]);
+  for (int j = 1; j < PF; ++j) gload(ra[j], rb[j]);
   for (int step0 = 0; step0 < steps; step0 += PF) {
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
-      const int step = step0 + j;
-      if (step < steps) {
-        if (step + PF < steps) gload(ra[j], rb[j]);  // set j is free: its step is in LDS
+      gload(ra[j], rb[j]);  // set j is free: its step is in LDS
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-          // lane (r, h) holds k = 16*ks + 8h .. +7 of its row: one 16-B LDS read per operand
-          bf16x8 af[2], bf[NT];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        // lane (r, h) holds k = 16*ks + 8h .. +7 of its row: one 16-B LDS read per operand
+        bf16x8 af[2], bf[NT];
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-            af[t] = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 * t + r) * LDB + ks * 32 + h * 16]);
+        for (int t = 0; t < 2; ++t)
+          af[t] = *reinterpret_cast<const bf16x8*>(&As[(wm + 32 * t + r) * LDB + ks * 32 + h * 16]);
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+          bf[u] = *reinterpret_cast<const bf16x8*>(&Bs[(wn + 32 * u + r) * LDB + ks * 32 + h * 16]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int u = 0; u < NT; ++u)
-            bf[u] = *reinterpret_cast<const bf16x8*>(&Bs[(wn + 32 * u + r) * LDB + ks * 32 + h * 16]);
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-              acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bf[u], acc[t][u], 0, 0, 0);
-        }
-        __syncthreads();
-        if (step + 1 < steps) {
-          lstore(ra[(j + 1) % PF], rb[(j + 1) % PF]);
-          __syncthreads();
-        }
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bf[u], acc[t][u], 0, 0, 0);
       }
+      __syncthreads();
+      lstore(ra[(j + 1) % PF], rb[(j + 1) % PF]);
+      __syncthreads();
     }
   }
 
@@ -225,11 +224,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
 }
 
 // ----------------------------------------------------------------------------- backward weight
+// dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p shifted by tap][ci]: both operands have the pixel
+// axis as K, which is the strided axis of NHWC, so both go through LDS and are fetched with the
+// transposing read.  A workgroup owns 32*TC output channels x 4*TU "units" (unit = one tap x 32 input
+// channels) over a slice of the pixel reduction; wave w owns units 4w*TU/4.. i.e. TU consecutive units,
+// and every wave reuses its TC dY fragments across its TU X fragments (LDS reads per MFMA:
+// (2 TC + 2 TU) / (TC TU) -> 3 for <2,1>, 2 for <2,2>, 1.5 for <4,2>; the kernel is LDS-bandwidth-bound).
 constexpr int WKP = 64;          // pixels per k-step
-constexpr int WCO = 64;          // output channels per workgroup
-constexpr int WUW = 1;           // (tap, 32-channel) units per wave (dY fragments reused across them)
-constexpr int WUN = 4 * WUW;     // units per workgroup
-constexpr int D_LD = 192;        // dY tile row stride (bytes): 128 B data + 64 B pad -> tr reads conflict-free
 constexpr int X_LD = 64;         // X tile row stride (bytes): 32 bf16, rows land 16 banks apart
 
 struct WgradArgsB {
@@ -247,8 +248,13 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <int PF>
+template <int TC, int TU, int PF>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
+  constexpr int WCO = 32 * TC;              // output channels per workgroup
+  constexpr int WUN = 4 * TU;               // units per workgroup
+  constexpr int D_LD = TC == 4 ? 320 : 192; // dY tile row stride (bytes): 4 consecutive rows 64 B apart mod 256
+  constexpr int DSEG = 4 * TC;              // 16-B pieces per dY row
+  constexpr int DROWS = 256 / DSEG;         // dY rows staged per pass (TC passes)
   __shared__ __attribute__((aligned(16))) unsigned char Ds[WKP * D_LD];
   __shared__ __attribute__((aligned(16))) unsigned char Xs[WUN * WKP * X_LD];
   const int tid = threadIdx.x;
@@ -277,16 +283,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
     uky[u] = t / a.KW;
     ukx[u] = t - uky[u] * a.KW;
   }
-  // staging maps: dY tile 64 px x 128 B = 512 16-B pieces (2 per thread); X tile per unit 64 px x 64 B
-  // = 256 pieces (1 per thread and unit)
-  const int dpx = tid >> 3, dseg = tid & 7;   // + 32 rows on the second pass
+  // staging maps: dY tile 64 px x 64*TC B = 256*TC 16-B pieces (TC per thread); X tile per unit
+  // 64 px x 64 B = 256 pieces (1 per thread and unit)
+  const int dpx = tid / DSEG, dseg = tid % DSEG;   // + DROWS rows per pass
   const int xpx = tid >> 2, xseg = tid & 3;
 
-  f32x16 acc[2][WUW];
+  f32x16 acc[TC][TU];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < TC; ++t)
 #pragma unroll
-    for (int u = 0; u < WUW; ++u)
+    for (int u = 0; u < TU; ++u)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
@@ -313,11 +319,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const int adv_oy = adv_rem / a.OW, adv_ox = adv_rem - adv_oy * a.OW;
   int it_p = (int)p_begin;  // first pixel of the k-step about to be loaded
   const int pend = (int)p_end;
-  u32x4 rd[PF][2], rx[PF][WUN];
-  auto gload = [&](u32x4 (&rd)[2], u32x4 (&rx)[WUN]) {
+  u32x4 rd[PF][TC], rx[PF][WUN];
+  auto gload = [&](u32x4 (&rd)[TC], u32x4 (&rx)[WUN]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int p = it_p + dpx + 32 * i;
+    for (int i = 0; i < TC; ++i) {
+      int p = it_p + dpx + DROWS * i;
       bool ok = co_ok && p < pend;
       rd[i] = buf_load16(rs_dy, ok ? (p * a.Cout + co0 + dseg * 8) * 2 : -1);
     }
@@ -337,9 +343,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
     if (it_oy >= a.OH) { it_oy -= a.OH; ++it_b; }
     it_b += adv_b;
   };
-  auto lstore = [&](const u32x4 (&rd)[2], const u32x4 (&rx)[WUN]) {
+  auto lstore = [&](const u32x4 (&rd)[TC], const u32x4 (&rx)[WUN]) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&Ds[(dpx + 32 * i) * D_LD + dseg * 16]) = rd[i];
+    for (int i = 0; i < TC; ++i) *reinterpret_cast<u32x4*>(&Ds[(dpx + DROWS * i) * D_LD + dseg * 16]) = rd[i];
 #pragma unroll
     for (int u = 0; u < WUN; ++u) *reinterpret_cast<u32x4*>(&Xs[(u * WKP + xpx) * X_LD + xseg * 16]) = rx[u];
   };
@@ -348,57 +354,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const int li = lane & 15, q = li >> 2, p4 = li & 3;
   const int half16 = (lane >> 4) & 1;  // which 16 of the 32 MFMA rows/cols this 16-lane group owns
   const int h = lane >> 5;             // k half: pixels 8h .. 8h+7 of a 16-pixel MFMA step
-  const unsigned char* a_base0 = &Ds[(8 * h + q) * D_LD + (half16 * 16 + p4 * 4) * 2];        // co 0..31
-  const unsigned char* a_base1 = a_base0 + 64;                                                 // co 32..63
-  const unsigned char* b_base = &Xs[(wave * WUW * WKP + 8 * h + q) * X_LD + (half16 * 16 + p4 * 4) * 2];
+  const unsigned char* a_base = &Ds[(8 * h + q) * D_LD + (half16 * 16 + p4 * 4) * 2];   // + 64 t: co 32t..32t+31
+  const unsigned char* b_base = &Xs[(wave * TU * WKP + 8 * h + q) * X_LD + (half16 * 16 + p4 * 4) * 2];
 
-  if (p_begin < p_end) {
-    gload(rd[0], rx[0]);
-    lstore(rd[0], rx[0]);
-  }
+  // branch-free main loop over a multiple of PF k-steps (pieces past p_end load zeros), see the igemm loop
+  gload(rd[0], rx[0]);
+  lstore(rd[0], rx[0]);
   __syncthreads();
 #pragma unroll
-  for (int j = 1; j < PF; ++j)
-    if (p_begin + (int64_t)j * WKP < p_end) gload(rd[j], rx[j]);
+  for (int j = 1; j < PF; ++j) gload(rd[j], rx[j]);
   for (int64_t pb = p_begin; pb < p_end; pb += (int64_t)PF * WKP) {
 #pragma unroll
-   for (int j = 0; j < PF; ++j) {
-    const int64_t p0 = pb + (int64_t)j * WKP;
-    if (p0 >= p_end) break;
-    bool more = p0 + WKP < p_end;
-    if (p0 + (int64_t)PF * WKP < p_end) gload(rd[j], rx[j]);
+    for (int j = 0; j < PF; ++j) {
+      gload(rd[j], rx[j]);
 #pragma unroll
-    for (int ks = 0; ks < WKP / 16; ++ks) {
-      bf16x4 a0l = tr_read(a_base0 + (16 * ks) * D_LD), a0h = tr_read(a_base0 + (16 * ks + 4) * D_LD);
-      bf16x4 a1l = tr_read(a_base1 + (16 * ks) * D_LD), a1h = tr_read(a_base1 + (16 * ks + 4) * D_LD);
-      bf16x8 a0 = __builtin_shufflevector(a0l, a0h, 0, 1, 2, 3, 4, 5, 6, 7);
-      bf16x8 a1 = __builtin_shufflevector(a1l, a1h, 0, 1, 2, 3, 4, 5, 6, 7);
+      for (int ks = 0; ks < WKP / 16; ++ks) {
+        bf16x8 af[TC], bfr[TU];
 #pragma unroll
-      for (int u = 0; u < WUW; ++u) {
-        const unsigned char* bp = b_base + u * WKP * X_LD;
-        bf16x4 bl = tr_read(bp + (16 * ks) * X_LD), bh = tr_read(bp + (16 * ks + 4) * X_LD);
-        bf16x8 bb = __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][u], 0, 0, 0);
-        acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][u], 0, 0, 0);
+        for (int t = 0; t < TC; ++t) {
+          bf16x4 l = tr_read(a_base + 64 * t + (16 * ks) * D_LD), hh = tr_read(a_base + 64 * t + (16 * ks + 4) * D_LD);
+          af[t] = __builtin_shufflevector(l, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          const unsigned char* bp = b_base + u * WKP * X_LD;
+          bf16x4 l = tr_read(bp + (16 * ks) * X_LD), hh = tr_read(bp + (16 * ks + 4) * X_LD);
+          bfr[u] = __builtin_shufflevector(l, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+#pragma unroll
+          for (int t = 0; t < TC; ++t) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfr[u], acc[t][u], 0, 0, 0);
       }
-    }
-    __syncthreads();
-    if (more) {
+      __syncthreads();
       lstore(rd[(j + 1) % PF], rx[(j + 1) % PF]);
       __syncthreads();
     }
-   }
   }
   const int r = lane & 31;
   const int taps = a.KH * a.KW;
 #pragma unroll
-  for (int u = 0; u < WUW; ++u) {
-    const int uu = u0 + wave * WUW + u;
+  for (int u = 0; u < TU; ++u) {
+    const int uu = u0 + wave * TU + u;
     if (uu >= a.units) continue;
     const int tap = uu / cchunks;
     const int ci = (uu - tap * cchunks) * 32 + r;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TC; ++t) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         int co = co0 + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
@@ -418,7 +420,7 @@ int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int strid
 }
 
 // register prefetch depth (k-steps in flight).  Measured on MI355X (tools/bench_conv.py): the igemm
-// kernels are fastest at 1 (deeper costs a wave of occupancy), backward-weight at 2.
+// kernels are fastest at 1 (deeper costs occupancy, which hides more latency than the prefetch does).
 int conv_prefetch(int dflt) {
   static int v = -2;
   if (v == -2) {
@@ -493,8 +495,15 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
                (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0};
   a.units = KH * KW * (Cin / 32);
   a.npix = (int64_t)B * OH * OW;
-  int gx = (int)wsmg_cdiv(a.units, WUN), gy = (int)wsmg_cdiv(Cout, WCO);
-  int64_t want = wsmg_cdiv(2048, (int64_t)gx * gy);
+  // tile shape (measured per layer, tools/bench_conv.py): 128 co x 8 units where both dimensions are
+  // large (cated 765 vs 660 TFLOP/s), else 64 co x 4 units, which keeps 5 workgroups per CU resident
+  int tc = (Cout % 128 == 0 && a.units >= 48) ? 4 : 2, tu = tc == 4 ? 2 : 1;
+  if (const char* e = getenv("WSMG_WGRAD_TILE")) {   // debug: "42", "21", "22"
+    int v = atoi(e);
+    if (v == 42 || v == 21 || v == 22) { tc = v / 10; tu = v % 10; }
+  }
+  int gx = (int)wsmg_cdiv(a.units, 4 * tu), gy = (int)wsmg_cdiv(Cout, 32 * tc);
+  int64_t want = wsmg_cdiv(tc * tu >= 4 ? 1024 : 2048, (int64_t)gx * gy);
   int64_t maxz = wsmg_cdiv(a.npix, WKP * 8);
   int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);
   if (gz < 1) gz = 1;
@@ -504,10 +513,15 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
   a.gx = gx;
   a.gy = gy;
   dim3 grid((unsigned)((int64_t)gx * gy * gz));
-  switch (conv_prefetch(2)) {
-    case 1: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, wsmg_s(stream), a); break;
-    case 3: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<3>, grid, dim3(256), 0, wsmg_s(stream), a); break;
-    default: hipLaunchKernelGGL(conv_wgrad_bf16_kernel<2>, grid, dim3(256), 0, wsmg_s(stream), a); break;
+  const int pf = conv_prefetch(1);
+#define WSMG_WGRAD(TC_, TU_, PF_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TC_, TU_, PF_>), grid, dim3(256), 0, wsmg_s(stream), a)
+  if (tc == 4) {
+    if (pf == 1) WSMG_WGRAD(4, 2, 1); else WSMG_WGRAD(4, 2, 2);
+  } else if (tu == 2) {
+    if (pf == 1) WSMG_WGRAD(2, 2, 1); else if (pf == 3) WSMG_WGRAD(2, 2, 3); else WSMG_WGRAD(2, 2, 2);
+  } else {
+    if (pf == 1) WSMG_WGRAD(2, 1, 1); else if (pf == 3) WSMG_WGRAD(2, 1, 3); else WSMG_WGRAD(2, 1, 2);
   }
+#undef WSMG_WGRAD
   WSMG_RETURN_LAUNCH();
 }
