@@ -248,10 +248,11 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <int TC, int TU, int PF>
+template <int TC, int TU, int PF, int UPT>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   constexpr int WCO = 32 * TC;              // output channels per workgroup
   constexpr int WUN = 4 * TU;               // units per workgroup
+  constexpr int NG = WUN / UPT;             // tap groups: UPT consecutive units share one tap (Cin/32 % UPT == 0)
   constexpr int D_LD = TC == 4 ? 320 : 192; // dY tile row stride (bytes): 4 consecutive rows 64 B apart mod 256
   constexpr int DSEG = 4 * TC;              // 16-B pieces per dY row
   constexpr int DROWS = 256 / DSEG;         // dY rows staged per pass (TC passes)
@@ -272,16 +273,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const int cchunks = a.Cin / 32;
   const int ohw = a.OH * a.OW;
 
-  int uky[WUN], ukx[WUN], uci[WUN];
-  bool uok[WUN];
+  // a group's UPT units are consecutive 32-channel chunks of ONE tap: one bounds test and one base offset
+  // per group and k-step, the units inside it differ by a 64-byte immediate
+  int gky[NG], gkx[NG], gci[NG];
+  bool gok[NG];
 #pragma unroll
-  for (int u = 0; u < WUN; ++u) {
-    int uu = u0 + u;
-    uok[u] = uu < a.units;
-    int t = uok[u] ? uu / cchunks : 0;
-    uci[u] = uok[u] ? (uu - t * cchunks) * 32 : 0;
-    uky[u] = t / a.KW;
-    ukx[u] = t - uky[u] * a.KW;
+  for (int g = 0; g < NG; ++g) {
+    int uu = u0 + g * UPT;
+    gok[g] = uu < a.units;
+    int t = gok[g] ? uu / cchunks : 0;
+    gci[g] = gok[g] ? (uu - t * cchunks) * 32 : 0;
+    gky[g] = t / a.KW;
+    gkx[g] = t - gky[g] * a.KW;
   }
   // staging maps: dY tile 64 px x 64*TC B = 256*TC 16-B pieces (TC per thread); X tile per unit
   // 64 px x 64 B = 256 pieces (1 per thread and unit)
@@ -302,9 +305,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes);
   const __amdgpu_buffer_rsrc_t rs_dy = make_rsrc(a.dy, a.dy_bytes);
   const bool co_ok = (co0 + dseg * 8) < a.Cout;
-  int udelta[WUN];
+  int gdelta[NG];
 #pragma unroll
-  for (int u = 0; u < WUN; ++u) udelta[u] = (uky[u] * a.W + ukx[u]) * a.Cin + uci[u] + xseg * 8;
+  for (int g = 0; g < NG; ++g) gdelta[g] = (gky[g] * a.W + gkx[g]) * a.Cin + gci[g] + xseg * 8;
   // pixel iterator of the X staging row (pixel p_begin + xpx + k*WKP)
   int it_b, it_oy, it_ox;
   {
@@ -331,9 +334,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
     const int y0 = it_oy * a.stride - a.pad, x0 = it_ox * a.stride - a.pad;
     const int base = ((it_b * a.H + y0) * a.W + x0) * a.Cin;
 #pragma unroll
-    for (int u = 0; u < WUN; ++u) {
-      bool ok = pok && uok[u] && (unsigned)(y0 + uky[u]) < (unsigned)a.H && (unsigned)(x0 + ukx[u]) < (unsigned)a.W;
-      rx[u] = buf_load16(rs_x, ok ? (base + udelta[u]) * 2 : -1);
+    for (int g = 0; g < NG; ++g) {
+      bool ok = pok && gok[g] && (unsigned)(y0 + gky[g]) < (unsigned)a.H && (unsigned)(x0 + gkx[g]) < (unsigned)a.W;
+      const int off = ok ? (base + gdelta[g]) * 2 : (int)0x80000000;   // 2 GiB + 64 j is still out of range
+#pragma unroll
+      for (int j = 0; j < UPT; ++j) rx[g * UPT + j] = buf_load16(rs_x, off + 64 * j);
     }
     // advance by WKP pixels
     it_p += WKP;
@@ -513,15 +518,26 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
   a.gx = gx;
   a.gy = gy;
   dim3 grid((unsigned)((int64_t)gx * gy * gz));
-  const int pf = conv_prefetch(1);
-#define WSMG_WGRAD(TC_, TU_, PF_) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TC_, TU_, PF_>), grid, dim3(256), 0, wsmg_s(stream), a)
+  const int pf = conv_prefetch(1) >= 2 ? 2 : 1;
+  const int cch = Cin / 32, wun = 4 * tu;
+  int upt = 1;
+  for (int c = wun; c > 1; c >>= 1)
+    if (cch % c == 0) { upt = c; break; }
+#define WSMG_WGRAD(TC_, TU_, PF_, UPT_) \
+  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TC_, TU_, PF_, UPT_>), grid, dim3(256), 0, wsmg_s(stream), a)
+#define WSMG_WGRAD_U4(TC_, TU_, PF_) \
+  do { if (upt >= 4) WSMG_WGRAD(TC_, TU_, PF_, 4); else if (upt == 2) WSMG_WGRAD(TC_, TU_, PF_, 2); else WSMG_WGRAD(TC_, TU_, PF_, 1); } while (0)
+#define WSMG_WGRAD_U8(TC_, TU_, PF_) \
+  do { if (upt == 8) WSMG_WGRAD(TC_, TU_, PF_, 8); else WSMG_WGRAD_U4(TC_, TU_, PF_); } while (0)
   if (tc == 4) {
-    if (pf == 1) WSMG_WGRAD(4, 2, 1); else WSMG_WGRAD(4, 2, 2);
+    if (pf == 1) WSMG_WGRAD_U8(4, 2, 1); else WSMG_WGRAD_U8(4, 2, 2);
   } else if (tu == 2) {
-    if (pf == 1) WSMG_WGRAD(2, 2, 1); else if (pf == 3) WSMG_WGRAD(2, 2, 3); else WSMG_WGRAD(2, 2, 2);
+    if (pf == 1) WSMG_WGRAD_U8(2, 2, 1); else WSMG_WGRAD_U8(2, 2, 2);
   } else {
-    if (pf == 1) WSMG_WGRAD(2, 1, 1); else if (pf == 3) WSMG_WGRAD(2, 1, 3); else WSMG_WGRAD(2, 1, 2);
+    if (pf == 1) WSMG_WGRAD_U4(2, 1, 1); else WSMG_WGRAD_U4(2, 1, 2);
   }
+#undef WSMG_WGRAD_U8
+#undef WSMG_WGRAD_U4
 #undef WSMG_WGRAD
   WSMG_RETURN_LAUNCH();
 }

@@ -84,108 +84,169 @@ struct GruFwdArgs {
   float* sz;
   float* sn;
   float* sghn;         // W_hn h + b_hn
-  unsigned* sync;      // [0] arrival counter, [1] error word (zeroed by the launcher)
-  float* xh;           // exchange [T][NWG][NB][UNITS_WG]: every 128-B line is written ONCE, by ONE workgroup
+  unsigned* sync;      // [1] error word (zeroed by the launcher)
+  unsigned long long* xh;  // exchange [T][NWG][NB][UNITS_WG] of {value, tag} words, each written once per launch
   int T, N;
+  unsigned tagbase;    // launch-unique tag bits (epoch << 10); a word is valid for step t when tag == tagbase | (t + 1)
 };
 
-__global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
-  __shared__ int ok_lds;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
-  // W_hh rows of this wave in registers: row r = gate*4 + unit, k = 4*lane + e (+256 for e >= 4)
-  float w[12][8];
+// Flag-in-data exchange (forward): every h value travels as one 8-byte {value, tag} word written with a
+// single agent-scope store and read with agent-scope loads, so a reader that sees the step's tag has the
+// step's value — no counter, no fences, no separate data read after a barrier: ONE memory round trip per
+// step instead of three.  All 256 threads of a workgroup poll the 4096 words of the step (16 each: one
+// 128-byte row of one producer workgroup and batch), drop the values into LDS, and the four waves read
+// h_{t-1} from there.  Tags are launch-unique (epoch) and slots step-indexed, so stale contents of the
+// image — from an older launch or an older step — can never match.
+__device__ __forceinline__ bool poll_row16(const unsigned long long* src, unsigned want, unsigned* sync, float (&out)[16]) {
+  unsigned n = 0;
+  for (;;) {
+    unsigned long long v[16];
 #pragma unroll
-  for (int r = 0; r < 12; ++r) {
-    const int row = (r >> 2) * H + u0 + (r & 3);
-    f32x4 lo = *reinterpret_cast<const f32x4*>(a.whh + (size_t)row * H + 4 * lane);
-    f32x4 hi = *reinterpret_cast<const f32x4*>(a.whh + (size_t)row * H + 256 + 4 * lane);
+    for (int i = 0; i < 16; ++i) v[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { w[r][e] = lo[e]; w[r][4 + e] = hi[e]; }
+    for (int i = 0; i < 16; ++i) ok = ok && ((unsigned)(v[i] >> 32) == want);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) out[i] = __uint_as_float((unsigned)v[i]);
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if (++n > SPIN_LIMIT || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
   }
-  // after the butterfly lane l (< 48) holds row_local = l/4 (gate = l/16, unit = (l/4)&3), batches 2*(l&3)+{0,1}
-  const int my_unit = u0 + ((lane >> 2) & 3);
-  const int my_b0 = 2 * (lane & 3);
-  float br = 0.f, bz = 0.f, bn = 0.f;
-  if (lane < 16) { br = a.bhh[my_unit]; bz = a.bhh[H + my_unit]; bn = a.bhh[2 * H + my_unit]; }
+}
 
-  // element (b, k) of the exchange image: [(k / 16) workgroup][b][k % 16]
-  const int xk_lo = ((4 * lane) >> 4) * NB * UNITS_WG + ((4 * lane) & 15);
-  const int xk_hi = ((256 + 4 * lane) >> 4) * NB * UNITS_WG + ((4 * lane) & 15);
-  const int xw = (blockIdx.x * NB) * UNITS_WG + wave * UNITS_WAVE + ((lane >> 2) & 3);  // + b*16: this lane's slot
+// lane-local cross-lane moves inside a 16-lane row: DPP (VALU rate) where the pattern exists
+// (xor 1 / xor 2 = quad_perm, xor 8 = row rotate by 8), ds_bpermute only for xor 4
+template <int D>
+__device__ __forceinline__ float row_xor(float v) {
+  const int x = __float_as_int(v);
+  if constexpr (D == 1) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  else if constexpr (D == 8) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));  // row_ror:8
+  else return __shfl_xor(v, D, 64);
+}
+// halving butterfly inside 16-lane rows: C live values per lane, xor distance D; afterwards C/2
+template <int C, int D, int NV>
+__device__ __forceinline__ void halve_row(float (&v)[NV], int lane) {
+  const bool up = (lane & D) != 0;
+#pragma unroll
+  for (int i = 0; i < C / 2; ++i) {
+    float keep = up ? v[i + C / 2] : v[i];
+    float send = up ? v[i] : v[i + C / 2];
+    v[i] = keep + row_xor<D>(send);
+  }
+}
+
+// Work split: wave = 4 hidden units; 16-lane row g of the wave owns unit u0+g (its r, z, n rows of W_hh in
+// registers); the 16 lanes of a row split K = 512 (32 k each, as 8 interleaved float4s), so the reduction
+// is a 4-stage butterfly inside a row (31 lane exchanges per step, 23 of them DPP) instead of a 7-stage
+// one across the wave (127 ds_bpermute, which measured 3.7 us of a 9.9 us step).
+__global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float hs[2][NB][H];   // h_{t-1}, double-buffered by step parity
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, kl = lane & 15;
+  const int my_unit = blockIdx.x * UNITS_WG + wave * UNITS_WAVE + grp;
+  // W_hh rows (r, z, n) of my_unit: k = 64 j + 4 kl + e
+  float w[3][32];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.whh + (size_t)(g * H + my_unit) * H + 64 * j + 4 * kl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[g][4 * j + e] = v[e];
+    }
+  // after the butterfly lane kl of a row holds acc index 2 kl + {0,1} with index = 4 b + gate: even lanes
+  // (r, z) of batch kl/2, odd lanes (n, -).  Even lanes do the gate math for (my_unit, my_b).
+  const int my_b = kl >> 1;
+  const bool worker = ((kl & 1) == 0) && (my_b < a.N);
+  const float br = a.bhh[my_unit], bz = a.bhh[H + my_unit], bn = a.bhh[2 * H + my_unit];
+
+  // staging role of this thread: the 16 units of producer workgroup sw for batch sb
+  const int sw = tid >> 3, sb = tid & 7;
+  const int xw = (blockIdx.x * NB + my_b) * UNITS_WG + wave * UNITS_WAVE + grp;   // this lane's slot in a step image
   for (int t = 0; t < a.T; ++t) {
-    const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;   // own previous value only
-    // step-indexed slots: a line is never re-used inside the launch, so no XCD's L2 can hold an
-    // older copy of it (the agent-scope acquire only invalidates the reader's L1)
-    const float* xprev = a.xh + (size_t)(t > 0 ? t - 1 : 0) * NWG * NB * UNITS_WG;  // written in step t-1
-    float* xnext = a.xh + (size_t)t * NWG * NB * UNITS_WG;
-    float hp[NB][8];
+    float (*hcur)[H] = hs[t & 1];
+    // inputs of this step's gate math do not depend on the recurrence: fetch them before waiting
+    float gr = 0.f, gz = 0.f, gn = 0.f, mk = 0.f;
+    const size_t orow = (size_t)t * a.N + my_b;
+    if (worker) {
+      const float* g = a.gi + orow * 3 * H;
+      gr = g[my_unit]; gz = g[H + my_unit]; gn = g[2 * H + my_unit];
+      mk = a.masks[t * a.N + my_b];
+    }
+    {
+      float row[16];
+      bool good = true;
+      if (sb >= a.N) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) row[i] = 0.f;
+      } else if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)sb * H + sw * UNITS_WG + 4 * i);
+          row[4 * i] = v[0]; row[4 * i + 1] = v[1]; row[4 * i + 2] = v[2]; row[4 * i + 3] = v[3];
+        }
+      } else {
+        const unsigned long long* src = a.xh + ((size_t)(t - 1) * NWG + sw) * NB * UNITS_WG + sb * UNITS_WG;
+        good = poll_row16(src, a.tagbase | (unsigned)t, a.sync, row);
+      }
+      // the mask of this step is applied once, here (h_{t-1} * mask_t is what every consumer needs)
+      const float sm = sb < a.N ? a.masks[t * a.N + sb] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = {row[4 * i] * sm, row[4 * i + 1] * sm, row[4 * i + 2] * sm, row[4 * i + 3] * sm};
+        *reinterpret_cast<f32x4*>(&hcur[sb][sw * UNITS_WG + 4 * i]) = v;
+      }
+      // one workgroup barrier per step; it also orders the re-use of hs[t & 1] two steps later
+      if (__syncthreads_or(good ? 0 : 1)) return;   // timeout or error elsewhere: every thread leaves
+    }
+    float acc[32];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      float m = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
       if (b < a.N) {
-        m = a.masks[t * a.N + b];
-        if (t == 0) {
-          lo = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * H + 4 * lane);
-          hi = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)b * H + 256 + 4 * lane);
-        } else {
-          lo = *reinterpret_cast<const f32x4*>(xprev + xk_lo + b * UNITS_WG);
-          hi = *reinterpret_cast<const f32x4*>(xprev + xk_hi + b * UNITS_WG);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(&hcur[b][64 * j + 4 * kl]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 = fmaf(w[0][4 * j + e], hv[e], s0);
+            s1 = fmaf(w[1][4 * j + e], hv[e], s1);
+            s2 = fmaf(w[2][4 * j + e], hv[e], s2);
+          }
         }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { hp[b][e] = lo[e] * m; hp[b][4 + e] = hi[e] * m; }
+      acc[4 * b] = s0; acc[4 * b + 1] = s1; acc[4 * b + 2] = s2; acc[4 * b + 3] = 0.f;
     }
-    float acc[128];
-#pragma unroll
-    for (int i = 96; i < 128; ++i) acc[i] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 12; ++r) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(w[r][e], hp[b][e], s);
-        acc[r * 8 + b] = s;
-      }
+    halve_row<32, 8>(acc, lane);
+    halve_row<16, 4>(acc, lane);
+    halve_row<8, 2>(acc, lane);
+    halve_row<4, 1>(acc, lane);
+    const float nsum = row_xor<1>(acc[0]);   // odd lane's acc[0] = n gate of the same batch
+    if (worker) {
+      const float ghr = acc[0] + br, ghz = acc[1] + bz, ghn = nsum + bn;
+      const float r = sigmoidf_(gr + ghr);
+      const float z = sigmoidf_(gz + ghz);
+      const float nn = tanhf(gn + r * ghn);
+      const float hprev = hcur[my_b][my_unit];   // already masked
+      const float h = (1.0f - z) * nn + z * hprev;
+      // publish first: the other workgroups are waiting for exactly this word
+      if (t + 1 < a.T)
+        __hip_atomic_store(a.xh + (size_t)t * NWG * NB * UNITS_WG + xw,
+                           ((unsigned long long)(a.tagbase | (unsigned)(t + 1)) << 32) | __float_as_uint(h),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.y[orow * H + my_unit] = h;
+      a.sr[orow * H + my_unit] = r;
+      a.sz[orow * H + my_unit] = z;
+      a.sn[orow * H + my_unit] = nn;
+      a.sghn[orow * H + my_unit] = ghn;
     }
-    halve<128, 32>(acc, lane);
-    halve<64, 16>(acc, lane);
-    halve<32, 8>(acc, lane);
-    halve<16, 4>(acc, lane);
-    halve<8, 2>(acc, lane);
-    halve<4, 1>(acc, lane);
-    // acc[0], acc[1]: row_local = lane/4, batch = my_b0 + {0,1}.  Bring z (lanes 16..31) and n (32..47) to lanes 0..15.
-    float z0 = __shfl(acc[0], lane + 16, 64), z1 = __shfl(acc[1], lane + 16, 64);
-    float n0 = __shfl(acc[0], lane + 32, 64), n1 = __shfl(acc[1], lane + 32, 64);
-    if (lane < 16) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int b = my_b0 + i;
-        if (b < a.N) {
-          const size_t row = (size_t)t * a.N + b;
-          const float* g = a.gi + row * 3 * H;
-          float ghr = (i ? acc[1] : acc[0]) + br;
-          float ghz = (i ? z1 : z0) + bz;
-          float ghn = (i ? n1 : n0) + bn;
-          float r = sigmoidf_(g[my_unit] + ghr);
-          float z = sigmoidf_(g[H + my_unit] + ghz);
-          float nn = tanhf(g[2 * H + my_unit] + r * ghn);
-          float hprev = hsrc[(size_t)b * H + my_unit] * a.masks[t * a.N + b];
-          float h = (1.0f - z) * nn + z * hprev;
-          a.y[row * H + my_unit] = h;
-          xnext[xw + b * UNITS_WG] = h;
-          a.sr[row * H + my_unit] = r;
-          a.sz[row * H + my_unit] = z;
-          a.sn[row * H + my_unit] = nn;
-          a.sghn[row * H + my_unit] = ghn;
-        }
-      }
-    }
-    if (t + 1 < a.T) {
-      if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(t + 1), tid, &ok_lds)) return;
-    }
+    (void)mk;
   }
 }
 
@@ -306,7 +367,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
 // Requesting (almost) the CU's whole 160 KiB LDS makes co-residency with any LDS-using workgroup, and
 // of two of these workgroups, impossible.  WSMG_RNN_EXCL=0 disables, any other value is KiB (debug).
 constexpr unsigned EXCL_LDS_BYTES = 159 * 1024;
-static unsigned rnn_excl_lds() {
+static unsigned rnn_excl_total() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("WSMG_RNN_EXCL");
@@ -314,14 +375,25 @@ static unsigned rnn_excl_lds() {
   }
   return v == 0 ? 0u : (v == 1 ? EXCL_LDS_BYTES : (unsigned)v * 1024u);
 }
+// dynamic LDS to request so that the static + dynamic LDS of `kernel` together own the CU
 template <class K>
-static hipError_t allow_big_lds(K kernel) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)(160 * 1024 - 64));
+static hipError_t excl_lds(K kernel, unsigned* dyn) {
+  hipFuncAttributes at;
+  hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kernel));
+  if (e != hipSuccess) return e;
+  const unsigned total = rnn_excl_total(), st = (unsigned)at.sharedSizeBytes;
+  *dyn = total > st ? total - st : 0u;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn);
+}
+// launch-unique tag bits for the flag-in-data exchange (22-bit epoch above the 10-bit step number)
+static unsigned next_tagbase() {
+  static unsigned epoch = 0;
+  return (__atomic_add_fetch(&epoch, 1u, __ATOMIC_RELAXED) & 0x3FFFFFu) << 10;
 }
 
 // per step: forward image NWG*NB*UNITS_WG floats (16 KB), backward image 3x that (48 KB)
-extern "C" int64_t wsmg_gru_workspace_bytes(int T) { return 256 + (int64_t)T * NWG * NB * 3 * UNITS_WG * 4; }
+// 256 B of control words + per step 4096 (batch, unit) slots of up to four 8-byte {value, tag} words
+extern "C" int64_t wsmg_gru_workspace_bytes(int T) { return 256 + (int64_t)T * NWG * NB * UNITS_WG * 32; }
 
 extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
                             int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
@@ -331,10 +403,12 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
   hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
+  if (T > 1023) return WSMG_EINVAL;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
-               (float*)((char*)sync_ws + 256), T, N};
-  if ((e = allow_big_lds(gru_fwd_kernel)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), rnn_excl_lds(), s, a);
+               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase()};
+  unsigned dyn = 0;
+  if ((e = excl_lds(gru_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -349,8 +423,9 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   if (e != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
                (float*)((char*)sync_ws + 256), T, N};
-  if ((e = allow_big_lds(gru_bwd_kernel)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), rnn_excl_lds(), s, a);
+  unsigned dyn = 0;
+  if ((e = excl_lds(gru_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -583,8 +658,9 @@ extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_
   if (e != hipSuccess) return (int)e;
   LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)((char*)state_ws + 256), save_gates, save_c,
                 (unsigned*)state_ws, U, L};
-  if ((e = allow_big_lds(lstm_fwd_kernel)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), rnn_excl_lds(), s, a);
+  unsigned dyn = 0;
+  if ((e = excl_lds(lstm_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), dyn, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -597,7 +673,8 @@ extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t
   hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
   LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)state_ws, (float*)((char*)state_ws + 256), U, L};
-  if ((e = allow_big_lds(lstm_bwd_kernel)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), rnn_excl_lds(), s, a);
+  unsigned dyn = 0;
+  if ((e = excl_lds(lstm_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), dyn, s, a);
   WSMG_RETURN_LAUNCH();
 }
