@@ -20,10 +20,18 @@ for _ in range(3): fwd()
 torch.cuda.synchronize()
 assert L.wsmg_debug_set_trace(ctypes.c_void_p(tr.data_ptr())) == 0
 fwd(); torch.cuda.synchronize()
-t = tr.view(T, 8).cpu().double() * 10.0  # ns (100 MHz)
-names = ["poll+stage+sync", "LDS read + FMA", "butterfly", "gates + stores"]
-for i, n in enumerate(names):
-    d = (t[5:60, i + 1] - t[5:60, i])
-    print(f"{n:18s} mean {d.mean():8.0f} ns  min {d.min():6.0f} max {d.max():6.0f}")
-d = t[6:60, 0] - t[5:59, 0]
-print(f"step period        mean {d.mean():8.0f} ns")
+def report(title, names):
+    t = tr.view(T, 8).cpu().double() * 10.0  # ns (100 MHz)
+    print(title)
+    for i, n in enumerate(names):
+        d = (t[5:60, i + 1] - t[5:60, i])
+        print(f"  {n:28s} mean {d.mean():8.0f} ns  min {d.min():6.0f} max {d.max():6.0f}")
+    d = (t[6:60, 0] - t[5:59, 0]).abs()
+    print(f"  step period                  mean {d.mean():8.0f} ns")
+report("GRU fwd", ["poll+stage+sync", "LDS read + FMA", "butterfly", "gates + stores"])
+gy = torch.randn(T, N, H, device="cuda")
+dgi = torch.empty(T, N, 3 * H, device="cuda"); dgh = torch.empty_like(dgi); dh0 = torch.empty(N, H, device="cuda")
+tr.zero_()
+_abi.call("wsmg_gru_bwd", P(gy), None, P(whh), P(h0), P(masks), P(y), *[P(s) for s in saves], T, N, H, P(dgi), P(dgh), P(dh0), P(ws), st())
+torch.cuda.synchronize()
+report("GRU bwd", ["elementwise + publish", "prefetch + poll+stage+sync", "LDS read + FMA", "butterfly + carry"])

@@ -61,15 +61,40 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, in
   return *ok_lds != 0;
 }
 
-// halving butterfly: C live values per lane, xor distance D; afterwards C/2 live values
+// cross-lane exchange with lane ^ D at VALU rate where the ISA has a pattern for it: xor 1 / xor 2 =
+// DPP quad_perm, xor 8 = DPP row rotate by 8; xor 4 falls back to ds_bpermute
+template <int D>
+__device__ __forceinline__ float lane_xor(float v) {
+  const int x = __float_as_int(v);
+  if constexpr (D == 1) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  else if constexpr (D == 8) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));  // row_ror:8
+  else return __shfl_xor(v, D, 64);
+}
+// Halving butterfly step: C live values per lane, xor distance D; afterwards C/2 live values: lanes with
+// bit D clear hold the sums of the lower half, lanes with bit D set those of the upper half.  For D = 32 and
+// 16 one v_permlane{32,16}_swap exchanges the halves of a register pair (gfx950), so a step costs one swap
+// and one add per output instead of a ds_bpermute and two selects (the 127-exchange butterfly of the
+// forward kernel measured 3.7 us per step with ds_bpermute).
 template <int C, int D, int NV>
 __device__ __forceinline__ void halve(float (&v)[NV], int lane) {
-  const bool up = (lane & D) != 0;
+  if constexpr (D == 32 || D == 16) {
 #pragma unroll
-  for (int i = 0; i < C / 2; ++i) {
-    float keep = up ? v[i + C / 2] : v[i];
-    float send = up ? v[i] : v[i + C / 2];
-    v[i] = keep + __shfl_xor(send, D, 64);
+    for (int i = 0; i < C / 2; ++i) {
+      const int lo = __float_as_int(v[i]), hi = __float_as_int(v[i + C / 2]);
+      // swap: lanes with bit D set of `lo` <-> lanes with bit D clear of `hi`
+      auto r = (D == 32) ? __builtin_amdgcn_permlane32_swap(lo, hi, false, false)
+                         : __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+      v[i] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    }
+  } else {
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int i = 0; i < C / 2; ++i) {
+      float keep = up ? v[i + C / 2] : v[i];
+      float send = up ? v[i] : v[i + C / 2];
+      v[i] = keep + lane_xor<D>(send);
+    }
   }
 }
 
@@ -119,16 +144,8 @@ __device__ __forceinline__ bool poll_row16(const unsigned long long* src, unsign
   }
 }
 
-// lane-local cross-lane moves inside a 16-lane row: DPP (VALU rate) where the pattern exists
-// (xor 1 / xor 2 = quad_perm, xor 8 = row rotate by 8), ds_bpermute only for xor 4
 template <int D>
-__device__ __forceinline__ float row_xor(float v) {
-  const int x = __float_as_int(v);
-  if constexpr (D == 1) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-  else if constexpr (D == 2) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-  else if constexpr (D == 8) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));  // row_ror:8
-  else return __shfl_xor(v, D, 64);
-}
+__device__ __forceinline__ float row_xor(float v) { return lane_xor<D>(v); }
 // halving butterfly inside 16-lane rows: C live values per lane, xor distance D; afterwards C/2
 template <int C, int D, int NV>
 __device__ __forceinline__ void halve_row(float (&v)[NV], int lane) {
@@ -298,7 +315,7 @@ __device__ __forceinline__ float reduce32(float (&acc)[32], int lane) {
   halve<8, 8>(acc, lane);
   halve<4, 4>(acc, lane);
   halve<2, 2>(acc, lane);
-  return acc[0] + __shfl_xor(acc[0], 1, 64);
+  return acc[0] + lane_xor<1>(acc[0]);
 }
 
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
