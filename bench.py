@@ -233,6 +233,16 @@ def main():
                             frac=round(ach / peak, 4), traffic=None,
                             avg_launch_ms=round(r["ms_total"] / r["launches"], 4), launches=r["launches"],
                             alg_gflop_per_launch=round(r["flops_total"] / r["launches"] / 1e9, 3))
+            # HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes over this very
+            # command (FETCH_SIZE and WRITE_SIZE in separate runs, folded by tools/pmc_traffic.py); PMC
+            # collection cannot run inside a timed bench, so the figure is read from profiles/, not measured live
+            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_bf16_hbm_traffic.json")
+            if args.dtype == "bf16" and os.path.exists(tfile):
+                tk = json.load(open(tfile)).get("kernels", {}).get(dom.replace("<*>", ""))
+                if tk:
+                    roofline["traffic"] = round(tk["hbm_bytes_per_launch"])
+                    roofline["traffic_unit"] = "HBM bytes per launch (1024*(2*FETCH_SIZE+WRITE_SIZE))"
+                    roofline["traffic_source"] = "profiles/r01_bench_bf16_hbm_traffic.json"
         out = {
             "metric": "policy steps/sec (fwd+bwd), CMA batch=8 seq=64",
             "value": round(steps_per_s, 2),
