@@ -197,6 +197,17 @@ int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, const float
                        const float* dattn, float scale, int B, int I, int C, float* dq, void* dk, void* dv,
                        wsmg_stream_t stream);
 
+/* fp8 (OCP e4m3) text attention, BASELINE configs[4] (B=64, L=160): the k=1 Conv1d key projection of
+ * mg_map_policy.py:126-127 is folded into the single query — q.(W_k x_l + b_k) = (W_k^T q).x_l + q.b_k — so
+ * every token of x is read from HBM once, as bytes.  q_folded [B][C] = W_k^T q (float32), q_dot_bias [B] = q.b_k
+ * or null, x_e4m3 [B][L][C] with real value = byte value * x_scale, lengths [B] (tokens >= length get the
+ * reference's -1e8 additive mask, mg_map_policy.py:175) or null; out [B][C], attn [B][L] float32.  L <= 224. */
+int wsmg_attn_fp8_fused_fwd(const float* q_folded, const float* q_dot_bias, const uint8_t* x_e4m3, float x_scale,
+                            const int* lengths, float scale, int B, int L, int C, float* out, float* attn,
+                            wsmg_stream_t stream);
+/* y = e4m3(clamp(x * inv_scale, +-448)), round to nearest even; n a multiple of 4. */
+int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, uint8_t* y, wsmg_stream_t stream);
+
 /* ============================ persistent masked-GRU state encoders ============================ */
 /* habitat-lab RNNStateEncoder (GRU, hidden 512) as used at mg_map_policy.py:118-123,147-152,220-227,242-249:
  * h_{t-1} is multiplied by masks[t] before every step (episode restarts), gate order r,z,n.

@@ -548,3 +548,57 @@ def test_rnn_handoff_under_concurrent_load(ops, Tn):
         torch.cuda.synchronize()
     finally:
         ops._POISON = old
+
+
+# ------------------------------------------------------------------ fp8 text attention (configs[4])
+def _cfg5_inputs(B=64, L=160, C=256, seed=5):
+    rng = np.random.RandomState(seed)
+    q = rng.randn(B, C).astype(np.float32)
+    w = (rng.randn(C, C) / 16).astype(np.float32)
+    b = (rng.randn(C) * 0.1).astype(np.float32)
+    x = rng.randn(B, L, C).astype(np.float32)
+    lengths = rng.randint(1, L + 1, size=B).astype(np.int32)
+    lengths[0], lengths[1] = L, 1
+    return q, w, b, x, lengths
+
+
+@pytest.mark.gpu
+def test_quantize_e4m3_bit_exact(ops):
+    """The HIP quantiser and the oracle's (torch CPU cast) agree on every code, incl. ties, subnormals, saturation."""
+    from oracle import attn_fp8_ref as ar
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.randn(4096) * s for s in (1e-3, 0.02, 1.0, 30.0, 300.0)]
+                       + [np.array([0.0, -0.0, 448.0, -448.0, 500.0, -1e9, 2 ** -9, 2 ** -10, 0.0009765625 * 1.5, 17.0, 18.0, 19.0],
+                                   dtype=np.float64)]).astype(np.float32)
+    x = x[: len(x) // 4 * 4]
+    for scale in (1.0, 0.0371):
+        want = ar.quantize_e4m3(x, scale)
+        got = ops.quantize_e4m3(T(x).cuda(), scale).cpu().numpy()
+        assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.gpu
+def test_attn_fp8_fused_cfg5(ops):
+    """BASELINE configs[4]: B=64, L=160 (ragged lengths incl. 1 and L), e4m3 tokens, float32 accumulate.  The fused
+    kernel (key projection folded into the query, x read once) against the float64 evaluation of the reference
+    formula on the same de-quantised tokens: attention weights within 2e-5, outputs within 2e-5 * max|out|."""
+    from oracle import attn_fp8_ref as ar
+    q, w, b, x, lengths = _cfg5_inputs()
+    x_scale = float(np.abs(x).max() / ar.E4M3_MAX)
+    codes = ar.quantize_e4m3(x, x_scale)
+    out_ref, attn_ref = ar.attn_fp8(q, w, b, codes, x_scale, lengths, 1.0 / 16)
+    codes_dev = ops.quantize_e4m3(T(x).cuda(), x_scale)
+    assert np.array_equal(codes_dev.cpu().numpy(), codes)
+    out, attn = ops.attn_fp8_fused(T(q).cuda(), T(w).cuda(), T(b).cuda(), codes_dev, x_scale, torch.from_numpy(lengths).cuda(), 1.0 / 16)
+    out, attn = out.cpu().numpy(), attn.cpu().numpy()
+    assert np.abs(attn - attn_ref).max() <= 2e-5
+    assert np.abs(out - out_ref).max() <= 2e-5 * np.abs(out_ref).max()
+    # masked tokens carry exactly zero weight; every row sums to one
+    L = x.shape[1]
+    assert all(float(np.abs(attn[i, lengths[i]:]).sum()) == 0.0 for i in range(len(lengths)))
+    assert np.abs(attn.sum(1) - 1).max() <= 1e-5
+    # against the unquantised float32 formula the error is the e4m3 quantisation error (3 mantissa bits)
+    k = x @ w.T + b
+    lg = (np.einsum("bc,blc->bl", q, k) - 1e8 * (np.arange(L)[None] >= lengths[:, None])) / 16
+    a32 = np.exp(lg - lg.max(1, keepdims=True)); a32 /= a32.sum(1, keepdims=True)
+    assert np.abs(attn - a32).max() <= 0.08

@@ -122,3 +122,23 @@ def test_g5_attention():
     assert np.all(a.numpy()[1, 1:] == 0)  # fully masked tail gets exactly 0 weight
     o2, a2 = policy_ref.attn(T(q), T(k), T(v), None)
     np.testing.assert_allclose(o2.numpy(), g["out_nomask"], atol=1e-6, rtol=1e-5)
+
+
+def test_fp8_oracle_matches_f32_formula_on_representable_inputs():
+    """oracle/attn_fp8_ref.py: on inputs that e4m3 represents exactly, the fp8 restatement equals the plain formula
+    of g5 (mg_map_policy.py:173-178) and the codes round-trip; quantisation saturates at +-448."""
+    from oracle import attn_fp8_ref as ar
+    rng = np.random.RandomState(1)
+    x = rng.choice(np.array([-2.0, -1.5, -0.5, 0.0, 0.25, 0.875, 1.0, 3.5], dtype=np.float32), size=(3, 11, 256))
+    q = rng.randn(3, 256).astype(np.float32)
+    w = (rng.randn(256, 256) / 16).astype(np.float32)
+    b = rng.randn(256).astype(np.float32)
+    lengths = np.array([11, 4, 1])
+    codes = ar.quantize_e4m3(x, 1.0)
+    assert np.array_equal(ar.dequantize_e4m3(codes, 1.0), x.astype(np.float64))
+    out, attn = ar.attn_fp8(q, w, b, codes, 1.0, lengths, 1 / 16)
+    k = x.astype(np.float64) @ w.astype(np.float64).T + b
+    lg = (np.einsum("bc,blc->bl", q.astype(np.float64), k) - 1e8 * (np.arange(11)[None] >= lengths[:, None])) / 16
+    a = np.exp(lg - lg.max(1, keepdims=True)); a /= a.sum(1, keepdims=True)
+    assert np.abs(attn - a).max() < 1e-12 and np.abs(out - np.einsum("bl,blc->bc", a, x)).max() < 1e-12
+    assert ar.dequantize_e4m3(ar.quantize_e4m3(np.array([1e6, -1e6, 460.0, 0.0], np.float32), 1.0), 1.0).tolist() == [448.0, -448.0, 448.0, 0.0]

@@ -57,6 +57,8 @@ for _n in ["wsmg_channel_sum", "wsmg_bn_act_fwd", "wsmg_bn_act_bwd", "wsmg_relu_
     _SIG[_n + "_bf16"] = list(_SIG[_n])
 _SIG["wsmg_conv2d_fwd_bf16"] = [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
 _SIG["wsmg_conv2d_bwd_data_bf16"] = [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
+_SIG["wsmg_attn_fp8_fused_fwd"] = [c_p, c_p, c_p, c_f, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p]
+_SIG["wsmg_quantize_e4m3"] = [c_p, c_l, c_f, c_p, c_p]
 _SIG["wsmg_gru_workspace_bytes"] = [c_i]
 _SIG["wsmg_gru_fwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_p]
 _SIG["wsmg_gru_bwd"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_p]

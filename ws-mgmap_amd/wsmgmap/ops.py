@@ -441,6 +441,36 @@ def attention(q, k, v, mask=None, scale=1.0 / 16):
 
 
 # ----------------------------------------------------------------------------- persistent masked GRU
+def quantize_e4m3(x, scale):
+    """float32 tensor -> uint8 tensor of OCP e4m3 codes of x / scale (saturating, round to nearest even)."""
+    _req(x)
+    _f32(x)
+    if x.numel() % 4:
+        raise _abi.WsmgError("quantize_e4m3 needs a multiple of 4 elements")
+    y = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    _abi.call("wsmg_quantize_e4m3", _p(x), x.numel(), 1.0 / float(scale), _p(y), _stream())
+    return y
+
+
+def attn_fp8_fused(q, w_k, b_k, x_q, x_scale, lengths, scale):
+    """Text attention of BASELINE configs[4] (no autograd): q [B,C] float32, w_k [C,C] / b_k [C] the k=1 Conv1d key
+    projection (mg_map_policy.py:126-127), x_q [B,L,C] uint8 e4m3 codes of the instruction embedding / x_scale,
+    lengths [B] int32.  Returns (out [B,C], attn [B,L]) = softmax((q.(W_k x + b_k) - 1e8 mask) * scale) applied
+    to x, with W_k folded into the query so x is read once."""
+    _req(q, x_q, lengths)
+    _f32(q)
+    if x_q.dtype != torch.uint8 or (lengths is not None and lengths.dtype != torch.int32):
+        raise _abi.WsmgError("attn_fp8_fused: x_q must be uint8 (e4m3 codes), lengths int32")
+    B, L, C = x_q.shape
+    qf = (q @ w_k.float()).contiguous()                      # W_k^T q  (w_k is [C_out, C_in])
+    qb = None if b_k is None else (q @ b_k.float()).contiguous()
+    out = torch.empty(B, C, device=q.device, dtype=torch.float32)
+    attn = torch.empty(B, L, device=q.device, dtype=torch.float32)
+    _abi.call("wsmg_attn_fp8_fused_fwd", _p(qf), _p(qb), _p(x_q), float(x_scale), _p(lengths), float(scale), B, L, C,
+              _p(out), _p(attn), _stream())
+    return out, attn
+
+
 def _rnn_workspace(nbytes, device):
     """Barrier words + exchange image of the persistent RNN kernels.  WSMG_RNN_POISON=1 (stress tool) fills
     it with NaN first so that any stale or missed hand-off read poisons the results visibly."""
