@@ -146,6 +146,8 @@ int wsmg_attn_fwd(const float* q, const float* k, const float* v, const uint8_t*
 
 /* backward: given dout [B][C] and dattn [B][I] (NULL = zeros; the contrastive monitor differentiates
  * the weights themselves, policy.py:80-84) write dq [B][C], dk [B][I][C], dv [B][I][C]. */
+/* wsmg_attn_bwd*: passing dk == dv selects the keys-are-values form (k == v): ONE gradient tensor
+ * dk[i] = dl[i] q + attn[i] dout is written (used when the key projection is folded into the query). */
 int wsmg_attn_bwd(const float* q, const float* k, const float* v, const float* attn, const float* dout,
                   const float* dattn, float scale, int B, int I, int C, float* dq, float* dk, float* dv,
                   wsmg_stream_t stream);

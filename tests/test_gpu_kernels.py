@@ -602,3 +602,37 @@ def test_attn_fp8_fused_cfg5(ops):
     lg = (np.einsum("bc,blc->bl", q, k) - 1e8 * (np.arange(L)[None] >= lengths[:, None])) / 16
     a32 = np.exp(lg - lg.max(1, keepdims=True)); a32 /= a32.sum(1, keepdims=True)
     assert np.abs(attn - a32).max() <= 0.08
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attention_with_folded_key_projection(ops, dt):
+    """ops.attention_folded == softmax(scale * q.(W x + b)) . x of mg_map_policy.py:126-132,173-178 with the
+    Conv1d key projection applied explicitly (plain torch, float64), forward and every gradient; the key
+    bias gets an exactly-zero gradient (its logit contribution is constant over the tokens)."""
+    torch.manual_seed(3)
+    B, I, C = 6, 37, 256
+    q = torch.randn(B, C, device="cuda")
+    w = torch.randn(C, C, 1, device="cuda") / 16
+    b = torch.randn(C, device="cuda") * 0.3
+    x = torch.randn(B, I, C, device="cuda")
+    if dt == "bf16":
+        x = x.bfloat16()
+    gout, gattn = torch.randn(B, C, device="cuda"), torch.randn(B, I, device="cuda") * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (q, w, b, x)]
+    out, attn = ops.attention_folded(leaves[0], leaves[1], leaves[2], leaves[3], None, 1 / 16)
+    ((out * gout).sum() + (attn * gattn).sum()).backward()
+    ref = [t.detach().double().requires_grad_(True) for t in (q, w, b, x)]
+    k = ref[3] @ ref[1][:, :, 0].t() + ref[2]
+    a = torch.softmax(torch.einsum("bc,bic->bi", ref[0], k) / 16, dim=1)
+    o = torch.einsum("bi,bic->bc", a, ref[3])
+    ((o * gout.double()).sum() + (a * gattn.double()).sum()).backward()
+    tol = 1e-5 if dt == "f32" else 2e-2
+    assert float((out.double() - o).abs().max()) <= tol and float((attn.double() - a).abs().max()) <= 1e-5
+    for name, l, r in zip(("dq", "dw", "db", "dx"), leaves, ref):
+        scale = float(r.grad.abs().max()) + 1e-12
+        err = float((l.grad.double() - r.grad).abs().max())
+        if name == "db":
+            assert float(l.grad.abs().max()) == 0.0 and scale < 1e-9
+        else:
+            assert err <= (2e-5 if dt == "f32" else 2e-2) * scale, (name, err, scale)

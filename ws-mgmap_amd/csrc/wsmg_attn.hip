@@ -94,6 +94,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 
 // backward: da = dout.v + dattn; s = sum attn*da; dl = attn*(da-s)*scale;
 //           dq = sum_i dl[i] k[i]; dk[i] = dl[i] q; dv[i] = attn[i] dout
+// dk == dv (same buffer) selects the keys-are-values form used when the key projection is folded into the
+// query: one gradient tensor dk[i] = dl[i] q + attn[i] dout is written instead of two.
 template <class T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v,
@@ -114,16 +116,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   T* dkb = dk + (size_t)b * I * AC + lane * 4;
   T* dvb = dv + (size_t)b * I * AC + lane * 4;
   const float* ab = attn + (size_t)b * I;
+  const bool same = (dk == dv);
 
   for (int i = wave; i < I; i += AWAVES) {
     f32x4 vv = ld4(vb + (size_t)i * AC);
     float d = gv[0] * vv[0] + gv[1] * vv[1] + gv[2] * vv[2] + gv[3] * vv[3];
     d = wave_sum(d);
     float a = ab[i];
-    f32x4 o;
+    if (!same) {
+      f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
-    st4(dvb + (size_t)i * AC, o);
+      for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
+      st4(dvb + (size_t)i * AC, o);
+    }
     if (lane == 0) da[i] = d + (dattn ? dattn[(size_t)b * I + i] : 0.f);
   }
   __syncthreads();
@@ -141,6 +146,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int j = 0; j < 4; ++j) {
       acc[j] += dl * kv[j];
       o[j] = dl * qv[j];
+    }
+    if (same) {
+      const float a = ab[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += a * gv[j];
     }
     st4(dkb + (size_t)i * AC, o);
   }

@@ -204,8 +204,11 @@ class MGMapNet(nn.Module):
         text_embedding, _ = self._attn(self.state_text_q_layer(state), text_k, text_v, text_mask)
 
         # map attention
-        map_k = self._key_projection(self.text_map_k_layer, map_tokens)
-        map_embedding, self.att_map_t_m = self._attn(self.text_map_q_layer(text_embedding), map_k, map_tokens, None)
+        # text_map_k_layer is folded into the query (ops._AttnFolded): the 576 map tokens are read once, as
+        # keys and values, and no projected key tensor exists
+        map_embedding, self.att_map_t_m = ops.attention_folded(
+            self.text_map_q_layer(text_embedding).contiguous(), self.text_map_k_layer.weight, self.text_map_k_layer.bias,
+            map_tokens.contiguous(), None, self._scale_f)
 
         parts = [state, text_embedding] + ([map_embedding] if "map" in self._inputs else [])
         x = self.second_state_compress(torch.cat(parts, dim=1))

@@ -441,6 +441,49 @@ def attention(q, k, v, mask=None, scale=1.0 / 16):
 
 
 # ----------------------------------------------------------------------------- persistent masked GRU
+class _AttnFolded(torch.autograd.Function):
+    """Single-query attention whose keys are a k=1 Conv1d of the values (mg_map_policy.py:126-132,173-178):
+    q.(W x_i + b) = (W^T q).x_i + q.b, and q.b is the same for every token, so it cancels in the softmax.
+    The projection is therefore folded into the query ([B,C] x [C,C]) and the tokens x are read once as both
+    keys and values; no key tensor is ever materialised."""
+
+    @staticmethod
+    def forward(ctx, q, w, b, x, mask, scale):
+        _req(q, x, mask)
+        _f32(q)
+        B, I, C = x.shape
+        wf = w.reshape(w.shape[0], -1).float()
+        qf = (q @ wf).contiguous()
+        out = torch.empty(B, C, device=q.device, dtype=torch.float32)
+        attn = torch.empty(B, I, device=q.device, dtype=torch.float32)
+        _abi.call("wsmg_attn_fwd" + _sfx(x), _p(qf), _p(x), _p(x), _p(mask), float(scale), B, I, C, _p(out), _p(attn), _stream())
+        ctx.save_for_backward(q, wf, qf, x, attn)
+        ctx.scale = float(scale)
+        ctx.wshape = w.shape
+        ctx.has_b = b is not None
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        q, wf, qf, x, attn = ctx.saved_tensors
+        B, I, C = x.shape
+        dout = torch.zeros_like(q) if dout is None else dout.contiguous().float()
+        dattn = None if dattn is None else dattn.contiguous().float()
+        dqf = torch.empty_like(qf)
+        dx = torch.empty_like(x)
+        _abi.call("wsmg_attn_bwd" + _sfx(x), _p(qf), _p(x), _p(x), _p(attn), _p(dout), _p(dattn), ctx.scale, B, I, C,
+                  _p(dqf), _p(dx), _p(dx), _stream())
+        dq = dqf @ wf.t()
+        dw = (q.t() @ dqf).reshape(ctx.wshape)
+        db = torch.zeros(ctx.wshape[0], device=q.device, dtype=torch.float32) if ctx.has_b else None   # exactly zero
+        return dq, dw, db, dx, None, None
+
+
+def attention_folded(q, w, b, x, mask, scale):
+    """(context [B,C], weights [B,I]) of softmax(scale * (q . (W x_i + b) - 1e8 mask_i)) over x [B,I,C]."""
+    return _AttnFolded.apply(q, w, b, x, mask, scale)
+
+
 def quantize_e4m3(x, scale):
     """float32 tensor -> uint8 tensor of OCP e4m3 codes of x / scale (saturating, round to nearest even)."""
     _req(x)
