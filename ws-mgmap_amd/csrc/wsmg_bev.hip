@@ -139,17 +139,19 @@ __global__ __launch_bounds__(256) void rotate_nchw_to_nhwc_kernel(const float* _
                                                                   const float* __restrict__ heading, float sign,
                                                                   int C, int E, float* __restrict__ out) {
   __shared__ float sh[64 * 65];
+  // one workgroup = an 8 x 8 block of output pixels x all channels: the taps of a block fall into a ~12 x 12
+  // source patch per channel plane (a 64 x 1 line would touch up to 64 source rows at 45 degrees)
   const int b = blockIdx.y;
-  const int pix0 = blockIdx.x * 64;
+  const int nbx = (E + 7) >> 3;
+  const int by = blockIdx.x / nbx, bx = blockIdx.x - by * nbx;
   const int tid = threadIdx.x;
   const int pl = tid & 63, cq = tid >> 6;
   const int E2 = E * E;
   float t = sign * heading[b];
   Rot r{cosf(t), sinf(t)};
-  int p = pix0 + pl;
-  bool pok = p < E2;
-  int y = pok ? p / E : 0, x = pok ? p - y * E : 0;
-  Taps tp = rot_taps(x, y, E, r);
+  const int y = by * 8 + (pl >> 3), x = bx * 8 + (pl & 7);
+  const bool pok = y < E && x < E;
+  Taps tp = rot_taps(pok ? x : 0, pok ? y : 0, E, r);
   bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
   bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
   for (int c = cq; c < C; c += 4) {
@@ -166,32 +168,35 @@ __global__ __launch_bounds__(256) void rotate_nchw_to_nhwc_kernel(const float* _
   __syncthreads();
   for (int i = tid; i < 64 * C; i += 256) {
     int q = i / C, c = i - q * C;
-    if (pix0 + q < E2) out[((size_t)b * E2 + pix0 + q) * C + c] = sh[q * 65 + c];
+    const int qy = by * 8 + (q >> 3), qx = bx * 8 + (q & 7);
+    if (qy < E && qx < E) out[((size_t)b * E2 + qy * E + qx) * C + c] = sh[q * 65 + c];
   }
 }
 
-// final rotation: NHWC in, NHWC out (thread = (pixel, channel), channel fastest)
+// final rotation: NHWC in, NHWC out (thread = (pixel, 4 channels): the tap geometry is computed once per
+// 16 bytes instead of once per float, and every access is a 16-byte one; per-element arithmetic order unchanged)
 __global__ __launch_bounds__(256) void rotate_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ heading,
                                                           float sign, int C, int E, float* __restrict__ out) {
   const int b = blockIdx.y;
-  const int E2 = E * E;
+  const int E2 = E * E, C4 = C >> 2;
   float t = sign * heading[b];
   Rot r{cosf(t), sinf(t)};
-  const float* ib = in + (size_t)b * E2 * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)E2 * C;
+  const f32x4* ib = reinterpret_cast<const f32x4*>(in + (size_t)b * E2 * C);
+  f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * E2 * C);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)E2 * C4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    int p = (int)(i / C);
+    int c = (int)(i % C4);
+    int p = (int)(i / C4);
     int y = p / E, x = p - y * E;
     Taps tp = rot_taps(x, y, E, r);
     bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
     bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
-    float v = 0.f;
-    if (y0ok && x0ok) v += ib[((size_t)tp.y0 * E + tp.x0) * C + c] * tp.w00;
-    if (y0ok && x1ok) v += ib[((size_t)tp.y0 * E + tp.x0 + 1) * C + c] * tp.w01;
-    if (y1ok && x0ok) v += ib[((size_t)(tp.y0 + 1) * E + tp.x0) * C + c] * tp.w10;
-    if (y1ok && x1ok) v += ib[((size_t)(tp.y0 + 1) * E + tp.x0 + 1) * C + c] * tp.w11;
-    out[(size_t)b * E2 * C + i] = v;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (y0ok && x0ok) { f32x4 q = ib[((size_t)tp.y0 * E + tp.x0) * C4 + c]; for (int j = 0; j < 4; ++j) v[j] += q[j] * tp.w00; }
+    if (y0ok && x1ok) { f32x4 q = ib[((size_t)tp.y0 * E + tp.x0 + 1) * C4 + c]; for (int j = 0; j < 4; ++j) v[j] += q[j] * tp.w01; }
+    if (y1ok && x0ok) { f32x4 q = ib[((size_t)(tp.y0 + 1) * E + tp.x0) * C4 + c]; for (int j = 0; j < 4; ++j) v[j] += q[j] * tp.w10; }
+    if (y1ok && x1ok) { f32x4 q = ib[((size_t)(tp.y0 + 1) * E + tp.x0 + 1) * C4 + c]; for (int j = 0; j < 4; ++j) v[j] += q[j] * tp.w11; }
+    ob[i] = v;
   }
 }
 
@@ -234,31 +239,37 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(const float* __restrict__
   const float ty = -(ps.gx - a.halfG) / a.halfG;
   const int wy0 = a.lo + (int)(ps.gx - a.halfG) - 2;
   const int wx0 = a.lo + (int)(ps.gy - a.halfG) - 2;
-  const float* eb = ego + (size_t)b * a.E * a.E * a.C;
-  float* gb = gm + (size_t)b * a.G * a.G * a.C;
+  const int C4 = a.C >> 2;
+  const f32x4* eb = reinterpret_cast<const f32x4*>(ego + (size_t)b * a.E * a.E * a.C);
+  f32x4* gb = reinterpret_cast<f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
   const int hi = a.lo + a.E;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)WN * WN * a.C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)WN * WN * C4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % a.C);
-    int p = (int)(i / a.C);
+    int c = (int)(i % C4);
+    int p = (int)(i / C4);
     int wy = p / WN, wx = p - wy * WN;
     int Y = wy0 + wy, X = wx0 + wx;
     if (Y < 0 || Y >= a.G || X < 0 || X >= a.G) continue;
     float gx = base_coord(X, a.G) + tx;
     float gy = base_coord(Y, a.G) + ty;
     Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
-    float v = 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
       float w = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
       // zero padding of grid_sample, then the zero border of the agent view around the paste
-      if (yy >= a.lo && yy < hi && xx >= a.lo && xx < hi && yy < a.G && xx < a.G)
-        v += eb[((size_t)(yy - a.lo) * a.E + (xx - a.lo)) * a.C + c] * w;
+      if (yy >= a.lo && yy < hi && xx >= a.lo && xx < hi && yy < a.G && xx < a.G) {
+        const f32x4 q = eb[((size_t)(yy - a.lo) * a.E + (xx - a.lo)) * C4 + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += q[j] * w;
+      }
     }
-    size_t o = ((size_t)Y * a.G + X) * a.C + c;
-    float g = gb[o];
-    gb[o] = v > g ? v : g;
+    size_t o = ((size_t)Y * a.G + X) * C4 + c;
+    f32x4 g = gb[o];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = v[j] > g[j] ? v[j] : g[j];
+    gb[o] = g;
   }
 }
 
@@ -269,23 +280,29 @@ __global__ __launch_bounds__(256) void map_crop_kernel(const float* __restrict__
   Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
   const float tx = (ps.gy - a.halfG) / a.halfG;
   const float ty = (ps.gx - a.halfG) / a.halfG;
-  const float* gb = gm + (size_t)b * a.G * a.G * a.C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)a.E * a.E * a.C;
+  const int C4 = a.C >> 2;
+  const f32x4* gb = reinterpret_cast<const f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
+  f32x4* cb = reinterpret_cast<f32x4*>(crop + (size_t)b * a.E * a.E * a.C);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)a.E * a.E * C4;
        i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % a.C);
-    int p = (int)(i / a.C);
+    int c = (int)(i % C4);
+    int p = (int)(i / C4);
     int y = p / a.E, x = p - y * a.E;
     float gx = base_coord(a.lo + x, a.G) + tx;
     float gy = base_coord(a.lo + y, a.G) + ty;
     Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
-    float v = 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
       float w = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
-      if (yy >= 0 && yy < a.G && xx >= 0 && xx < a.G) v += gb[((size_t)yy * a.G + xx) * a.C + c] * w;
+      if (yy >= 0 && yy < a.G && xx >= 0 && xx < a.G) {
+        const f32x4 q = gb[((size_t)yy * a.G + xx) * C4 + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += q[j] * w;
+      }
     }
-    crop[(size_t)b * a.E * a.E * a.C + i] = v;
+    cb[i] = v;
   }
 }
 
@@ -353,7 +370,8 @@ extern "C" int wsmg_bev_scatter_max(const float* feat, const int32_t* lin_idx, i
 extern "C" int wsmg_bev_rotate(const float* in, const float* heading, float sign, int B, int C, int E, float* out,
                                wsmg_stream_t stream) {
   if (B <= 0 || C <= 0 || C > 64 || E <= 1 || B > 65535) return WSMG_EINVAL;
-  dim3 grid((unsigned)wsmg_cdiv(E * E, 64), (unsigned)B);
+  const int nb8 = (E + 7) / 8;
+  dim3 grid((unsigned)(nb8 * nb8), (unsigned)B);
   hipLaunchKernelGGL(rotate_nchw_to_nhwc_kernel, grid, dim3(256), 0, wsmg_s(stream), in, heading, sign, C, E, out);
   WSMG_RETURN_LAUNCH();
 }
@@ -364,16 +382,16 @@ extern "C" int wsmg_map_fuse(const float* ego_rot, float* global_map, const floa
   MapArgs a = map_args(B, C, E, G, resolution);
   int64_t n4 = (int64_t)G * G * C / 4;
   hipLaunchKernelGGL(map_reset_kernel, dim3(sgrid(n4, 1024), B), dim3(256), 0, wsmg_s(stream), global_map, masks, n4);
-  int64_t n = (int64_t)(E + 4) * (E + 4) * C;
+  int64_t n = (int64_t)(E + 4) * (E + 4) * (C / 4);
   hipLaunchKernelGGL(map_fuse_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), ego_rot, global_map, gps, a);
   WSMG_RETURN_LAUNCH();
 }
 
 extern "C" int wsmg_map_retrieve(const float* global_map, const float* gps, const float* compass, int B, int C, int E,
                                  int G, float resolution, float* scratch, float* out, wsmg_stream_t stream) {
-  if (B <= 0 || C <= 0 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
+  if (B <= 0 || C <= 0 || C % 4 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
   MapArgs a = map_args(B, C, E, G, resolution);
-  int64_t n = (int64_t)E * E * C;
+  int64_t n = (int64_t)E * E * (C / 4);
   hipLaunchKernelGGL(map_crop_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), global_map, gps, a, scratch);
   hipLaunchKernelGGL(rotate_nhwc_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), scratch, compass, 1.0f, C, E,
                      out);
