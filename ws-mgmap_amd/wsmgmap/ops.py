@@ -112,7 +112,7 @@ class _Conv2d(torch.autograd.Function):
     x bf16 -> the weight is cast to bf16 for the MFMA, dW comes back float32."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad):
+    def forward(ctx, x, w, bias, stride, pad, bias_grad_zero=False):
         _req(x, w, bias)
         _f32(w, bias)
         sfx = _sfx(x)
@@ -130,6 +130,7 @@ class _Conv2d(torch.autograd.Function):
             _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), *dims, _stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = dims + (bias is not None, sfx)
+        ctx.bias_grad_zero = bool(bias_grad_zero)
         return y
 
     @staticmethod
@@ -151,8 +152,10 @@ class _Conv2d(torch.autograd.Function):
             dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
             _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw), *dims, _stream())
         if has_bias and ctx.needs_input_grad[2]:
-            db = channel_sum(dy.view(-1, Cout))
-        return dx, dw, db, None, None
+            # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
+            # the caller says so and the channel reduction over dy is skipped
+            db = torch.zeros(Cout, device=dy.device, dtype=torch.float32) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
+        return dx, dw, db, None, None, None
 
 
 class _ConvT2d(torch.autograd.Function):
@@ -202,10 +205,11 @@ class _ConvT2d(torch.autograd.Function):
         return dx, dw, None, None
 
 
-def conv2d(x, weight_oihw, bias, stride=1, pad=0):
+def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False):
     """x NHWC; weight in the reference's OIHW parameter layout (re-laid out to OHWI on the fly,
-    inside the autograd graph so the parameter's .grad comes back OIHW)."""
-    return _Conv2d.apply(x, weight_oihw.permute(0, 2, 3, 1).contiguous(), bias, stride, pad)
+    inside the autograd graph so the parameter's .grad comes back OIHW).  bias_grad_zero: the output feeds a
+    train-mode BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros."""
+    return _Conv2d.apply(x, weight_oihw.permute(0, 2, 3, 1).contiguous(), bias, stride, pad, bias_grad_zero)
 
 
 def conv_transpose2d(x, weight_iohw, stride=2, pad=1):
