@@ -107,8 +107,10 @@ int wsmg_bn_act_fwd(const float* x, const float* residual, const float* gamma, c
                     double* workspace, int64_t workspace_bytes, wsmg_stream_t stream);
 
 /* backward of the above (train statistics).  dy, x, y: [rows][C]; writes dx, dgamma, dbeta and, if
- * dresidual != NULL, the gradient of the residual input (= masked dy). */
-int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+ * dresidual != NULL, the gradient of the residual input (= masked dy).  y may be NULL when relu != 0 and there
+ * was no residual: the ReLU mask is then recomputed from x, mean, invstd, gamma, beta (one tensor less to read
+ * in each of the two passes, and y need not be kept for the backward). */
+int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
                     float* dx, float* dresidual, float* dgamma, float* dbeta, double* workspace,
                     int64_t workspace_bytes, wsmg_stream_t stream);
@@ -173,7 +175,7 @@ int wsmg_bn_act_fwd_bf16(const void* x, const void* residual, const float* gamma
                          float* running_mean, float* running_var, float momentum, float eps, int train,
                          int relu, int64_t rows, int C, void* y, float* save_mean, float* save_invstd,
                          double* workspace, int64_t workspace_bytes, wsmg_stream_t stream);
-int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const float* gamma,
+int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                          const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
                          void* dx, void* dresidual, float* dgamma, float* dbeta, double* workspace,
                          int64_t workspace_bytes, wsmg_stream_t stream);

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
                                                                  const T* __restrict__ dy,
                                                                  const T* __restrict__ y,
                                                                  const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, int relu,
+                                                                 const float* __restrict__ invstd,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int relu,
                                                                  int64_t rows, int C, double* __restrict__ part) {
   __shared__ double sh[2][4][RED_THREADS];
   const int tid = threadIdx.x;
@@ -41,7 +43,11 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
   const int rpi = RED_THREADS / C4;
   double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
   f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
-  if (MODE == 2) { mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c); }
+  f32x4 gm = {1.f, 1.f, 1.f, 1.f}, bt = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 2) {
+    mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c);
+    if (relu && !y) { gm = *reinterpret_cast<const f32x4*>(gamma + c); bt = *reinterpret_cast<const f32x4*>(beta + c); }
+  }
   for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
     size_t o = (size_t)r * C + c;
     if (MODE == 0) {
@@ -55,9 +61,14 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
     } else {
       f32x4 g = ld4(dy + o), xv = ld4(x + o);
       if (relu) {
-        f32x4 yv = ld4(y + o);
+        if (y) {
+          f32x4 yv = ld4(y + o);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+          for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+        } else {   // no residual: the forward value is recomputed (same expression as bn_apply_kernel) instead of read
+#pragma unroll
+          for (int j = 0; j < 4; ++j) g[j] = ((xv[j] - mu[j]) * is[j] * gm[j] + bt[j]) > 0.f ? g[j] : 0.f;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -184,6 +195,7 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const T* __restrict__ y,
                                                            const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dgamma,
@@ -199,6 +211,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
   const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c);
   const f32x4 db = *reinterpret_cast<const f32x4*>(dbeta + c);
+  f32x4 bt = {0.f, 0.f, 0.f, 0.f};
+  if (relu && !y) bt = *reinterpret_cast<const f32x4*>(beta + c);
   f32x4 k0, k1, k2;  // dx = k0 * (g - k1 - xhat * k2)
 #pragma unroll
   for (int j = 0; j < 4; ++j) { k0[j] = gm[j] * is[j]; k1[j] = db[j] * inv_n; k2[j] = dg[j] * inv_n; }
@@ -207,9 +221,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     f32x4 g = ld4(dy + o);
     f32x4 xv = ld4(x + o);
     if (relu) {
-      f32x4 yv = ld4(y + o);
+      if (y) {
+        f32x4 yv = ld4(y + o);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+        for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = ((xv[j] - mu[j]) * is[j] * gm[j] + bt[j]) > 0.f ? g[j] : 0.f;
+      }
     }
     if (dres) st4(dres + o, g);
     f32x4 out;
@@ -239,7 +258,7 @@ int channel_sum_t(const T* x, int64_t rows, int C, float* out, double* workspace
   if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
   int nb = red_blocks(rows, C);
   hipLaunchKernelGGL((col_reduce_kernel<0, T>), dim3(nb), dim3(RED_THREADS), 0, wsmg_s(stream), x, (const T*)nullptr,
-                     (const T*)nullptr, nullptr, nullptr, 0, rows, C, workspace);
+                     (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, rows, C, workspace);
   hipLaunchKernelGGL(sum_finalize_kernel, dim3(C), dim3(64), 0, wsmg_s(stream), workspace, nb, C, out);
   WSMG_RETURN_LAUNCH();
 }
@@ -255,7 +274,7 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
     if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
     int nb = red_blocks(rows, C);
     hipLaunchKernelGGL((col_reduce_kernel<1, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, (const T*)nullptr,
-                       (const T*)nullptr, nullptr, nullptr, 0, rows, C, workspace);
+                       (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, rows, C, workspace);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, rows, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd);
   } else {
@@ -268,17 +287,18 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
 }
 
 template <class T>
-int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const float* save_mean,
+int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, int relu, int64_t rows, int C, T* dx, T* dresidual, float* dgamma,
                  float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream) {
   if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  if (relu && !y && (!beta || dresidual)) return WSMG_EINVAL;   // the mask can only be recomputed without a residual
   if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
   hipStream_t s = wsmg_s(stream);
   int nb = red_blocks(rows, C);
   hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
-                     relu, rows, C, workspace);
+                     gamma, beta, relu, rows, C, workspace);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
                      save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual);
   WSMG_RETURN_LAUNCH();
 }
@@ -315,17 +335,17 @@ extern "C" int wsmg_bn_act_fwd_bf16(const void* x, const void* residual, const f
                               stream);
 }
 
-extern "C" int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma,
+extern "C" int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
                                float* dx, float* dresidual, float* dgamma, float* dbeta, double* workspace,
                                int64_t workspace_bytes, wsmg_stream_t stream) {
-  return bn_act_bwd_t<float>(dy, x, y, gamma, save_mean, save_invstd, relu, rows, C, dx, dresidual, dgamma, dbeta,
+  return bn_act_bwd_t<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, rows, C, dx, dresidual, dgamma, dbeta,
                              workspace, workspace_bytes, stream);
 }
-extern "C" int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const float* gamma,
+extern "C" int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const float* gamma, const float* beta,
                                     const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C,
                                     void* dx, void* dresidual, float* dgamma, float* dbeta, double* workspace,
                                     int64_t workspace_bytes, wsmg_stream_t stream) {
-  return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, save_mean, save_invstd, relu,
+  return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, beta, save_mean, save_invstd, relu,
                               rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream);
 }

@@ -35,7 +35,7 @@ _SIG = {
     "wsmg_channel_sum": [c_p, c_l, c_i, c_p, c_p, c_l, c_p],
     "wsmg_channel_reduce_workspace_bytes": [c_l, c_i],
     "wsmg_bn_act_fwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_f, c_i, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_p],
-    "wsmg_bn_act_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
+    "wsmg_bn_act_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "wsmg_relu_fwd": [c_p, c_p, c_l, c_p],
     "wsmg_relu_bwd": [c_p, c_p, c_p, c_l, c_p],
     "wsmg_maxpool3x3s2_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],

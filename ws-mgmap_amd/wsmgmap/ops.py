@@ -244,13 +244,15 @@ class _BnAct(torch.autograd.Function):
         _abi.call("wsmg_bn_act_fwd" + sfx, _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                   float(momentum), float(eps), int(train), int(relu), rows, C, _p(y), _p(mean), _p(invstd),
                   _p(ws), ws.numel() * 8, _stream())
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        # without a residual the ReLU mask is recomputed from x in the backward kernels: y is neither kept nor read
+        keep_y = relu and residual is not None
+        ctx.save_for_backward(x, y if keep_y else None, gamma, beta, mean, invstd)
         ctx.cfg = (rows, C, int(relu), residual is not None, bool(train), sfx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, beta, mean, invstd = ctx.saved_tensors
         rows, C, relu, has_res, train, sfx = ctx.cfg
         if not train:
             raise _abi.WsmgError("backward through eval-mode BatchNorm is not part of the reference's path")
@@ -260,7 +262,7 @@ class _BnAct(torch.autograd.Function):
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         ws = _workspace(x.device)
-        _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), relu, rows, C,
+        _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
                   _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None
 
