@@ -212,6 +212,16 @@ int wsmg_attn_fp8_fused_fwd(const float* q_folded, const float* q_dot_bias, cons
 /* y = e4m3(clamp(x * inv_scale, +-448)), round to nearest even; n a multiple of 4. */
 int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, uint8_t* y, wsmg_stream_t stream);
 
+/* ============================ trajectory-cache collate ============================ */
+/* dagger_trainer.py:40-113 (collate_fn: time-major pad + stack over the N episodes of a batch) fused with the
+ * trainer's float32 conversion (:614-617), on the device: src = device array of N device pointers to episode
+ * tensors [length_n][elems] in their on-disk dtype (src_dtype 0 float16, 1 uint8, 2 int64, 3 float32, see
+ * common_trainer.py:514-532), lengths = device int32 [N]; dst [T][N][elems] float32, element (t, n, :) = the
+ * episode's step t if t < length_n (episodes longer than T are truncated, :82-83) else `pad` (1.0 for
+ * observations, 0 for actions and weights, :85-91). */
+int wsmg_collate_pad(const void* const* src, const int* lengths, int N, int T, int64_t elems, int src_dtype,
+                     float pad, float* dst, wsmg_stream_t stream);
+
 /* ============================ persistent masked-GRU state encoders ============================ */
 /* habitat-lab RNNStateEncoder (GRU, hidden 512) as used at mg_map_policy.py:118-123,147-152,220-227,242-249:
  * h_{t-1} is multiplied by masks[t] before every step (episode restarts), gate order r,z,n.

@@ -636,3 +636,30 @@ def test_attention_with_folded_key_projection(ops, dt):
             assert float(l.grad.abs().max()) == 0.0 and scale < 1e-9
         else:
             assert err <= (2e-5 if dt == "f32" else 2e-2) * scale, (name, err, scale)
+
+
+# ------------------------------------------------------------------ trajectory-cache device collate
+@pytest.mark.gpu
+def test_device_collate_matches_reference_golden(ops):
+    """DeviceCollator (compact dtypes over PCIe, pad + interleave + float32 conversion in wsmg_collate_pad) produces
+    bit-for-bit what the reference's collate_fn + `.float().to(device)` produces (g6: ragged batch; 200-step cap)."""
+    import hashlib
+    import os
+    from oracle import data_cases as dc
+    from wsmgmap.data import DeviceCollator
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_g7_data.npz"))
+    dsha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    coll = DeviceCollator("cuda")
+    for tag, lengths in (("rag", dc.COLLATE_LENGTHS), ("long", dc.LONG_LENGTHS)):
+        batch = [dc.episode(100 + i, n) + (torch.ones(n),) for i, n in enumerate(lengths)]
+        ob, prev, masks, corr, wts = coll(batch)
+        torch.cuda.synchronize()
+        for k, v in ob.items():
+            assert v.dtype == torch.float32 and list(v.shape) == g[f"g6_{tag}_obs_{k}_shape"].tolist()
+            assert dsha(v.cpu().numpy()) == str(g[f"g6_{tag}_obs_{k}_sha"]), (tag, k)
+        for name, v in (("prev", prev), ("masks", masks), ("corr", corr), ("wts", wts)):
+            assert list(v.shape) == g[f"g6_{tag}_{name}_shape"].tolist()
+            assert dsha(v.cpu().numpy()) == str(g[f"g6_{tag}_{name}_sha"]), (tag, name)
+    # a second call re-uses the pinned staging buffer
+    ob2, *_ = coll([dc.episode(100 + i, n) + (torch.ones(n),) for i, n in enumerate(dc.COLLATE_LENGTHS)])
+    assert torch.equal(ob2["progress"].cpu(), torch.from_numpy(g["g6_rag_progress"]))

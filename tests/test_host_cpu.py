@@ -143,3 +143,67 @@ def test_instruction_encoder_dedup_matches_oracle():
     assert torch.allclose(hid, hr, atol=1e-6)
     u, m, inv = enc.encode_unique(instr, stock=True)
     assert u.shape[0] == 2 and inv.shape[0] == 8
+
+
+# ------------------------------------------------------------------ trajectory cache host logic
+def _data_gold():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g6_g7_data.npz"))
+
+
+def _dsha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_data_collate_fn_matches_reference_golden():
+    from oracle import data_cases as dc
+    from wsmgmap.data import collate_fn
+    g = _data_gold()
+    for tag, lengths in (("rag", dc.COLLATE_LENGTHS), ("long", dc.LONG_LENGTHS)):
+        batch = [dc.episode(100 + i, n) + (torch.ones(n),) for i, n in enumerate(lengths)]
+        ob, prev, masks, corr, wts = collate_fn(batch)
+        for k, v in ob.items():
+            assert list(v.shape) == g[f"g6_{tag}_obs_{k}_shape"].tolist() and str(v.dtype) == str(g[f"g6_{tag}_obs_{k}_dtype"])
+            assert _dsha(v.float().numpy()) == str(g[f"g6_{tag}_obs_{k}_sha"]), (tag, k)
+        for name, v in (("prev", prev), ("masks", masks), ("corr", corr), ("wts", wts)):
+            assert _dsha(v.float().numpy()) == str(g[f"g6_{tag}_{name}_sha"]), (tag, name)
+
+
+def test_data_dataset_order_codec_and_sharding_match_reference_golden():
+    """TrajectoryDataset over an in-memory store of packed records reproduces IWTrajectoryDataset's yield order
+    (rank / worker shard, block shuffle, length-sorted preload, weights) for the same `random` seed; records written
+    by the oracle's restatement of the msgpack_numpy format are readable and vice versa."""
+    import random
+    import types
+    from oracle import data_cases as dc, data_ref as dr
+    from wsmgmap.data import TrajectoryDataset, pack_record, unpack_record, block_shuffle, change_data_type
+    g = _data_gold()
+    store = {}
+    for i, n in enumerate(dc.DATASET_LENGTHS):
+        obs, prev, oracle = dc.episode(1000 + i, n)
+        store[i] = pack_record(obs, prev, oracle) if i % 2 else dr.pack_record(obs, prev, oracle)   # both writers
+    for ci, (world, rank, nworkers, wid, bs, seed) in enumerate(dc.DATASET_CASES):
+        ds = TrajectoryDataset(store.__getitem__, len(store), use_iw=True, inflection_weight_coef=3.2, batch_size=bs,
+                               rank=rank, world_size=world)
+        info = None if nworkers == 0 else types.SimpleNamespace(num_workers=nworkers, id=wid)
+        old = torch.utils.data.get_worker_info
+        torch.utils.data.get_worker_info = lambda info=info: info
+        try:
+            random.seed(seed)
+            lens, wsum, first = [], [], []
+            for obs, prev, oracle, w in ds:
+                lens.append(len(prev)); wsum.append(float(w.sum())); first.append(float(prev[0, 0]))
+            assert lens == g[f"g7_{ci}_yield_lengths"].tolist()
+            assert wsum == g[f"g7_{ci}_weight_sums"].tolist() and first == g[f"g7_{ci}_first_prev"].tolist()
+            assert ds.loaded_indices == g[f"g7_{ci}_order"].tolist() and len(ds) == int(g[f"g7_{ci}_len"])
+        finally:
+            torch.utils.data.get_worker_info = old
+    random.seed(3)
+    assert block_shuffle(list(range(17)), 4) == g["g7_block_shuffle"].tolist()
+    obs, prev, oracle = dc.episode(7, 6)
+    o2, p2, a2 = dr.unpack_record(pack_record(obs, prev, oracle))
+    assert all(o2[k].dtype == obs[k].dtype and np.array_equal(o2[k], obs[k]) for k in obs) and np.array_equal(p2, prev)
+    rec = unpack_record(dr.pack_record(dict(obs, ep_id=np.int64(3)), prev, oracle))
+    assert "ep_id" not in rec[0] and np.array_equal(rec[2], oracle)
+    assert change_data_type({"rgb": np.ones((2, 3), np.float32), "gps": np.ones(2, np.float32)})["rgb"].dtype == np.uint8

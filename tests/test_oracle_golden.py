@@ -142,3 +142,63 @@ def test_fp8_oracle_matches_f32_formula_on_representable_inputs():
     a = np.exp(lg - lg.max(1, keepdims=True)); a /= a.sum(1, keepdims=True)
     assert np.abs(attn - a).max() < 1e-12 and np.abs(out - np.einsum("bl,blc->bc", a, x)).max() < 1e-12
     assert ar.dequantize_e4m3(ar.quantize_e4m3(np.array([1e6, -1e6, 460.0, 0.0], np.float32), 1.0), 1.0).tolist() == [448.0, -448.0, 448.0, 0.0]
+
+
+# ------------------------------------------------------------------ trajectory cache
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_data_oracle_collate_matches_reference_golden():
+    """oracle/data_ref.collate == dagger_trainer.py collate_fn (g6: ragged batch, and the 200-step cap)."""
+    from oracle import data_cases as dc, data_ref as dr
+    g = np.load(os.path.join(GOLD, "g6_g7_data.npz"))
+    for tag, lengths in (("rag", dc.COLLATE_LENGTHS), ("long", dc.LONG_LENGTHS)):
+        batch = []
+        for i, n in enumerate(lengths):
+            obs, prev, oracle = dc.episode(100 + i, n)
+            batch.append(({k: torch.from_numpy(v.copy()) for k, v in obs.items()}, torch.from_numpy(prev.copy()),
+                          torch.from_numpy(oracle.copy()), torch.ones(n)))
+        ob, prev, masks, corr, wts = dr.collate(batch)
+        for k, v in ob.items():
+            assert list(v.shape) == g[f"g6_{tag}_obs_{k}_shape"].tolist() and str(v.dtype) == str(g[f"g6_{tag}_obs_{k}_dtype"])
+            assert _sha(v.float().numpy()) == str(g[f"g6_{tag}_obs_{k}_sha"]), (tag, k)
+        for name, v in (("prev", prev), ("masks", masks), ("corr", corr), ("wts", wts)):
+            assert _sha(v.float().numpy()) == str(g[f"g6_{tag}_{name}_sha"]), (tag, name)
+
+
+def test_data_oracle_dataset_order_matches_reference_golden():
+    """Sharding, block shuffle and length-sorted preload order == IWTrajectoryDataset (g7), same `random` stream."""
+    import random
+    from oracle import data_cases as dc, data_ref as dr
+    g = np.load(os.path.join(GOLD, "g6_g7_data.npz"))
+    for ci, (world, rank, nworkers, wid, bs, seed) in enumerate(dc.DATASET_CASES):
+        random.seed(seed)
+        order = list(dr.dataset_order(dc.DATASET_LENGTHS, rank, world, nworkers, wid, bs))
+        assert [dc.DATASET_LENGTHS[i] for i in order] == g[f"g7_{ci}_yield_lengths"].tolist()
+        assert sorted(order) == sorted(g[f"g7_{ci}_order"].tolist())
+        first = [float(dc.episode(1000 + i, dc.DATASET_LENGTHS[i])[1][0, 0]) for i in order]
+        assert first == g[f"g7_{ci}_first_prev"].tolist()
+        assert dr.shard_range(len(dc.DATASET_LENGTHS), rank, world, nworkers, wid)[2] == int(g[f"g7_{ci}_len"])
+    random.seed(3)
+    assert dr.block_shuffle(list(range(17)), 4) == g["g7_block_shuffle"].tolist()
+
+
+def test_data_oracle_codec_round_trip_and_wire_format():
+    from oracle import data_cases as dc, data_ref as dr
+    import msgpack, zlib
+    obs, prev, oracle = dc.episode(7, 6)
+    blob = dr.pack_record(obs, prev, oracle)
+    o2, p2, a2 = dr.unpack_record(blob)
+    assert set(o2) == set(obs) and all(o2[k].dtype == obs[k].dtype and np.array_equal(o2[k], obs[k]) for k in obs)
+    assert np.array_equal(p2, prev) and np.array_equal(a2, oracle)
+    raw = msgpack.unpackb(zlib.decompress(blob), raw=False, strict_map_key=False)   # msgpack_numpy's field names
+    e = raw[0]["rgb_ego_map"]
+    assert e[b"nd"] is True and e[b"type"] == "<f2" and e[b"shape"] == [6, 4, 5, 5] and len(e[b"data"]) == 6 * 100 * 2
+    assert dr.change_data_type({"gt_semantic_map": np.ones((2, 3), np.float32)})["gt_semantic_map"].dtype == np.int64

@@ -1,0 +1,88 @@
+// Time-major collate of cached trajectories on the device (reference dagger_trainer.py:40-113
+// followed by the trainer's `v.float().to(device)` at :614-617).
+//
+// The reference pads and stacks on the host in the on-disk dtypes, converts every observation tensor to float32
+// on the CPU (1.3 GB per update for the ego map alone) and ships float32 over PCIe.  Here the episodes travel in
+// their compact on-disk dtypes (float16 / uint8 / int64 / float32) and ONE kernel per sensor writes the padded,
+// episode-interleaved float32 tensor [T][N][elems] the policy consumes: element (t, n, e) = src_n[t][e] for
+// t < length_n, else the pad value (1.0 for observations, 0 for actions / weights).
+#include "wsmg_common.h"
+
+namespace {
+
+enum { DT_F16 = 0, DT_U8 = 1, DT_I64 = 2, DT_F32 = 3 };
+
+template <int DT>
+__device__ __forceinline__ float load_as_float(const void* p, int64_t i) {
+  if constexpr (DT == DT_F16) return (float)reinterpret_cast<const _Float16*>(p)[i];
+  else if constexpr (DT == DT_U8) return (float)reinterpret_cast<const uint8_t*>(p)[i];
+  else if constexpr (DT == DT_I64) return (float)reinterpret_cast<const int64_t*>(p)[i];
+  else return reinterpret_cast<const float*>(p)[i];
+}
+
+// one thread = 4 consecutive elements of one (t, n) row when elems % 4 == 0 (V = 4), else one element (V = 1)
+template <int DT, int V>
+__global__ __launch_bounds__(256) void collate_pad_kernel(const void* const* __restrict__ src, const int* __restrict__ lengths,
+                                                          int N, int T, int64_t elems, float pad, float* __restrict__ dst) {
+  const int64_t per_row = elems / V;
+  const int64_t total = (int64_t)T * N * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / per_row;          // t * N + n
+    const int64_t e = (i - row * per_row) * V;
+    const int t = (int)(row / N), n = (int)(row - (int64_t)t * N);
+    float v[V];
+    if (t < lengths[n]) {
+      const void* s = src[n];
+      const int64_t o = (int64_t)t * elems + e;
+      if constexpr (V == 4 && DT == DT_F16) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 q = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(s) + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (float)q[j];
+      } else if constexpr (V == 4 && DT == DT_F32) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(s) + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = q[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[j] = load_as_float<DT>(s, o + j);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = pad;
+    }
+    if constexpr (V == 4) {
+      *reinterpret_cast<f32x4*>(dst + row * elems + e) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+      dst[row * elems + e] = v[0];
+    }
+  }
+}
+
+template <int DT>
+int launch(const void* const* src, const int* lengths, int N, int T, int64_t elems, float pad, float* dst, hipStream_t s) {
+  const bool v4 = (elems % 4) == 0;
+  const int64_t total = (int64_t)T * N * (v4 ? elems / 4 : elems);
+  int64_t g = wsmg_cdiv(total, 256);
+  if (g > 16384) g = 16384;
+  if (v4)
+    hipLaunchKernelGGL((collate_pad_kernel<DT, 4>), dim3((unsigned)g), dim3(256), 0, s, src, lengths, N, T, elems, pad, dst);
+  else
+    hipLaunchKernelGGL((collate_pad_kernel<DT, 1>), dim3((unsigned)g), dim3(256), 0, s, src, lengths, N, T, elems, pad, dst);
+  WSMG_RETURN_LAUNCH();
+}
+
+}  // namespace
+
+extern "C" int wsmg_collate_pad(const void* const* src, const int* lengths, int N, int T, int64_t elems, int src_dtype,
+                                float pad, float* dst, wsmg_stream_t stream) {
+  if (N <= 0 || T <= 0 || elems <= 0) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  switch (src_dtype) {
+    case DT_F16: return launch<DT_F16>(src, lengths, N, T, elems, pad, dst, s);
+    case DT_U8: return launch<DT_U8>(src, lengths, N, T, elems, pad, dst, s);
+    case DT_I64: return launch<DT_I64>(src, lengths, N, T, elems, pad, dst, s);
+    case DT_F32: return launch<DT_F32>(src, lengths, N, T, elems, pad, dst, s);
+    default: return WSMG_EINVAL;
+  }
+}

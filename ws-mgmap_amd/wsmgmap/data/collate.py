@@ -1,0 +1,104 @@
+"""Batch assembly for the policy update.
+
+`collate_fn` is the host form with the reference's exact semantics (dagger_trainer.py:40-113).  `DeviceCollator`
+produces the tensors the trainer hands to `_update_agent` (:614-625: every observation float32 on the device) but
+moves the episodes in their compact on-disk dtypes and pads / interleaves / converts them on the GPU with
+`wsmg_collate_pad`: half (float16 sensors) to an eighth (uint8) of the reference's PCIe bytes and no host-side
+float32 materialisation."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _abi
+
+LIMITED_LEN_BY_GPU = 200   # dagger_trainer.py:82
+_DT = {np.dtype(np.float16): 0, np.dtype(np.uint8): 1, np.dtype(np.int64): 2, np.dtype(np.float32): 3}
+
+
+def _pad(t, max_len, fill):
+    n = max_len - t.size(0)
+    if n <= 0:
+        return t[:max_len]
+    return torch.cat([t, torch.full_like(t[0:1], fill).expand(n, *t.size()[1:])], dim=0)
+
+
+def collate_fn(batch):
+    """[(obs, prev_actions, oracle_actions, weights)] -> (obs [T*N, ...], prev_actions [T*N, 2], not_done_masks [T*N, 1],
+    corrected_actions [T, N, 2], weights [T, N]) on the host, dtypes as stored."""
+    as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.array(a))  # noqa: E731
+    obs_l = [{k: as_t(v) for k, v in b[0].items()} for b in batch]
+    prev_l, corr_l, w_l = [as_t(b[1]) for b in batch], [as_t(b[2]) for b in batch], [as_t(b[3]) for b in batch]
+    T = min(max(p.size(0) for p in prev_l), LIMITED_LEN_BY_GPU)
+    obs = {}
+    for k in obs_l[0]:
+        s = torch.stack([_pad(o[k], T, 1.0) for o in obs_l], dim=1)
+        obs[k] = s.view(-1, *s.size()[2:])
+    prev = torch.stack([_pad(p, T, 0) for p in prev_l], dim=1)
+    corr = torch.stack([_pad(c, T, 0) for c in corr_l], dim=1)
+    wts = torch.stack([_pad(w, T, 0) for w in w_l], dim=1)
+    masks = torch.ones_like(wts, dtype=torch.float)
+    masks[0] = 0
+    return obs, prev.view(-1, 2), masks.view(-1, 1), corr, wts
+
+
+class DeviceCollator:
+    """collate + `.float().to(device)` of the reference, assembled on the GPU.  One pinned staging buffer per call
+    holds all episodes of all sensors back to back; it goes to the device in ONE asynchronous copy on `stream`, then
+    one `wsmg_collate_pad` launch per sensor writes the padded float32 tensors."""
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self._pinned = None
+
+    def _staging(self, nbytes):
+        if self._pinned is None or self._pinned.numel() < nbytes:
+            self._pinned = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+        return self._pinned
+
+    def __call__(self, batch, stream=None):
+        stream = stream or torch.cuda.current_stream(self.device)
+        N = len(batch)
+        lengths = [int(len(b[1])) for b in batch]
+        T = min(max(lengths), LIMITED_LEN_BY_GPU)
+        # plan: (name, per-episode arrays, pad value); episodes longer than T are cut before they travel
+        plan = [(k, [np.ascontiguousarray(np.asarray(b[0][k])[:T]) for b in batch], 1.0) for k in batch[0][0]]
+        plan.append(("__prev", [np.ascontiguousarray(np.asarray(b[1], dtype=np.float32)[:T]) for b in batch], 0.0))
+        plan.append(("__corr", [np.ascontiguousarray(np.asarray(b[2], dtype=np.float32)[:T]) for b in batch], 0.0))
+        plan.append(("__wts", [np.ascontiguousarray(np.asarray(b[3], dtype=np.float32)[:T]) for b in batch], 0.0))
+        offs, total = [], 0
+        for _, arrs, _ in plan:
+            if arrs[0].dtype not in _DT:
+                raise _abi.WsmgError(f"unsupported on-disk dtype {arrs[0].dtype} in the trajectory cache")
+            for a in arrs:
+                total = (total + 15) & ~15
+                offs.append(total)
+                total += a.nbytes
+        host = self._staging(total + 16)
+        hview = host.numpy()
+        it = iter(offs)
+        for _, arrs, _ in plan:
+            for a in arrs:
+                o = next(it)
+                hview[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        with torch.cuda.stream(stream):
+            dev = torch.empty(total + 16, dtype=torch.uint8, device=self.device)
+            dev.copy_(host[: total + 16], non_blocking=True)
+            base = dev.data_ptr()
+            lens_dev = torch.tensor([min(n, T) for n in lengths], dtype=torch.int32, device=self.device)
+            ptrs_dev = torch.tensor([base + o for o in offs], dtype=torch.int64, device=self.device)
+            out, it, row = {}, iter(range(len(offs))), 0
+            for name, arrs, pad in plan:
+                elems = int(np.prod(arrs[0].shape[1:], dtype=np.int64))
+                dst = torch.empty((T, N) + tuple(arrs[0].shape[1:]), dtype=torch.float32, device=self.device)
+                _abi.call("wsmg_collate_pad", ctypes.c_void_p(ptrs_dev.data_ptr() + 8 * row), ctypes.c_void_p(lens_dev.data_ptr()),
+                          N, T, max(elems, 1), _DT[arrs[0].dtype], float(pad), ctypes.c_void_p(dst.data_ptr()),
+                          ctypes.c_void_p(stream.cuda_stream))
+                row += N
+                out[name] = dst
+            dev.record_stream(stream)
+        prev, corr, wts = out.pop("__prev"), out.pop("__corr"), out.pop("__wts")
+        obs = {k: v.view(-1, *v.shape[2:]) for k, v in out.items()}
+        masks = torch.ones(T, N, dtype=torch.float32, device=self.device)
+        masks[0] = 0
+        return obs, prev.view(-1, 2), masks.view(-1, 1), corr, wts
