@@ -663,3 +663,43 @@ def test_device_collate_matches_reference_golden(ops):
     # a second call re-uses the pinned staging buffer
     ob2, *_ = coll([dc.episode(100 + i, n) + (torch.ones(n),) for i, n in enumerate(dc.COLLATE_LENGTHS)])
     assert torch.equal(ob2["progress"].cpu(), torch.from_numpy(g["g6_rag_progress"]))
+
+
+class _Store:
+    """picklable in-memory record store (stands in for the reference's LMDB)"""
+    def __init__(self, blobs):
+        self.blobs = blobs
+
+    def __call__(self, i):
+        return self.blobs[i]
+
+
+@pytest.mark.gpu
+def test_device_feeder_end_to_end(ops):
+    """Records -> TrajectoryDataset -> DeviceFeeder (side-stream DeviceCollator, 2 batches ahead) yields the same
+    batches as the host path (same `random` seed, in-process decode); with worker processes every record of the
+    shard arrives exactly once."""
+    import random
+    from oracle import data_cases as dc
+    from wsmgmap.data import TrajectoryDataset, DeviceFeeder, collate_fn, pack_record
+    store = _Store([pack_record(*dc.episode(1000 + i, n)) for i, n in enumerate(dc.DATASET_LENGTHS)])
+    mk = lambda: TrajectoryDataset(store, len(store.blobs), batch_size=4, rank=0, world_size=1)  # noqa: E731
+    random.seed(21)
+    want = []
+    items = [x for x in mk()]          # one __iter__ call, like the DataLoader fetcher
+    for i in range(0, len(items) - len(items) % 4, 4):
+        want.append(collate_fn(items[i:i + 4]))
+    random.seed(21)
+    got = list(DeviceFeeder(mk(), 4, "cuda", num_workers=0, prefetch=2))
+    torch.cuda.synchronize()
+    assert len(got) == len(want) == 5
+    for (ob, prev, masks, corr, wts), (ob2, prev2, masks2, corr2, wts2) in zip(want, got):
+        assert all(torch.equal(ob[k].float(), ob2[k].cpu()) for k in ob)
+        assert torch.equal(prev, prev2.cpu()) and torch.equal(masks, masks2.cpu()) and torch.equal(corr, corr2.cpu()) and torch.equal(wts, wts2.cpu())
+    firsts = []
+    for ob, prev, masks, corr, wts in DeviceFeeder(mk(), 2, "cuda", num_workers=2, prefetch=2):
+        firsts += prev.view(-1, 2, 2)[0, :, 0].cpu().tolist()       # prev_actions[t=0, n, 0] of the batch's episodes
+    # 2 workers x 11 records (floor sharding, 22 of 23); drop_last=True as in the reference (dagger_trainer.py:591)
+    # drops each worker's odd record: 20 distinct episodes arrive, each once
+    pool = [float(dc.episode(1000 + i, n)[1][0, 0]) for i, n in enumerate(dc.DATASET_LENGTHS[:22])]
+    assert len(firsts) == 20 and len(set(firsts)) == 20 and set(firsts) <= set(pool)

@@ -3,3 +3,4 @@ iteration, and the device-side collate.  Mirrors vlnce_baselines/dagger_trainer.
 from .codec import pack_record, unpack_record, change_data_type  # noqa: F401
 from .dataset import TrajectoryDataset, block_shuffle, shard_range  # noqa: F401
 from .collate import DeviceCollator, collate_fn  # noqa: F401
+from .feeder import DeviceFeeder  # noqa: F401
