@@ -225,11 +225,13 @@ int wsmg_collate_pad(const void* const* src, const int* lengths, int N, int T, i
 /* ============================ persistent masked-GRU state encoders ============================ */
 /* habitat-lab RNNStateEncoder (GRU, hidden 512) as used at mg_map_policy.py:118-123,147-152,220-227,242-249:
  * h_{t-1} is multiplied by masks[t] before every step (episode restarts), gate order r,z,n.
- * One launch runs all T steps (32 cooperating workgroups, W_hh in registers, one bounded-spin grid
- * barrier per step).  gi = x W_ih^T + b_ih [T][N][3H] is computed by the caller; N <= 8.
- * sync_ws: wsmg_gru_workspace_bytes(T) bytes of 128-B-aligned device scratch: barrier words (zeroed by the
- * call; word 1 != 0 afterwards means a barrier timed out) + the step-indexed exchange image through which
- * h_t crosses workgroups (each 128-B line written once by one workgroup and never re-used in the launch).
+ * One launch runs all T <= 1023 steps: 32 cooperating workgroups (each owns its CU for the duration), W_hh in
+ * registers.  gi = x W_ih^T + b_ih [T][N][3H] is computed by the caller; N <= 8.
+ * sync_ws: wsmg_gru_workspace_bytes(T) bytes of 128-B-aligned device scratch, cleared by the call: control words
+ * (word 1 != 0 afterwards means a wait timed out) + the step-indexed exchange image.  Forward: every h value
+ * crosses workgroups as one 8-byte {value, launch-unique tag} word (flag-in-data: one memory round trip per
+ * step); backward: one bounded-spin agent-scope release/acquire barrier per step.  Every word / 128-B line of the
+ * image is written once per launch, by one workgroup.
  * save_*: [T][N][H] each, consumed by wsmg_gru_bwd. */
 int64_t wsmg_gru_workspace_bytes(int T);
 int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,

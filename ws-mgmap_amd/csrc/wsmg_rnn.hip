@@ -418,9 +418,11 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
-  if (e != hipSuccess) return (int)e;
   if (T > 1023) return WSMG_EINVAL;
+  // the control words AND the {value, tag} image are cleared: tags are launch-unique within a process, but device
+  // memory handed to a new process can still hold a previous process's image with the same epoch numbers
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)T * NWG * NB * UNITS_WG * 8, s);
+  if (e != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase()};
   unsigned dyn = 0;
