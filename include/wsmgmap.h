@@ -212,6 +212,17 @@ int wsmg_attn_fp8_fused_fwd(const float* q_folded, const float* q_dot_bias, cons
 /* y = e4m3(clamp(x * inv_scale, +-448)), round to nearest even; n a multiple of 4. */
 int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, uint8_t* y, wsmg_stream_t stream);
 
+/* per-pixel cross-entropy of the semantic-hallucination head straight from the NHWC logits (policy.py:61-66:
+ * F.cross_entropy(pred_sem_map, target, reduction='none')): logits [rows][32] (classes <= 32 valid channels, the rest
+ * padding), target int64 [rows]; loss [rows] = logsumexp - logit[target].  bwd: dlogits [rows][32] =
+ * (softmax - onehot) * gloss[row], padded channels 0. */
+int wsmg_ce_nhwc_fwd(const float* logits, const int64_t* target, int64_t rows, int classes, float* loss, wsmg_stream_t stream);
+int wsmg_ce_nhwc_bwd(const float* logits, const int64_t* target, const float* gloss, int64_t rows, int classes,
+                     float* dlogits, wsmg_stream_t stream);
+int wsmg_ce_nhwc_fwd_bf16(const void* logits, const int64_t* target, int64_t rows, int classes, float* loss, wsmg_stream_t stream);
+int wsmg_ce_nhwc_bwd_bf16(const void* logits, const int64_t* target, const float* gloss, int64_t rows, int classes,
+                          void* dlogits, wsmg_stream_t stream);
+
 /* ============================ trajectory-cache collate ============================ */
 /* dagger_trainer.py:40-113 (collate_fn: time-major pad + stack over the N episodes of a batch) fused with the
  * trainer's float32 conversion (:614-617), on the device: src = device array of N device pointers to episode

@@ -703,3 +703,28 @@ def test_device_feeder_end_to_end(ops):
     # drops each worker's odd record: 20 distinct episodes arrive, each once
     pool = [float(dc.episode(1000 + i, n)[1][0, 0]) for i, n in enumerate(dc.DATASET_LENGTHS[:22])]
     assert len(firsts) == 20 and len(set(firsts)) == 20 and set(firsts) <= set(pool)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_cross_entropy_nhwc(ops, dt):
+    """Fused per-pixel CE over NHWC logits == F.cross_entropy on the NCHW view (policy.py:61-66), loss and gradient;
+    padded channels 27..31 receive zero gradient."""
+    torch.manual_seed(2)
+    B, S, C = 3, 10, 27
+    logits = torch.randn(B, S, S, 32, device="cuda") * 3
+    logits[..., C:] = 0
+    if dt == "bf16":
+        logits = logits.bfloat16()
+    target = torch.randint(0, C, (B, S, S), device="cuda")
+    gl = torch.randn(B, S, S, device="cuda")
+    x = logits.clone().requires_grad_(True)
+    loss = ops.cross_entropy_nhwc(x, target, C)
+    (loss * gl).sum().backward()
+    xr = logits.double().requires_grad_(True)
+    ref = F.cross_entropy(xr[..., :C].permute(0, 3, 1, 2), target, reduction="none")
+    (ref * gl.double()).sum().backward()
+    assert float((loss.double() - ref).abs().max()) <= 2e-6 * (1 + float(ref.abs().max()))
+    tol = 2e-6 if dt == "f32" else 1e-2
+    assert float((x.grad.double() - xr.grad).abs().max()) <= tol * float(xr.grad.abs().max())
+    assert float(x.grad[..., C:].abs().max()) == 0.0

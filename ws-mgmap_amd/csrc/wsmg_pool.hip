@@ -268,6 +268,63 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc64_kernel(const float* __rest
   }
 }
 
+// ---- fused per-pixel cross-entropy over NHWC logits (policy.py:61-66: F.cross_entropy(pred_sem_map, target,
+// reduction='none')): the 27 classes of a pixel are one 64/128-byte run of the 32-channel-padded conv output, so the
+// loss needs no NHWC->NCHW transpose and no materialised log-softmax.  One thread per pixel row.
+template <class T>
+__global__ __launch_bounds__(256) void ce_nhwc_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                          int64_t rows, int classes, float* __restrict__ loss) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float v[32];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x4 q = ld4(logits + r * 32 + 4 * j);
+    v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3];
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) if (c < classes) mx = fmaxf(mx, v[c]);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) if (c < classes) sum += expf(v[c] - mx);
+  const int t = (int)target[r];
+  float vt = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) if (c == t) vt = v[c];
+  loss[r] = (mx + logf(sum)) - vt;
+}
+
+// dlogits[r][c] = (softmax(logits[r])[c] - [c == target[r]]) * gscale[r / rows_per_sample]; padded channels get 0
+template <class T>
+__global__ __launch_bounds__(256) void ce_nhwc_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ target,
+                                                          const float* __restrict__ gloss, int64_t rows, int classes,
+                                                          T* __restrict__ dlogits) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float v[32];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x4 q = ld4(logits + r * 32 + 4 * j);
+    v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3];
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) if (c < classes) mx = fmaxf(mx, v[c]);
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) { v[c] = c < classes ? expf(v[c] - mx) : 0.f; sum += v[c]; }
+  const float g = gloss[r], inv = 1.f / sum;
+  const int t = (int)target[r];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    f32x4 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = 4 * j + e; q[e] = c < classes ? (v[c] * inv - (c == t ? 1.f : 0.f)) * g : 0.f; }
+    st4(dlogits + r * 32 + 4 * j, q);
+  }
+}
+
 template <class T>
 int relu_fwd_t(const T* x, T* y, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
@@ -362,3 +419,24 @@ extern "C" int wsmg_nchw_to_nhwc(const float* x, float* y, int B, int C_src, int
 extern "C" int wsmg_nchw_to_nhwc_bf16(const float* x, void* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<true, float, bf16_t>(x, B16(y), B, C_src, H, W, C_dst, s); }
 extern "C" int wsmg_nhwc_to_nchw(const float* x, float* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<false, float, float>(x, y, B, C_src, H, W, C_dst, s); }
 extern "C" int wsmg_nhwc_to_nchw_bf16(const void* x, float* y, int B, int C_src, int H, int W, int C_dst, wsmg_stream_t s) { return transpose_t<false, bf16_t, float>(CB16(x), y, B, C_src, H, W, C_dst, s); }
+
+extern "C" int wsmg_ce_nhwc_fwd(const float* logits, const int64_t* target, int64_t rows, int classes, float* loss, wsmg_stream_t s) {
+  if (rows <= 0 || classes <= 0 || classes > 32) return WSMG_EINVAL;
+  hipLaunchKernelGGL(ce_nhwc_fwd_kernel<float>, dim3((unsigned)wsmg_cdiv(rows, 256)), dim3(256), 0, wsmg_s(s), logits, target, rows, classes, loss);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_ce_nhwc_fwd_bf16(const void* logits, const int64_t* target, int64_t rows, int classes, float* loss, wsmg_stream_t s) {
+  if (rows <= 0 || classes <= 0 || classes > 32) return WSMG_EINVAL;
+  hipLaunchKernelGGL(ce_nhwc_fwd_kernel<bf16_t>, dim3((unsigned)wsmg_cdiv(rows, 256)), dim3(256), 0, wsmg_s(s), CB16(logits), target, rows, classes, loss);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_ce_nhwc_bwd(const float* logits, const int64_t* target, const float* gloss, int64_t rows, int classes, float* dlogits, wsmg_stream_t s) {
+  if (rows <= 0 || classes <= 0 || classes > 32) return WSMG_EINVAL;
+  hipLaunchKernelGGL(ce_nhwc_bwd_kernel<float>, dim3((unsigned)wsmg_cdiv(rows, 256)), dim3(256), 0, wsmg_s(s), logits, target, gloss, rows, classes, dlogits);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_ce_nhwc_bwd_bf16(const void* logits, const int64_t* target, const float* gloss, int64_t rows, int classes, void* dlogits, wsmg_stream_t s) {
+  if (rows <= 0 || classes <= 0 || classes > 32) return WSMG_EINVAL;
+  hipLaunchKernelGGL(ce_nhwc_bwd_kernel<bf16_t>, dim3((unsigned)wsmg_cdiv(rows, 256)), dim3(256), 0, wsmg_s(s), CB16(logits), target, gloss, rows, classes, B16(dlogits));
+  WSMG_RETURN_LAUNCH();
+}

@@ -87,6 +87,8 @@ class MGMapNet(nn.Module):
         self._output_size = hid
         self.att_map_t_m = None
         self._side_stream = None
+        self.skip_pred_map_nchw = False   # set by BasePolicy around its own forward: it consumes sem_logits_nhwc
+        self.sem_logits_nhwc = None
         # storage type of the map-stack activations: float32 (parity mode, f32 MFMA) or bfloat16
         # (BASELINE configs[1]; bf16 MFMA, float32 accumulation, float32 master weights)
         self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16}.get(
@@ -150,7 +152,10 @@ class MGMapNet(nn.Module):
         w6 = torch.nn.functional.pad(c[6].weight, (0, 0, 0, 0, 0, 0, 0, pad_o))   # [32,32,1,1]
         b6 = torch.nn.functional.pad(c[6].bias, (0, pad_o))
         sem = ops.conv2d(y, w6, b6, 1, 0)                                        # [B,2S,2S,32], channels 27.. are 0
-        pred_sem_map = ops.to_nchw(sem, SEM_CLASSES)
+        # the loss reads the NHWC logits directly (policy.aux_prediction); the reference-layout [B,27,2S,2S] tensor is
+        # only materialised for callers that ask for it
+        self.sem_logits_nhwc = sem
+        pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
         wcl = torch.nn.functional.pad(self.map_classified_linear[0].weight, (0, 0, 0, 0, 0, pad_o))  # [128,32,3,3]
         cls_proj = ops.relu(ops.conv2d(ops.avgpool2(sem), wcl, self.map_classified_linear[0].bias, 1, 1))
         emb = conv(torch.cat([enc_proj, cls_proj], dim=-1), self.map_cated_linear, 1)

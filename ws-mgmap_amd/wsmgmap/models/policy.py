@@ -7,13 +7,16 @@ Same constructor, `forward` / `act` / `update_map` signatures, attribute tree
 compute behind `self.net` runs in the gfx950 kernels of libwsmgmap.so.  `CMAPolicy` is an alias
 (BASELINE.json names the surface that way; the reference class is `BasePolicy`).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..common.aux_losses import AuxLosses
 from ..common.distributions import DiagGaussian
-from .mg_map_policy import MGMapNet
+from .. import ops
+from .mg_map_policy import MGMapNet, SEM_CLASSES
 
 
 class CriticHead(nn.Module):
@@ -59,9 +62,12 @@ class BasePolicy(nn.Module):
         if not AuxLosses.is_active():
             return
         if cfg.PREDICTION_MONITOR.use:
-            side = pred_map.shape[-1]
+            side = self.net.sem_logits_nhwc.shape[1] if pred_map is None else pred_map.shape[-1]
             target = F.interpolate(observations["gt_semantic_map"].unsqueeze(1), size=(side, side)).squeeze(1).long()
-            loss = F.cross_entropy(pred_map, target, reduction="none").mean([1, 2])
+            if pred_map is None:   # fused path: per-pixel CE straight from the NHWC logits of the conv engine
+                loss = ops.cross_entropy_nhwc(self.net.sem_logits_nhwc, target, SEM_CLASSES).mean([1, 2])
+            else:
+                loss = F.cross_entropy(pred_map, target, reduction="none").mean([1, 2])
             AuxLosses.register_loss("prediction_monitor", loss, cfg.PREDICTION_MONITOR.alpha)
         if cfg.CONTRASTIVE_MONITOR.use:
             size = self.net.map_encoder.output_shape[-1]
@@ -77,7 +83,11 @@ class BasePolicy(nn.Module):
 
     # -- teacher forcing / DAgger update ---------------------------------------------
     def forward(self, observations, rnn_hidden_states, prev_actions, masks, weights):
-        features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
+        self.net.skip_pred_map_nchw = os.environ.get("WSMG_FUSED_CE", "1") != "0"   # the only consumer of pred_sem_map is the loss below
+        try:
+            features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
+        finally:
+            self.net.skip_pred_map_nchw = False
         pred = self.action_distribution(features).mean
         self.aux_prediction(features, observations, pred_map)
         aux_loss = AuxLosses.reduce((weights > 0).view(-1))

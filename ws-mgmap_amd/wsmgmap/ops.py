@@ -447,6 +447,33 @@ def attention(q, k, v, mask=None, scale=1.0 / 16):
 
 
 # ----------------------------------------------------------------------------- persistent masked GRU
+class _CrossEntropyNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, classes):
+        _req(logits, target)
+        if logits.shape[-1] != 32 or target.dtype != torch.int64:
+            raise _abi.WsmgError("cross_entropy_nhwc: logits [..., 32] (padded classes), target int64")
+        rows = logits.numel() // 32
+        loss = torch.empty(target.shape, device=logits.device, dtype=torch.float32)
+        _abi.call("wsmg_ce_nhwc_fwd" + _sfx(logits), _p(logits), _p(target), rows, int(classes), _p(loss), _stream())
+        ctx.save_for_backward(logits, target)
+        ctx.classes = int(classes)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        logits, target = ctx.saved_tensors
+        g = gloss.contiguous().float()
+        d = torch.empty_like(logits)
+        _abi.call("wsmg_ce_nhwc_bwd" + _sfx(logits), _p(logits), _p(target), _p(g), logits.numel() // 32, ctx.classes, _p(d), _stream())
+        return d, None, None
+
+
+def cross_entropy_nhwc(logits, target, classes):
+    """F.cross_entropy(logits_nchw[:, :classes], target, reduction='none') computed from NHWC logits [..., 32]."""
+    return _CrossEntropyNHWC.apply(logits.contiguous(), target.contiguous(), classes)
+
+
 class _AttnFolded(torch.autograd.Function):
     """Single-query attention whose keys are a k=1 Conv1d of the values (mg_map_policy.py:126-132,173-178):
     q.(W x_i + b) = (W^T q).x_i + q.b, and q.b is the same for every token, so it cancels in the softmax.
