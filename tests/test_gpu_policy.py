@@ -292,3 +292,30 @@ def test_cfg4_map_encoder_c40_e200():
     assert tuple(y.shape) == (2, 256, 49, 49)
     err = float((y.cpu() - ref).abs().max())
     assert err <= 2e-4, err
+
+
+def test_frozen_rgb_unet_on_the_bf16_engine_tracks_the_stock_path():
+    """with compute_dtype=bf16 the frozen RGB ResNet-UNet runs on the NHWC conv engine.  Same module,
+    same weights (default init), 224^2 and 256^2 frames: layer4 and proj_feat stay within bf16 rounding of the
+    float32 stock path (relative L2 error < 2 %), the forward hook on layer4_1x1 still fires with a float32
+    [B,512,H/32,W/32] tensor, and proj_feat keeps its post-ReLU range."""
+    from wsmgmap.models.encoders.unet_encoder import ResNetUNet
+    torch.manual_seed(4)
+    net = ResNetUNet(3, 27).cuda().eval()
+    for m in net.modules():   # non-trivial BN statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.8, 1.2); m.bias.data.normal_(0, 0.1)
+    seen = {}
+    net.layer4_1x1.register_forward_hook(lambda m, i, o: seen.update(l4=o))
+    for hw in (224, 256):
+        rgb = torch.randint(0, 256, (2, hw, hw, 3), device="cuda").float()
+        with torch.no_grad():
+            net.engine_dtype = None
+            l4_ref, proj_ref = net({"rgb": rgb})
+            net.engine_dtype = torch.bfloat16
+            l4, proj = net({"rgb": rgb})
+        assert l4.dtype == torch.float32 and tuple(l4.shape) == (2, 512, hw // 32, hw // 32) and seen["l4"] is l4
+        assert proj.dtype == torch.float32 and tuple(proj.shape) == (2, 64, hw, hw) and float(proj.min()) >= 0.0
+        for a, b, name in ((l4, l4_ref, "layer4"), (proj, proj_ref, "proj_feat")):
+            rel = float((a - b).norm() / b.norm())
+            assert rel < 2e-2, (hw, name, rel)

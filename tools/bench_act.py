@@ -38,9 +38,9 @@ def timed(f, n=20):
 
 AuxLosses.deactivate()
 gen = torch.Generator(device="cuda"); gen.manual_seed(0)
-for B in (1, 8):
+for B, mode in ((1, "f32"), (1, "bf16"), (8, "f32"), (8, "bf16")):
     torch.manual_seed(0)
-    pol = BasePolicy(None, _Box(), default_model_config(num_proc=B)).cuda().eval()
+    pol = BasePolicy(None, _Box(), default_model_config(num_proc=B, compute_dtype=mode)).cuda().eval()
     obs = obs_of(B, 256, gen)
     h = torch.zeros(2, B, 512, device="cuda"); prev = torch.zeros(B, 2, device="cuda"); masks = torch.ones(B, 1, device="cuda")
     with torch.no_grad():
@@ -48,5 +48,5 @@ for B in (1, 8):
         t_rgb = timed(lambda: pol.net.rgb_encoder(obs))
         emb, proj = pol.net.rgb_encoder(obs)
         t_bev = timed(lambda: pol.net.rgb_mapping_module(proj, dict(obs), masks))
-    print(f"B={B}: act() {t_act:.2f} ms per env-step ({B / t_act * 1e3:.0f} env-steps/s) | frozen RGB ResNet-UNet {t_rgb:.2f} ms | "
+    print(f"B={B} {mode}: act() {t_act:.2f} ms per env-step ({B / t_act * 1e3:.0f} env-steps/s) | frozen RGB ResNet-UNet {t_rgb:.2f} ms | "
           f"BEV operator (index, scatter, rotate, fuse, retrieve, rotate) {t_bev:.3f} ms | rest {t_act - t_rgb - t_bev:.2f} ms")

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
         int dp = dpix[row];
         if (dp < 0) continue;
         float v = acc[t][u][g] + bv;
-        if (a.out_f32)
+        if (a.out_f32 & 2) v = v > 0.f ? v : 0.f;   // fused ReLU (inference path of the frozen encoders)
+        if (a.out_f32 & 1)
           reinterpret_cast<float*>(a.dst)[(size_t)dp * a.N + n] = v;
         else
           reinterpret_cast<unsigned short*>(a.dst)[(size_t)dp * a.N + n] = f2bf_bits(v);
@@ -421,6 +422,8 @@ int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int strid
   if (stride != 1 && stride != 2) return WSMG_EINVAL;
   if (OH != (H + 2 * pad - KH) / stride + 1 || OW != (W + 2 * pad - KW) / stride + 1) return WSMG_EINVAL;
   if ((int64_t)B * H * W >= (1ll << 31) || (int64_t)B * OH * OW >= (1ll << 31)) return WSMG_EINVAL;
+  // 32-bit byte offsets into the buffer resources
+  if ((int64_t)B * H * W * Cin * 2 >= (1ll << 31) || (int64_t)B * OH * OW * Cout * 2 >= (1ll << 31)) return WSMG_EINVAL;
   return 0;
 }
 

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-bool chan_ok(int C) { return C == 32 || C == 64 || C == 128 || C == 256; }
+bool chan_ok(int C) { return C == 32 || C == 64 || C == 128 || C == 256 || C == 512; }
 
 int stream_grid(int64_t rows, int C) {
   int64_t rpi = 256 / (C / 4);
@@ -278,7 +278,7 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, rows, momentum, eps,
                        running_mean, running_var, save_mean, save_invstd);
   } else {
-    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, running_mean, running_var, eps, C,
+    hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((unsigned)wsmg_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, eps, C,
                        save_mean, save_invstd);
   }
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, x, residual, gamma, beta,

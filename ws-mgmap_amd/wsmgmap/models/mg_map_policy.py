@@ -93,6 +93,8 @@ class MGMapNet(nn.Module):
         # (BASELINE configs[1]; bf16 MFMA, float32 accumulation, float32 master weights)
         self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16}.get(
             str(getattr(mc, "COMPUTE_DTYPE", "f32")).lower(), torch.float32)
+        if self.compute_dtype == torch.bfloat16:   # the frozen RGB UNet follows: bf16 NHWC engine on the rollout path
+            self.rgb_encoder.base_model.engine_dtype = torch.bfloat16
 
         self.train()
         self.depth_encoder.eval()

@@ -212,6 +212,22 @@ def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False):
     return _Conv2d.apply(x, weight_oihw.permute(0, 2, 3, 1).contiguous(), bias, stride, pad, bias_grad_zero)
 
 
+def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
+    """Inference-only bf16 convolution with a pre-laid-out OHWI bf16 weight, float32 bias and optional fused ReLU
+    (one launch; used by the frozen encoders with eval-mode BatchNorm folded into weight and bias)."""
+    _req(x, w_ohwi_bf16, bias)
+    if x.dtype != torch.bfloat16 or w_ohwi_bf16.dtype != torch.bfloat16:
+        raise _abi.WsmgError("conv2d_infer_bf16 needs bf16 activations and weights")
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, Cin2 = w_ohwi_bf16.shape
+    assert Cin == Cin2, (x.shape, w_ohwi_bf16.shape)
+    OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
+    y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.bfloat16)
+    _launch("wsmg_conv2d_fwd_bf16", 2.0 * B * OH * OW * Cout * Cin * KH * KW, _p(x), _p(w_ohwi_bf16), _p(bias), _p(y),
+            2 if relu else 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+    return y
+
+
 def conv_transpose2d(x, weight_iohw, stride=2, pad=1):
     """nn.ConvTranspose2d weight is [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW."""
     return _ConvT2d.apply(x, weight_iohw.permute(0, 2, 3, 1).contiguous(), stride, pad)
