@@ -213,6 +213,16 @@ int wsmg_attn_fp8_fused_fwd(const float* q_folded, const float* q_dot_bias, cons
 /* y = e4m3(clamp(x * inv_scale, +-448)), round to nearest even; n a multiple of 4. */
 int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, uint8_t* y, wsmg_stream_t stream);
 
+/* Conv weight layouts of one layer in one launch: the reference's OIHW float32 parameter (checkpoint layout) ->
+ * OHWI (operand of wsmg_conv2d_fwd / _bwd_weight) and, if w_ihwo != NULL, IHWO (operand of _bwd_data), input
+ * channels zero-padded to I_pad; wsmg_weight_grad_to_oihw brings the OHWI float32 weight gradient back to OIHW. */
+int wsmg_weight_relayout(const float* w_oihw, int O, int I, int KH, int KW, int I_pad, float* w_ohwi, float* w_ihwo,
+                         wsmg_stream_t stream);
+int wsmg_weight_relayout_bf16(const float* w_oihw, int O, int I, int KH, int KW, int I_pad, void* w_ohwi, void* w_ihwo,
+                              wsmg_stream_t stream);
+int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW, int I_pad, float* dw_oihw,
+                             wsmg_stream_t stream);
+
 /* per-pixel cross-entropy of the semantic-hallucination head straight from the NHWC logits (policy.py:61-66:
  * F.cross_entropy(pred_sem_map, target, reduction='none')): logits [rows][32] (classes <= 32 valid channels, the rest
  * padding), target int64 [rows]; loss [rows] = logsumexp - logit[target].  bwd: dlogits [rows][32] =

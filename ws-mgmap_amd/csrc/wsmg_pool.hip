@@ -325,6 +325,38 @@ __global__ __launch_bounds__(256) void ce_nhwc_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ---- conv weight layouts in one launch: OIHW float32 parameter -> OHWI (forward / weight-gradient operand) and IHWO
+// (backward-data operand) in the compute dtype, input channels zero-padded to I_pad.  Replaces per layer and update a
+// permute copy, a dtype cast, a second permute copy (and an F.pad when the engine pads channels).
+template <class T>
+__global__ __launch_bounds__(256) void weight_relayout_kernel(const float* __restrict__ w, int O, int I, int KH, int KW, int I_pad,
+                                                              T* __restrict__ ohwi, T* __restrict__ ihwo) {
+  const int64_t n = (int64_t)O * KH * KW * I_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx % I_pad);
+    int64_t r = idx / I_pad;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH);
+    const int o = (int)(r / KH);
+    const float v = i < I ? w[(((int64_t)o * I + i) * KH + kh) * KW + kw] : 0.f;
+    stf(ohwi + idx, v);
+    if (ihwo) stf(ihwo + (((int64_t)i * KH + kh) * KW + kw) * O + o, v);
+  }
+}
+// dW [O][KH][KW][I_pad] float32 -> the parameter's OIHW gradient (padded channels dropped)
+__global__ __launch_bounds__(256) void weight_grad_to_oihw_kernel(const float* __restrict__ dw, int O, int I, int KH, int KW,
+                                                                  int I_pad, float* __restrict__ out) {
+  const int64_t n = (int64_t)O * I * KH * KW;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+    const int kw = (int)(idx % KW);
+    int64_t r = idx / KW;
+    const int kh = (int)(r % KH); r /= KH;
+    const int i = (int)(r % I);
+    const int o = (int)(r / I);
+    out[idx] = dw[(((int64_t)o * KH + kh) * KW + kw) * I_pad + i];
+  }
+}
+
 template <class T>
 int relu_fwd_t(const T* x, T* y, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
@@ -438,5 +470,26 @@ extern "C" int wsmg_ce_nhwc_bwd(const float* logits, const int64_t* target, cons
 extern "C" int wsmg_ce_nhwc_bwd_bf16(const void* logits, const int64_t* target, const float* gloss, int64_t rows, int classes, void* dlogits, wsmg_stream_t s) {
   if (rows <= 0 || classes <= 0 || classes > 32) return WSMG_EINVAL;
   hipLaunchKernelGGL(ce_nhwc_bwd_kernel<bf16_t>, dim3((unsigned)wsmg_cdiv(rows, 256)), dim3(256), 0, wsmg_s(s), CB16(logits), target, gloss, rows, classes, B16(dlogits));
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_weight_relayout(const float* w_oihw, int O, int I, int KH, int KW, int I_pad, float* w_ohwi, float* w_ihwo,
+                                    wsmg_stream_t s) {
+  if (O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || I_pad < I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(weight_relayout_kernel<float>, dim3(sgrid((int64_t)O * KH * KW * I_pad)), dim3(256), 0, wsmg_s(s), w_oihw, O, I, KH,
+                     KW, I_pad, w_ohwi, w_ihwo);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_weight_relayout_bf16(const float* w_oihw, int O, int I, int KH, int KW, int I_pad, void* w_ohwi, void* w_ihwo,
+                                         wsmg_stream_t s) {
+  if (O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || I_pad < I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(weight_relayout_kernel<bf16_t>, dim3(sgrid((int64_t)O * KH * KW * I_pad)), dim3(256), 0, wsmg_s(s), w_oihw, O, I,
+                     KH, KW, I_pad, B16(w_ohwi), B16(w_ihwo));
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW, int I_pad, float* dw_oihw, wsmg_stream_t s) {
+  if (O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || I_pad < I) return WSMG_EINVAL;
+  hipLaunchKernelGGL(weight_grad_to_oihw_kernel, dim3(sgrid((int64_t)O * I * KH * KW)), dim3(256), 0, wsmg_s(s), dw_ohwi, O, I, KH, KW,
+                     I_pad, dw_oihw);
   WSMG_RETURN_LAUNCH();
 }

@@ -21,10 +21,8 @@ def bump(bn: nn.BatchNorm2d, train: bool):
 
 def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
     """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
-    w = conv.weight
-    if x.shape[-1] != w.shape[1]:  # input channels were zero-padded to a multiple of 32: pad the weight too
-        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, x.shape[-1] - w.shape[1]))
-    y = ops.conv2d(x, w, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
+    # (if x carries zero-padded channels, ops.conv2d pads the weight's input channels to match)
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
     bump(bn, train)
     return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
 

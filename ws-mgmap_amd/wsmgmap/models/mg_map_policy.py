@@ -158,8 +158,8 @@ class MGMapNet(nn.Module):
         # only materialised for callers that ask for it
         self.sem_logits_nhwc = sem
         pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
-        wcl = torch.nn.functional.pad(self.map_classified_linear[0].weight, (0, 0, 0, 0, 0, pad_o))  # [128,32,3,3]
-        cls_proj = ops.relu(ops.conv2d(ops.avgpool2(sem), wcl, self.map_classified_linear[0].bias, 1, 1))
+        # (27 -> 32 input channels: ops.conv2d zero-pads the weight to the activation's channel count)
+        cls_proj = ops.relu(ops.conv2d(ops.avgpool2(sem), self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1))
         emb = conv(torch.cat([enc_proj, cls_proj], dim=-1), self.map_cated_linear, 1)
         b, s1, s2, ch = emb.shape
         return emb.view(b, s1 * s2, ch), pred_sem_map

@@ -107,50 +107,69 @@ def _launch(name, flops, *args):
 
 
 # ----------------------------------------------------------------------------- convolution
+def _weight_layouts(w_oihw, cin_pad, dtype, need_ihwo):
+    """(OHWI, IHWO or None) of an OIHW float32 parameter in `dtype`, input channels zero-padded to cin_pad: ONE launch
+    (wsmg_weight_relayout) instead of permute copy + cast + second permute (+ pad)."""
+    O, I, KH, KW = w_oihw.shape
+    w_ohwi = torch.empty(O, KH, KW, cin_pad, device=w_oihw.device, dtype=dtype)
+    w_ihwo = torch.empty(cin_pad, KH, KW, O, device=w_oihw.device, dtype=dtype) if need_ihwo else None
+    _abi.call("wsmg_weight_relayout" + ("_bf16" if dtype == torch.bfloat16 else ""), _p(w_oihw), O, I, KH, KW, cin_pad,
+              _p(w_ohwi), _p(w_ihwo), _stream())
+    return w_ohwi, w_ihwo
+
+
+def _weight_grad_oihw(dw_ohwi, I):
+    O, KH, KW, Ipad = dw_ohwi.shape
+    out = torch.empty(O, I, KH, KW, device=dw_ohwi.device, dtype=torch.float32)
+    _abi.call("wsmg_weight_grad_to_oihw", _p(dw_ohwi), O, I, KH, KW, Ipad, _p(out), _stream())
+    return out
+
+
 class _Conv2d(torch.autograd.Function):
-    """y = conv2d(x, w) + b on NHWC x / OHWI float32 master weight.  x float32 -> f32 MFMA engine;
-    x bf16 -> the weight is cast to bf16 for the MFMA, dW comes back float32."""
+    """y = conv2d(x, w) + b on NHWC x; w is the reference's OIHW float32 parameter (its .grad comes back OIHW
+    float32).  x float32 -> f32 MFMA engine; x bf16 -> bf16 operands, float32 accumulation and dW.  If x has more
+    channels than w (the engine pads activations to multiples of 32) the weight is zero-padded to match."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, bias_grad_zero=False):
-        _req(x, w, bias)
-        _f32(w, bias)
+    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False):
+        _req(x, w_oihw, bias)
+        _f32(w_oihw, bias)
         sfx = _sfx(x)
         B, H, W, Cin = x.shape
-        Cout, KH, KW, Cin2 = w.shape
-        assert Cin == Cin2, (x.shape, w.shape)
+        Cout, Cin_w, KH, KW = w_oihw.shape
+        assert Cin >= Cin_w, (x.shape, w_oihw.shape)
+        w, w_ihwo = _weight_layouts(w_oihw.contiguous(), Cin, x.dtype, ctx.needs_input_grad[0])
         OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
         y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         dims = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)
         if sfx:
-            w = w.to(torch.bfloat16)
             _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias), _p(y), 0, *dims, _stream())
         else:
             _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), *dims, _stream())
-        ctx.save_for_backward(x, w)
-        ctx.cfg = dims + (bias is not None, sfx)
+        ctx.save_for_backward(x, w_ihwo)
+        ctx.cfg = dims + (bias is not None, sfx, Cin_w)
         ctx.bias_grad_zero = bool(bias_grad_zero)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        *dims, has_bias, sfx = ctx.cfg
+        x, w_ihwo = ctx.saved_tensors
+        *dims, has_bias, sfx, Cin_w = ctx.cfg
         B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
         dy = dy.contiguous()
         dx = dw = db = None
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         if ctx.needs_input_grad[0]:
-            w_ihwo = w.permute(3, 1, 2, 0).contiguous()
             dx = torch.empty_like(x)
             if sfx:
                 _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
-            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw), *dims, _stream())
+            dw_ohwi = torch.zeros(Cout, KH, KW, Cin, device=x.device, dtype=torch.float32)
+            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
+            dw = _weight_grad_oihw(dw_ohwi, Cin_w)
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
@@ -159,21 +178,19 @@ class _Conv2d(torch.autograd.Function):
 
 
 class _ConvT2d(torch.autograd.Function):
-    """ConvTranspose2d(k4,s2,p1) = backward-data of the adjoint convolution.  `w` is the adjoint
-    conv's OHWI float32 weight: [Cin_t][KH][KW][Cout_t] for a transposed conv Cin_t -> Cout_t."""
+    """ConvTranspose2d(k4,s2,p1) = backward-data of the adjoint convolution.  `w_iohw` is the nn.ConvTranspose2d
+    parameter [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW weight (O = Cin_t channels on the small grid)."""
 
     @staticmethod
-    def forward(ctx, x, w, stride, pad):
-        _req(x, w)
-        _f32(w)
+    def forward(ctx, x, w_iohw, stride, pad):
+        _req(x, w_iohw)
+        _f32(w_iohw)
         sfx = _sfx(x)
         B, Hs, Ws, Ct_in = x.shape           # small grid (adjoint conv's output)
-        O, KH, KW, I = w.shape               # adjoint conv: I channels (big grid) -> O channels (small grid)
+        O, I, KH, KW = w_iohw.shape          # adjoint conv: I channels (big grid) -> O channels (small grid)
         assert O == Ct_in
         Hb, Wb = (Hs - 1) * stride - 2 * pad + KH, (Ws - 1) * stride - 2 * pad + KW
-        if sfx:
-            w = w.to(torch.bfloat16)
-        w_ihwo = w.permute(3, 1, 2, 0).contiguous()
+        w, w_ihwo = _weight_layouts(w_iohw.contiguous(), I, x.dtype, True)
         y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * Hs * Ws * O * I * KH * KW
         dims = (B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws)
@@ -200,16 +217,17 @@ class _ConvT2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(w.shape, device=w.device, dtype=torch.float32)
-            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(dy), _p(x), _p(dw), *dims, _stream())
+            dw_ohwi = torch.zeros(O, KH, KW, I, device=x.device, dtype=torch.float32)
+            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(dy), _p(x), _p(dw_ohwi), *dims, _stream())
+            dw = _weight_grad_oihw(dw_ohwi, I)
         return dx, dw, None, None
 
 
 def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False):
-    """x NHWC; weight in the reference's OIHW parameter layout (re-laid out to OHWI on the fly,
-    inside the autograd graph so the parameter's .grad comes back OIHW).  bias_grad_zero: the output feeds a
-    train-mode BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros."""
-    return _Conv2d.apply(x, weight_oihw.permute(0, 2, 3, 1).contiguous(), bias, stride, pad, bias_grad_zero)
+    """x NHWC; weight = the reference's OIHW parameter (laid out for the engine in one launch inside the autograd
+    node, so the parameter's .grad comes back OIHW float32).  bias_grad_zero: the output feeds a train-mode
+    BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros."""
+    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero)
 
 
 def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
@@ -230,7 +248,7 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
 
 def conv_transpose2d(x, weight_iohw, stride=2, pad=1):
     """nn.ConvTranspose2d weight is [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW."""
-    return _ConvT2d.apply(x, weight_iohw.permute(0, 2, 3, 1).contiguous(), stride, pad)
+    return _ConvT2d.apply(x, weight_iohw, stride, pad)
 
 
 def channel_sum(x2d):
