@@ -165,16 +165,21 @@ class MGMapNet(nn.Module):
         return emb.view(b, s1 * s2, ch), pred_sem_map
 
     # -- forward -------------------------------------------------------------------
-    def _encode_instruction(self, observations):
+    def _encode_instruction(self, observations, entry):
         """Instruction branch (dedup + packed bi-LSTM + key projection) on a side stream: it is
         independent of the map stack, its persistent 16-workgroup kernels leave 94 % of the CUs free,
         and autograd replays its backward on the same stream — so it overlaps the convolutions in
-        both directions.  Joined (event wait) right before the text attention."""
-        cur = torch.cuda.current_stream()
+        both directions.  Joined (event wait) right before the text attention.
+
+        `entry` is an event recorded on the main stream when forward() was entered: the side stream waits for
+        that (its inputs — the tokens and the parameters — are complete there), not for the map stack, and this
+        method is CALLED after the map stack has been queued: the dedup needs one host read-back (the number of
+        unique instructions), and while the host waits for it the GPU still has the map-stack forward to run,
+        instead of draining (measured: 0.9 ms of idle GPU per update when the read-back came first)."""
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
-        side.wait_stream(cur)
+        side.wait_event(entry)
         with torch.cuda.stream(side):
             instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"])
             text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
@@ -184,12 +189,14 @@ class MGMapNet(nn.Module):
         return (text_k, text_v, text_mask), side
 
     def forward(self, observations, rnn_hidden_states, prev_actions, masks):
-        text, side = self._encode_instruction(observations)
+        entry = torch.cuda.Event()
+        entry.record(torch.cuda.current_stream())
         rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)
         depth_embedding = self.depth_encoder(observations)
 
         self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
         map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
+        text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
 
         state_in = []
         if "rgb" in self._inputs:
