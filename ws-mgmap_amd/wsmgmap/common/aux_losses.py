@@ -35,8 +35,13 @@ class _Registry:
         assert self._on
         total = 0.0
         for loss, alpha in self._entries.values():
-            picked = loss if mask is None else torch.masked_select(loss, mask)
-            total = total + alpha * picked.mean()
+            if mask is None:
+                total = total + alpha * loss.mean()
+            else:
+                # = masked_select(loss, mask).mean() (NaN for an empty selection, like the reference), without the
+                # data-dependent output size — masked_select makes the host wait for the whole forward pass
+                m = mask.to(loss.dtype)
+                total = total + alpha * ((loss * m).sum() / m.sum())
         return total
 
 
