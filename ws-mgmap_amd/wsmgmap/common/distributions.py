@@ -35,4 +35,7 @@ class DiagGaussian(nn.Module):
     def forward(self, x):
         mean = self.fc_mean(x)
         logstd = self.logstd(torch.zeros_like(mean))
-        return ActionNormal(mean, logstd.exp())
+        # validate_args=False: torch.distributions' default argument check ends in `.all()` on the host, i.e. a
+        # device synchronisation in every forward pass (the host then cannot queue the backward pass, or the next
+        # update, while the GPU is still busy); the values are unchanged
+        return ActionNormal(mean, logstd.exp(), validate_args=False)
