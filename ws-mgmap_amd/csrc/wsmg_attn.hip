@@ -50,13 +50,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const T* vb = v + (size_t)b * I * AC + lane * 4;
 
   // phase 1: logits (one wave per token; 64 lanes x float4 = the 256 channels)
-  for (int i = wave; i < I; i += AWAVES) {
-    f32x4 kv = ld4(kb + (size_t)i * AC);
-    float d = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
-    d = wave_sum(d);
+  // four tokens per trip: four independent 512-byte loads in flight per wave (one token per trip was bound by the
+  // load -> shuffle-reduce latency chain: 1.7 TB/s on the 576-token map stage)
+  for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
+    f32x4 kv[4];
+    float d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kv[u] = (i0 + u < I) ? ld4(kb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = wave_sum(qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3]);
     if (lane == 0) {
-      if (mask && mask[(size_t)b * I + i]) d = d - 1e8f;
-      lg[i] = d * scale;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u;
+        if (i < I) {
+          float v = d[u];
+          if (mask && mask[(size_t)b * I + i]) v = v - 1e8f;
+          lg[i] = v * scale;
+        }
+      }
     }
   }
   __syncthreads();
@@ -80,11 +92,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   __syncthreads();
   // phase 3: out = attn . v (each wave a token subset, combined through LDS)
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int i = wave; i < I; i += AWAVES) {
-    float a = lg[i];
-    f32x4 vv = ld4(vb + (size_t)i * AC);
+  for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
+    f32x4 vv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += a * vv[j];
+    for (int u = 0; u < 4; ++u) vv[u] = (i0 + u < I) ? ld4(vb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = (i0 + u < I) ? lg[i0 + u] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += a * vv[u][j];
+    }
   }
   reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
   __syncthreads();
@@ -118,18 +135,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const float* ab = attn + (size_t)b * I;
   const bool same = (dk == dv);
 
-  for (int i = wave; i < I; i += AWAVES) {
-    f32x4 vv = ld4(vb + (size_t)i * AC);
-    float d = gv[0] * vv[0] + gv[1] * vv[1] + gv[2] * vv[2] + gv[3] * vv[3];
-    d = wave_sum(d);
-    float a = ab[i];
-    if (!same) {
-      f32x4 o;
+  for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
+    f32x4 vv[4];
+    float d[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
-      st4(dvb + (size_t)i * AC, o);
+    for (int u = 0; u < 4; ++u) vv[u] = (i0 + u < I) ? ld4(vb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = wave_sum(gv[0] * vv[u][0] + gv[1] * vv[u][1] + gv[2] * vv[u][2] + gv[3] * vv[u][3]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u;
+      if (i >= I) break;
+      if (!same) {
+        const float a = ab[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
+        st4(dvb + (size_t)i * AC, o);
+      }
+      if (lane == 0) da[i] = d[u] + (dattn ? dattn[(size_t)b * I + i] : 0.f);
     }
-    if (lane == 0) da[i] = d + (dattn ? dattn[(size_t)b * I + i] : 0.f);
   }
   __syncthreads();
   float s = 0.f;
@@ -138,21 +163,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   for (int i = tid; i < I; i += 256) da[i] = ab[i] * (da[i] - s) * scale;
   __syncthreads();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int i = wave; i < I; i += AWAVES) {
-    float dl = da[i];
-    f32x4 kv = ld4(kb + (size_t)i * AC);
-    f32x4 o;
+  for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
+    f32x4 kv[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc[j] += dl * kv[j];
-      o[j] = dl * qv[j];
-    }
-    if (same) {
-      const float a = ab[i];
+    for (int u = 0; u < 4; ++u) kv[u] = (i0 + u < I) ? ld4(kb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] += a * gv[j];
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u;
+      if (i >= I) break;
+      const float dl = da[i];
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] += dl * kv[u][j];
+        o[j] = dl * qv[j];
+      }
+      if (same) {
+        const float a = ab[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += a * gv[j];
+      }
+      st4(dkb + (size_t)i * AC, o);
     }
-    st4(dkb + (size_t)i * AC, o);
   }
   reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
   __syncthreads();
