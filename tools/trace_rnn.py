@@ -34,4 +34,4 @@ dgi = torch.empty(T, N, 3 * H, device="cuda"); dgh = torch.empty_like(dgi); dh0 
 tr.zero_()
 _abi.call("wsmg_gru_bwd", P(gy), None, P(whh), P(h0), P(masks), P(y), *[P(s) for s in saves], T, N, H, P(dgi), P(dgh), P(dh0), P(ws), st())
 torch.cuda.synchronize()
-report("GRU bwd", ["elementwise + publish", "prefetch + poll+stage+sync", "LDS read + FMA", "butterfly + carry"])
+report("GRU bwd", ["elementwise + stores", "grid barrier", "global reads + FMA", "butterfly + carry"])
