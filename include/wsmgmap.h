@@ -202,6 +202,24 @@ int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, const float
                        const float* dattn, float scale, int B, int I, int C, float* dq, void* dk, void* dv,
                        wsmg_stream_t stream);
 
+/* Shared-set form of the attention above: the B query rows attend over U << B key / value / mask sets (one per unique
+ * instruction; row b uses set row_index[b], int64) — the update path repeats every instruction T times, and the
+ * reference materialises the per-row copies (mg_map_policy.py:229-232).  k_sets, v_sets [U][I][C], mask_sets [U][I].
+ * Backward writes dq [B][C] and dlogits [B][I] (d loss / d logit); the caller forms the per-set gradients
+ * dK_u = sum_{b in u} dlogits[b]^T q[b], dV_u = sum_{b in u} attn[b]^T dout[b] with two small batched GEMMs. */
+int wsmg_attn_shared_fwd(const float* q, const float* k_sets, const float* v_sets, const uint8_t* mask_sets,
+                         const int64_t* row_index, float scale, int B, int I, int C, float* out, float* attn,
+                         wsmg_stream_t stream);
+int wsmg_attn_shared_bwd(const float* q, const float* k_sets, const float* v_sets, const float* attn, const float* dout,
+                         const float* dattn, const int64_t* row_index, float scale, int B, int I, int C, float* dq,
+                         float* dlogits, wsmg_stream_t stream);
+int wsmg_attn_shared_fwd_bf16(const float* q, const void* k_sets, const void* v_sets, const uint8_t* mask_sets,
+                              const int64_t* row_index, float scale, int B, int I, int C, float* out, float* attn,
+                              wsmg_stream_t stream);
+int wsmg_attn_shared_bwd_bf16(const float* q, const void* k_sets, const void* v_sets, const float* attn, const float* dout,
+                              const float* dattn, const int64_t* row_index, float scale, int B, int I, int C, float* dq,
+                              float* dlogits, wsmg_stream_t stream);
+
 /* fp8 (OCP e4m3) text attention, BASELINE configs[4] (B=64, L=160): the k=1 Conv1d key projection of
  * mg_map_policy.py:126-127 is folded into the single query — q.(W_k x_l + b_k) = (W_k^T q).x_l + q.b_k — so
  * every token of x is read from HBM once, as bytes.  q_folded [B][C] = W_k^T q (float32), q_dot_bias [B] = q.b_k

@@ -728,3 +728,36 @@ def test_cross_entropy_nhwc(ops, dt):
     tol = 2e-6 if dt == "f32" else 1e-2
     assert float((x.grad.double() - xr.grad).abs().max()) <= tol * float(xr.grad.abs().max())
     assert float(x.grad[..., C:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attention_over_shared_sets(ops, dt):
+    """ops.attention_shared(q, k_sets, v_sets, mask_sets, inverse) == the reference attention (mg_map_policy.py:173-178)
+    on per-row gathered copies k_sets[inverse], v_sets[inverse], mask_sets[inverse] (float64 torch), forward and the
+    gradients w.r.t. q and the U shared sets (rows of one set accumulate)."""
+    torch.manual_seed(6)
+    B, U, I, C = 40, 3, 37, 256
+    q = torch.randn(B, C, device="cuda")
+    k = torch.randn(U, I, C, device="cuda")
+    v = torch.randn(U, I, C, device="cuda")
+    if dt == "bf16":
+        k, v = k.bfloat16(), v.bfloat16()
+    lens = torch.tensor([37, 12, 1], device="cuda")
+    mask = (torch.arange(I, device="cuda")[None] >= lens[:, None])
+    inverse = torch.randint(0, U, (B,), device="cuda")
+    inverse[:3] = torch.arange(3, device="cuda")
+    gout, gattn = torch.randn(B, C, device="cuda"), torch.randn(B, I, device="cuda") * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    out, attn = ops.attention_shared(leaves[0], leaves[1], leaves[2], mask.to(torch.uint8), inverse, 1 / 16)
+    ((out * gout).sum() + (attn * gattn).sum()).backward()
+    ref = [t.detach().double().requires_grad_(True) for t in (q, k, v)]
+    kk, vv = ref[1][inverse], ref[2][inverse]
+    lg = (torch.einsum("bc,bic->bi", ref[0], kk) - 1e8 * mask[inverse].double()) / 16
+    a = torch.softmax(lg, dim=1)
+    o = torch.einsum("bi,bic->bc", a, vv)
+    ((o * gout.double()).sum() + (a * gattn.double()).sum()).backward()
+    assert float((attn.double() - a).abs().max()) <= 1e-5 and float((out.double() - o).abs().max()) <= 1e-4
+    for name, l, r in zip(("dq", "dk_sets", "dv_sets"), leaves, ref):
+        tol = (3e-5 if dt == "f32" else 2e-2) * float(r.grad.abs().max())
+        assert float((l.grad.double() - r.grad).abs().max()) <= tol, name

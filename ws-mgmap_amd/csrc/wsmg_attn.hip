@@ -39,15 +39,18 @@ template <class T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const T* __restrict__ k,
                                                        const T* __restrict__ v,
                                                        const uint8_t* __restrict__ mask, float scale, int I,
-                                                       float* __restrict__ out, float* __restrict__ attn) {
+                                                       float* __restrict__ out, float* __restrict__ attn,
+                                                       const int64_t* __restrict__ row_index) {
   __shared__ float lg[AMAX_I];
   __shared__ float red[AWAVES];
   __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // row_index: keys / values / mask are shared between rows (one set per unique instruction); kr = the row's set
+  const size_t kr = row_index ? (size_t)row_index[b] : (size_t)b;
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
-  const T* kb = k + (size_t)b * I * AC + lane * 4;
-  const T* vb = v + (size_t)b * I * AC + lane * 4;
+  const T* kb = k + kr * I * AC + lane * 4;
+  const T* vb = v + kr * I * AC + lane * 4;
 
   // phase 1: logits (one wave per token; 64 lanes x float4 = the 256 channels)
   // four tokens per trip: four independent 512-byte loads in flight per wave (one token per trip was bound by the
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         const int i = i0 + u;
         if (i < I) {
           float v = d[u];
-          if (mask && mask[(size_t)b * I + i]) v = v - 1e8f;
+          if (mask && mask[kr * I + i]) v = v - 1e8f;
           lg[i] = v * scale;
         }
       }
@@ -120,7 +123,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ dout,
                                                        const float* __restrict__ dattn, float scale, int I,
                                                        float* __restrict__ dq, T* __restrict__ dk,
-                                                       T* __restrict__ dv) {
+                                                       T* __restrict__ dv, const int64_t* __restrict__ row_index,
+                                                       float* __restrict__ dlogits) {
   __shared__ float da[AMAX_I];
   __shared__ float red[AWAVES];
   __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
@@ -128,12 +132,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
   const f32x4 gv = reinterpret_cast<const f32x4*>(dout + (size_t)b * AC)[lane];
-  const T* kb = k + (size_t)b * I * AC + lane * 4;
-  const T* vb = v + (size_t)b * I * AC + lane * 4;
+  // shared-set form (row_index != NULL): k / v belong to the row's instruction; dk / dv are NOT written per row
+  // (they are sums over the rows of a set: the caller forms them from dlogits, attn, q and dout with two small GEMMs)
+  const size_t kr = row_index ? (size_t)row_index[b] : (size_t)b;
+  const bool shared = row_index != nullptr;
+  const T* kb = k + kr * I * AC + lane * 4;
+  const T* vb = v + kr * I * AC + lane * 4;
   T* dkb = dk + (size_t)b * I * AC + lane * 4;
   T* dvb = dv + (size_t)b * I * AC + lane * 4;
   const float* ab = attn + (size_t)b * I;
-  const bool same = (dk == dv);
+  const bool same = (dk == dv) && !shared;
 
   for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
     f32x4 vv[4];
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u;
       if (i >= I) break;
-      if (!same) {
+      if (!same && !shared) {
         const float a = ab[i];
         f32x4 o;
 #pragma unroll
@@ -160,7 +168,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   float s = 0.f;
   for (int i = tid; i < I; i += 256) s += ab[i] * da[i];
   s = block_reduce_sum(s, red, wave, lane);
-  for (int i = tid; i < I; i += 256) da[i] = ab[i] * (da[i] - s) * scale;
+  for (int i = tid; i < I; i += 256) {
+    const float dl = ab[i] * (da[i] - s) * scale;
+    da[i] = dl;
+    if (dlogits) dlogits[(size_t)b * I + i] = dl;
+  }
   __syncthreads();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] += a * gv[j];
       }
-      st4(dkb + (size_t)i * AC, o);
+      if (!shared) st4(dkb + (size_t)i * AC, o);
     }
   }
   reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256) void quantize_e4m3_kernel(const float* __restr
 extern "C" int wsmg_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float scale, int B,
                              int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
-  hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn);
+  hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn, (const int64_t*)nullptr);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -291,7 +303,7 @@ extern "C" int wsmg_attn_fwd_bf16(const float* q, const void* k, const void* v, 
                                   int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
-                     (const bf16_t*)v, mask, scale, I, out, attn);
+                     (const bf16_t*)v, mask, scale, I, out, attn, (const int64_t*)nullptr);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -300,7 +312,7 @@ extern "C" int wsmg_attn_bwd(const float* q, const float* k, const float* v, con
                              wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, attn, dout, dattn, scale,
-                     I, dq, dk, dv);
+                     I, dq, dk, dv, (const int64_t*)nullptr, (float*)nullptr);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -309,7 +321,7 @@ extern "C" int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, 
                                   wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
-                     (const bf16_t*)v, attn, dout, dattn, scale, I, dq, (bf16_t*)dk, (bf16_t*)dv);
+                     (const bf16_t*)v, attn, dout, dattn, scale, I, dq, (bf16_t*)dk, (bf16_t*)dv, (const int64_t*)nullptr, (float*)nullptr);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -327,5 +339,41 @@ extern "C" int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, ui
   const int64_t n4 = n / 4;
   hipLaunchKernelGGL(quantize_e4m3_kernel, dim3((unsigned)wsmg_cdiv(n4, 256)), dim3(256), 0, wsmg_s(stream), x, n4, inv_scale,
                      reinterpret_cast<unsigned*>(y));
+  WSMG_RETURN_LAUNCH();
+}
+
+// ---- shared-set form: B query rows attend over U << B key/value sets (one per unique instruction; row b uses set
+// row_index[b]).  Replaces the reference's per-row copies of the instruction keys / values (mg_map_policy.py:229-232 on
+// tensors that repeat every instruction T times) — nothing is gathered, and dK / dV of a set are formed by the caller.
+extern "C" int wsmg_attn_shared_fwd(const float* q, const float* k_sets, const float* v_sets, const uint8_t* mask_sets,
+                                    const int64_t* row_index, float scale, int B, int I, int C, float* out, float* attn,
+                                    wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I || !row_index) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k_sets, v_sets, mask_sets, scale, I, out,
+                     attn, row_index);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_attn_shared_fwd_bf16(const float* q, const void* k_sets, const void* v_sets, const uint8_t* mask_sets,
+                                         const int64_t* row_index, float scale, int B, int I, int C, float* out, float* attn,
+                                         wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I || !row_index) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k_sets,
+                     (const bf16_t*)v_sets, mask_sets, scale, I, out, attn, row_index);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_attn_shared_bwd(const float* q, const float* k_sets, const float* v_sets, const float* attn,
+                                    const float* dout, const float* dattn, const int64_t* row_index, float scale, int B, int I,
+                                    int C, float* dq, float* dlogits, wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I || !row_index || !dlogits) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k_sets, v_sets, attn, dout, dattn, scale, I,
+                     dq, (float*)nullptr, (float*)nullptr, row_index, dlogits);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_attn_shared_bwd_bf16(const float* q, const void* k_sets, const void* v_sets, const float* attn,
+                                         const float* dout, const float* dattn, const int64_t* row_index, float scale, int B,
+                                         int I, int C, float* dq, float* dlogits, wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || I <= 0 || I > AMAX_I || !row_index || !dlogits) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k_sets,
+                     (const bf16_t*)v_sets, attn, dout, dattn, scale, I, dq, (bf16_t*)nullptr, (bf16_t*)nullptr, row_index, dlogits);
   WSMG_RETURN_LAUNCH();
 }

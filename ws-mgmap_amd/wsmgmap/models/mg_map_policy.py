@@ -183,10 +183,9 @@ class MGMapNet(nn.Module):
         with torch.cuda.stream(side):
             instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"])
             text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
-            text_k = text_k_u.index_select(0, inverse)
-            text_v = instr_u.index_select(0, inverse)
-            text_mask = mask_u.index_select(0, inverse).contiguous()
-        return (text_k, text_v, text_mask), side
+            # the B rows attend over the U unique sets in place (ops.attention_shared): no per-row copies
+            text = (text_k_u.contiguous(), instr_u.contiguous(), mask_u.to(torch.uint8).contiguous(), inverse.contiguous())
+        return text, side
 
     def forward(self, observations, rnn_hidden_states, prev_actions, masks):
         entry = torch.cuda.Event()
@@ -212,10 +211,11 @@ class MGMapNet(nn.Module):
 
         # instruction attention: keys projected once per unique instruction, gathered per row
         torch.cuda.current_stream().wait_stream(side)
-        text_k, text_v, text_mask = text
+        text_k_u, text_v_u, text_mask_u, inverse = text
         for t in text:
             t.record_stream(torch.cuda.current_stream())
-        text_embedding, _ = self._attn(self.state_text_q_layer(state), text_k, text_v, text_mask)
+        text_embedding, _ = ops.attention_shared(self.state_text_q_layer(state).contiguous(), text_k_u, text_v_u, text_mask_u,
+                                                 inverse, self._scale_f)
 
         # map attention
         # text_map_k_layer is folded into the query (ops._AttnFolded): the 576 map tokens are read once, as

@@ -508,6 +508,54 @@ def cross_entropy_nhwc(logits, target, classes):
     return _CrossEntropyNHWC.apply(logits.contiguous(), target.contiguous(), classes)
 
 
+class _AttnShared(torch.autograd.Function):
+    """Single-query attention of B rows over U << B shared key / value sets (row b uses set inverse[b]): the update path
+    repeats every instruction T times; the reference (and `attention` above) would need per-row copies of the
+    instruction keys and values.  Forward reads the sets in place; backward gets d logits from the kernel and forms
+    dK_u = sum_{b in u} dl_b^T q_b and dV_u = sum_{b in u} attn_b^T dout_b with two batched GEMMs over a one-hot
+    membership matrix — no [B, I, C] tensor exists in either direction."""
+
+    @staticmethod
+    def forward(ctx, q, k_sets, v_sets, mask_sets, inverse, scale):
+        _req(q, k_sets, v_sets, mask_sets, inverse)
+        _f32(q)
+        if v_sets.dtype != k_sets.dtype or inverse.dtype != torch.int64:
+            raise _abi.WsmgError("attention_shared: k/v sets share a dtype, inverse is int64")
+        if mask_sets is not None and mask_sets.dtype != torch.uint8:
+            raise _abi.WsmgError("attention mask must be uint8")
+        U, I, C = k_sets.shape
+        B = q.shape[0]
+        out = torch.empty(B, C, device=q.device, dtype=torch.float32)
+        attn = torch.empty(B, I, device=q.device, dtype=torch.float32)
+        _abi.call("wsmg_attn_shared_fwd" + _sfx(k_sets), _p(q), _p(k_sets), _p(v_sets), _p(mask_sets), _p(inverse), float(scale),
+                  B, I, C, _p(out), _p(attn), _stream())
+        ctx.save_for_backward(q, k_sets, v_sets, attn, inverse)
+        ctx.scale = float(scale)
+        ctx.set_materialize_grads(False)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        q, k_sets, v_sets, attn, inverse = ctx.saved_tensors
+        U, I, C = k_sets.shape
+        B = q.shape[0]
+        dout = torch.zeros_like(q) if dout is None else dout.contiguous().float()
+        dattn = None if dattn is None else dattn.contiguous().float()
+        dq = torch.empty_like(q)
+        dl = torch.empty(B, I, device=q.device, dtype=torch.float32)
+        _abi.call("wsmg_attn_shared_bwd" + _sfx(k_sets), _p(q), _p(k_sets), _p(v_sets), _p(attn), _p(dout), _p(dattn), _p(inverse),
+                  ctx.scale, B, I, C, _p(dq), _p(dl), _stream())
+        member = torch.nn.functional.one_hot(inverse, U).to(torch.float32).t()            # [U, B]
+        dk = torch.matmul((member.unsqueeze(2) * dl.unsqueeze(0)).transpose(1, 2), q)       # [U, I, B] x [B, C]
+        dv = torch.matmul((member.unsqueeze(2) * attn.unsqueeze(0)).transpose(1, 2), dout)
+        return dq, dk.to(k_sets.dtype), dv.to(v_sets.dtype), None, None, None
+
+
+def attention_shared(q, k_sets, v_sets, mask_sets, inverse, scale):
+    """(context [B,C], weights [B,I]); row b attends over k_sets[inverse[b]], v_sets[inverse[b]], mask_sets[inverse[b]]."""
+    return _AttnShared.apply(q, k_sets, v_sets, mask_sets, inverse, scale)
+
+
 class _AttnFolded(torch.autograd.Function):
     """Single-query attention whose keys are a k=1 Conv1d of the values (mg_map_policy.py:126-132,173-178):
     q.(W x_i + b) = (W^T q).x_i + q.b, and q.b is the same for every token, so it cancels in the softmax.
