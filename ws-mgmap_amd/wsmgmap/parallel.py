@@ -1,6 +1,7 @@
 """Data-parallel gradient exchange for the teacher-forcing / DAgger update: one process per
 GPU, one averaged all-reduce of the LIVE gradients per update over RCCL/xGMI (backend "nccl"),
-bucketed and launched from autograd hooks so it overlaps the rest of backward.
+bucketed and launched from autograd hooks so it overlaps the rest of backward.  Per update and bucket: one
+multi-tensor pack, one all-reduce, one scale; the averaged gradients stay in the bucket (`p.grad` becomes a view of it).
 
 Replaces `DistributedDataParallel(find_unused_parameters=True)` at the reference's
 common_trainer.py:61-66.  The reference all-reduces all 19.76 M trainable floats (79 MB) although
@@ -63,7 +64,11 @@ class GradAllReducer:
             for p in ps:
                 self._where[id(p)] = (bi, off)
                 off += p.numel()
-            out.append(dict(params=ps, flat=flat, pending=len(ps), total=len(ps)))
+            views, o2 = [], 0
+            for p in ps:
+                views.append(flat[o2:o2 + p.numel()].view_as(p))
+                o2 += p.numel()
+            out.append(dict(params=ps, flat=flat, views=views, pending=len(ps), total=len(ps)))
         self._buckets = out
 
     @property
@@ -83,9 +88,11 @@ class GradAllReducer:
                                "call reset() to re-discover the live set")
         bi, off = loc
         b = self._buckets[bi]
-        b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
         b["pending"] -= 1
         if b["pending"] == 0:
+            # the whole bucket is ready: ONE multi-tensor copy packs it (instead of a copy kernel per parameter), then
+            # the exchange starts while backward continues
+            torch._foreach_copy_(b["views"], [q.grad for q in b["params"]])
             self._works.append((bi, dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def reset(self):
@@ -98,10 +105,7 @@ class GradAllReducer:
         if self._buckets is None:  # first update: discovery pass, exchange synchronously
             self._build_buckets()
             for b in self._buckets:
-                off = 0
-                for p in b["params"]:
-                    b["flat"][off:off + p.numel()].copy_(p.grad.reshape(-1))
-                    off += p.numel()
+                torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])
                 dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
             done = range(len(self._buckets))
         else:
@@ -114,9 +118,8 @@ class GradAllReducer:
         inv = 1.0 / self.world
         for bi in done:
             b = self._buckets[bi]
-            off = 0
-            for p in b["params"]:
-                p.grad.copy_(b["flat"][off:off + p.numel()].view_as(p.grad)).mul_(inv)
-                off += p.numel()
+            b["flat"].mul_(inv)                      # one kernel per bucket
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v                           # the averaged gradient lives in the bucket: no copy back
             b["pending"] = b["total"]
         self._works = []
