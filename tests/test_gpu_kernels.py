@@ -761,3 +761,86 @@ def test_attention_over_shared_sets(ops, dt):
     for name, l, r in zip(("dq", "dk_sets", "dv_sets"), leaves, ref):
         tol = (3e-5 if dt == "f32" else 2e-2) * float(r.grad.abs().max())
         assert float((l.grad.double() - r.grad).abs().max()) <= tol, name
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE's full sizes
+@pytest.mark.gpu
+def test_fullsize_conv_linearity_bf16_cfg2(ops):
+    """BASELINE configs[1] batch (B = T*N = 512), layer enc6 (128 -> 256, k3, 24x24): scaling the input by 2 (exact in
+    bf16) doubles y bit for bit and leaves dx bit-identical (the engine has no data-dependent path); dW doubles up
+    to the order in which the float32 atomics of the pixel-split reduction land (1e-5 relative)."""
+    torch.manual_seed(9)
+    B, Cin, Cout, H = 512, 128, 256, 24
+    x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.03)
+    gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
+
+    def run(xin):
+        xi = xin.clone().requires_grad_(True)
+        wi = w.clone().requires_grad_(True)
+        y = ops.conv2d(xi, wi, None, 1, 1)
+        y.backward(gy)
+        return y.detach(), xi.grad, wi.grad
+    y1, dx1, dw1 = run(x)
+    y2, dx2, dw2 = run(x * 2)
+    assert torch.equal(y2.float(), y1.float() * 2)
+    assert torch.equal(dx2, dx1)                         # dx does not depend on x
+    assert float((dw2 - 2 * dw1).abs().max()) <= 1e-5 * float(dw1.abs().max())
+    assert bool(torch.isfinite(dw1).all())
+
+
+@pytest.mark.gpu
+def test_fullsize_map_fuse_idempotent_cfg4(ops):
+    """BASELINE configs[3] geometry (B=32, E=200, C=40, 256^2 RGB-D): fusing the same ego map twice leaves the global
+    map bit-identical (max is idempotent), retrieval of the fused map is deterministic, and every retrieved value is
+    bounded by the maximum of what was scattered."""
+    torch.manual_seed(10)
+    B, E, C, G = 32, 200, 40, 480
+    depth = torch.rand(B, 256, 256, device="cuda")
+    depth[:, :8] = 0
+    feat = torch.relu(torch.randn(B, 64, 256, 256, device="cuda"))
+    gps = (torch.rand(B, 2, device="cuda") - 0.5) * 4
+    compass = (torch.rand(B, device="cuda") - 0.5) * 6.28
+    masks = torch.ones(B, device="cuda")
+    lin = ops.bev_index(depth, 256, 256, E)
+    assert int(lin.max()) < E * E and int(lin.min()) >= -1
+    planes = ops.bev_scatter_max(feat, lin, C, E)
+    assert torch.equal(planes, ops.bev_scatter_max(feat, lin, C, E))
+    rot = ops.bev_rotate(planes, compass, -1.0)
+    gm = torch.zeros(B, G, G, C, device="cuda")
+    ops.map_fuse(rot, gm, gps, masks, 0.12)
+    once = gm.clone()
+    ops.map_fuse(rot, gm, gps, masks, 0.12)
+    assert torch.equal(gm, once)
+    e1 = ops.map_retrieve(gm, gps, compass, E, 0.12)
+    e2 = ops.map_retrieve(gm, gps, compass, E, 0.12)
+    assert torch.equal(e1, e2) and float(e1.min()) >= 0.0
+    assert float(e1.max()) <= float(planes.max()) * (1 + 1e-6)
+
+
+@pytest.mark.gpu
+def test_fullsize_gru_sequence_split_cfg2(ops):
+    """T=64, N=8 (configs[1]): one 64-step launch == two 32-step launches with the hidden state carried over, bit for
+    bit, forward (y) and backward (d gi, d h0) — the recurrence has no dependence on how the sequence is cut."""
+    torch.manual_seed(12)
+    Tn, N, Hd = 64, 8, 512
+    gi = torch.randn(Tn, N, 3 * Hd, device="cuda")
+    whh = torch.randn(3 * Hd, Hd, device="cuda") * 0.04
+    bhh = torch.randn(3 * Hd, device="cuda") * 0.1
+    h0 = torch.randn(N, Hd, device="cuda")
+    masks = torch.ones(Tn, N, device="cuda")
+    masks[0] = 0
+    masks[40, 2] = 0
+    gy = torch.randn(Tn, N, Hd, device="cuda")
+    g1 = gi.clone().requires_grad_(True)
+    h1 = h0.clone().requires_grad_(True)
+    y = ops.masked_gru(g1, whh, bhh, h1, masks)
+    (y * gy).sum().backward()
+    ga, gb = gi[:32].clone().requires_grad_(True), gi[32:].clone().requires_grad_(True)
+    h2 = h0.clone().requires_grad_(True)
+    ya = ops.masked_gru(ga, whh, bhh, h2, masks[:32].contiguous())
+    yb = ops.masked_gru(gb, whh, bhh, ya[-1], masks[32:].contiguous())
+    ((ya * gy[:32]).sum() + (yb * gy[32:]).sum()).backward()
+    assert torch.equal(torch.cat([ya, yb]), y)
+    assert torch.equal(torch.cat([ga.grad, gb.grad]), g1.grad)
+    assert torch.equal(h2.grad, h1.grad)
