@@ -143,6 +143,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   const float* ab = attn + (size_t)b * I;
   const bool same = (dk == dv) && !shared;
 
+  // the incoming gradient of the attention weights goes to LDS with coalesced loads first (a per-token scalar load
+  // by lane 0 inside the token loop sat on its critical path: 261 vs 149 us on the map stage)
+  for (int i = tid; i < I; i += 256) da[i] = dattn ? dattn[(size_t)b * I + i] : 0.f;
+  __syncthreads();
   for (int i0 = wave * 4; i0 < I; i0 += AWAVES * 4) {
     f32x4 vv[4];
     float d[4];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int j = 0; j < 4; ++j) o[j] = a * gv[j];
         st4(dvb + (size_t)i * AC, o);
       }
-      if (lane == 0) da[i] = d[u] + (dattn ? dattn[(size_t)b * I + i] : 0.f);
+      if (lane == 0) da[i] += d[u];
     }
   }
   __syncthreads();
