@@ -844,3 +844,27 @@ def test_fullsize_gru_sequence_split_cfg2(ops):
     assert torch.equal(torch.cat([ya, yb]), y)
     assert torch.equal(torch.cat([ga.grad, gb.grad]), g1.grad)
     assert torch.equal(h2.grad, h1.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_with_fused_relu(ops, dt):
+    """ops.conv2d(..., relu=True) == relu(conv2d(...)) (mg_map_policy.py:89-100 Conv3+ReLU heads), forward and all
+    gradients, in both modes (bf16: ReLU in the conv epilogue, gradient masked with the saved output)."""
+    torch.manual_seed(8)
+    B, Cin, Cout, H = 3, 64, 128, 12
+    x = torch.randn(B, H, H, Cin, device="cuda")
+    w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+    b = torch.randn(Cout, device="cuda") * 0.1
+    gy = torch.randn(B, H, H, Cout, device="cuda")
+    if dt == "bf16":
+        x, gy = x.bfloat16(), gy.bfloat16()
+    outs = []
+    for fused in (True, False):
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv2d(xi, wi, bi, 1, 1, relu=True) if fused else ops.relu(ops.conv2d(xi, wi, bi, 1, 1))
+        y.backward(gy)
+        outs.append((y.detach().float(), xi.grad.float(), wi.grad, bi.grad))
+    for a, c, name in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
+        assert float((a - c).abs().max()) <= 1e-5 * (1 + float(c.abs().max())), name
+    assert float(outs[0][0].min()) >= 0.0

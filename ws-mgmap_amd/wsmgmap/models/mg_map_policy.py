@@ -139,7 +139,7 @@ class MGMapNet(nn.Module):
         train = self.training
         x = self._ego_to_nhwc(ego_map)
         enc = self.map_encoder(x)
-        conv = lambda t, seq, pad: ops.relu(ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad))  # noqa: E731
+        conv = lambda t, seq, pad: ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad, relu=True)  # noqa: E731
         enc_proj = conv(enc, self.map_encoded_linear, 1)
         dec = self.map_decoder(enc)
         c = self.map_classfier
@@ -159,7 +159,7 @@ class MGMapNet(nn.Module):
         self.sem_logits_nhwc = sem
         pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
         # (27 -> 32 input channels: ops.conv2d zero-pads the weight to the activation's channel count)
-        cls_proj = ops.relu(ops.conv2d(ops.avgpool2(sem), self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1))
+        cls_proj = ops.conv2d(ops.avgpool2(sem), self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True)
         emb = conv(torch.cat([enc_proj, cls_proj], dim=-1), self.map_cated_linear, 1)
         b, s1, s2, ch = emb.shape
         return emb.view(b, s1 * s2, ch), pred_sem_map

@@ -131,7 +131,7 @@ class _Conv2d(torch.autograd.Function):
     channels than w (the engine pads activations to multiples of 32) the weight is zero-padded to match."""
 
     @staticmethod
-    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False):
+    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False):
         _req(x, w_oihw, bias)
         _f32(w_oihw, bias)
         sfx = _sfx(x)
@@ -143,21 +143,27 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         dims = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)
-        if sfx:
-            _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias), _p(y), 0, *dims, _stream())
+        if sfx:   # ReLU, when asked for, runs in the conv epilogue (flag bit 1)
+            _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias), _p(y), 2 if relu else 0, *dims, _stream())
         else:
             _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), *dims, _stream())
-        ctx.save_for_backward(x, w_ihwo)
+            if relu:
+                _abi.call("wsmg_relu_fwd", _p(y), _p(y), y.numel(), _stream())
+        ctx.save_for_backward(x, w_ihwo, y if relu else None)
         ctx.cfg = dims + (bias is not None, sfx, Cin_w)
         ctx.bias_grad_zero = bool(bias_grad_zero)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w_ihwo = ctx.saved_tensors
+        x, w_ihwo, y_relu = ctx.saved_tensors
         *dims, has_bias, sfx, Cin_w = ctx.cfg
         B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
         dy = dy.contiguous()
+        if y_relu is not None:   # fused ReLU: mask the incoming gradient with the saved output first
+            masked = torch.empty_like(dy)
+            _abi.call("wsmg_relu_bwd" + sfx, _p(dy), _p(y_relu), _p(masked), dy.numel(), _stream())
+            dy = masked
         dx = dw = db = None
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         if ctx.needs_input_grad[0]:
@@ -174,7 +180,7 @@ class _Conv2d(torch.autograd.Function):
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
             db = torch.zeros(Cout, device=dy.device, dtype=torch.float32) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _ConvT2d(torch.autograd.Function):
@@ -223,11 +229,12 @@ class _ConvT2d(torch.autograd.Function):
         return dx, dw, None, None
 
 
-def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False):
+def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False):
     """x NHWC; weight = the reference's OIHW parameter (laid out for the engine in one launch inside the autograd
     node, so the parameter's .grad comes back OIHW float32).  bias_grad_zero: the output feeds a train-mode
-    BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros."""
-    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero)
+    BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros.  relu: y = relu(conv + bias), fused into
+    the conv epilogue in bf16 mode."""
+    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu)
 
 
 def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
