@@ -151,12 +151,21 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         opt.step()
         return loss
 
-    for _ in range(warmup):
+    # which conv-engine kernel family dominates is learned on the warm-up updates (all six entry points timed); inside
+    # the timed region only that family is bracketed with HIP events — every timed launch costs two event records on a
+    # host that is within 10 % of being the bottleneck, and `value` should not pay for the other five
+    warm_prof = {}
+    for i in range(warmup):
+        if i == warmup - 1:
+            ops.profile_begin()      # the last warm-up update: first-launch effects are over
         update()
+    if warmup > 0:
+        warm_prof = ops.profile_end()
+    dom_entry = max(warm_prof.values(), key=lambda r: r["ms_total"])["entry"] if warm_prof else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ops.profile_begin()
+    ops.profile_begin(only=[dom_entry] if dom_entry else None)
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = update()
@@ -166,6 +175,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = ops.profile_end()
+    for name, r in warm_prof.items():     # the other families: per-launch figures from the warm-up updates, labelled so
+        if name not in prof:
+            prof[name] = dict(r, per_steps=1, phase="last warm-up update")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -221,9 +233,12 @@ def main():
         kernels = {}
         for name, r in prof.items():
             avg_ms = r["ms_total"] / max(r["launches"], 1)
-            kernels[name] = dict(launches=r["launches"], avg_ms=avg_ms, ms_per_update=r["ms_total"] / args.steps,
-                                 tflops=r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12 if r["ms_total"] > 0 else 0.0)
-        dom = max(kernels, key=lambda k: kernels[k]["ms_per_update"]) if kernels else None
+            per = r.get("per_steps", args.steps)
+            kernels[name] = dict(launches=r["launches"], avg_ms=avg_ms, ms_per_update=r["ms_total"] / max(per, 1),
+                                 tflops=r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12 if r["ms_total"] > 0 else 0.0,
+                                 measured_in=r.get("phase", "timed region"))
+        timed = [k for k in kernels if kernels[k]["measured_in"] == "timed region"]
+        dom = max(timed, key=lambda k: kernels[k]["ms_per_update"]) if timed else None
         roofline = None
         if dom:
             r = prof[dom]

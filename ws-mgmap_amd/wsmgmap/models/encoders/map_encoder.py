@@ -14,9 +14,33 @@ from ... import ops
 from .resnet18 import ResNet18
 
 
+_PENDING_BUMPS = None   # while a map-stack forward is collecting: the num_batches_tracked counters to advance
+
+
 def bump(bn: nn.BatchNorm2d, train: bool):
+    """nn.BatchNorm2d advances num_batches_tracked on every train-mode forward.  Inside `batched_bumps()` the counters
+    are collected and advanced by ONE multi-tensor add at the end (16 one-element kernels per update otherwise)."""
     if train and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if _PENDING_BUMPS is not None:
+            _PENDING_BUMPS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+
+
+class batched_bumps:
+    def __enter__(self):
+        global _PENDING_BUMPS
+        self._outer = _PENDING_BUMPS
+        _PENDING_BUMPS = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PENDING_BUMPS
+        todo, _PENDING_BUMPS = _PENDING_BUMPS, self._outer
+        if todo and exc[0] is None:
+            with torch.no_grad():
+                torch._foreach_add_(todo, 1)
+        return False
 
 
 def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):

@@ -136,6 +136,11 @@ class MGMapNet(nn.Module):
 
     def map_stack(self, ego_map):
         """ego map [B,C,E,E] -> (map tokens [B, S*S, 256] token-major, pred_sem_map [B,27,2S,2S])."""
+        from .encoders.map_encoder import batched_bumps
+        with batched_bumps():
+            return self._map_stack(ego_map)
+
+    def _map_stack(self, ego_map):
         train = self.training
         x = self._ego_to_nhwc(ego_map)
         enc = self.map_encoder(x)

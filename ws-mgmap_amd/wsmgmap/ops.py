@@ -78,25 +78,32 @@ KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trac
 }
 
 
-def profile_begin():
-    global _prof
+_prof_only = None
+
+
+def profile_begin(only=None):
+    """Start bracketing conv-engine launches with HIP events.  only: set of C-ABI entry names to time (None = all six
+    conv entry points); every timed launch costs two event records on the host, so bench.py times only the dominant
+    kernel family inside its timed region and learns which one that is during the warm-up updates."""
+    global _prof, _prof_only
     _prof = {}
+    _prof_only = set(only) if only else None
 
 
 def profile_end():
     """-> {kernel: dict(launches, ms_total, flops_total)}; synchronises."""
-    global _prof
-    rec, _prof = _prof, None
+    global _prof, _prof_only
+    rec, _prof, _prof_only = _prof, None, None
     torch.cuda.synchronize()
     out = {}
     for name, items in (rec or {}).items():
         ms = sum(s.elapsed_time(e) for s, e, _ in items)
-        out[KERNEL_OF[name]] = dict(launches=len(items), ms_total=ms, flops_total=float(sum(f for _, _, f in items)))
+        out[KERNEL_OF[name]] = dict(launches=len(items), ms_total=ms, flops_total=float(sum(f for _, _, f in items)), entry=name)
     return out
 
 
 def _launch(name, flops, *args):
-    if _prof is None:
+    if _prof is None or (_prof_only is not None and name not in _prof_only):
         _abi.call(name, *args)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
