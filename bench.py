@@ -167,9 +167,14 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     torch.cuda.synchronize()
     ops.profile_begin(only=[dom_entry] if dom_entry else None)
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(steps):
+        h0 = time.perf_counter()
         loss = update()
+        host += time.perf_counter() - h0
     torch.cuda.synchronize()
+    if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
+        print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -39,42 +39,53 @@ __global__ void relu_bwd_kernel(const T* dy, const T* y, T* dx, int64_t n4) {
 }
 
 // ---- MaxPool2d(kernel 3, stride 2, pad 1): first maximum in (ky,kx) scan order wins ties (ATen)
+// All pool / upsample kernels below: one thread = 4 consecutive channels of one pixel (16-byte f32 / 8-byte bf16
+// accesses; C % 4 == 0 is guaranteed by the engine's 32-channel padding), pixel geometry computed once per 4 values.
+#define PIX_DECODE(i, C4, WW, HH, c, px, py, b)   \
+  const int c = (int)((i) % (C4)) * 4;             \
+  const int64_t p_ = (i) / (C4);                   \
+  const int px = (int)(p_ % (WW));                 \
+  const int py = (int)((p_ / (WW)) % (HH));        \
+  const int b = (int)(p_ / ((int64_t)(WW) * (HH)));
+
 template <class T>
 __global__ void maxpool_fwd_kernel(const T* x, T* y, int B, int H, int W, int C, int OH, int OW) {
-  int64_t n = (int64_t)B * OH * OW * C;
+  const int C4 = C / 4;
+  int64_t n = (int64_t)B * OH * OW * C4;
   GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int ox = (int)(p % OW);
-    int oy = (int)((p / OW) % OH);
-    int b = (int)(p / ((int64_t)OW * OH));
-    float best = -INFINITY;
+    PIX_DECODE(i, C4, OW, OH, c, ox, oy, b)
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int ky = 0; ky < 3; ++ky) {
       int iy = oy * 2 - 1 + ky;
       if (iy < 0 || iy >= H) continue;
       for (int kx = 0; kx < 3; ++kx) {
         int ix = ox * 2 - 1 + kx;
         if (ix < 0 || ix >= W) continue;
-        float v = ldf(x + (((size_t)b * H + iy) * W + ix) * C + c);
-        if (v > best || v != v) best = v;
+        f32x4 v = ld4(x + (((size_t)b * H + iy) * W + ix) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > best[j] || v[j] != v[j]) best[j] = v[j];
       }
     }
-    stf(y + i, best);
+    st4(y + i * 4, best);
   }
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <class T>
-__device__ inline int maxpool_argmax(const T* x, int b, int oy, int ox, int c, int H, int W, int C) {
-  float best = -INFINITY;
-  int arg = -1;
+__device__ inline i32x4 maxpool_argmax4(const T* x, int b, int oy, int ox, int c, int H, int W, int C) {
+  f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  i32x4 arg = {-1, -1, -1, -1};
   for (int ky = 0; ky < 3; ++ky) {
     int iy = oy * 2 - 1 + ky;
     if (iy < 0 || iy >= H) continue;
     for (int kx = 0; kx < 3; ++kx) {
       int ix = ox * 2 - 1 + kx;
       if (ix < 0 || ix >= W) continue;
-      float v = ldf(x + (((size_t)b * H + iy) * W + ix) * C + c);
-      if (v > best || v != v || arg < 0) { best = v; arg = iy * W + ix; }
+      f32x4 v = ld4(x + (((size_t)b * H + iy) * W + ix) * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (v[j] > best[j] || v[j] != v[j] || arg[j] < 0) { best[j] = v[j]; arg[j] = iy * W + ix; }
     }
   }
   return arg;
@@ -83,25 +94,25 @@ __device__ inline int maxpool_argmax(const T* x, int b, int oy, int ox, int c, i
 template <class T>
 __global__ void maxpool_bwd_kernel(const T* dy, const T* x, T* dx, int B, int H, int W, int C, int OH,
                                    int OW) {
-  int64_t n = (int64_t)B * H * W * C;
+  const int C4 = C / 4;
+  int64_t n = (int64_t)B * H * W * C4;
   GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int ix = (int)(p % W);
-    int iy = (int)((p / W) % H);
-    int b = (int)(p / ((int64_t)W * H));
-    float g = 0.f;
+    PIX_DECODE(i, C4, W, H, c, ix, iy, b)
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
     int oy0 = iy / 2, oy1 = (iy + 1) / 2;  // windows [2oy-1, 2oy+1] containing iy
     int ox0 = ix / 2, ox1 = (ix + 1) / 2;
     for (int oy = oy0; oy <= oy1; ++oy) {
       if (oy >= OH) continue;
       for (int ox = ox0; ox <= ox1; ++ox) {
         if (ox >= OW) continue;
-        if (maxpool_argmax(x, b, oy, ox, c, H, W, C) == iy * W + ix)
-          g += ldf(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
+        const i32x4 arg = maxpool_argmax4(x, b, oy, ox, c, H, W, C);
+        const f32x4 d = ld4(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (arg[j] == iy * W + ix) g[j] += d[j];
       }
     }
-    stf(dx + i, g);
+    st4(dx + i * 4, g);
   }
 }
 
@@ -116,40 +127,35 @@ __device__ inline void up_src(int o, int in, float scale, int& i0, int& i1, floa
 
 template <class T>
 __global__ void upsample_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
-  const int OH = 2 * H, OW = 2 * W;
+  const int OH = 2 * H, OW = 2 * W, C4 = C / 4;
   const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-  int64_t n = (int64_t)B * OH * OW * C;
+  int64_t n = (int64_t)B * OH * OW * C4;
   GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int ox = (int)(p % OW);
-    int oy = (int)((p / OW) % OH);
-    int b = (int)(p / ((int64_t)OW * OH));
+    PIX_DECODE(i, C4, OW, OH, c, ox, oy, b)
     int y0, y1, x0, x1;
     float hy0, hy1, wx0, wx1;
     up_src(oy, H, sh, y0, y1, hy0, hy1);
     up_src(ox, W, sw, x0, x1, wx0, wx1);
     const T* xb = x + (size_t)b * H * W * C + c;
-    float v00 = ldf(xb + ((size_t)y0 * W + x0) * C), v01 = ldf(xb + ((size_t)y0 * W + x1) * C);
-    float v10 = ldf(xb + ((size_t)y1 * W + x0) * C), v11 = ldf(xb + ((size_t)y1 * W + x1) * C);
-    stf(y + i, hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11));
+    const f32x4 v00 = ld4(xb + ((size_t)y0 * W + x0) * C), v01 = ld4(xb + ((size_t)y0 * W + x1) * C);
+    const f32x4 v10 = ld4(xb + ((size_t)y1 * W + x0) * C), v11 = ld4(xb + ((size_t)y1 * W + x1) * C);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = hy0 * (wx0 * v00[j] + wx1 * v01[j]) + hy1 * (wx0 * v10[j] + wx1 * v11[j]);
+    st4(y + i * 4, o);
   }
 }
 
 template <class T>
 __global__ void upsample_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int C) {
-  const int OH = 2 * H, OW = 2 * W;
+  const int OH = 2 * H, OW = 2 * W, C4 = C / 4;
   const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-  int64_t n = (int64_t)B * H * W * C;
+  int64_t n = (int64_t)B * H * W * C4;
   GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int ix = (int)(p % W);
-    int iy = (int)((p / W) % H);
-    int b = (int)(p / ((int64_t)W * H));
-    float g = 0.f;
+    PIX_DECODE(i, C4, W, H, c, ix, iy, b)
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
     int oy_lo = 2 * iy - 2 < 0 ? 0 : 2 * iy - 2, oy_hi = 2 * iy + 3 > OH - 1 ? OH - 1 : 2 * iy + 3;
     int ox_lo = 2 * ix - 2 < 0 ? 0 : 2 * ix - 2, ox_hi = 2 * ix + 3 > OW - 1 ? OW - 1 : 2 * ix + 3;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
@@ -164,39 +170,41 @@ __global__ void upsample_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int
         up_src(ox, W, sw, x0, x1, wx0, wx1);
         float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
         if (wx == 0.f) continue;
-        g += wy * wx * ldf(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
+        const f32x4 d = ld4(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] += wgt * d[j];
       }
     }
-    stf(dx + i, g);
+    st4(dx + i * 4, g);
   }
 }
 
 // ---- avg_pool2d(2,2), H and W even
 template <class T>
 __global__ void avgpool_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
-  const int OH = H / 2, OW = W / 2;
-  int64_t n = (int64_t)B * OH * OW * C;
+  const int OH = H / 2, OW = W / 2, C4 = C / 4;
+  int64_t n = (int64_t)B * OH * OW * C4;
   GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int ox = (int)(p % OW);
-    int oy = (int)((p / OW) % OH);
-    int b = (int)(p / ((int64_t)OW * OH));
+    PIX_DECODE(i, C4, OW, OH, c, ox, oy, b)
     const T* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
-    stf(y + i, (ldf(xb) + ldf(xb + C) + ldf(xb + (size_t)W * C) + ldf(xb + (size_t)W * C + C)) * 0.25f);
+    const f32x4 a0 = ld4(xb), a1 = ld4(xb + C), a2 = ld4(xb + (size_t)W * C), a3 = ld4(xb + (size_t)W * C + C);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (a0[j] + a1[j] + a2[j] + a3[j]) * 0.25f;
+    st4(y + i * 4, o);
   }
 }
 template <class T>
 __global__ void avgpool_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int C) {
-  const int OH = H / 2, OW = W / 2;
-  int64_t n = (int64_t)B * H * W * C;
+  const int OH = H / 2, OW = W / 2, C4 = C / 4;
+  int64_t n = (int64_t)B * H * W * C4;
   GRID_STRIDE(i, n) {
-    int c = (int)(i % C);
-    int64_t p = i / C;
-    int ix = (int)(p % W);
-    int iy = (int)((p / W) % H);
-    int b = (int)(p / ((int64_t)W * H));
-    stf(dx + i, ldf(dy + (((size_t)b * OH + iy / 2) * OW + ix / 2) * C + c) * 0.25f);
+    PIX_DECODE(i, C4, W, H, c, ix, iy, b)
+    f32x4 d = ld4(dy + (((size_t)b * OH + iy / 2) * OW + ix / 2) * C + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] *= 0.25f;
+    st4(dx + i * 4, d);
   }
 }
 
@@ -371,43 +379,43 @@ int relu_bwd_t(const T* dy, const T* y, T* dx, int64_t n, wsmg_stream_t stream) 
 }
 template <class T>
 int maxpool_fwd_t(const T* x, T* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t stream) {
-  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(sgrid((int64_t)B * OH * OW * C)), dim3(256), 0, wsmg_s(stream), x, y, B,
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(sgrid((int64_t)B * OH * OW * C / 4)), dim3(256), 0, wsmg_s(stream), x, y, B,
                      H, W, C, OH, OW);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
 int maxpool_bwd_t(const T* dy, const T* x, T* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t stream) {
-  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, x, dx,
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), dy, x, dx,
                      B, H, W, C, OH, OW);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
 int upsample_fwd_t(const T* x, T* y, int B, int H, int W, int C, wsmg_stream_t stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(sgrid((int64_t)B * 4 * H * W * C)), dim3(256), 0, wsmg_s(stream), x,
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), x,
                      y, B, H, W, C);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
 int upsample_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx,
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), dy, dx,
                      B, H, W, C);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
 int avgpool_fwd_t(const T* x, T* y, int B, int H, int W, int C, wsmg_stream_t stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return WSMG_EINVAL;
-  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), x, y,
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (H & 1) || (W & 1)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 16)), dim3(256), 0, wsmg_s(stream), x, y,
                      B, H, W, C);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
 int avgpool_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1)) return WSMG_EINVAL;
-  hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (H & 1) || (W & 1)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(avgpool_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), dy, dx, B,
                      H, W, C);
   WSMG_RETURN_LAUNCH();
 }

@@ -25,6 +25,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int H = 512;
 constexpr int NB = 8;            // batch slots per step
 constexpr int UNITS_WAVE = 4;
@@ -281,95 +282,149 @@ struct GruBwdArgs {
   float* dgi;          // [T][N][3H]
   float* dgh;          // [T][N][3H]
   float* dh0;          // [N][H]
-  unsigned* sync;
-  float* xg;           // exchange [T][NWG][NB][3][UNITS_WG]: each 128-B line written once by one workgroup
+  unsigned* sync;      // [1] error word (zeroed by the launcher)
+  unsigned long long* xp;  // exchange ring [BWD_RING][consumer WG][producer WG][NB][UNITS_WG] of {value, tag} words
   int T, N;
+  unsigned tagbase;    // launch-unique tag bits; a word belongs to step t when tag == tagbase | (t + 1)
 };
 
-// partial sums of W_hh^T dgh over this lane's K slice: acc[u*8+b], u = 0..3 units of the wave
-__device__ __forceinline__ void gru_bwd_partials(const float* xcur, const float (&wt)[4][24], int N, int lane,
-                                                 float (&acc)[32]) {
-  constexpr int XG_WG = NB * 3 * UNITS_WG;
+// Backward exchange: PARTIAL SUMS of dh, not gate gradients.  dh_{t-1}[k] needs sum over all 3H gate rows of
+// W_hh[row][k] * dgate_t[row]; the gate gradients of unit u are produced by the workgroup that owns u.  Shipping
+// them to every workgroup (the first version of this kernel) is 3 words per unit = 48 KB per workgroup and step
+// behind a grid barrier: three memory round trips, 9.7 us per step.  Here the producer keeps its 48 gate rows
+// (r, z, n of its 16 units) of W_hh in registers — the SAME rows the forward kernel holds — multiplies them with
+// its own gate gradients straight out of LDS (768 FMAs per lane, no cross-lane reduction: a thread owns two
+// columns k and all 8 batch slots), and publishes its contribution to dh_{t-1}[k][b] for ALL 512 k as {value,
+// tag} words, grouped by the workgroup that owns k.  A consumer polls the 32 producers' words for its 16 units
+// (4096 words = 32 KB, exactly the forward's volume and code path) and adds them: ONE round trip per step.
+// Ring of 4 step slots: a producer can be at step t only after every workgroup has published step t+1, i.e.
+// has finished reading step t+2, so slots t+2 and older are free for reuse.
+constexpr int BWD_RING = 4;
+constexpr size_t XP_CONSUMER = (size_t)NWG * NB * UNITS_WG;   // words one consumer polls per step (4096)
+constexpr size_t XP_SLOT = (size_t)NWG * XP_CONSUMER;         // words per ring slot (1 MB)
+
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[NWG][NB][UNITS_WG];   // the 32 producers' partial sums for my units
+  __shared__ __attribute__((aligned(16))) float dgs[3 * UNITS_WG][NB];     // my gate gradients of this step: rows r, z, n
+  const int tid = threadIdx.x;
+  // gate rows (g, u) of my 16 units, columns k = 2 tid, 2 tid + 1
+  f32x2 w[3 * UNITS_WG];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  for (int g = 0; g < 3; ++g)
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b < N) {
+    for (int u = 0; u < UNITS_WG; ++u)
+      w[g * UNITS_WG + u] = *reinterpret_cast<const f32x2*>(a.whh + (size_t)(g * H + blockIdx.x * UNITS_WG + u) * H + 2 * tid);
+  // element-wise role (threads 0..127): unit wu of this workgroup, batch slot wb
+  const int wu = tid & 15, wb = tid >> 4;
+  const bool worker = tid < 128 && wb < a.N;
+  const int my_unit = blockIdx.x * UNITS_WG + wu;
+  // polling role: the 16 units of producer pq for batch slot pb
+  const int pq = tid >> 3, pb = tid & 7;
+  // publishing role: columns 2 tid, 2 tid + 1 belong to consumer workgroup tid / 8, its units (2 tid) % 16 and + 1
+  const size_t pub = ((size_t)(tid >> 3) * NWG + blockIdx.x) * NB * UNITS_WG + ((2 * tid) & 15);
+
+  float direct = 0.f, mk_next = 0.f;   // dh_{t+1} * z_{t+1} and mask_{t+1}: the non-recurrent part of dh_t
+  for (int t = a.T - 1; t >= -1; --t) {
+    // this step's element-wise inputs do not depend on the recurrence: fetch them before waiting
+    float dyv = 0.f, r = 0.f, z = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, mk = 0.f;
+    size_t row = 0;
+    if (worker && t >= 0) {
+      row = (size_t)t * a.N + wb;
+      const size_t o = row * H + my_unit;
+      mk = a.masks[t * a.N + wb];
+      const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
+      hprev = hsrc[(size_t)wb * H + my_unit] * mk;
+      dyv = a.dy[o];
+      r = a.sr[o]; z = a.sz[o]; nn = a.sn[o]; ghn = a.sghn[o];
+    }
+    // gradient flowing into h_t from step t+1: mask_{t+1} * (dh_{t+1} z_{t+1} + sum_rows W_hh[row][u] dgate_{t+1}[row])
+    float carry = 0.f;
+    if (t == a.T - 1) {
+      if (worker && a.dhT) carry = a.dhT[(size_t)wb * H + my_unit];
+    } else {
+      bool good = true;
+      if (pb < a.N) {
+        float rowv[16];
+        const unsigned long long* src = a.xp + (size_t)((t + 1) % BWD_RING) * XP_SLOT + (size_t)blockIdx.x * XP_CONSUMER +
+                                        ((size_t)pq * NB + pb) * UNITS_WG;
+        good = poll_row16(src, a.tagbase | (unsigned)(t + 2), a.sync, rowv);
 #pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        // gate row k = 256q + 4 lane + e  ->  gate k/512, unit k%512 -> [unit/16 workgroup][b][gate][unit%16]
-        const int k = 256 * q + 4 * lane;
-        const int gate = k >> 9, unit = k & 511;
-        f32x4 g = *reinterpret_cast<const f32x4*>(xcur + (unit >> 4) * XG_WG + b * 3 * UNITS_WG + gate * UNITS_WG + (unit & 15));
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = {rowv[4 * i], rowv[4 * i + 1], rowv[4 * i + 2], rowv[4 * i + 3]};
+          *reinterpret_cast<f32x4*>(&part[pq][pb][4 * i]) = v;
+        }
+      }
+      if (__syncthreads_or(good ? 0 : 1)) return;   // timeout or error elsewhere: every thread leaves
+      if (worker) {
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int q = 0; q < NWG; q += 2) { s0 += part[q][wb][wu]; s1 += part[q + 1][wb][wu]; }
+        carry = (direct + (s0 + s1)) * mk_next;
+      }
+    }
+    if (t < 0) {
+      if (worker) a.dh0[(size_t)wb * H + my_unit] = carry;
+      break;
+    }
+    if (tid < 128) {
+      float dr_pre = 0.f, dz_pre = 0.f, dnr = 0.f;
+      if (worker) {
+        const float dh = dyv + carry;
+        const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
+        dz_pre = dh * (hprev - nn) * z * (1.0f - z);
+        dr_pre = dn_pre * ghn * r * (1.0f - r);
+        dnr = dn_pre * r;
+        float* gi = a.dgi + row * 3 * H;
+        float* gh = a.dgh + row * 3 * H;
+        gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
+        gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dnr;
+        direct = dh * z;
+        mk_next = mk;
+      }
+      dgs[wu][wb] = dr_pre; dgs[UNITS_WG + wu][wb] = dz_pre; dgs[2 * UNITS_WG + wu][wb] = dnr;   // zeros for unused batch slots
+    }
+    __syncthreads();   // dgs complete; also: every read of part[] is done before the next step overwrites it
+    // my two columns of W_hh^T dgate for all batch slots
+    float acc0[NB], acc1[NB];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) acc[u * 8 + b] = fmaf(wt[u][q * 4 + e], g[e], acc[u * 8 + b]);
+    for (int b = 0; b < NB; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
+    // Groups of 8 rows, LDS reads in inline asm, each group's reads ordered behind the previous group's FMAs.  Left to
+    // itself the compiler issues all 96 reads first (384 live registers on top of the 96 weights): the weights end up
+    // in AGPRs / scratch and every FMA pays a v_accvgpr_read.  (v_pk_fma_f32 was tried: hipcc materialises the {w, w}
+    // broadcast pairs instead of using op_sel, 418 registers and 240 extra moves.)
+    const unsigned dgs_addr = (unsigned)(size_t)&dgs[0][0];
+#pragma unroll
+    for (int c8 = 0; c8 < 3 * UNITS_WG; c8 += 8) {
+      f32x4 d[16];
+      // asm volatile statements keep their order, and this one consumes every accumulator
+      asm volatile("" :: "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]), "v"(acc0[6]), "v"(acc0[7]),
+                         "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]), "v"(acc1[3]), "v"(acc1[4]), "v"(acc1[5]), "v"(acc1[6]), "v"(acc1[7]));
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[i]) : "v"(dgs_addr), "n"((c8 * NB + 4 * i) * 4) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
+                     "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rw = c8 + i;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc0[b] = fmaf(w[rw][0], d[2 * i][b], acc0[b]);             acc1[b] = fmaf(w[rw][1], d[2 * i][b], acc1[b]);
+          acc0[4 + b] = fmaf(w[rw][0], d[2 * i + 1][b], acc0[4 + b]); acc1[4 + b] = fmaf(w[rw][1], d[2 * i + 1][b], acc1[4 + b]);
+        }
+      }
+    }
+    unsigned long long* dst = a.xp + (size_t)(t % BWD_RING) * XP_SLOT + pub;
+    const unsigned long long tag = (unsigned long long)(a.tagbase | (unsigned)(t + 1)) << 32;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b < a.N) {
+        __hip_atomic_store(dst + b * UNITS_WG, tag | __float_as_uint(acc0[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + b * UNITS_WG + 1, tag | __float_as_uint(acc1[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
-}
-__device__ __forceinline__ float reduce32(float (&acc)[32], int lane) {
-  halve<32, 32>(acc, lane);
-  halve<16, 16>(acc, lane);
-  halve<8, 8>(acc, lane);
-  halve<4, 4>(acc, lane);
-  halve<2, 2>(acc, lane);
-  return acc[0] + lane_xor<1>(acc[0]);
-}
-
-__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
-  __shared__ int ok_lds;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int u0 = blockIdx.x * UNITS_WG + wave * UNITS_WAVE;
-  // columns u0..u0+3 of W_hh over all 3H rows: k = 256*q + 4*lane + e, q = 0..5
-  float wt[4][24];
-#pragma unroll
-  for (int q = 0; q < 6; ++q)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = 256 * q + 4 * lane + e;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) wt[u][q * 4 + e] = a.whh[(size_t)row * H + u0 + u];
-    }
-  // after the reduction lane l holds (unit = l/16, batch = (l>>1)&7); even lanes do the element-wise work
-  const int my_unit = u0 + (lane >> 4);
-  const int my_b = (lane >> 1) & 7;
-  const bool worker = ((lane & 1) == 0) && (my_b < a.N);
-  float carry = 0.f;
-  if (worker && a.dhT) carry = a.dhT[(size_t)my_b * H + my_unit];
-
-  constexpr int XG_WG = NB * 3 * UNITS_WG;   // floats per workgroup per step
-  const int xgw = blockIdx.x * XG_WG + my_b * 3 * UNITS_WG + wave * UNITS_WAVE + (lane >> 4);  // + gate*16
-  for (int t = a.T - 1; t >= 0; --t) {
-    float* xcur = a.xg + (size_t)t * NWG * XG_WG;
-    float dh_direct = 0.f, mk = 0.f;
-    if (worker) {
-      const size_t row = (size_t)t * a.N + my_b;
-      const size_t o = row * H + my_unit;
-      mk = a.masks[t * a.N + my_b];
-      const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
-      float hprev = hsrc[(size_t)my_b * H + my_unit] * mk;
-      float dh = a.dy[o] + carry;
-      float r = a.sr[o], z = a.sz[o], nn = a.sn[o], ghn = a.sghn[o];
-      float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
-      float dz_pre = dh * (hprev - nn) * z * (1.0f - z);
-      float dr_pre = dn_pre * ghn * r * (1.0f - r);
-      float* gi = a.dgi + row * 3 * H;
-      float* gh = a.dgh + row * 3 * H;
-      gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
-      gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dn_pre * r;
-      xcur[xgw] = dr_pre; xcur[xgw + UNITS_WG] = dz_pre; xcur[xgw + 2 * UNITS_WG] = dn_pre * r;
-      dh_direct = dh * z;
-    }
-    if (!grid_barrier(a.sync, (unsigned)NWG * (unsigned)(a.T - t), tid, &ok_lds)) return;
-    // dh_{t-1}[b][u] = mask * (dh*z + sum_k dgh[b][k] * W_hh[k][u])
-    float acc[32];
-    gru_bwd_partials(xcur, wt, a.N, lane, acc);
-    const float s = reduce32(acc, lane);
-    carry = (dh_direct + s) * mk;
-  }
-  if (worker) a.dh0[(size_t)my_b * H + my_unit] = carry;
 }
 
 }  // namespace
@@ -408,9 +463,12 @@ static unsigned next_tagbase() {
   return (__atomic_add_fetch(&epoch, 1u, __ATOMIC_RELAXED) & 0x3FFFFFu) << 10;
 }
 
-// per step: forward image NWG*NB*UNITS_WG floats (16 KB), backward image 3x that (48 KB)
-// 256 B of control words + per step 4096 (batch, unit) slots of up to four 8-byte {value, tag} words
-extern "C" int64_t wsmg_gru_workspace_bytes(int T) { return 256 + (int64_t)T * NWG * NB * UNITS_WG * 32; }
+// 256 B of control words + the larger of: forward image (per step 4096 (batch, unit) {value, tag} words = 32 KB),
+// backward ring (BWD_RING step slots of 32 consumers x 4096 words = 4 MB)
+extern "C" int64_t wsmg_gru_workspace_bytes(int T) {
+  const int64_t fwd = (int64_t)T * NWG * NB * UNITS_WG * 8, bwd = (int64_t)BWD_RING * XP_SLOT * 8;
+  return 256 + (fwd > bwd ? fwd : bwd);
+}
 
 extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
                             int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
@@ -438,10 +496,12 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
   hipStream_t s = wsmg_s(stream);
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
+  if (T > 1023) return WSMG_EINVAL;
+  // control words and the ring of {value, tag} words are cleared (see wsmg_gru_fwd)
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)BWD_RING * XP_SLOT * 8, s);
   if (e != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
-               (float*)((char*)sync_ws + 256), T, N};
+               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase()};
   unsigned dyn = 0;
   if ((e = excl_lds(gru_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), dyn, s, a);

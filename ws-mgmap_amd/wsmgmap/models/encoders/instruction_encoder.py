@@ -11,6 +11,8 @@ Differences in data flow (results identical):
 import gzip
 import json
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -34,12 +36,21 @@ class InstructionEncoder(nn.Module):
     def output_size(self):
         return self.config.hidden_size * (2 if self.bidir else 1)
 
+    _diag_memo = None
+
     @staticmethod
     def _dedup(tokens):
         """Unique rows of a [B, L] token matrix without a row-wise sort: a 64-bit polynomial hash per
         row, a 1-D unique over the B hashes, and an exact on-device check (a hash collision falls back
         to torch.unique(dim=0)).  Returns (unique rows [U, L], inverse [B], lengths on host, on device)."""
         B, L = tokens.shape
+        memo = InstructionEncoder._diag_memo if os.environ.get("WSMG_DIAG_DEDUP_MEMO") == "1" else None
+        if memo is not None and memo[0] == (B, L):   # diagnostic only (static inputs): no host read-back at all
+            U, host, inverse = memo[1], memo[2], memo[3]
+            rep = torch.full((U,), B, device=tokens.device, dtype=torch.int64)
+            rep.scatter_reduce_(0, inverse, torch.arange(B, device=tokens.device), reduce="amin")
+            uniq = tokens[rep]
+            return uniq, inverse, host[1:], (uniq != 0).long().sum(dim=1)
         mult = (torch.arange(1, L + 1, device=tokens.device, dtype=torch.int64) * 0x9E3779B97F4A7C15) | 1
         h = (tokens * mult).sum(dim=1)
         _, inverse = torch.unique(h, return_inverse=True)
@@ -54,6 +65,8 @@ class InstructionEncoder(nn.Module):
             uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
             lengths = (uniq != 0).long().sum(dim=1)
             return uniq, inverse, lengths.cpu(), lengths
+        if os.environ.get("WSMG_DIAG_DEDUP_MEMO") == "1":
+            InstructionEncoder._diag_memo = ((B, L), U, host, inverse)
         return uniq, inverse, host[1:], lengths
 
     def encode_unique(self, instruction, stock=False):
