@@ -161,7 +161,16 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         update()
     if warmup > 0:
         warm_prof = ops.profile_end()
-    dom_entry = max(warm_prof.values(), key=lambda r: r["ms_total"])["entry"] if warm_prof else None
+    dom_entry = None
+    if warm_prof:
+        # forward and backward-weight are within a few per cent of each other (3.1 vs 3.2 ms per update; rocprofv3 ranks
+        # backward-weight first in every trace of this round) and one warm-up sample can rank them either way: families
+        # within 8 % of the largest count as tied and the tie goes to the backward-weight family, so that the `roofline`
+        # object names the same kernel from run to run
+        top = max(r["ms_total"] for r in warm_prof.values())
+        tied = [r for r in warm_prof.values() if r["ms_total"] >= 0.92 * top]
+        tied.sort(key=lambda r: (r["entry"] != "wsmg_conv2d_bwd_weight_bf16", -r["ms_total"]))
+        dom_entry = tied[0]["entry"]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -159,8 +159,11 @@ int wsmg_attn_bwd(const float* q, const float* k, const float* v, const float* a
  * elements), float32 arithmetic / accumulation, float32 parameters, statistics and weight gradients.
  * Convolutions take bf16 weights (the host casts the float32 master weights once per update) and run on
  * v_mfma_f32_32x32x16_bf16; backward-weight reads its pixel-major tiles with ds_read_b64_tr_b16.
- * `out_f32` is a flag word: bit 0 makes the conv write float32 instead of bf16, bit 1 (forward only) applies ReLU
- * after the bias in the epilogue (inference of the frozen encoders: conv + folded eval-mode BN + ReLU in one launch). */
+ * `out_f32` is a flag word: bit 0 makes the conv write float32 instead of bf16, bit 1 applies ReLU after the bias
+ * in the epilogue (conv + folded eval-mode BN + ReLU of the frozen encoders, conv + ReLU heads), bit 2 ADDS the
+ * result to the existing contents of y / dx before the ReLU (a convolution over channel-concatenated inputs is run
+ * part by part over the unconcatenated tensors: conv(cat[a,b], W) = conv(a, W[:, :Ca]) + conv(b, W[:, Ca:]), which
+ * replaces torch.cat at map_encoder.py:104,110 and mg_map_policy.py:99 and the slice copies of its backward). */
 int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, int B, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                          wsmg_stream_t stream);

@@ -868,3 +868,51 @@ def test_conv2d_with_fused_relu(ops, dt):
     for a, c, name in zip(outs[0], outs[1], ("y", "dx", "dw", "db")):
         assert float((a - c).abs().max()) <= 1e-5 * (1 + float(c.abs().max())), name
     assert float(outs[0][0].min()) >= 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("relu,pad_last", [(False, 0), (True, 0), (True, 5)])
+def test_conv2d_over_concatenated_parts(ops, relu, pad_last):
+    """ops.conv2d_cat([a, b], w) == conv2d(torch.cat([a, b], -1), w) (map_encoder.py:104,110 / mg_map_policy.py:99):
+    the bf16 engine runs one launch per part with the second accumulating into y (flag bit 2), and backward works on
+    the parts, so forward and every gradient are held against a float64 evaluation of the concatenated convolution.
+    pad_last: the last part carries 5 zero-padded channels beyond the weight's (27 -> 32 logits case)."""
+    torch.manual_seed(11)
+    B, Ca, Cb, Cout, H = 3, 64, 32, 64, 12
+    a = torch.randn(B, H, H, Ca, device="cuda").bfloat16()
+    b = torch.randn(B, H, H, Cb, device="cuda").bfloat16()
+    if pad_last:
+        b[..., Cb - pad_last:] = 0
+    w = torch.randn(Cout, Ca + Cb - pad_last, 3, 3, device="cuda") * 0.05
+    bias = torch.randn(Cout, device="cuda") * 0.1
+    gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
+    ai, bi = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    wi, biasi = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    y = ops._Conv2dCat.apply(wi, biasi, 1, 1, False, relu, ai, bi)   # (ops.conv2d_cat takes this route with WSMG_CONV_CAT=1)
+    assert y.dtype == torch.bfloat16
+    y.backward(gy)
+    # float64 reference on the same bf16-rounded inputs.  With ReLU the gradient is taken through the mask the engine
+    # actually applied (its bf16 output > 0): pre-activations within rounding distance of zero can fall on either side,
+    # which is a property of bf16 storage, not of the part-by-part route
+    ar, br = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    wr, biasr = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    xcat = torch.cat([ar, br[..., :Cb - pad_last]], dim=-1).permute(0, 3, 1, 2)
+    pre = F.conv2d(xcat, wr, biasr, 1, 1)
+    yr = F.relu(pre) if relu else pre
+    out = pre * (nchw(y.detach().float()) > 0).double() if relu else pre
+    out.backward(gy.double().permute(0, 3, 1, 2))
+    # y is rounded to bf16 once per part, and the first part's partial sum can be as large as the largest output while
+    # the final value is small: the error bound is relative to the output scale, two half-ulps of bf16 (2^-9 each)
+    sy = float(yr.detach().abs().max())
+    close("cat.y", nchw(y.float()), yr, 2.0 ** -8, 2.0 ** -8 * sy)
+
+    def rel(got, ref):
+        return float((got.double() - ref).norm() / (ref.norm() + 1e-30))
+    assert rel(ai.grad.float(), ar.grad) < 1e-2
+    assert rel(bi.grad.float()[..., :Cb - pad_last], br.grad[..., :Cb - pad_last]) < 1e-2
+    assert rel(wi.grad, wr.grad) < 1e-2 and rel(biasi.grad, biasr.grad) < 1e-2
+    if pad_last:
+        assert tuple(bi.grad.shape) == tuple(b.shape)
+    # and the single-tensor route of the same operator agrees to bf16 rounding
+    y1 = ops.conv2d(torch.cat([a, b], dim=-1), w, bias, 1, 1, relu=relu)
+    assert float((y1.float() - y.float()).abs().max()) <= 2.0 ** -6 * sy

@@ -101,6 +101,22 @@ def main():
     print("%-22s %5s %9s  %s" % ("op", "calls", "gpu us", "where"))
     for (n, w), c in sorted(groups.items(), key=lambda t: -dur[t[0]])[:90]:
         print("%-22s %5d %9.1f  %s" % (n, c, dur[(n, w)], w))
+    if os.environ.get("BIG", "0") == "1":
+        # every aten op that directly owns >= 15 us of kernels, with shapes and the enclosing ops
+        rows = []
+        for e in ev:
+            if not e.name.startswith("aten::") or not e.kernels:
+                continue
+            d = sum(kk.duration for kk in e.kernels)
+            if d < 15:
+                continue
+            names, p = [], e.cpu_parent
+            while p is not None and len(names) < 4:
+                names.append(p.name[:40]); p = p.cpu_parent
+            rows.append((d, e.name, str(e.input_shapes)[:70], " < ".join(names)))
+        print("\naten ops owning >= 15 us of kernels:")
+        for d, n, sh, ch in sorted(rows, reverse=True):
+            print("%7.1f  %-22s %-70s %s" % (d, n, sh, ch))
     # device copies / fills: who launches them (chain of enclosing CPU ops)
     chain = collections.Counter()
     for e in ev:

@@ -214,7 +214,12 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
         int dp = dpix[row];
         if (dp < 0) continue;
         float v = acc[t][u][g] + bv;
-        if (a.out_f32 & 2) v = v > 0.f ? v : 0.f;   // fused ReLU (inference path of the frozen encoders)
+        if (a.out_f32 & 4) {   // accumulate into the existing output (a convolution over concatenated inputs, part by part)
+          const size_t o = (size_t)dp * a.N + n;
+          v += (a.out_f32 & 1) ? reinterpret_cast<const float*>(a.dst)[o]
+                               : __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(a.dst)[o] << 16);
+        }
+        if (a.out_f32 & 2) v = v > 0.f ? v : 0.f;   // fused ReLU
         if (a.out_f32 & 1)
           reinterpret_cast<float*>(a.dst)[(size_t)dp * a.N + n] = v;
         else

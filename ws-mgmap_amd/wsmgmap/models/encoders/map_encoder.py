@@ -46,7 +46,10 @@ class batched_bumps:
 def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
     """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
     # (if x carries zero-padded channels, ops.conv2d pads the weight's input channels to match)
-    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
+    if isinstance(x, (list, tuple)):   # convolution over a channel concatenation, run part by part (no torch.cat)
+        y = ops.conv2d_cat(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
+    else:
+        y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
     bump(bn, train)
     return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
 
@@ -120,6 +123,6 @@ class MapDecoder(nn.Module):
         for blk in stem.layer1:
             layer1 = self._block(layer1, blk, train)
         up = ops.upsample2x(cr(layer1, self.layer1_1x1))
-        up = cr(torch.cat([up, cr(layer0, self.layer0_1x1)], dim=-1), self.conv_up0)
+        up = cr([up, cr(layer0, self.layer0_1x1)], self.conv_up0)        # torch.cat(dim=1) of the reference, folded into the conv
         up = ops.upsample2x(up)
-        return cr(torch.cat([up, x_original], dim=-1), self.conv_original_size2)
+        return cr([up, x_original], self.conv_original_size2)

@@ -165,7 +165,7 @@ class MGMapNet(nn.Module):
         pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
         # (27 -> 32 input channels: ops.conv2d zero-pads the weight to the activation's channel count)
         cls_proj = ops.conv2d(ops.avgpool2(sem), self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True)
-        emb = conv(torch.cat([enc_proj, cls_proj], dim=-1), self.map_cated_linear, 1)
+        emb = ops.conv2d_cat([enc_proj, cls_proj], self.map_cated_linear[0].weight, self.map_cated_linear[0].bias, 1, 1, relu=True)
         b, s1, s2, ch = emb.shape
         return emb.view(b, s1 * s2, ch), pred_sem_map
 
@@ -208,7 +208,7 @@ class MGMapNet(nn.Module):
         if "depth" in self._inputs:
             state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
         if "map" in self._inputs:
-            state_in.append(self.map_linear[3](self.map_linear[2](map_tokens.mean(dim=1, dtype=torch.float32))))
+            state_in.append(self.map_linear[3](self.map_linear[2](ops.token_mean(map_tokens))))
         state_in = torch.cat(state_in, dim=1)
 
         n1 = self.state_encoder.num_recurrent_layers

@@ -125,6 +125,43 @@ def _weight_layouts(w_oihw, cin_pad, dtype, need_ihwo):
     return w_ohwi, w_ihwo
 
 
+# Zero-initialised float32 scratch of ONE backward pass (the split-K accumulators of the weight-gradient kernels, the
+# exactly-zero bias gradients): carved from one buffer per stream that is cleared by a single fill, instead of one
+# 3.5-us fill launch per request (29 per update).  The first backward pass measures how much is needed; a callback at
+# the end of every pass (autograd engine) retires the buffer, so the next pass starts from a fresh, cleared one.
+_zero_pool = {}      # stream id -> dict(buf, off, used, cap, armed)
+
+
+def _zero_pool_retire():
+    for z in _zero_pool.values():
+        z["cap"] = max(z["cap"], z["used"])
+        z["buf"], z["off"], z["used"], z["armed"] = None, 0, 0, False
+
+
+def _zeros_f32(shape, device):
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    n = (numel + 63) // 64 * 64   # 256-byte granules
+    engine = torch.autograd.Variable._execution_engine
+    z = _zero_pool.setdefault(torch.cuda.current_stream().cuda_stream, dict(buf=None, off=0, used=0, cap=0, armed=False))
+    z["used"] += n
+    if not z["armed"]:
+        try:
+            engine.queue_callback(_zero_pool_retire)   # only legal while a backward pass is running
+            z["armed"] = True
+        except RuntimeError:
+            z["used"] -= n
+            return torch.zeros(shape, device=device, dtype=torch.float32)
+    if z["buf"] is None and z["cap"] >= n:
+        z["buf"], z["off"] = torch.zeros(z["cap"], device=device, dtype=torch.float32), 0
+    if z["buf"] is None or z["off"] + n > z["buf"].numel() or z["buf"].device != device:
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    out = z["buf"][z["off"]:z["off"] + numel].view(shape)
+    z["off"] += n
+    return out
+
+
 def _weight_grad_oihw(dw_ohwi, I):
     O, KH, KW, Ipad = dw_ohwi.shape
     out = torch.empty(O, I, KH, KW, device=dw_ohwi.device, dtype=torch.float32)
@@ -180,13 +217,13 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw_ohwi = torch.zeros(Cout, KH, KW, Cin, device=x.device, dtype=torch.float32)
+            dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
             _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
             dw = _weight_grad_oihw(dw_ohwi, Cin_w)
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
-            db = torch.zeros(Cout, device=dy.device, dtype=torch.float32) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
+            db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
         return dx, dw, db, None, None, None, None
 
 
@@ -230,7 +267,7 @@ class _ConvT2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw_ohwi = torch.zeros(O, KH, KW, I, device=x.device, dtype=torch.float32)
+            dw_ohwi = _zeros_f32((O, KH, KW, I), x.device)
             _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(dy), _p(x), _p(dw_ohwi), *dims, _stream())
             dw = _weight_grad_oihw(dw_ohwi, I)
         return dx, dw, None, None
@@ -242,6 +279,89 @@ def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=Fal
     BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros.  relu: y = relu(conv + bias), fused into
     the conv epilogue in bf16 mode."""
     return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+
+
+class _Conv2dCat(torch.autograd.Function):
+    """conv2d(cat(xs, channel axis), w) + b without the concatenation (bf16 engine): one launch per part over the
+    matching input-channel slice of w, parts after the first accumulate into y in the epilogue (flag bit 2), the optional
+    ReLU runs in the last part's epilogue.  Backward: one backward-data and one backward-weight launch per part on the
+    parts themselves, so no gradient slice of a concatenated tensor is ever copied out.  Only the last part may carry
+    zero-padded channels beyond the weight's."""
+
+    @staticmethod
+    def forward(ctx, w_oihw, bias, stride, pad, bias_grad_zero, relu, *xs):
+        _req(w_oihw, bias, *xs)
+        _f32(w_oihw, bias)
+        B, H, W, _ = xs[0].shape
+        Cout, Cin_w, KH, KW = w_oihw.shape
+        OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
+        y = torch.empty(B, OH, OW, Cout, device=xs[0].device, dtype=torch.bfloat16)
+        parts, c0 = [], 0
+        for i, x in enumerate(xs):
+            if x.dtype != torch.bfloat16 or tuple(x.shape[:3]) != (B, H, W):
+                raise _abi.WsmgError("conv2d_cat: parts must be bf16 NHWC tensors of one spatial size")
+            Ci = x.shape[3]
+            Ci_w = min(Ci, Cin_w - c0)
+            if Ci_w <= 0 or (Ci_w < Ci and i != len(xs) - 1):
+                raise _abi.WsmgError("conv2d_cat: only the last part may have padded channels")
+            w, w_ihwo = _weight_layouts(w_oihw[:, c0:c0 + Ci_w].contiguous(), Ci, torch.bfloat16, ctx.needs_input_grad[6 + i])
+            fl = 2.0 * B * OH * OW * Cout * Ci * KH * KW
+            dims = (B, H, W, Ci, Cout, KH, KW, stride, pad, OH, OW)
+            flags = (4 if i else 0) | (2 if relu and i == len(xs) - 1 else 0)
+            _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias if i == 0 else None), _p(y), flags, *dims, _stream())
+            parts.append((dims, fl, Ci_w, w_ihwo))
+            c0 += Ci_w
+        if c0 != Cin_w:
+            raise _abi.WsmgError(f"conv2d_cat: parts cover {c0} of the weight's {Cin_w} input channels")
+        ctx.save_for_backward(*xs, *[p[3] for p in parts if p[3] is not None], *([y] if relu else []))
+        ctx.parts = [(p[0], p[1], p[2], p[3] is not None) for p in parts]
+        ctx.has_bias, ctx.bias_grad_zero, ctx.relu = bias is not None, bool(bias_grad_zero), bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        saved = list(ctx.saved_tensors)
+        n = len(ctx.parts)
+        xs, rest = saved[:n], saved[n:]
+        dy = dy.contiguous()
+        if ctx.relu:
+            y = rest.pop()
+            masked = torch.empty_like(dy)
+            _abi.call("wsmg_relu_bwd_bf16", _p(dy), _p(y), _p(masked), dy.numel(), _stream())
+            dy = masked
+        dxs, dws = [], []
+        for i, (x, (dims, fl, Ci_w, has_ihwo)) in enumerate(zip(xs, ctx.parts)):
+            B, H, W, Ci, Cout, KH, KW, stride, pad, OH, OW = dims
+            dx = None
+            if has_ihwo:
+                w_ihwo = rest.pop(0)
+                dx = torch.empty_like(x)
+                _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
+            dxs.append(dx)
+            if ctx.needs_input_grad[0]:
+                dw_ohwi = _zeros_f32((Cout, KH, KW, Ci), x.device)
+                _launch("wsmg_conv2d_bwd_weight_bf16", fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
+                dws.append(_weight_grad_oihw(dw_ohwi, Ci_w))
+        dw = torch.cat(dws, dim=1) if dws else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            Cout = ctx.parts[0][0][4]
+            db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
+        return (dw, db, None, None, None, None, *dxs)
+
+
+def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False):
+    """conv2d over the channel concatenation of the NHWC tensors `xs` (see _Conv2dCat); float32 activations take the
+    plain route (torch.cat + conv2d)."""
+    xs = list(xs)
+    if len(xs) == 1:
+        return conv2d(xs[0], weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+    # measured on the T=64 x N=8 update: 15.30-15.39 ms with the part-by-part route against 15.14 ms with torch.cat + one
+    # conv — two shorter reductions, two epilogues (the second re-reads y) and twice the weight-gradient launches cost
+    # more than the 0.35 ms of concatenation and slice copies they remove — so the part-by-part route is opt-in
+    if xs[0].dtype != torch.bfloat16 or _os.environ.get("WSMG_CONV_CAT", "0") != "1":
+        return conv2d(torch.cat(xs, dim=-1), weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+    return _Conv2dCat.apply(weight_oihw, bias, stride, pad, bias_grad_zero, relu, *xs)
 
 
 def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
@@ -611,6 +731,26 @@ class _AttnFolded(torch.autograd.Function):
 def attention_folded(q, w, b, x, mask, scale):
     """(context [B,C], weights [B,I]) of softmax(scale * (q . (W x_i + b) - 1e8 mask_i)) over x [B,I,C]."""
     return _AttnFolded.apply(q, w, b, x, mask, scale)
+
+
+class _TokenMean(torch.autograd.Function):
+    """mean over the token axis of x [B, I, C] in float32.  The gradient of a mean is one [B, C] row repeated over the
+    I tokens: it is returned as a stride-0 expanded view in x's dtype (autograd adds it to the attention's gradient of
+    the same tokens in one pass) instead of MeanBackward's materialised float32 [B, I, C] tensor, its conversion
+    and the add (div 112 us + copy 92 us + add 73 us at B=512, I=576, C=256)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return x.mean(dim=1, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * (1.0 / ctx.shape[1])).to(ctx.dtype).unsqueeze(1).expand(ctx.shape)
+
+
+def token_mean(x):
+    return _TokenMean.apply(x)
 
 
 def quantize_e4m3(x, scale):
