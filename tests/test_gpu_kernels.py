@@ -605,8 +605,9 @@ def test_attn_fp8_fused_cfg5(ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-def test_attention_with_folded_key_projection(ops, dt):
+def test_attention_with_folded_key_projection(ops, dt, masked):
     """ops.attention_folded == softmax(scale * q.(W x + b)) . x of mg_map_policy.py:126-132,173-178 with the
     Conv1d key projection applied explicitly (plain torch, float64), forward and every gradient; the key
     bias gets an exactly-zero gradient (its logit contribution is constant over the tokens)."""
@@ -620,11 +621,23 @@ def test_attention_with_folded_key_projection(ops, dt):
         x = x.bfloat16()
     gout, gattn = torch.randn(B, C, device="cuda"), torch.randn(B, I, device="cuda") * 0.1
     leaves = [t.clone().requires_grad_(True) for t in (q, w, b, x)]
-    out, attn = ops.attention_folded(leaves[0], leaves[1], leaves[2], leaves[3], None, 1 / 16)
+    # (keys are values here: the one-pass / read-pass + write-pass kernels of csrc/wsmg_attn.hip; 37 tokens = 4 full
+    # trips of 8 and a ragged one; masked rows keep at least their first token)
+    mask = None
+    if masked:
+        mask = torch.rand(B, I, device="cuda") < 0.4
+        mask[:, 0] = False
+        mask[2] = False
+        mask[3, 1:] = True
+    out, attn = ops.attention_folded(leaves[0], leaves[1], leaves[2], leaves[3], mask, 1 / 16)
     ((out * gout).sum() + (attn * gattn).sum()).backward()
     ref = [t.detach().double().requires_grad_(True) for t in (q, w, b, x)]
     k = ref[3] @ ref[1][:, :, 0].t() + ref[2]
-    a = torch.softmax(torch.einsum("bc,bic->bi", ref[0], k) / 16, dim=1)
+    lgt = torch.einsum("bc,bic->bi", ref[0], k)
+    if masked:
+        lgt = lgt - 1e8 * mask.double()
+        assert float(attn[3, 1:].abs().max()) == 0.0 and abs(float(attn[3, 0]) - 1.0) < 1e-6
+    a = torch.softmax(lgt / 16, dim=1)
     o = torch.einsum("bi,bic->bc", a, ref[3])
     ((o * gout.double()).sum() + (a * gattn.double()).sum()).backward()
     tol = 1e-5 if dt == "f32" else 2e-2

@@ -39,3 +39,19 @@ print("idle by gap size (us bucket: ms/update):", {k: round(v / 1e6 / n_upd, 3) 
 print("largest gaps:")
 for g, a, b in sorted(gaps, reverse=True)[:25]:
     print("  %7.1f us  after %-50s before %s" % (g / 1e3, a[:50], b[:60]))
+
+import re
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"at::native::", "", n)
+    return n[:100]
+mainq = perq.most_common(1)[0][0]
+agg = collections.defaultdict(lambda: [0, 0])
+for s_, e_, n, q in tail:
+    if q == mainq:
+        a = agg[short(n)]
+        a[0] += e_ - s_; a[1] += 1
+print("main queue, per update (ms, launches):")
+for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 60]:
+    print("  %7.3f %5.1f  %s" % (t / 1e6 / n_upd, c / n_upd, n))

@@ -209,6 +209,196 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 
 
 // ---------------------------------------------------------------------------------------------------
+// Keys ARE values (k == v): the map stage after the key projection has been folded into the query
+// (ops._AttnFolded; mg_map_policy.py:233-235 on the 576 map tokens).  The generic kernels above read the
+// token tensor twice per pass (logits, then the weighted sum; gradient dots, then dq) — 295 KB per row,
+// more than a CU's share of L2 — and pay a six-step shuffle reduction per token.  Here:
+//   forward  = ONE pass, online softmax (running max / sum per wave, rescaled accumulator), raw logits kept
+//              in LDS so the attention weights can still be written out;
+//   backward = one READ pass + one WRITE pass.  With da_i = dattn_i + dout.x_i and s = sum_i a_i da_i:
+//              dq = scale * (sum_i a_i da_i x_i - s * sum_i a_i x_i)   -> both sums accumulate in the read pass;
+//              dx_i = a_i (da_i - s) scale * q + a_i * dout            -> needs no x at all (write-only pass).
+// Eight tokens per trip and wave; their eight partial dot products are reduced together with a halving
+// butterfly (v_permlane32/16_swap, DPP): 10 lane exchanges per 8 tokens instead of 48.
+template <int C, int D, int NV>
+__device__ __forceinline__ void halve8(float (&v)[NV], int lane) {
+  if constexpr (D == 32 || D == 16) {
+#pragma unroll
+    for (int i = 0; i < C / 2; ++i) {
+      const int lo = __float_as_int(v[i]), hi = __float_as_int(v[i + C / 2]);
+      auto r = (D == 32) ? __builtin_amdgcn_permlane32_swap(lo, hi, false, false)
+                         : __builtin_amdgcn_permlane16_swap(lo, hi, false, false);
+      v[i] = __int_as_float(r[0]) + __int_as_float(r[1]);
+    }
+  } else {   // D == 8: DPP row rotate by 8
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int i = 0; i < C / 2; ++i) {
+      const float keep = up ? v[i + C / 2] : v[i];
+      const float send = up ? v[i] : v[i + C / 2];
+      const int x = __float_as_int(send);
+      v[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));
+    }
+  }
+}
+// dot products of 8 token rows with one vector, all 8 results in every lane: d[u] = sum_c g[c] x_u[c]
+__device__ __forceinline__ void dots8(const f32x4 (&xv)[8], const f32x4 g, int lane, float (&d)[8]) {
+  float p[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) p[u] = g[0] * xv[u][0] + g[1] * xv[u][1] + g[2] * xv[u][2] + g[3] * xv[u][3];
+  halve8<8, 32>(p, lane);
+  halve8<4, 16>(p, lane);
+  halve8<2, 8>(p, lane);
+  float r = p[0];   // token ((lane>>5)&1)*4 + ((lane>>4)&1)*2 + ((lane>>3)&1), summed over lanes that differ in bits 3..5
+  {
+    int x = __float_as_int(r);
+    r += __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    x = __float_as_int(r);
+    r += __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    x = __float_as_int(r);
+    r += __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false));  // row_half_mirror: lane i <-> 7 - i
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) d[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 8 * u));
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_same_fwd_kernel(const float* __restrict__ q, const T* __restrict__ x,
+                                                            const uint8_t* __restrict__ mask, float scale, int I,
+                                                            float* __restrict__ out, float* __restrict__ attn) {
+  __shared__ float lg[AMAX_I];
+  __shared__ float wm[AWAVES], wsum[AWAVES];
+  __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
+  const T* xb = x + (size_t)b * I * AC + lane * 4;
+  float m = -INFINITY, ssum = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int i0 = wave * 8; i0 < I; i0 += AWAVES * 8) {
+    f32x4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = (i0 + u < I) ? ld4(xb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+    float d[8];
+    dots8(xv, qv, lane, d);
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float l = d[u];
+      if (mask && i0 + u < I && mask[(size_t)b * I + i0 + u]) l = l - 1e8f;
+      l = (i0 + u < I) ? l * scale : -INFINITY;
+      d[u] = l;
+      mx = fmaxf(mx, l);
+    }
+    if (lane < 8 && i0 + lane < I) {
+      float mine = d[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u) mine = (lane == u) ? d[u] : mine;
+      lg[i0 + lane] = mine;
+    }
+    const float corr = expf(m - mx);   // m = -inf on the first trip: exp(-inf) = 0 and acc, ssum are 0
+    ssum *= corr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= corr;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float e = expf(d[u] - mx);   // tokens past I: exp(-inf) = 0
+      ssum += e;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += e * xv[u][j];
+    }
+    m = mx;
+  }
+  if (lane == 0) { wm[wave] = m; wsum[wave] = ssum; }
+  reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
+  __syncthreads();
+  float M = wm[0];
+#pragma unroll
+  for (int w = 1; w < AWAVES; ++w) M = fmaxf(M, wm[w]);
+  float S = 0.f, o = 0.f;
+#pragma unroll
+  for (int w = 0; w < AWAVES; ++w) {
+    const float f = expf(wm[w] - M);   // a wave that saw no token has m = -inf, f = 0
+    S += wsum[w] * f;
+    o += part[w][tid] * f;
+  }
+  const float inv = 1.f / S;
+  out[(size_t)b * AC + tid] = o * inv;
+  for (int i = tid; i < I; i += 256) attn[(size_t)b * I + i] = expf(lg[i] - M) * inv;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_same_bwd_kernel(const float* __restrict__ q, const T* __restrict__ x,
+                                                            const float* __restrict__ attn,
+                                                            const float* __restrict__ dout,
+                                                            const float* __restrict__ dattn, float scale, int I,
+                                                            float* __restrict__ dq, T* __restrict__ dx,
+                                                            float* __restrict__ dlogits) {
+  __shared__ float da[AMAX_I];
+  __shared__ float wsum[AWAVES];
+  __shared__ __attribute__((aligned(16))) float pa[AWAVES][AC], po[AWAVES][AC];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
+  const f32x4 gv = reinterpret_cast<const f32x4*>(dout + (size_t)b * AC)[lane];
+  const T* xb = x + (size_t)b * I * AC + lane * 4;
+  T* dxb = dx + (size_t)b * I * AC + lane * 4;
+  const float* ab = attn + (size_t)b * I;
+  const float* dab = dattn ? dattn + (size_t)b * I : nullptr;
+  // read pass
+  float s = 0.f;
+  f32x4 A = {0.f, 0.f, 0.f, 0.f}, O = {0.f, 0.f, 0.f, 0.f};
+  for (int i0 = wave * 8; i0 < I; i0 += AWAVES * 8) {
+    f32x4 xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = (i0 + u < I) ? ld4(xb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // the per-token scalars of this trip: lane u < 8 fetches token i0 + u, then broadcast
+    float a_l = 0.f, g_l = 0.f;
+    if (lane < 8 && i0 + lane < I) { a_l = ab[i0 + lane]; g_l = dab ? dab[i0 + lane] : 0.f; }
+    float d[8];
+    dots8(xv, gv, lane, d);
+    float mine = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), u));
+      const float dai = d[u] + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_l), u));
+      const float w = a * dai;   // a = 0 past I
+      s += w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { A[j] += w * xv[u][j]; O[j] += a * xv[u][j]; }
+      mine = (lane == u) ? dai : mine;
+    }
+    if (lane < 8 && i0 + lane < I) da[i0 + lane] = mine;
+  }
+  if (lane == 0) wsum[wave] = s;
+  reinterpret_cast<f32x4*>(&pa[wave][0])[lane] = A;
+  reinterpret_cast<f32x4*>(&po[wave][0])[lane] = O;
+  __syncthreads();
+  s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  dq[(size_t)b * AC + tid] = scale * ((pa[0][tid] + pa[1][tid] + pa[2][tid] + pa[3][tid]) -
+                                      s * (po[0][tid] + po[1][tid] + po[2][tid] + po[3][tid]));
+  // write pass: dx_i = dl_i * q + a_i * dout
+  for (int i0 = wave * 8; i0 < I; i0 += AWAVES * 8) {
+    float a_l = 0.f, dl_l = 0.f;
+    if (lane < 8 && i0 + lane < I) {
+      a_l = ab[i0 + lane];
+      dl_l = a_l * (da[i0 + lane] - s) * scale;
+      if (dlogits) dlogits[(size_t)b * I + i0 + lane] = dl_l;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (i0 + u >= I) break;
+      const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a_l), u));
+      const float dl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dl_l), u));
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = dl * qv[j] + a * gv[j];
+      st4(dxb + (size_t)(i0 + u) * AC, o);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) text attention with the key projection folded into the query (BASELINE configs[4]).
 // The reference computes k = W_k x + b_k per token and logits = q . k (mg_map_policy.py:126-132,173-178):
 // 2*256*256 FLOP per token, 99 % of the attention FLOPs, for ONE query per row.  Because there is a single
@@ -299,6 +489,10 @@ __global__ __launch_bounds__(256) void quantize_e4m3_kernel(const float* __restr
 extern "C" int wsmg_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* mask, float scale, int B,
                              int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  if (k == v) {   // keys are values: one-pass form
+    hipLaunchKernelGGL(attn_same_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, mask, scale, I, out, attn);
+    WSMG_RETURN_LAUNCH();
+  }
   hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn, (const int64_t*)nullptr);
   WSMG_RETURN_LAUNCH();
 }
@@ -306,6 +500,10 @@ extern "C" int wsmg_attn_fwd(const float* q, const float* k, const float* v, con
 extern "C" int wsmg_attn_fwd_bf16(const float* q, const void* k, const void* v, const uint8_t* mask, float scale, int B,
                                   int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  if (k == v) {
+    hipLaunchKernelGGL(attn_same_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k, mask, scale, I, out, attn);
+    WSMG_RETURN_LAUNCH();
+  }
   hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
                      (const bf16_t*)v, mask, scale, I, out, attn, (const int64_t*)nullptr);
   WSMG_RETURN_LAUNCH();
@@ -315,6 +513,11 @@ extern "C" int wsmg_attn_bwd(const float* q, const float* k, const float* v, con
                              const float* dattn, float scale, int B, int I, int C, float* dq, float* dk, float* dv,
                              wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  if (k == v && dk == dv) {   // keys are values: one read pass + one write pass
+    hipLaunchKernelGGL(attn_same_bwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, attn, dout, dattn, scale, I, dq, dk,
+                       (float*)nullptr);
+    WSMG_RETURN_LAUNCH();
+  }
   hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, attn, dout, dattn, scale,
                      I, dq, dk, dv, (const int64_t*)nullptr, (float*)nullptr);
   WSMG_RETURN_LAUNCH();
@@ -324,6 +527,11 @@ extern "C" int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, 
                                   const float* dattn, float scale, int B, int I, int C, float* dq, void* dk, void* dv,
                                   wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
+  if (k == v && dk == dv) {
+    hipLaunchKernelGGL(attn_same_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k, attn, dout, dattn, scale, I,
+                       dq, (bf16_t*)dk, (float*)nullptr);
+    WSMG_RETURN_LAUNCH();
+  }
   hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
                      (const bf16_t*)v, attn, dout, dattn, scale, I, dq, (bf16_t*)dk, (bf16_t*)dv, (const int64_t*)nullptr, (float*)nullptr);
   WSMG_RETURN_LAUNCH();

@@ -701,6 +701,8 @@ class _AttnFolded(torch.autograd.Function):
         _req(q, x, mask)
         _f32(q)
         B, I, C = x.shape
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
         wf = w.reshape(w.shape[0], -1).float()
         qf = (q @ wf).contiguous()
         out = torch.empty(B, C, device=q.device, dtype=torch.float32)
