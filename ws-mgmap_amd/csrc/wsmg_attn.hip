@@ -15,6 +15,7 @@ namespace {
 constexpr int AC = 256;       // channels (hidden_size/2)
 constexpr int AWAVES = 4;
 constexpr int AMAX_I = 1024;  // logits kept in LDS
+constexpr int SAME_WAVES = 16;  // waves per row of the keys-are-values kernels (B = 512 rows alone give only 2 workgroups per CU)
 
 __device__ inline float block_reduce_max(float v, float* sh, int wave, int lane) {
   v = wave_max(v);
@@ -262,23 +263,32 @@ __device__ __forceinline__ void dots8(const f32x4 (&xv)[8], const f32x4 g, int l
   for (int u = 0; u < 8; ++u) d[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 8 * u));
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void attn_same_fwd_kernel(const float* __restrict__ q, const T* __restrict__ x,
+template <class T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_same_fwd_kernel(const float* __restrict__ q, const T* __restrict__ x,
                                                             const uint8_t* __restrict__ mask, float scale, int I,
                                                             float* __restrict__ out, float* __restrict__ attn) {
   __shared__ float lg[AMAX_I];
-  __shared__ float wm[AWAVES], wsum[AWAVES];
-  __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
+  __shared__ float wm[NW], wsum[NW];
+  __shared__ __attribute__((aligned(16))) float part[NW][AC];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
   const T* xb = x + (size_t)b * I * AC + lane * 4;
   float m = -INFINITY, ssum = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int i0 = wave * 8; i0 < I; i0 += AWAVES * 8) {
-    f32x4 xv[8];
+  // the next trip's eight token rows are requested before this trip is reduced (the loop is latency-bound otherwise:
+  // 8 waves per CU, one 8-load batch in flight per wave)
+  f32x4 xv[8], xn[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xv[u] = (i0 + u < I) ? ld4(xb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 8; ++u) xn[u] = (wave * 8 + u < I) ? ld4(xb + (size_t)(wave * 8 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i0 = wave * 8; i0 < I; i0 += NW * 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = xn[u];
+    const int i1 = i0 + NW * 8;
+    if (i1 < I) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xn[u] = (i1 + u < I) ? ld4(xb + (size_t)(i1 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float d[8];
     dots8(xv, qv, lane, d);
     float mx = m;
@@ -314,29 +324,29 @@ __global__ __launch_bounds__(256) void attn_same_fwd_kernel(const float* __restr
   __syncthreads();
   float M = wm[0];
 #pragma unroll
-  for (int w = 1; w < AWAVES; ++w) M = fmaxf(M, wm[w]);
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, wm[w]);
   float S = 0.f, o = 0.f;
 #pragma unroll
-  for (int w = 0; w < AWAVES; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const float f = expf(wm[w] - M);   // a wave that saw no token has m = -inf, f = 0
     S += wsum[w] * f;
-    o += part[w][tid] * f;
+    o += part[w][tid & (AC - 1)] * f;
   }
   const float inv = 1.f / S;
-  out[(size_t)b * AC + tid] = o * inv;
-  for (int i = tid; i < I; i += 256) attn[(size_t)b * I + i] = expf(lg[i] - M) * inv;
+  if (tid < AC) out[(size_t)b * AC + tid] = o * inv;
+  for (int i = tid; i < I; i += NW * 64) attn[(size_t)b * I + i] = expf(lg[i] - M) * inv;
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void attn_same_bwd_kernel(const float* __restrict__ q, const T* __restrict__ x,
+template <class T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_same_bwd_kernel(const float* __restrict__ q, const T* __restrict__ x,
                                                             const float* __restrict__ attn,
                                                             const float* __restrict__ dout,
                                                             const float* __restrict__ dattn, float scale, int I,
                                                             float* __restrict__ dq, T* __restrict__ dx,
                                                             float* __restrict__ dlogits) {
   __shared__ float da[AMAX_I];
-  __shared__ float wsum[AWAVES];
-  __shared__ __attribute__((aligned(16))) float pa[AWAVES][AC], po[AWAVES][AC];
+  __shared__ float wsum[NW];
+  __shared__ __attribute__((aligned(16))) float pa[NW][AC], po[NW][AC];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4 qv = reinterpret_cast<const f32x4*>(q + (size_t)b * AC)[lane];
@@ -348,10 +358,17 @@ __global__ __launch_bounds__(256) void attn_same_bwd_kernel(const float* __restr
   // read pass
   float s = 0.f;
   f32x4 A = {0.f, 0.f, 0.f, 0.f}, O = {0.f, 0.f, 0.f, 0.f};
-  for (int i0 = wave * 8; i0 < I; i0 += AWAVES * 8) {
-    f32x4 xv[8];
+  f32x4 xv[8], xn[8];   // (next trip prefetched, as in the forward kernel)
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xv[u] = (i0 + u < I) ? ld4(xb + (size_t)(i0 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 8; ++u) xn[u] = (wave * 8 + u < I) ? ld4(xb + (size_t)(wave * 8 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i0 = wave * 8; i0 < I; i0 += NW * 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xv[u] = xn[u];
+    const int i1 = i0 + NW * 8;
+    if (i1 < I) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xn[u] = (i1 + u < I) ? ld4(xb + (size_t)(i1 + u) * AC) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // the per-token scalars of this trip: lane u < 8 fetches token i0 + u, then broadcast
     float a_l = 0.f, g_l = 0.f;
     if (lane < 8 && i0 + lane < I) { a_l = ab[i0 + lane]; g_l = dab ? dab[i0 + lane] : 0.f; }
@@ -374,11 +391,13 @@ __global__ __launch_bounds__(256) void attn_same_bwd_kernel(const float* __restr
   reinterpret_cast<f32x4*>(&pa[wave][0])[lane] = A;
   reinterpret_cast<f32x4*>(&po[wave][0])[lane] = O;
   __syncthreads();
-  s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  dq[(size_t)b * AC + tid] = scale * ((pa[0][tid] + pa[1][tid] + pa[2][tid] + pa[3][tid]) -
-                                      s * (po[0][tid] + po[1][tid] + po[2][tid] + po[3][tid]));
+  s = 0.f;
+  float sa = 0.f, so = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { s += wsum[w]; sa += pa[w][tid & (AC - 1)]; so += po[w][tid & (AC - 1)]; }
+  if (tid < AC) dq[(size_t)b * AC + tid] = scale * (sa - s * so);
   // write pass: dx_i = dl_i * q + a_i * dout
-  for (int i0 = wave * 8; i0 < I; i0 += AWAVES * 8) {
+  for (int i0 = wave * 8; i0 < I; i0 += NW * 8) {
     float a_l = 0.f, dl_l = 0.f;
     if (lane < 8 && i0 + lane < I) {
       a_l = ab[i0 + lane];
@@ -490,7 +509,7 @@ extern "C" int wsmg_attn_fwd(const float* q, const float* k, const float* v, con
                              int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   if (k == v) {   // keys are values: one-pass form
-    hipLaunchKernelGGL(attn_same_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, mask, scale, I, out, attn);
+    hipLaunchKernelGGL((attn_same_fwd_kernel<float, SAME_WAVES>), dim3(B), dim3(SAME_WAVES * 64), 0, wsmg_s(stream), q, k, mask, scale, I, out, attn);
     WSMG_RETURN_LAUNCH();
   }
   hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, v, mask, scale, I, out, attn, (const int64_t*)nullptr);
@@ -501,7 +520,7 @@ extern "C" int wsmg_attn_fwd_bf16(const float* q, const void* k, const void* v, 
                                   int I, int C, float* out, float* attn, wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   if (k == v) {
-    hipLaunchKernelGGL(attn_same_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k, mask, scale, I, out, attn);
+    hipLaunchKernelGGL((attn_same_fwd_kernel<bf16_t, SAME_WAVES>), dim3(B), dim3(SAME_WAVES * 64), 0, wsmg_s(stream), q, (const bf16_t*)k, mask, scale, I, out, attn);
     WSMG_RETURN_LAUNCH();
   }
   hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
@@ -514,7 +533,7 @@ extern "C" int wsmg_attn_bwd(const float* q, const float* k, const float* v, con
                              wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   if (k == v && dk == dv) {   // keys are values: one read pass + one write pass
-    hipLaunchKernelGGL(attn_same_bwd_kernel<float>, dim3(B), dim3(256), 0, wsmg_s(stream), q, k, attn, dout, dattn, scale, I, dq, dk,
+    hipLaunchKernelGGL((attn_same_bwd_kernel<float, SAME_WAVES>), dim3(B), dim3(SAME_WAVES * 64), 0, wsmg_s(stream), q, k, attn, dout, dattn, scale, I, dq, dk,
                        (float*)nullptr);
     WSMG_RETURN_LAUNCH();
   }
@@ -528,7 +547,7 @@ extern "C" int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, 
                                   wsmg_stream_t stream) {
   if (C != AC || B <= 0 || I <= 0 || I > AMAX_I) return WSMG_EINVAL;
   if (k == v && dk == dv) {
-    hipLaunchKernelGGL(attn_same_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k, attn, dout, dattn, scale, I,
+    hipLaunchKernelGGL((attn_same_bwd_kernel<bf16_t, SAME_WAVES>), dim3(B), dim3(SAME_WAVES * 64), 0, wsmg_s(stream), q, (const bf16_t*)k, attn, dout, dattn, scale, I,
                        dq, (bf16_t*)dk, (float*)nullptr);
     WSMG_RETURN_LAUNCH();
   }
