@@ -72,7 +72,7 @@ class BasePolicy(nn.Module):
         if cfg.CONTRASTIVE_MONITOR.use:
             size = self.net.map_encoder.output_shape[-1]
             dis = observations["gt_path"] if "gt_path" in observations.keys() else observations["waypoint_distribution"]
-            hi, lo = dis.max(), dis.min()  # batch-global normalisation, as the reference does
+            lo, hi = torch.aminmax(dis)  # batch-global normalisation, as the reference does (dis.max(), dis.min()) in one pass
             target = F.interpolate(((hi - dis) / (hi - lo)).unsqueeze(1), size=[size, size], mode="area").squeeze(1)
             target = F.softmax(target.reshape(target.shape[0], -1) / cfg.CONTRASTIVE_MONITOR.target_tau, dim=1)
             kl = F.kl_div(torch.log(self.net.att_map_t_m), target, reduction="none").mean(-1)
