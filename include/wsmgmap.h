@@ -244,6 +244,11 @@ int wsmg_weight_relayout_bf16(const float* w_oihw, int O, int I, int KH, int KW,
 int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW, int I_pad, float* dw_oihw,
                              wsmg_stream_t stream);
 
+/* torch.cat([a, b], dim=1) of the reference's NCHW tensors (UNet skip connections map_encoder.py:104,110, map
+ * projections mg_map_policy.py:99) on NHWC storage: y[p] = a[p] ++ b[p] for `rows` pixels; a pixel's channel run is
+ * bytes_a / bytes_b bytes (multiples of 16; any element type), 16-byte aligned pointers. */
+int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t rows, int bytes_a, int bytes_b, wsmg_stream_t stream);
+
 /* per-pixel cross-entropy of the semantic-hallucination head straight from the NHWC logits (policy.py:61-66:
  * F.cross_entropy(pred_sem_map, target, reduction='none')): logits [rows][32] (classes <= 32 valid channels, the rest
  * padding), target int64 [rows]; loss [rows] = logsumexp - logit[target].  bwd: dlogits [rows][32] =

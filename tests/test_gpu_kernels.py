@@ -929,3 +929,21 @@ def test_conv2d_over_concatenated_parts(ops, relu, pad_last):
     # and the single-tensor route of the same operator agrees to bf16 rounding
     y1 = ops.conv2d(torch.cat([a, b], dim=-1), w, bias, 1, 1, relu=relu)
     assert float((y1.float() - y.float()).abs().max()) <= 2.0 ** -6 * sy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_cat_channels_matches_torch_cat(ops, dt):
+    """ops.cat_channels == torch.cat(dim=-1) on NHWC tensors (the reference's torch.cat(dim=1), map_encoder.py:104,110,
+    mg_map_policy.py:99), bit for bit, gradients included (they are the channel slices of dy)."""
+    torch.manual_seed(5)
+    a = torch.randn(3, 12, 12, 64, device="cuda").to(dt).requires_grad_(True)
+    b = torch.randn(3, 12, 12, 128, device="cuda").to(dt).requires_grad_(True)
+    y = ops.cat_channels(a, b)
+    assert torch.equal(y, torch.cat([a, b], dim=-1))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    assert torch.equal(a.grad, gy[..., :64]) and torch.equal(b.grad, gy[..., 64:])
+    # a channel run that is not a multiple of 16 bytes takes the torch.cat route
+    c = torch.randn(2, 5, 5, 3, device="cuda").to(dt)
+    assert torch.equal(ops.cat_channels(c, c), torch.cat([c, c], dim=-1))

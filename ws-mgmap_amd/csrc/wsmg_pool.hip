@@ -365,6 +365,20 @@ __global__ __launch_bounds__(256) void weight_grad_to_oihw_kernel(const float* _
   }
 }
 
+// ---- channel concatenation of two NHWC tensors (the UNet skip connections, map_encoder.py:104,110, and
+// mg_map_policy.py:99): out[p] = a[p] ++ b[p], one 16-byte chunk per thread, the pixel index computed once per chunk
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__global__ void cat_channels_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b, u32x4_t* __restrict__ y,
+                                    int64_t rows, int ca, int cb) {
+  const int cy = ca + cb;
+  const int64_t n = rows * cy;
+  GRID_STRIDE(i, n) {
+    const int64_t p = i / cy;
+    const int c = (int)(i - p * cy);
+    y[i] = c < ca ? a[p * ca + c] : b[p * cb + (c - ca)];
+  }
+}
+
 template <class T>
 int relu_fwd_t(const T* x, T* y, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
@@ -439,6 +453,14 @@ int transpose_t(const TI* x, TO* y, int B, int C_src, int H, int W, int C_dst, w
 
 #define B16(p) ((bf16_t*)(p))
 #define CB16(p) ((const bf16_t*)(p))
+extern "C" int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t rows, int bytes_a, int bytes_b, wsmg_stream_t s) {
+  if (rows <= 0 || bytes_a <= 0 || bytes_b <= 0 || (bytes_a & 15) || (bytes_b & 15)) return WSMG_EINVAL;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) return WSMG_EINVAL;
+  const int ca = bytes_a / 16, cb = bytes_b / 16;
+  hipLaunchKernelGGL(cat_channels_kernel, dim3(sgrid(rows * (ca + cb))), dim3(256), 0, wsmg_s(s), (const u32x4_t*)a, (const u32x4_t*)b,
+                     (u32x4_t*)y, rows, ca, cb);
+  WSMG_RETURN_LAUNCH();
+}
 extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<float>(x, y, n, s); }
 extern "C" int wsmg_relu_fwd_bf16(const void* x, void* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<bf16_t>(CB16(x), B16(y), n, s); }
 extern "C" int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<float>(dy, y, dx, n, s); }

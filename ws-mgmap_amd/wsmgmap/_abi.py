@@ -66,6 +66,7 @@ _SIG["wsmg_quantize_e4m3"] = [c_p, c_l, c_f, c_p, c_p]
 _SIG["wsmg_weight_relayout"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_weight_relayout_bf16"] = list(_SIG["wsmg_weight_relayout"])
 _SIG["wsmg_weight_grad_to_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
+_SIG["wsmg_cat_channels"] = [c_p, c_p, c_p, c_l, c_i, c_i, c_p]
 _SIG["wsmg_ce_nhwc_fwd"] = [c_p, c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_ce_nhwc_bwd"] = [c_p, c_p, c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_ce_nhwc_fwd_bf16"] = list(_SIG["wsmg_ce_nhwc_fwd"])

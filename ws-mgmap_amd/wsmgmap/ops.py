@@ -360,7 +360,8 @@ def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, rel
     # conv — two shorter reductions, two epilogues (the second re-reads y) and twice the weight-gradient launches cost
     # more than the 0.35 ms of concatenation and slice copies they remove — so the part-by-part route is opt-in
     if xs[0].dtype != torch.bfloat16 or _os.environ.get("WSMG_CONV_CAT", "0") != "1":
-        return conv2d(torch.cat(xs, dim=-1), weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+        x = cat_channels(xs[0], xs[1]) if len(xs) == 2 else torch.cat(xs, dim=-1)
+        return conv2d(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu)
     return _Conv2dCat.apply(weight_oihw, bias, stride, pad, bias_grad_zero, relu, *xs)
 
 
@@ -733,6 +734,36 @@ class _AttnFolded(torch.autograd.Function):
 def attention_folded(q, w, b, x, mask, scale):
     """(context [B,C], weights [B,I]) of softmax(scale * (q . (W x_i + b) - 1e8 mask_i)) over x [B,I,C]."""
     return _AttnFolded.apply(q, w, b, x, mask, scale)
+
+
+class _CatChannels(torch.autograd.Function):
+    """torch.cat([a, b], dim=-1) of two NHWC tensors in one 16-byte-vectorised launch (wsmg_cat_channels); the gradients
+    are the two channel slices of dy (views, as torch.cat returns them)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _req(a, b)
+        if a.dtype != b.dtype or a.shape[:-1] != b.shape[:-1]:
+            raise _abi.WsmgError("cat_channels: tensors must agree in dtype and in every dimension but the last")
+        ca, cb = a.shape[-1], b.shape[-1]
+        y = torch.empty(a.shape[:-1] + (ca + cb,), device=a.device, dtype=a.dtype)
+        es = a.element_size()
+        _abi.call("wsmg_cat_channels", _p(a), _p(b), _p(y), a.numel() // ca, ca * es, cb * es, _stream())
+        ctx.ca = ca
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy[..., :ctx.ca], dy[..., ctx.ca:]
+
+
+def cat_channels(a, b):
+    """Channel concatenation of two NHWC activations (falls back to torch.cat when a channel run is not a multiple of 16
+    bytes)."""
+    es = a.element_size()
+    if (a.shape[-1] * es) % 16 or (b.shape[-1] * es) % 16:
+        return torch.cat([a, b], dim=-1)
+    return _CatChannels.apply(a.contiguous(), b.contiguous())
 
 
 class _TokenMean(torch.autograd.Function):
