@@ -510,7 +510,9 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
   a.npix = (int64_t)B * OH * OW;
   // tile shape (measured per layer, tools/bench_conv.py): 128 co x 8 units where both dimensions are
   // large (cated 765 vs 660 TFLOP/s), else 64 co x 4 units, which keeps 5 workgroups per CU resident
-  int tc = (Cout % 128 == 0 && a.units >= 48) ? 4 : 2, tu = tc == 4 ? 2 : 1;
+  // (the 64-channel k8 stem, 128 units of 64 input channels: 64 co x 8 units measured 0.94 vs 0.99 ms; every other
+  // 64-wide layer is faster with 4 units)
+  int tc = (Cout % 128 == 0 && a.units >= 48) ? 4 : 2, tu = (tc == 4 || (Cin == 64 && a.units >= 128)) ? 2 : 1;
   if (const char* e = getenv("WSMG_WGRAD_TILE")) {   // debug: "42", "21", "22"
     int v = atoi(e);
     if (v == 42 || v == 21 || v == 22) { tc = v / 10; tu = v % 10; }
