@@ -63,3 +63,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// wsmg_conv_win.hip: direct convolution with an LDS-resident input window (64 -> 64 channels, k8 s2 p3); WSMG_EINVAL for
+// any other shape
+int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int relu, int B, int H, int W, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s);

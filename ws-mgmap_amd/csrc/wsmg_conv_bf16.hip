@@ -478,6 +478,16 @@ extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const flo
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
                                     int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  if (Cin == 64 && Cout == 64 && KH == 8 && KW == 8 && stride == 2 && pad == 3 && (out_f32 & 5) == 0) {
+    // the map encoder's stem: direct convolution out of an LDS-resident input window (wsmg_conv_win.hip); WSMG_CONV_WIN=0
+    // keeps the implicit-GEMM kernel (A/B)
+    static int use_win = -1;
+    if (use_win < 0) { const char* e = getenv("WSMG_CONV_WIN"); use_win = e ? atoi(e) : 1; }
+    if (use_win) {
+      int rc = wsmg_conv_win_fwd_bf16(x, w_ohwi, bias, y, (out_f32 & 2) != 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
+      if (rc != WSMG_EINVAL) return rc;
+    }
+  }
   ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32,
               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2)};
   launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream));
