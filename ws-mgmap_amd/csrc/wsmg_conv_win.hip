@@ -148,8 +148,16 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
   fload(0, cur);
 #pragma unroll
   for (int tap = 0; tap < K * K; ++tap) {
-    // The 12 fragment reads of tap t+1 are interleaved with the 8 MFMAs of tap t (MFMA, 2 reads, MFMA, 1 read, ...): a wave
-    // issues in order, so 12 reads in a row hold back its first MFMA until the LDS queue (shared with the other three
+    // (1) the weight slice of tap t+2 goes to LDS FIRST: its buffer held tap t-1, which every wave finished reading a
+    // barrier ago.  LDS operations of a wave complete in order, so at the end of the tap `lgkmcnt(12)` — everything but
+    // the 12 fragment reads issued after these two writes — means the writes have landed, without waiting for the tail
+    // of the reads (which the next tap's MFMAs wait for one by one).
+    if (tap + 2 < K * K) {
+      wstore((tap + 2) % 3, ring[(tap + 2) % RING][0], ring[(tap + 2) % RING][1]);
+      if (tap + 2 + RING < K * K) wload(tap + 2 + RING, ring[(tap + 2) % RING][0], ring[(tap + 2) % RING][1]);   // refill the slot
+    }
+    // (2) The 12 fragment reads of tap t+1 are interleaved with the 8 MFMAs of tap t (MFMA, 2 reads, MFMA, 1 read, ...): a
+    // wave issues in order, so 12 reads in a row hold back its first MFMA until the LDS queue (shared with the other three
     // waves' 36 reads) has taken them — LDS time and MFMA time added up instead of overlapping (580 clocks per tap) —
     // and left to itself the scheduler folds the two fragment sets into one and reads each fragment just before its use.
     __builtin_amdgcn_sched_barrier(0);
@@ -167,14 +175,11 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (tap + 2 < K * K) {   // LDS buffer (tap + 2) % 3 held tap - 1: every wave finished reading it a barrier ago
-      wstore((tap + 2) % 3, ring[(tap + 2) % RING][0], ring[(tap + 2) % RING][1]);
-      if (tap + 2 + RING < K * K) wload(tap + 2 + RING, ring[(tap + 2) % RING][0], ring[(tap + 2) % RING][1]);   // refill the slot
-    }
     if (tap + 1 < K * K) {
       // raw barrier: __syncthreads() also waits for vmcnt(0), i.e. for every weight slice still in flight in the ring —
-      // a memory round trip per tap.  LDS writes of this wave are complete at lgkmcnt(0); nothing else crosses waves.
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // a memory round trip per tap
+      if (tap + 2 < K * K) asm volatile("s_waitcnt lgkmcnt(12)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_barrier" ::: "memory");
       cur = nxt;
     }
   }
