@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   constexpr int APASS = BM / RPP;            // A passes per thread
   constexpr int BPASS = BN / RPP;            // B passes per thread
   constexpr int NT = BN / 64;                // 32-wide n-tiles per wave
-  __shared__ __attribute__((aligned(16))) unsigned char As[BM * LDB];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * LDB];
+  constexpr int OPITCH = BN * 2 + 16;   // row pitch of the output tile that is staged in the same memory by the epilogue
+  constexpr int SMEM = (BM + BN) * LDB > BM * OPITCH ? (BM + BN) * LDB : BM * OPITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];   // A tile, B tile; the output tile afterwards
+  unsigned char* const As = smem;
+  unsigned char* const Bs = smem + BM * LDB;
   __shared__ int dpix[BM];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -201,6 +204,42 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
     }
   }
 
+  // bf16 output, no accumulate: the tile is transposed through LDS (the operand tiles are dead) and leaves as 16-byte
+  // stores, 8 channels per lane — the C layout of the 32x32 MFMA (a lane holds ONE channel of 16 rows) made the direct
+  // route 16 two-byte stores per accumulator tile and lane, which was a third of the short-reduction launches
+  // (backward-data of the 64-channel layers: 9 k-steps per tile)
+  constexpr int OP = OPITCH;
+  {
+    if ((a.out_f32 & 5) == 0 && (a.N & 7) == 0) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int col = wn + 32 * u + r;
+        const float bv = (a.bias && n0 + col < a.N) ? a.bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int row = wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+            float v = acc[t][u][g] + bv;
+            if (a.out_f32 & 2) v = v > 0.f ? v : 0.f;
+            *reinterpret_cast<unsigned short*>(smem + row * OP + col * 2) = f2bf_bits(v);
+          }
+      }
+      __syncthreads();
+      constexpr int CPR = BN / 8;   // 16-byte pieces per row
+#pragma unroll
+      for (int j = 0; j < BM * CPR / 256; ++j) {
+        const int c = tid + 256 * j;
+        const int row = c / CPR, ch = c - row * CPR;
+        const int dp = dpix[row];
+        const int n = n0 + ch * 8;
+        if (dp < 0 || n >= a.N) continue;
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)dp * a.N + n) * 2) =
+            *reinterpret_cast<const u32x4*>(smem + row * OP + ch * 16);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const int n = n0 + wn + 32 * u + r;
