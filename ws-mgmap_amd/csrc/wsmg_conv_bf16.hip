@@ -567,7 +567,11 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
     if (v == 42 || v == 21 || v == 22) { tc = v / 10; tu = v % 10; }
   }
   int gx = (int)wsmg_cdiv(a.units, 4 * tu), gy = (int)wsmg_cdiv(Cout, 32 * tc);
-  int64_t target = tc == 4 ? 1024 : 2048;   // workgroups over the pixel reduction (the k8 stem's 64 x 8 tile: 0.90 ms at 2048, 0.96 at 1024)
+  // workgroups over the pixel reduction (the k8 stem's 64 x 8 tile: 0.90 ms at 2048, 0.96 at 1024).  Every workgroup ends
+  // with a tile of float32 atomics, which is 40-50 % of the launch for the small layers (tools sweep, WSMG_WGRAD_WANT):
+  // below 40 GFLOP fewer, longer workgroups win (768: -0.08 ms over the six small layers of the update)
+  const double gflop = 2.0 * (double)a.npix * Cout * Cin * KH * KW * 1e-9;
+  int64_t target = tc == 4 ? 1024 : (gflop < 40.0 ? 768 : 2048);
   if (const char* e = getenv("WSMG_WGRAD_WANT")) { int v = atoi(e); if (v > 0) target = v; }
   int64_t want = wsmg_cdiv(target, (int64_t)gx * gy);
   int64_t maxz = wsmg_cdiv(a.npix, WKP * 8);
