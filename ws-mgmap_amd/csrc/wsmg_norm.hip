@@ -6,6 +6,10 @@
 // tail (relu(bn2(conv2) + identity)).  Train-mode BN couples the whole T*N batch, so it is a
 // two-pass structure: (1) a chip-wide column reduction in float64 partials, (2) a streaming
 // normalise pass.  HBM-bound: pass 1 reads x once, pass 2 reads x (+res) and writes y.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "wsmg_common.h"
 
 namespace {
@@ -266,6 +270,113 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ---- bf16 activations: 8 channels (one 16-byte access) per thread instead of 4 (8 bytes)
+typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void unpack8(const u32x4n raw, f32x4& lo, f32x4& hi) {
+  lo[0] = __uint_as_float(raw[0] << 16); lo[1] = __uint_as_float(raw[0] & 0xffff0000u);
+  lo[2] = __uint_as_float(raw[1] << 16); lo[3] = __uint_as_float(raw[1] & 0xffff0000u);
+  hi[0] = __uint_as_float(raw[2] << 16); hi[1] = __uint_as_float(raw[2] & 0xffff0000u);
+  hi[2] = __uint_as_float(raw[3] << 16); hi[3] = __uint_as_float(raw[3] & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  bf16_t x = (bf16_t)a, y = (bf16_t)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ u32x4n pack8(const f32x4& lo, const f32x4& hi) {
+  u32x4n r = {pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+  return r;
+}
+
+__global__ __launch_bounds__(256) void bn_apply8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        int relu, int64_t rows, int C, bf16_t* __restrict__ y) {
+  const int C8 = C >> 3;
+  const int c = (threadIdx.x % C8) * 8;
+  const int rl = threadIdx.x / C8;
+  const int rpi = 256 / C8;
+  f32x4 g[2], b[2], m[2], s[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    g[k] = *reinterpret_cast<const f32x4*>(gamma + c + 4 * k); b[k] = *reinterpret_cast<const f32x4*>(beta + c + 4 * k);
+    m[k] = *reinterpret_cast<const f32x4*>(mean + c + 4 * k);  s[k] = *reinterpret_cast<const f32x4*>(invstd + c + 4 * k);
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
+    const size_t o = (size_t)r * C + c;
+    f32x4 v[2], rr[2], out[2];
+    unpack8(*reinterpret_cast<const u32x4n*>(x + o), v[0], v[1]);
+    if (res) unpack8(*reinterpret_cast<const u32x4n*>(res + o), rr[0], rr[1]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = (v[k][j] - m[k][j]) * s[k][j] * g[k][j] + b[k][j];
+        if (res) t += rr[k][j];
+        if (relu) t = t > 0.f ? t : 0.f;
+        out[k][j] = t;
+      }
+    *reinterpret_cast<u32x4n*>(y + o) = pack8(out[0], out[1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ y, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ dgamma,
+                                                            const float* __restrict__ dbeta, int relu, float inv_n, int64_t rows,
+                                                            int C, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres) {
+  const int C8 = C >> 3;
+  const int c = (threadIdx.x % C8) * 8;
+  const int rl = threadIdx.x / C8;
+  const int rpi = 256 / C8;
+  f32x4 gm[2], mu[2], is[2], bt[2], k0[2], k1[2], k2[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    gm[k] = *reinterpret_cast<const f32x4*>(gamma + c + 4 * k);
+    mu[k] = *reinterpret_cast<const f32x4*>(mean + c + 4 * k);
+    is[k] = *reinterpret_cast<const f32x4*>(invstd + c + 4 * k);
+    const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c + 4 * k), db = *reinterpret_cast<const f32x4*>(dbeta + c + 4 * k);
+    bt[k] = (relu && !y) ? *reinterpret_cast<const f32x4*>(beta + c + 4 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k0[k][j] = gm[k][j] * is[k][j]; k1[k][j] = db[j] * inv_n; k2[k][j] = dg[j] * inv_n; }
+  }
+  for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
+    const size_t o = (size_t)r * C + c;
+    f32x4 g[2], xv[2], yv[2], out[2];
+    unpack8(*reinterpret_cast<const u32x4n*>(dy + o), g[0], g[1]);
+    unpack8(*reinterpret_cast<const u32x4n*>(x + o), xv[0], xv[1]);
+    if (relu && y) unpack8(*reinterpret_cast<const u32x4n*>(y + o), yv[0], yv[1]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (relu) {
+          const bool on = y ? yv[k][j] > 0.f : ((xv[k][j] - mu[k][j]) * is[k][j] * gm[k][j] + bt[k][j]) > 0.f;
+          g[k][j] = on ? g[k][j] : 0.f;
+        }
+        const float xh = (xv[k][j] - mu[k][j]) * is[k][j];
+        out[k][j] = k0[k][j] * (g[k][j] - k1[k][j] - xh * k2[k][j]);
+      }
+    if (dres) *reinterpret_cast<u32x4n*>(dres + o) = pack8(g[0], g[1]);
+    *reinterpret_cast<u32x4n*>(dx + o) = pack8(out[0], out[1]);
+  }
+}
+
+// WSMG_BN_VEC8=0: the 4-channel kernels for bf16 as well (A/B)
+bool bn_vec8() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("WSMG_BN_VEC8"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
+int stream_grid8(int64_t rows, int C) {
+  int64_t rpi = 256 / (C / 8);
+  int64_t g = wsmg_cdiv(rows, rpi * 4);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 bool chan_ok(int C) { return C == 32 || C == 64 || C == 128 || C == 256 || C == 512; }
 
 int stream_grid(int64_t rows, int C) {
@@ -306,6 +417,13 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((unsigned)wsmg_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, eps, C,
                        save_mean, save_invstd);
   }
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (bn_vec8()) {
+      hipLaunchKernelGGL(bn_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, s, x, residual, gamma, beta, save_mean,
+                         save_invstd, relu, rows, C, y);
+      WSMG_RETURN_LAUNCH();
+    }
+  }
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, x, residual, gamma, beta,
                      save_mean, save_invstd, relu, rows, C, y);
   WSMG_RETURN_LAUNCH();
@@ -323,6 +441,13 @@ int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const 
   hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
                      gamma, beta, relu, rows, C, workspace);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (bn_vec8()) {
+      hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
+                         save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual);
+      WSMG_RETURN_LAUNCH();
+    }
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
                      save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual);
   WSMG_RETURN_LAUNCH();
