@@ -379,15 +379,52 @@ __global__ void cat_channels_kernel(const u32x4_t* __restrict__ a, const u32x4_t
   }
 }
 
+// bf16: 8 values (one 16-byte access) per thread
+__device__ __forceinline__ unsigned relu2(unsigned v) {   // two packed bf16: x > 0 ? x : 0 (NaN -> 0, like the float compare)
+  const float lo = __uint_as_float(v << 16), hi = __uint_as_float(v & 0xffff0000u);
+  return (lo > 0.f ? (v & 0xffffu) : 0u) | (hi > 0.f ? (v & 0xffff0000u) : 0u);
+}
+__device__ __forceinline__ unsigned mask2(unsigned g, unsigned y) {   // g where y > 0, else 0
+  const float lo = __uint_as_float(y << 16), hi = __uint_as_float(y & 0xffff0000u);
+  return (lo > 0.f ? (g & 0xffffu) : 0u) | (hi > 0.f ? (g & 0xffff0000u) : 0u);
+}
+__global__ void relu_fwd8_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ y, int64_t n8) {
+  GRID_STRIDE(i, n8) {
+    const u32x4_t v = x[i];
+    u32x4_t o = {relu2(v[0]), relu2(v[1]), relu2(v[2]), relu2(v[3])};
+    y[i] = o;
+  }
+}
+__global__ void relu_bwd8_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* __restrict__ y, u32x4_t* __restrict__ dx, int64_t n8) {
+  GRID_STRIDE(i, n8) {
+    const u32x4_t g = dy[i], v = y[i];
+    u32x4_t o = {mask2(g[0], v[0]), mask2(g[1], v[1]), mask2(g[2], v[2]), mask2(g[3], v[3])};
+    dx[i] = o;
+  }
+}
+
 template <class T>
 int relu_fwd_t(const T* x, T* y, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (n % 8 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+      hipLaunchKernelGGL(relu_fwd8_kernel, dim3(sgrid(n / 8)), dim3(256), 0, wsmg_s(stream), (const u32x4_t*)x, (u32x4_t*)y, n / 8);
+      WSMG_RETURN_LAUNCH();
+    }
+  }
   hipLaunchKernelGGL(relu_fwd_kernel<T>, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), x, y, n / 4);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
 int relu_bwd_t(const T* dy, const T* y, T* dx, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (n % 8 == 0 && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15) == 0) {
+      hipLaunchKernelGGL(relu_bwd8_kernel, dim3(sgrid(n / 8)), dim3(256), 0, wsmg_s(stream), (const u32x4_t*)dy, (const u32x4_t*)y,
+                         (u32x4_t*)dx, n / 8);
+      WSMG_RETURN_LAUNCH();
+    }
+  }
   hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(sgrid(n / 4)), dim3(256), 0, wsmg_s(stream), dy, y, dx, n / 4);
   WSMG_RETURN_LAUNCH();
 }
