@@ -169,6 +169,38 @@ def _weight_grad_oihw(dw_ohwi, I):
     return out
 
 
+_wgrad_side = {}
+_side_join_armed = set()
+
+
+def _wgrad_side_stream():
+    """Side stream of the weight-gradient launches (WSMG_WGRAD_STREAM=1; not with a process group: the gradient
+    all-reduce hooks read p.grad on the main stream as soon as it is accumulated)."""
+    if _os.environ.get("WSMG_WGRAD_STREAM", "0") != "1":
+        return None
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return None
+    dev = torch.cuda.current_device()
+    if dev not in _wgrad_side:
+        _wgrad_side[dev] = torch.cuda.Stream()
+    return _wgrad_side[dev]
+
+
+def _join_side_at_end(main, side):
+    key = (main.cuda_stream, side.cuda_stream)
+    if key in _side_join_armed:
+        return
+
+    def join():
+        _side_join_armed.discard(key)
+        main.wait_stream(side)
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        _side_join_armed.add(key)
+    except RuntimeError:      # not inside a backward pass: join now
+        main.wait_stream(side)
+
+
 class _Conv2d(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC x; w is the reference's OIHW float32 parameter (its .grad comes back OIHW
     float32).  x float32 -> f32 MFMA engine; x bf16 -> bf16 operands, float32 accumulation and dW.  If x has more
@@ -217,9 +249,24 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
-            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
-            dw = _weight_grad_oihw(dw_ohwi, Cin_w)
+            side = _wgrad_side_stream()
+            if side is None:
+                dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
+                _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
+                dw = _weight_grad_oihw(dw_ohwi, Cin_w)
+            else:
+                # the weight gradient is a leaf of the backward graph: it runs on a side stream beside the backward-data
+                # chain and fills the tails of its launches (1.8-3.6 waves of workgroups each); the main stream joins the
+                # side stream once, at the end of the backward pass
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                x.record_stream(side)
+                dy.record_stream(side)
+                with torch.cuda.stream(side):
+                    dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
+                    _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
+                    dw = _weight_grad_oihw(dw_ohwi, Cin_w)
+                _join_side_at_end(main, side)
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
