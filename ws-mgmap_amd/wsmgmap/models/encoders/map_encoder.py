@@ -6,6 +6,8 @@ Module / parameter names reproduce the reference's state_dict contract
 conv / batch-norm / pooling kernels of libwsmgmap.so on NHWC activations (wsmgmap.ops).
 The nn.Conv2d / nn.BatchNorm2d children are parameter containers only.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -107,6 +109,7 @@ class MapDecoder(nn.Module):
         self.conv_original_size1 = convrelu(64, 64, 3, 1)
         self.conv_original_size2 = convrelu(64 + 128, 64, 3, 1)
         self.output_shape = [64, 100, 100]
+        self._side = None
 
     def _block(self, x, blk, train):
         y = conv_bn_relu(x, blk.conv1, blk.bn1, train)
@@ -116,7 +119,21 @@ class MapDecoder(nn.Module):
         import torch
         train = self.training
         cr = lambda t, seq: conv_bn_relu(t, seq[0], seq[1], train)  # noqa: E731
-        x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
+        # The full-resolution branch (two 3x3 convs) is independent of the resnet branch until the last concatenation, and
+        # the resnet branch is mostly launch-latency-bound (6x6 and 12x12 maps: ~15 us kernels that leave the chip idle):
+        # the full-resolution branch runs on a side stream beside it — in backward too, where autograd replays every node
+        # on its forward stream.  WSMG_DECODER_STREAMS=0: one stream.
+        side = None
+        if x.is_cuda and os.environ.get("WSMG_DECODER_STREAMS", "1") != "0":
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side, main = self._side, torch.cuda.current_stream()
+            side.wait_stream(main)
+            x.record_stream(side)   # x is saved for the side-stream backward of these layers: no reuse of its memory before that ran
+            with torch.cuda.stream(side):
+                x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
+        else:
+            x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
         stem = self.base_model
         layer0 = conv_bn_relu(x, stem.conv1, stem.bn1, train)
         layer1 = ops.maxpool3x3s2(layer0)
@@ -125,4 +142,7 @@ class MapDecoder(nn.Module):
         up = ops.upsample2x(cr(layer1, self.layer1_1x1))
         up = cr([up, cr(layer0, self.layer0_1x1)], self.conv_up0)        # torch.cat(dim=1) of the reference, folded into the conv
         up = ops.upsample2x(up)
+        if side is not None:
+            main.wait_stream(side)
+            x_original.record_stream(main)
         return cr([up, x_original], self.conv_original_size2)

@@ -51,7 +51,9 @@ def _sfx(t):
 
 def _workspace(device):
     """float64 scratch for the chip-wide column reductions (4 MiB covers 1024 blocks x 2 x 256)."""
-    key = (device.type, device.index)
+    # one buffer per STREAM: launches of one stream use it one after the other, but reductions on two streams (the decoder's
+    # side-stream branch, the instruction branch's bias gradient) run at the same time
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None:
         ws = torch.empty(1024 * 2 * 256, dtype=torch.float64, device=device)
