@@ -947,3 +947,36 @@ def test_cat_channels_matches_torch_cat(ops, dt):
     # a channel run that is not a multiple of 16 bytes takes the torch.cat route
     c = torch.randn(2, 5, 5, 3, device="cuda").to(dt)
     assert torch.equal(ops.cat_channels(c, c), torch.cat([c, c], dim=-1))
+
+
+@pytest.mark.gpu
+def test_bn_reductions_on_two_streams_do_not_share_scratch(ops):
+    """Train-mode BatchNorm launches on two streams at the same time (the decoder's side-stream branch beside the main
+    branch) must each get their own reduction scratch: every concurrent result is bit-identical to the result of the same
+    call made alone (a scratch buffer shared between streams made the statistics of one launch leak into the other)."""
+    torch.manual_seed(9)
+    C = 64
+    xs = [torch.randn(64, 48, 48, C, device="cuda").bfloat16() * (1 + i) + i for i in range(2)]
+    g, b = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+
+    def call(x):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        return ops.bn_act(x, g, b, rm, rv, True, True, None, 0.1, 1e-5)
+
+    alone = [call(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    big = torch.randn(4096, 4096, device="cuda")
+    for rep in range(30):
+        outs = []
+        for s in streams:       # back both queues up behind ~1 ms of work, so that the BN launches of the two streams
+            with torch.cuda.stream(s):   # become runnable together instead of one call after the other
+                big @ big
+        for s, x in zip(streams, xs):
+            with torch.cuda.stream(s):
+                outs.append(call(x))
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(outs[i], alone[i]), (rep, i)

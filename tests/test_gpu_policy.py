@@ -319,3 +319,25 @@ def test_frozen_rgb_unet_on_the_bf16_engine_tracks_the_stock_path():
         for a, b, name in ((l4, l4_ref, "layer4"), (proj, proj_ref, "proj_feat")):
             rel = float((a - b).norm() / b.norm())
             assert rel < 2e-2, (hw, name, rel)
+
+
+def test_update_gradients_repeatable_with_side_streams():
+    """The update runs parts of the graph on side streams (instruction branch, the decoder's full-resolution branch).
+    Two evaluations of the same update from the same state must give the same gradients up to the summation order of
+    the float32 atomics (cosine of the whole gradient >= 0.99999; a reduction workspace shared between streams — the bug
+    this guards — moved the loss by 10-20 % within 30 steps).  T=16 x N=8, bf16 mode, 3 repeats."""
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.policy import BasePolicy
+    torch.manual_seed(0)
+    state = BasePolicy(None, _Box(), default_model_config()).state_dict()
+    runs = [_bench_like_update("bf16", 16, 8, state) for _ in range(3)]
+    p0, l0, g0 = runs[0]
+    a = torch.cat([g0[n].flatten() for n in g0])
+    for p, l, g in runs[1:]:
+        assert float((p - p0).abs().max()) <= 1e-5, "forward differs between identical evaluations"
+        assert abs(l - l0) <= 1e-5 * abs(l0)
+        b = torch.cat([g[n].flatten() for n in g0])
+        cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        assert cos >= 0.99999, cos
+        worst = max(float((g[n] - g0[n]).abs().max()) / (float(g0[n].abs().max()) + 1e-12) for n in g0 if g0[n].numel() >= 4096)
+        assert worst <= 1e-2, worst
