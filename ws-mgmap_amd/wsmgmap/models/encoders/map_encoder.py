@@ -124,7 +124,11 @@ class MapDecoder(nn.Module):
         # the full-resolution branch runs on a side stream beside it — in backward too, where autograd replays every node
         # on its forward stream.  WSMG_DECODER_STREAMS=0: one stream.
         side = None
-        if x.is_cuda and os.environ.get("WSMG_DECODER_STREAMS", "1") != "0":
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        # (single-process only: with a process group the collective library brings its own stream, and two ranks sharing one
+        # GPU for the functional test went from 49 ms to 4.3 s per update with this third stream per process — hardware-queue
+        # oversubscription; not verifiable on a multi-GPU node from here, so the data-parallel path keeps two streams)
+        if x.is_cuda and not multi and os.environ.get("WSMG_DECODER_STREAMS", "1") != "0":
             if self._side is None:
                 self._side = torch.cuda.Stream()
             side, main = self._side, torch.cuda.current_stream()

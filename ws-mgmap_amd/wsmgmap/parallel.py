@@ -89,7 +89,17 @@ class GradAllReducer:
         bi, off = loc
         b = self._buckets[bi]
         b["pending"] -= 1
+        if p.is_cuda:
+            # parts of the backward graph run on side streams (instruction branch, decoder branch): the stream that packs
+            # the bucket must wait for the streams that produced the other gradients in it
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            b.setdefault("events", []).append(ev)
         if b["pending"] == 0:
+            if p.is_cuda:
+                cur = torch.cuda.current_stream()
+                for ev in b.pop("events", []):
+                    cur.wait_event(ev)
             # the whole bucket is ready: ONE multi-tensor copy packs it (instead of a copy kernel per parameter), then
             # the exchange starts while backward continues
             torch._foreach_copy_(b["views"], [q.grad for q in b["params"]])
