@@ -128,7 +128,8 @@ class MapDecoder(nn.Module):
         # (single-process only: with a process group the collective library brings its own stream, and two ranks sharing one
         # GPU for the functional test went from 49 ms to 4.3 s per update with this third stream per process — hardware-queue
         # oversubscription; not verifiable on a multi-GPU node from here, so the data-parallel path keeps two streams)
-        if x.is_cuda and not multi and os.environ.get("WSMG_DECODER_STREAMS", "1") != "0":
+        mode = os.environ.get("WSMG_DECODER_STREAMS", "1")   # "2": also under a process group (experiments)
+        if x.is_cuda and mode != "0" and (not multi or mode == "2"):
             if self._side is None:
                 self._side = torch.cuda.Stream()
             side, main = self._side, torch.cuda.current_stream()
