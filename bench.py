@@ -104,13 +104,22 @@ def cpu_baseline(state, T_full, N, budget_s=20.0):
         return time.perf_counter() - t0
 
     run(1)  # warm-up (thread pools, allocator)
-    t2 = run(2)
-    per_t = t2 / 2
-    T = int(max(2, min(T_full, budget_s / max(per_t, 1e-3))))
+    t4 = run(4)
+    per_t = t4 / 4
+    # SURVEY.md 8d / BASELINE.md 3: the same cfg2 shapes (T=64, B=512) when the host does them within the budget, else
+    # T=16 (B=128) scaled linearly, stated in `sample`; smaller only if even that does not fit.  The time per policy step
+    # falls with the batch (BatchNorm / conv efficiency), so the estimate from T=4 is an upper bound.
+    if per_t * T_full <= budget_s:
+        T = T_full
+    elif per_t * 16 <= budget_s:
+        T = min(16, T_full)
+    else:
+        T = int(max(2, min(T_full, budget_s / max(per_t, 1e-3))))
     dt = run(T)
+    scaled = "" if T == T_full else f" — T={T} instead of {T_full}: policy steps/s assumed linear in T"
     return dict(value=T * N / dt, unit="policy steps/s", cores=cores, kind="port",
                 sample=f"1 update of T={T} x N={N} ({T * N} policy steps, {dt:.1f} s) of the oracle (PyTorch-CPU fp32 port "
-                       f"of the reference update: fwd+loss+bwd+Adam), {cores} threads")
+                       f"of the reference update: fwd+loss+bwd+Adam), {cores} threads{scaled}")
 
 
 def measure(args, dtype, steps, warmup, rank, world, local, dev):
@@ -133,6 +142,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     reducer = GradAllReducer(policy.parameters()) if world > 1 else None
     if reducer:
         reducer.broadcast_parameters(policy)
+    measure.dp_info = None
 
     T, N = args.T, args.N
     obs, prev, masks, weights = synth_batch(T, N, dev, 1000 + rank)
@@ -189,6 +199,12 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = ops.profile_end()
+    ops.check_rnn_status()        # a persistent-RNN timeout anywhere in the run invalidates it: fail loudly
+    if reducer:
+        reducer.check()
+        measure.dp_info = dict(ranks_in_process_group=dist.get_world_size(), backend=dist.get_backend(),
+                               live_gradient_bytes=reducer.live_bytes, buckets=reducer.num_buckets,
+                               devices_visible=torch.cuda.device_count())
     for name, r in warm_prof.items():     # the other families: per-launch figures from the warm-up updates, labelled so
         if name not in prof:
             prof[name] = dict(r, per_steps=1, phase="last warm-up update")
@@ -204,7 +220,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--T", type=int, default=64)
@@ -213,15 +229,46 @@ def main():
                     help="storage/MFMA type of the map stack: bf16 = BASELINE configs[1] (default); f32 = parity mode (1e-4 vs reference)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra float32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=75.0,
+                    help="seconds the host may spend on the timed CPU-baseline update: T=64 if it fits, else T=16")
     args = ap.parse_args()
 
+    share = os.environ.get("WSMG_BENCH_SHARE_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus is None:
+            args.gpus = 1
+        if args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, as the reference does with
+            # torch.distributed.launch, README.md:80-84 / common_trainer.py:35-38) as CHILD processes and relay rank 0's
+            # line.  Nothing in this parent has touched the GPU (device_count() does not initialise HIP on this image).
+            have = torch.cuda.device_count()
+            if have < args.gpus and not share:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+            import socket
+            import subprocess
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("OMP_NUM_THREADS", "8")
+            raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
-    local = local % max(1, torch.cuda.device_count()) if os.environ.get("WSMG_BENCH_SHARE_GPU") else local
+    if world > torch.cuda.device_count() and not share:
+        raise SystemExit(f"{world} ranks but {torch.cuda.device_count()} GPU(s) visible: one process per GPU "
+                         "(WSMG_BENCH_SHARE_GPU=1 lets ranks share a GPU for a functional test)")
+    local = local % max(1, torch.cuda.device_count()) if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -234,6 +281,7 @@ def main():
 
     T, N = args.T, args.N
     dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)
+    dp_info = measure.dp_info
     parity = None
     if args.dtype == "bf16" and not args.no_f32:
         k32 = max(2, args.steps // 2)
@@ -288,6 +336,7 @@ def main():
             "config": {"workload": f"teacher-forcing update fwd+bwd+Adam, T={T} x N={N} rows/GPU (B={T * N}), E=100 C=64 "
                                    f"80-token instructions, cached rgb/depth/ego-map features (BASELINE configs[1])",
                        "T": T, "N_per_gpu": N, "parallelism": f"dp{world}"},
+            "data_parallel": dp_info,
             "whole_update_tflops": round(ALG_GFLOP_PER_STEP * steps_per_s / 1e3 / world, 2),
             "loss": round(final_loss, 5),
             "f32_parity_mode": parity,

@@ -310,6 +310,17 @@ int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t* lengths, 
                   const float* save_c, int U, int L, int hidden, float* dgates, void* state_ws,
                   wsmg_stream_t stream);
 
+/* Status of the four persistent kernels above.  All their waits are bounded; when one times out (a cooperating
+ * workgroup never became resident, e.g. CU oversubscription by another process) every workgroup leaves, the
+ * kernel's slice of its outputs (y / dgi, dgh, dh0 / out / dgates) is filled with NaN, and a bit is set in a
+ * process-wide word in host-mapped pinned memory: 1 gru_fwd, 2 gru_bwd, 4 lstm_fwd, 8 lstm_bwd.
+ * wsmg_rnn_status returns that word WITHOUT synchronising the device (clear != 0: and resets the bits it returns);
+ * a caller checks it at its next natural synchronisation point (the reference has no counterpart: cuDNN RNNs
+ * cannot time out; mg_map_policy.py:220-227,242-249, instruction_encoder.py:80-92 are the replaced call sites).
+ * wsmg_rnn_debug_spin_limit(n): bound every spin by n polls (0 = default, 2^20) — test hook to force a timeout. */
+int wsmg_rnn_status(int clear);
+int wsmg_rnn_debug_spin_limit(unsigned limit);
+
 #ifdef __cplusplus
 }
 #endif

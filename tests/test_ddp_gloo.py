@@ -64,6 +64,28 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(sd[0]) for _ in range(world)]
     dist.all_gather(gathered, sd[0])
     ok = ok and all(torch.equal(gathered[0], g) for g in gathered)
+    # error agreement: rank 1 alone sees a gradient outside the live set; nobody hangs, BOTH ranks raise at the next finish()
+    from wsmgmap.parallel import GradExchangeError
+    net.zero_grad(set_to_none=True)
+    xs, ts = data[rank * 6:(rank + 1) * 6], tgt[rank * 6:(rank + 1) * 6]
+    loss = ((net(xs) - ts) ** 2).mean()
+    if rank == 1:
+        loss = loss + net.unused(torch.ones(1, 3)).sum()
+    loss.backward()
+    red.finish()                      # completes on both ranks (rank 1 took part in every collective)
+    net.zero_grad(set_to_none=True)
+    ((net(xs) - ts) ** 2).mean().backward()
+    raised = False
+    try:
+        red.finish()
+    except GradExchangeError as e:
+        raised = ("1 of 2 ranks" in str(e)) and (("(this rank:" in str(e)) == (rank == 1))
+    ok = ok and raised and red._buckets is None     # reset: the next update re-discovers the live set
+    net.zero_grad(set_to_none=True)
+    ((net(xs) - ts) ** 2).mean().backward()
+    red.finish()
+    red.check()
+    ok = ok and torch.allclose(net.a.weight.grad, want[0], atol=1e-6)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

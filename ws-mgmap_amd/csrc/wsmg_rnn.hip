@@ -32,12 +32,27 @@ constexpr int UNITS_WAVE = 4;
 constexpr int WAVES = 4;
 constexpr int UNITS_WG = UNITS_WAVE * WAVES;   // 16
 constexpr int NWG = H / UNITS_WG;              // 32
-constexpr unsigned SPIN_LIMIT = 1u << 20;
+constexpr unsigned SPIN_LIMIT = 1u << 20;   // default bound of every spin; wsmg_rnn_debug_spin_limit() lowers it (tests)
+
+// What a kernel does when a spin timed out (or another workgroup reported one): the process-wide status word in
+// host-mapped pinned memory gets the kernel's bit (system-scope store: the host reads it without synchronising),
+// and the workgroup's slice of every output is filled with NaN, so nothing downstream can mistake the
+// uninitialised rows for results.
+__device__ __forceinline__ void rnn_fail(unsigned* host_status, unsigned bit) {
+  if (threadIdx.x == 0 && host_status) __hip_atomic_fetch_or(host_status, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// rows x [col0, col0 + ncols) of a row-major [rows][rowlen] float tensor <- NaN
+__device__ __forceinline__ void rnn_poison(float* base, size_t rows, int rowlen, int col0, int ncols) {
+  if (!base) return;
+  const float nan = __uint_as_float(0x7fc00000u);
+  for (size_t i = threadIdx.x; i < rows * (size_t)ncols; i += blockDim.x)
+    base[(i / ncols) * rowlen + col0 + (int)(i % ncols)] = nan;
+}
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // one-per-step grid barrier among NWG co-resident workgroups; returns false on timeout
-__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int tid, int* ok_lds) {
+__device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, int tid, int* ok_lds, unsigned limit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
@@ -48,7 +63,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, in
     int good = 1;
     while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++n > SPIN_LIMIT || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      if (++n > limit || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         good = 0;
         break;
@@ -114,6 +129,8 @@ struct GruFwdArgs {
   unsigned long long* xh;  // exchange [T][NWG][NB][UNITS_WG] of {value, tag} words, each written once per launch
   int T, N;
   unsigned tagbase;    // launch-unique tag bits (epoch << 10); a word is valid for step t when tag == tagbase | (t + 1)
+  unsigned* status;    // host-mapped process status word (rnn_fail)
+  unsigned spin;       // spin bound
 };
 
 // Flag-in-data exchange (forward): every h value travels as one 8-byte {value, tag} word written with a
@@ -123,7 +140,7 @@ struct GruFwdArgs {
 // 128-byte row of one producer workgroup and batch), drop the values into LDS, and the four waves read
 // h_{t-1} from there.  Tags are launch-unique (epoch) and slots step-indexed, so stale contents of the
 // image — from an older launch or an older step — can never match.
-__device__ __forceinline__ bool poll_row16(const unsigned long long* src, unsigned want, unsigned* sync, float (&out)[16]) {
+__device__ __forceinline__ bool poll_row16(const unsigned long long* src, unsigned want, unsigned* sync, float (&out)[16], unsigned limit) {
   unsigned n = 0;
   for (;;) {
     unsigned long long v[16];
@@ -138,7 +155,7 @@ __device__ __forceinline__ bool poll_row16(const unsigned long long* src, unsign
       return true;
     }
     __builtin_amdgcn_s_sleep(1);
-    if (++n > SPIN_LIMIT || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (++n > limit || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
       __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
         }
       } else {
         const unsigned long long* src = a.xh + ((size_t)(t - 1) * NWG + sw) * NB * UNITS_WG + sb * UNITS_WG;
-        good = poll_row16(src, a.tagbase | (unsigned)t, a.sync, row);
+        good = poll_row16(src, a.tagbase | (unsigned)t, a.sync, row, a.spin);
       }
       // the mask of this step is applied once, here (h_{t-1} * mask_t is what every consumer needs)
       const float sm = sb < a.N ? a.masks[t * a.N + sb] : 0.f;
@@ -221,7 +238,11 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
         *reinterpret_cast<f32x4*>(&hcur[sb][sw * UNITS_WG + 4 * i]) = v;
       }
       // one workgroup barrier per step; it also orders the re-use of hs[t & 1] two steps later
-      if (__syncthreads_or(good ? 0 : 1)) return;   // timeout or error elsewhere: every thread leaves
+      if (__syncthreads_or(good ? 0 : 1)) {   // timeout or error elsewhere: every thread leaves
+        rnn_fail(a.status, 1u);
+        rnn_poison(a.y, (size_t)a.T * a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
+        return;
+      }
     }
     float acc[32];
 #pragma unroll
@@ -286,6 +307,8 @@ struct GruBwdArgs {
   unsigned long long* xp;  // exchange ring [BWD_RING][consumer WG][producer WG][NB][UNITS_WG] of {value, tag} words
   int T, N;
   unsigned tagbase;    // launch-unique tag bits; a word belongs to step t when tag == tagbase | (t + 1)
+  unsigned* status;    // host-mapped process status word (rnn_fail)
+  unsigned spin;       // spin bound
 };
 
 // Backward exchange: PARTIAL SUMS of dh, not gate gradients.  dh_{t-1}[k] needs sum over all 3H gate rows of
@@ -347,14 +370,22 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
         float rowv[16];
         const unsigned long long* src = a.xp + (size_t)((t + 1) % BWD_RING) * XP_SLOT + (size_t)blockIdx.x * XP_CONSUMER +
                                         ((size_t)pq * NB + pb) * UNITS_WG;
-        good = poll_row16(src, a.tagbase | (unsigned)(t + 2), a.sync, rowv);
+        good = poll_row16(src, a.tagbase | (unsigned)(t + 2), a.sync, rowv, a.spin);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           f32x4 v = {rowv[4 * i], rowv[4 * i + 1], rowv[4 * i + 2], rowv[4 * i + 3]};
           *reinterpret_cast<f32x4*>(&part[pq][pb][4 * i]) = v;
         }
       }
-      if (__syncthreads_or(good ? 0 : 1)) return;   // timeout or error elsewhere: every thread leaves
+      if (__syncthreads_or(good ? 0 : 1)) {   // timeout or error elsewhere: every thread leaves
+        rnn_fail(a.status, 2u);
+        for (int g = 0; g < 3; ++g) {
+          rnn_poison(a.dgi, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
+          rnn_poison(a.dgh, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
+        }
+        rnn_poison(a.dh0, (size_t)a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
+        return;
+      }
       if (worker) {
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -458,6 +489,34 @@ static hipError_t excl_lds(K kernel, unsigned* dyn) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn);
 }
 // launch-unique tag bits for the flag-in-data exchange (22-bit epoch above the 10-bit step number)
+// Process-wide status word of the persistent kernels in host-mapped pinned memory: bit 0 gru_fwd, 1 gru_bwd, 2 lstm_fwd,
+// 3 lstm_bwd timed out.  The host polls it without synchronising (wsmg_rnn_status).
+static unsigned* g_status_host = nullptr;
+static unsigned* g_status_dev = nullptr;
+static unsigned g_spin = SPIN_LIMIT;
+static unsigned* rnn_status_dev() {
+  if (!g_status_host) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
+    *(volatile unsigned*)h = 0u;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { hipHostFree(h); return nullptr; }
+    g_status_host = (unsigned*)h;
+    g_status_dev = (unsigned*)d;
+  }
+  return g_status_dev;
+}
+extern "C" int wsmg_rnn_status(int clear) {
+  if (!g_status_host) return 0;
+  unsigned v = __atomic_load_n(g_status_host, __ATOMIC_ACQUIRE);
+  if (clear && v) __atomic_and_fetch(g_status_host, ~v, __ATOMIC_ACQ_REL);
+  return (int)v;
+}
+extern "C" int wsmg_rnn_debug_spin_limit(unsigned limit) {
+  g_spin = limit ? limit : SPIN_LIMIT;
+  return 0;
+}
+
 static unsigned next_tagbase() {
   static unsigned epoch = 0;
   return (__atomic_add_fetch(&epoch, 1u, __ATOMIC_RELAXED) & 0x3FFFFFu) << 10;
@@ -482,7 +541,7 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   hipError_t e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)T * NWG * NB * UNITS_WG * 8, s);
   if (e != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
-               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase()};
+               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
   unsigned dyn = 0;
   if ((e = excl_lds(gru_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
@@ -501,7 +560,7 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   hipError_t e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)BWD_RING * XP_SLOT * 8, s);
   if (e != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
-               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase()};
+               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
   unsigned dyn = 0;
   if ((e = excl_lds(gru_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
@@ -535,6 +594,8 @@ struct LstmFwdArgs {
   float* sc;           // [2][U][L][LH]    saved cell state c_t
   unsigned* sync;      // per direction 16 words: [0] counter, [1] error
   int U, L;
+  unsigned* status;    // host-mapped process status word (rnn_fail)
+  unsigned spin;
 };
 
 __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
@@ -620,7 +681,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(LstmFwdArgs a) {
       }
     }
     if (s + 1 < a.L) {
-      if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds)) return;
+      if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(s + 1), tid, &ok_lds, a.spin)) {
+        rnn_fail(a.status, 4u);
+        rnn_poison(a.out, (size_t)a.U * a.L, 2 * LH, dir * LH + wgi * UNITS_WG, UNITS_WG);
+        return;
+      }
     }
   }
 }
@@ -635,6 +700,8 @@ struct LstmBwdArgs {
   unsigned* sync;
   float* xg;           // exchange [2 dir][L][L_NWG][NB][4][UNITS_WG]: each line written once
   int U, L;
+  unsigned* status;    // host-mapped process status word (rnn_fail)
+  unsigned spin;
 };
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
@@ -693,7 +760,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(LstmBwdArgs a) {
         dh_direct = carry_h;  // frozen state: gradient passes straight through
       }
     }
-    if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds)) return;
+    if (!grid_barrier(sync, (unsigned)L_NWG * (unsigned)(a.L - s), tid, &ok_lds, a.spin)) {
+      rnn_fail(a.status, 8u);
+      for (int g = 0; g < 4; ++g)
+        rnn_poison(a.dg, (size_t)a.U * a.L, 2 * 4 * LH, dir * 4 * LH + g * LH + wgi * UNITS_WG, UNITS_WG);
+      return;
+    }
     float acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.f;
@@ -736,7 +808,7 @@ extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_
   hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);   // barrier words
   if (e != hipSuccess) return (int)e;
   LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)((char*)state_ws + 256), save_gates, save_c,
-                (unsigned*)state_ws, U, L};
+                (unsigned*)state_ws, U, L, rnn_status_dev(), g_spin};
   unsigned dyn = 0;
   if ((e = excl_lds(lstm_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), dyn, s, a);
@@ -751,7 +823,7 @@ extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t
   if (((uintptr_t)state_ws & 127) != 0) return WSMG_EINVAL;
   hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
-  LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)state_ws, (float*)((char*)state_ws + 256), U, L};
+  LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)state_ws, (float*)((char*)state_ws + 256), U, L, rnn_status_dev(), g_spin};
   unsigned dyn = 0;
   if ((e = excl_lds(lstm_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), dyn, s, a);

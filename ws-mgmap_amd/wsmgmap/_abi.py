@@ -78,6 +78,8 @@ _SIG["wsmg_gru_bwd"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_p]
 _SIG["wsmg_lstm_workspace_bytes"] = [c_i]
 _SIG["wsmg_lstm_fwd"] = [c_p] * 4 + [c_i] * 3 + [c_p] * 4 + [c_p]
 _SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
+_SIG["wsmg_rnn_status"] = [c_i]
+_SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
 _RESTYPE = {"wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
 
 _lib = None
@@ -112,6 +114,18 @@ def call(name, *args):
     if rc != 0:
         kind = {-1: "WSMG_EINVAL (rejected arguments)", -2: "WSMG_ENOMEM (workspace too small)"}.get(rc, f"hipError_t {rc}")
         raise WsmgError(f"{name} failed: {kind}")
+
+
+def check_rnn_status():
+    """Raise WsmgError if a persistent RNN kernel reported a timeout since the last check.  Reads a word in host-mapped
+    pinned memory: no device synchronisation.  Called at the host's natural sync points (the instruction dedup
+    read-back of every forward pass, GradAllReducer.finish(), the end of an update in bench / tests)."""
+    v = lib().wsmg_rnn_status(1)
+    if v:
+        names = [n for b, n in ((1, "gru_fwd"), (2, "gru_bwd"), (4, "lstm_fwd"), (8, "lstm_bwd")) if v & b]
+        raise WsmgError("persistent RNN kernel(s) timed out waiting for their cooperating workgroups: " + ", ".join(names) +
+                        " — their outputs were filled with NaN; results since the previous check are invalid "
+                        "(CU oversubscription? every RNN workgroup needs a whole CU, see WSMG_RNN_EXCL)")
 
 
 def exported_names():

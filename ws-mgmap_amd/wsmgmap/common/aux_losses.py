@@ -41,20 +41,22 @@ class _Registry:
                 if mask is None:
                     total = total + alpha * loss.mean()
                 else:
-                    m = mask.to(loss.dtype)
-                    total = total + alpha * ((loss * m).sum() / m.sum())
+                    # = masked_select(loss, mask).mean(): rows outside the mask are DROPPED (torch.where), not multiplied
+                    # by 0 — a non-finite loss on a padded row (log of an underflowed attention weight) must not
+                    # poison the total
+                    total = total + alpha * (torch.where(mask, loss, loss.new_zeros(())).sum() / mask.sum())
             return total
         # = sum_k alpha_k * masked_select(loss_k, mask).mean() (NaN for an empty selection, like the reference), without
         # the data-dependent output size — masked_select makes the host wait for the whole forward pass — and as ONE
         # stacked reduction: per loss the loop above is 7 tiny launches forward and as many backward, each ~5 us on the
         # critical path between the two recurrences' forward and backward
         first = entries[0][0]
-        m = mask.to(first.dtype)
         key = (tuple(float(a) for _, a in entries), first.device, first.dtype)
         if self._alpha_key != key:
             self._alpha_key, self._alpha = key, torch.tensor(key[0], device=first.device, dtype=first.dtype)
         stacked = torch.stack([l for l, _ in entries])            # [K, B]
-        return (((stacked * m).sum(dim=1) * self._alpha).sum()) / m.sum()
+        kept = torch.where(mask.unsqueeze(0), stacked, stacked.new_zeros(()))   # drop (not zero-multiply) masked-out rows
+        return ((kept.sum(dim=1) * self._alpha).sum()) / mask.sum()
 
 
 AuxLosses = _Registry()

@@ -28,12 +28,19 @@ class Mapping(nn.Module):
         G, C = self.global_map_size, self.global_map_depth
         # plain attributes (not buffers): they are rollout state, absent from the state_dict
         self.full_global_map = torch.zeros(self.num_proc, G, G, C)
-        self.agent_view = torch.zeros(self.num_proc, C, 0, 0)
+        # reference shape [num_proc, C, G, G] (rgb_mapping.py:30; the trainers read `.shape[1:]` and re-assign zeros of
+        # that shape, dagger_trainer.py:674-677, common_trainer.py:267) over ONE element per (proc, channel): the kernels
+        # never read it
+        self.agent_view = torch.zeros(self.num_proc, C, 1, 1).expand(self.num_proc, C, G, G)
 
     def _apply(self, fn, *a, **k):
         super()._apply(fn, *a, **k)
         self.full_global_map = fn(self.full_global_map)
-        self.agent_view = fn(self.agent_view)
+        av = self.agent_view
+        if av.stride()[-1] == 0:   # still the stride-0 placeholder: move the one-element core, keep the shape
+            self.agent_view = fn(av[:, :, :1, :1].contiguous()).expand(av.shape)
+        else:                      # a trainer assigned a real tensor
+            self.agent_view = fn(av)
         return self
 
     @torch.no_grad()

@@ -61,6 +61,11 @@ class InstructionEncoder(nn.Module):
         lengths = (uniq != 0).long().sum(dim=1)
         exact = (uniq[inverse] == tokens).all().view(1).long()
         host = torch.cat([exact, lengths]).cpu()
+        if tokens.is_cuda:
+            # the one host read-back of a forward pass: everything queued before it — the previous update's persistent
+            # GRU / LSTM launches included — has finished, so their status word (host-mapped memory, no extra sync) is final
+            from ... import ops
+            ops.check_rnn_status()
         if int(host[0]) != 1:  # hash collision: exact path
             uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
             lengths = (uniq != 0).long().sum(dim=1)

@@ -91,8 +91,15 @@ class MGMapNet(nn.Module):
         self.sem_logits_nhwc = None
         # storage type of the map-stack activations: float32 (parity mode, f32 MFMA) or bfloat16
         # (BASELINE configs[1]; bf16 MFMA, float32 accumulation, float32 master weights)
-        self.compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16}.get(
-            str(getattr(mc, "COMPUTE_DTYPE", "f32")).lower(), torch.float32)
+        # (not a reference field; both spellings are accepted: `COMPUTE_DTYPE` as yacs nodes are usually written and
+        # `compute_dtype` as default_model_config's keyword is called; anything but f32 / bf16 is an error, not a silent f32)
+        want = getattr(mc, "COMPUTE_DTYPE", None)
+        if want is None:
+            want = getattr(mc, "compute_dtype", "f32")
+        want = str(want).lower()
+        if want not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
+            raise ValueError(f"MODEL.COMPUTE_DTYPE must be 'f32' or 'bf16', got {want!r}")
+        self.compute_dtype = torch.bfloat16 if want in ("bf16", "bfloat16") else torch.float32
         if self.compute_dtype == torch.bfloat16:   # the frozen RGB UNet follows: bf16 NHWC engine on the rollout path
             self.rgb_encoder.base_model.engine_dtype = torch.bfloat16
 
@@ -193,6 +200,7 @@ class MGMapNet(nn.Module):
         return text, side
 
     def forward(self, observations, rnn_hidden_states, prev_actions, masks):
+        ops.reset_pass_state()
         entry = torch.cuda.Event()
         entry.record(torch.cuda.current_stream())
         rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)

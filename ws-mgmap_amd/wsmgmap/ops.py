@@ -140,6 +140,21 @@ def _zero_pool_retire():
         z["buf"], z["off"], z["used"], z["armed"] = None, 0, 0, False
 
 
+def reset_pass_state():
+    """Called at the entry of every policy forward pass.  The end-of-backward callbacks that retire the zero pool and
+    join the weight-gradient side stream do not run when backward() raises (a WsmgError from a kernel, OOM): without
+    this reset one failed backward would leave them 'armed' for ever — every later request would fall back to a
+    torch.zeros launch and, with WSMG_WGRAD_STREAM=1, optimizer.step could race the side-stream weight gradients."""
+    if any(z["armed"] for z in _zero_pool.values()):
+        _zero_pool_retire()
+    if _side_join_armed:
+        for main_id, side_id in list(_side_join_armed):
+            for side in _wgrad_side.values():
+                if side.cuda_stream == side_id:
+                    torch.cuda.current_stream().wait_stream(side)
+        _side_join_armed.clear()
+
+
 def _zeros_f32(shape, device):
     numel = 1
     for d in shape:
@@ -876,6 +891,15 @@ def _rnn_workspace(nbytes, device):
 
 import os as _os
 _POISON = _os.environ.get("WSMG_RNN_POISON", "0") == "1"
+_RNN_CHECK = _os.environ.get("WSMG_RNN_CHECK", "0") == "1"   # debug: synchronise and check after every persistent launch
+
+check_rnn_status = _abi.check_rnn_status
+
+
+def _rnn_launched():
+    if _RNN_CHECK:
+        torch.cuda.current_stream().synchronize()
+        _abi.check_rnn_status()
 
 
 class _MaskedGRU(torch.autograd.Function):
@@ -893,8 +917,8 @@ class _MaskedGRU(torch.autograd.Function):
         sync = _rnn_workspace(_abi.lib().wsmg_gru_workspace_bytes(T), dev)
         _abi.call("wsmg_gru_fwd", _p(gi), _p(w_hh), _p(b_hh), _p(h0), _p(masks), T, N, H, _p(y),
                   *[_p(s) for s in saves], _p(sync), _stream())
+        _rnn_launched()
         ctx.save_for_backward(w_hh, h0, masks, y, *saves)
-        ctx.sync = sync
         return y
 
     @staticmethod
@@ -909,6 +933,7 @@ class _MaskedGRU(torch.autograd.Function):
         sync = _rnn_workspace(_abi.lib().wsmg_gru_workspace_bytes(T), dev)
         _abi.call("wsmg_gru_bwd", _p(dy), None, _p(w_hh), _p(h0), _p(masks), _p(y), _p(sr), _p(sz), _p(sn), _p(sghn),
                   T, N, H, _p(dgi), _p(dgh), _p(dh0), _p(sync), _stream())
+        _rnn_launched()
         hprev = torch.cat([h0.unsqueeze(0), y[:-1]], dim=0) * masks.unsqueeze(-1)
         g2 = dgh.view(T * N, 3 * H)
         dw_hh = g2.t() @ hprev.view(T * N, H)
@@ -937,6 +962,7 @@ class _BiLSTM(torch.autograd.Function):
         sc = torch.zeros(2, U, L, H, device=dev, dtype=torch.float32)
         ws = _rnn_workspace(_abi.lib().wsmg_lstm_workspace_bytes(L), dev)
         _abi.call("wsmg_lstm_fwd", _p(gi), _p(w_hh), _p(b_hh), _p(lengths), U, L, H, _p(out), _p(sg), _p(sc), _p(ws), _stream())
+        _rnn_launched()
         ctx.save_for_backward(w_hh, lengths, out, sg, sc)
         return out
 
@@ -950,6 +976,7 @@ class _BiLSTM(torch.autograd.Function):
         dg = torch.empty(U, L, 2, 4 * H, device=dev, dtype=torch.float32)
         ws = _rnn_workspace(_abi.lib().wsmg_lstm_workspace_bytes(L), dev)
         _abi.call("wsmg_lstm_bwd", _p(dout), _p(w_hh), _p(lengths), _p(sg), _p(sc), U, L, H, _p(dg), _p(ws), _stream())
+        _rnn_launched()
         zero = torch.zeros(U, 1, H, device=dev, dtype=torch.float32)
         hprev_f = torch.cat([zero, out[:, :-1, :H]], dim=1)       # state before step t (forward direction)
         hprev_r = torch.cat([out[:, 1:, H:], zero], dim=1)        # state before step t (reverse direction)
@@ -998,9 +1025,25 @@ def bev_rotate(planes, heading, sign):
 
 
 @torch.no_grad()
+def _check_global_map(global_map, B, C, *f32s):
+    """The kernels index global_map[b] for b < B: the reference slices `full_global_map[:bs]` (rgb_mapping.py:43) and
+    fails with a shape error when the batch has more rows than num_proc — here that would be an out-of-bounds access."""
+    _f32(global_map, *f32s)
+    if global_map.dim() != 4 or global_map.shape[1] != global_map.shape[2]:
+        raise _abi.WsmgError(f"full_global_map must be [num_proc, G, G, C], got {tuple(global_map.shape)}")
+    if global_map.shape[0] < B:
+        raise _abi.WsmgError(f"batch of {B} rows but full_global_map holds {global_map.shape[0]} maps (num_proc): "
+                             "construct the policy with RGBMAPPING.num_proc >= the rollout batch")
+    if global_map.shape[3] != C:
+        raise _abi.WsmgError(f"full_global_map has {global_map.shape[3]} channels, the ego map {C}")
+
+
 def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12):
     _req(ego_rot, global_map, gps, masks)
     B, E, _, C = ego_rot.shape
+    _check_global_map(global_map, B, C, ego_rot, gps, masks)
+    if gps.shape[0] != B or masks.numel() != B:
+        raise _abi.WsmgError("map_fuse: gps [B,2] and masks [B] must match the ego maps' batch")
     G = global_map.shape[1]
     _abi.call("wsmg_map_fuse", _p(ego_rot), _p(global_map), _p(gps), _p(masks), B, C, E, G, float(resolution), _stream())
 
@@ -1009,6 +1052,9 @@ def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12):
 def map_retrieve(global_map, gps, compass, E, resolution=0.12):
     _req(global_map, gps, compass)
     B = gps.shape[0]
+    _check_global_map(global_map, B, global_map.shape[3] if global_map.dim() == 4 else -1, gps, compass)
+    if compass.numel() != B:
+        raise _abi.WsmgError("map_retrieve: compass [B] must match gps [B,2]")
     G, C = global_map.shape[1], global_map.shape[3]
     scratch = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
     out = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
