@@ -351,6 +351,7 @@ def test_stock_ddp_wrap_matches_goldens():
         for n in g3["grad.none"]:
             assert named[str(n)].grad is None
         # rollout through .module, on a fresh map state (what the trainers do between phases: dagger_trainer.py:668-678)
+        ddp.module.load_state_dict(state_dict_values(), strict=True)   # the update above moved the BatchNorm statistics
         ddp.eval()
         m = ddp.module.net.rgb_mapping_module
         m.full_global_map = torch.zeros([2] + list(m.full_global_map.shape[1:]), device="cuda")

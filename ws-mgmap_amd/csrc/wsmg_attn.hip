@@ -14,7 +14,7 @@ namespace {
 
 constexpr int AC = 256;       // channels (hidden_size/2)
 constexpr int AWAVES = 4;
-constexpr int AMAX_I = 1024;  // logits kept in LDS
+constexpr int AMAX_I = 2560;  // logits kept in LDS (10 KiB); 2304 = the 48 x 48 encoded map of the E=196 geometry
 constexpr int SAME_WAVES = 16;  // waves per row of the keys-are-values kernels (B = 512 rows alone give only 2 workgroups per CU)
 
 __device__ inline float block_reduce_max(float v, float* sh, int wave, int lane) {
