@@ -8,7 +8,7 @@ Follows (all under /root/reference/vlnce_baselines/):
     models/encoders/map_encoder.py:16-112  MapEncoder, MapDecoder (resnet18 stem: conv1,bn1,relu,maxpool,layer1)
     models/encoders/instruction_encoder.py:68-93
     models/encoders/unet_encoder.py:64-111 ResNetUNet (frozen, eval-mode BN)
-    models/encoders/resnet_encoders.py:72-102 (spatial embedding concat; ResNet50 itself is 3p -> depth_features given)
+    models/encoders/resnet_encoders.py:25-32,72-102 (DD-PPO GroupNorm ResNet50: 3p, restated; spatial embedding concat)
     common/distributions.py:42-57          DiagGaussian
     common/aux_losses.py:24-35             masked mean reduce
     dagger_trainer.py:526-533              action loss
@@ -188,6 +188,33 @@ def resnet_unet(P, rgb, pre="net.rgb_encoder.base_model"):
     return l4, proj
 
 
+# ----------------------------------------------------------------------------- frozen depth encoder (third-party)
+def ddppo_resnet50(P, depth, pre="net.depth_encoder.visual_encoder", ngroups=16):
+    """habitat-lab v0.1.5 ResNetEncoder(depth) with the resnet50 GroupNorm backbone, as instantiated at
+    resnet_encoders.py:25-32 (baseplanes 32, ngroups 16).  Third-party: restated from its published sources
+    (rl/ddppo/policy/resnet.py, resnet_policy.py) — parity UNPINNED.  depth [B,H,W,1] -> [B,128,H/64,W/64]."""
+    def gn(x, k, groups):
+        return F.group_norm(x, groups, P[k + ".weight"], P[k + ".bias"], 1e-5)
+
+    x = F.avg_pool2d(depth.permute(0, 3, 1, 2), 2)
+    bb = pre + ".backbone"
+    x = F.relu(gn(F.conv2d(x, P[bb + ".conv1.0.weight"], None, 2, 3), bb + ".conv1.1", ngroups))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, nblk in zip((1, 2, 3, 4), (3, 4, 6, 3)):
+        for b in range(nblk):
+            k = f"{bb}.layer{li}.{b}"
+            stride = 2 if (b == 0 and li > 1) else 1
+            y = F.relu(gn(F.conv2d(x, P[k + ".convs.0.weight"]), k + ".convs.1", ngroups))
+            y = F.relu(gn(F.conv2d(y, P[k + ".convs.3.weight"], None, stride, 1), k + ".convs.4", ngroups))
+            y = gn(F.conv2d(y, P[k + ".convs.6.weight"]), k + ".convs.7", ngroups)
+            idt = x
+            if (k + ".downsample.0.weight") in P:
+                idt = gn(F.conv2d(x, P[k + ".downsample.0.weight"], None, stride), k + ".downsample.1", ngroups)
+            x = F.relu(y + idt)
+    x = F.conv2d(x, P[pre + ".compression.0.weight"], None, 1, 1)
+    return F.relu(gn(x, pre + ".compression.1", 1))
+
+
 # ----------------------------------------------------------------------------- the network
 class PolicyRef:
     """Holds P (+ mapper state, AuxLosses-like registry) and restates BasePolicy's methods."""
@@ -211,7 +238,7 @@ class PolicyRef:
             rgb_emb, proj = obs["rgb_features"], None
         else:
             rgb_emb, proj = resnet_unet(P, obs["rgb"])
-        dx = obs["depth_features"]
+        dx = obs["depth_features"] if "depth_features" in obs else ddppo_resnet50(P, obs["depth"])   # resnet_encoders.py:79-82
         b = dx.size(0)
         se = P["net.depth_encoder.spatial_embeddings.weight"]
         depth_emb = torch.cat([dx, se.view(1, -1, dx.size(2), dx.size(3)).expand(b, se.size(1), dx.size(2), dx.size(3))], 1)

@@ -460,3 +460,56 @@ def test_data_parallel_two_ranks_real_policy():
         assert info["worst"] <= 2e-3, info
         assert info["differs_from_own"] > 1e-6, "the two ranks' gradients must actually differ"
         assert 32.0e6 < info["live_bytes"] < 33.5e6, info
+
+
+# ----------------------------------------------------------------------------- frozen encoders
+def test_act_from_raw_depth_vs_oracle():
+    """No `depth_features` in the observations: the DD-PPO GroupNorm ResNet50 runs (resnet_encoders.py:79-82).  float32 mode
+    (stock convolutions + F.group_norm) against the oracle: action within 1e-4; the backbone output within 1e-4."""
+    from wsmgmap.common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    pol = _policy(num_proc=2).eval()
+    ref = policy_ref.PolicyRef(make_params(grad=False), num_proc=2)
+    ref.train_mode = False
+    obs_np, masks = cases.act_inputs(0, B=2, tag="rawd")
+    del obs_np["depth_features"]
+    obs, oc = _cuda(obs_np), {k: T(v) for k, v in obs_np.items()}
+    seen = {}
+    hk = pol.net.depth_encoder.visual_encoder.register_forward_hook(lambda m, i, o: seen.update(feat=o))   # dagger_trainer.py:318
+    with torch.no_grad():
+        value, action, logp, h = pol.act(obs, torch.zeros(2, 2, 512, device="cuda"), torch.zeros(2, 2, device="cuda"),
+                                         T(masks).cuda(), deterministic=True)
+        vr, ar, lpr, hr = ref.act(oc, torch.zeros(2, 2, 512), None, T(masks))
+        feat_ref = policy_ref.ddppo_resnet50(ref.P, oc["depth"])
+    hk.remove()
+    assert tuple(seen["feat"].shape) == (2, 128, 4, 4)
+    assert float((seen["feat"].cpu() - feat_ref).abs().max()) <= 1e-4
+    assert float((action.cpu() - ar).abs().max()) <= 1e-4
+    assert float((value.cpu() - vr).abs().max()) <= 2e-4
+
+
+def test_frozen_encoders_on_the_bf16_engine_vs_oracle():
+    """compute_dtype = bf16: the frozen RGB ResNet-UNet and the depth ResNet50 run on the NHWC bf16 conv engine (folded
+    eval-mode BatchNorm / the group-norm kernel).  Held against the ORACLE (float32 CPU restatement of
+    unet_encoder.py:64-111 and of the third-party depth backbone) on the G4 inputs, hash-filled weights.  Written bf16 bars:
+    relative L2 error of `layer4` <= 2 %, of `proj_feat` <= 3 %, of the depth features <= 3 %; hook contract unchanged."""
+    pol = _policy(num_proc=2, compute_dtype="bf16").eval()
+    P = make_params(grad=False)
+    for hw in (224, 256):
+        obs_np, _ = cases.act_inputs(0, rgb_hw=hw)
+        rgb = T(obs_np["rgb"])
+        with torch.no_grad():
+            l4_ref, proj_ref = policy_ref.resnet_unet(P, rgb)
+            l4, proj = pol.net.rgb_encoder({"rgb": rgb.cuda()})
+        assert l4.dtype == torch.float32 and tuple(l4.shape) == (2, 512, hw // 32, hw // 32)
+        assert proj.dtype == torch.float32 and tuple(proj.shape) == (2, 64, hw, hw) and float(proj.min()) >= 0.0
+        for a, b, name, bar in ((l4, l4_ref, "layer4", 2e-2), (proj, proj_ref, "proj_feat", 3e-2)):
+            rel = float((a.cpu() - b).norm() / b.norm())
+            assert rel <= bar, (hw, name, rel)
+    depth = T(cases.act_inputs(0, B=2, tag="rawd")[0]["depth"])
+    with torch.no_grad():
+        f_ref = policy_ref.ddppo_resnet50(P, depth)
+        f = pol.net.depth_encoder.visual_encoder({"depth": depth.cuda()})
+    assert f.dtype == torch.float32 and tuple(f.shape) == (2, 128, 4, 4)
+    rel = float((f.cpu() - f_ref).norm() / f_ref.norm())
+    assert rel <= 3e-2, rel

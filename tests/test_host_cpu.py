@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import cases, policy_ref
-from util import T, make_params, state_dict_values, state_spec
+from util import T, golden, make_params, state_dict_values, state_spec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -207,3 +207,103 @@ def test_data_dataset_order_codec_and_sharding_match_reference_golden():
     rec = unpack_record(dr.pack_record(dict(obs, ep_id=np.int64(3)), prev, oracle))
     assert "ep_id" not in rec[0] and np.array_equal(rec[2], oracle)
     assert change_data_type({"rgb": np.ones((2, 3), np.float32), "gps": np.ones(2, np.float32)})["rgb"].dtype == np.uint8
+
+
+# ----------------------------------------------------------------------------- checkpoint / resume contract
+def _policy_with_golden_fill():
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.policy import BasePolicy
+
+    class Box:
+        shape = (2,)
+    pol = BasePolicy(None, Box(), default_model_config(num_proc=2))
+    pol.load_state_dict(state_dict_values(), strict=True)
+    return pol
+
+
+def test_checkpoint_file_matches_reference_golden(tmp_path):
+    """tests/golden/g8_ckpt.json was captured by running the UNMODIFIED reference save_checkpoint / resume_dagger /
+    load-for-finetune (common_trainer.py:71-76,91-139) on the hash-filled reference policy: same top-level keys, same
+    state_dict keys and values (sha-256 of a sample of tensors), same resume decisions on the same folder layouts."""
+    import hashlib
+    import json
+    import time
+    import numpy as np
+    from wsmgmap import checkpoint as ck
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g8_ckpt.json")))
+    pol = _policy_with_golden_fill()
+    folder = str(tmp_path / "ckpts")
+    ck.save_checkpoint(pol, folder, "ckpt.0.pth", config={"any": "object"}, extra_state={"dagger_it": 2})
+    time.sleep(0.05)
+    path = ck.save_checkpoint(pol, folder, "ckpt.3.pth", config={"any": "object"}, extra_state={"dagger_it": 2})
+    d = ck.load_checkpoint(path)
+    assert sorted(d.keys()) == g["top_level_keys"] and d["extra_state"] == g["extra_state"]
+    assert len(d["state_dict"]) == g["n_state_keys"]
+    for k, h in g["state_sha256"].items():
+        assert hashlib.sha256(np.ascontiguousarray(d["state_dict"][k].numpy()).tobytes()).hexdigest() == h, k
+    fresh = _policy_with_golden_fill()
+    with torch.no_grad():
+        fresh.prog_pred.bias.add_(1.0)
+    it, ep, rep = ck.resume_dagger(fresh, folder, epochs=g["cases"][0]["epochs"])
+    assert [it, ep] == g["cases"][0]["result"] and not rep.missing_keys and not rep.unexpected_keys
+    assert torch.equal(fresh.prog_pred.bias, pol.prog_pred.bias)
+    time.sleep(0.05)
+    ck.save_checkpoint(pol, folder, "ckpt.1.pth", extra_state={"dagger_it": 5})     # newest by mtime, not by name
+    it, ep, _ = ck.resume_dagger(fresh, folder, epochs=4)
+    assert [it, ep] == g["cases"][1]["result"]
+    assert ck.resume_dagger(fresh, str(tmp_path / "empty"), epochs=4)[:2] == (0, 0)
+    # load-for-finetune through a DDP-style wrapper: 'module.' prefix, strict=False, same report as the reference
+    wrapper = torch.nn.Module()
+    wrapper.module = fresh
+    sd = dict(d["state_dict"])
+    sd["not_a_key"] = torch.zeros(1)
+    del sd["prog_pred.bias"]
+    torch.save({"state_dict": sd, "config": None}, str(tmp_path / "ft.pth"))
+    msg = ck.load_pretrained(wrapper, str(tmp_path / "ft.pth"))
+    assert list(msg.missing_keys) == g["finetune_missing"] and list(msg.unexpected_keys) == g["finetune_unexpected"]
+
+
+def test_checkpoint_with_unimportable_config_class_still_loads(tmp_path):
+    """The authors' checkpoints pickle a yacs/habitat Config; neither package exists here or on the GPU box."""
+    import pickle
+    import sys
+    import types
+    from wsmgmap import checkpoint as ck
+    mod = types.ModuleType("fake_yacs_pkg")
+
+    CfgNode = type("CfgNode", (dict,), {"__module__": "fake_yacs_pkg", "__qualname__": "CfgNode"})
+    mod.CfgNode = CfgNode
+    sys.modules["fake_yacs_pkg"] = mod
+    try:
+        torch.save({"state_dict": {"w": torch.arange(3.0)}, "config": CfgNode(LR=1e-3), "extra_state": {"dagger_it": 1}},
+                   str(tmp_path / "c.pth"))
+    finally:
+        del sys.modules["fake_yacs_pkg"]
+    d = ck.load_checkpoint(str(tmp_path / "c.pth"))
+    assert torch.equal(d["state_dict"]["w"], torch.arange(3.0)) and d["extra_state"]["dagger_it"] == 1
+    assert d["config"]["LR"] == 1e-3
+
+
+# ----------------------------------------------------------------------------- depth branch from raw depth (SURVEY 8f-3)
+def test_depth_encoder_oracle_and_module_vs_golden():
+    """g9: the reference's VlnResnetDepthEncoder.forward from raw depth (around the restated third-party backbone).  The
+    oracle's functional restatement reproduces it, and so does the product module on its stock-operator (float32) path."""
+    from oracle import cases, policy_ref
+    from wsmgmap.models.encoders.resnet_encoders import VlnResnetDepthEncoder
+    g = golden("g9_depth.npz")
+    obs_np, _ = cases.act_inputs(0, B=2, tag="g9")
+    P = make_params(grad=False)
+    depth = T(obs_np["depth"])
+    with torch.no_grad():
+        feat = policy_ref.ddppo_resnet50(P, depth)
+    assert float((feat - T(g["feat"])).abs().max()) <= 1e-5
+    enc = VlnResnetDepthEncoder(None)
+    pre = "net.depth_encoder."
+    enc.load_state_dict({k[len(pre):]: v for k, v in state_dict_values().items() if k.startswith(pre)}, strict=True)
+    assert sum(p.numel() for p in enc.visual_encoder.parameters()) == int(g["n_params"])
+    assert not any(p.requires_grad for p in enc.visual_encoder.parameters())
+    with torch.no_grad():
+        out = enc({"depth": depth})
+    assert tuple(out.shape) == (2, 192, 4, 4)
+    assert float((out[:, :128] - T(g["feat"])).abs().max()) <= 1e-5
+    assert float((out[:, ::7] - T(g["out_sample"])).abs().max()) <= 1e-5

@@ -277,8 +277,95 @@ def g5():
     print("g5 out", o.detach().numpy().ravel()[:4])
 
 
+# ============================================================================= G9: depth branch from raw depth
+def g9():
+    """VlnResnetDepthEncoder.forward (resnet_encoders.py:72-102) from RAW depth: the reference's own plumbing (avg-pool
+    hand-off, spatial-embedding concat) around the restated third-party backbone of tools/ref_stubs.py."""
+    pol = build_policy()
+    enc = pol.net.depth_encoder
+    obs_np, _ = cases.act_inputs(0, B=2, tag="g9")
+    with torch.no_grad():
+        feat = enc.visual_encoder({"depth": T(obs_np["depth"])})
+        out = enc({"depth": T(obs_np["depth"])})
+    assert tuple(feat.shape) == (2, 128, 4, 4) and tuple(out.shape) == (2, 192, 4, 4)
+    np.savez_compressed(os.path.join(OUT, "g9_depth.npz"), feat=feat.numpy(), out_sample=out.numpy()[:, ::7, :, :],
+                        n_params=np.int64(sum(p.numel() for p in enc.visual_encoder.parameters())))
+    print("g9 feat", feat.numpy().ravel()[:4], "params", sum(p.numel() for p in enc.visual_encoder.parameters()))
+
+
+# ============================================================================= G8: checkpoint / resume contract
+class _FakeLogger:
+    def warning(self, *a, **k):
+        pass
+
+    info = warning
+
+
+def g8():
+    """The reference trainer's own save_checkpoint / resume_dagger / load-for-finetune code
+    (common_trainer.py:71-76,91-139), run UNMODIFIED as unbound methods on a stand-in `self` (the trainer class itself
+    needs Habitat to be constructed): what a checkpoint file contains, which file a resume picks, and the
+    (start_dagger_it, start_epoch_it) it derives."""
+    import json
+    import tempfile
+    import time
+    import types
+    for name, attrs in {
+        "habitat.utils": {}, "habitat.utils.visualizations": {}, "habitat.utils.visualizations.utils": {"append_text_to_image": None},
+        "habitat_baselines.common.base_trainer": {"BaseRLTrainer": object},
+        "habitat_baselines.common.environments": {"get_env_class": None},
+        "habitat_baselines.common.tensorboard_utils": {"TensorboardWriter": None},
+        "habitat_extensions": {}, "habitat_extensions.utils": {"observations_to_image": None},
+        "vlnce_baselines.common.env_utils": {"construct_envs_auto_reset_false": None},
+        "vlnce_baselines.common.utils": {"transform_obs": None}, "tqdm": {},
+    }.items():
+        m = sys.modules.get(name) or ref_stubs._mod(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+    sys.modules["habitat"].logger = _FakeLogger()
+    cu = sys.modules["habitat_baselines.common.utils"]
+    cu.batch_obs = cu.generate_video = cu.poll_checkpoint_folder = None
+    import vlnce_baselines.common_trainer as ct
+
+    pol = build_policy()
+    real_load = torch.load
+    # the reference was written for torch 1.6, where torch.load had no weights_only default to trip over its pickled config
+    torch.load = lambda f, *a, **k: real_load(f, *a, **{**k, "weights_only": False})
+    folder = tempfile.mkdtemp(prefix="g8_")
+    me = types.SimpleNamespace(actor_critic=types.SimpleNamespace(module=pol),
+                               config=Config(CHECKPOINT_FOLDER=folder, RESUME_CKPT=None, DAGGER=Config(EPOCHS=4)))
+    me.load_checkpoint = lambda path, *a, **k: ct.CommonTrainer.load_checkpoint(me, path, *a, **k)
+    out = {"cases": []}
+    ct.CommonTrainer.save_checkpoint(me, "ckpt.0.pth", extra_state={"dagger_it": 2})
+    time.sleep(0.05)
+    ct.CommonTrainer.save_checkpoint(me, "ckpt.3.pth", extra_state={"dagger_it": 2})
+    ck = torch.load(os.path.join(folder, "ckpt.3.pth"), map_location="cpu", weights_only=False)
+    out["top_level_keys"] = sorted(ck.keys())
+    out["extra_state"] = ck["extra_state"]
+    out["n_state_keys"] = len(ck["state_dict"])
+    out["state_sha256"] = {k: sha(v.numpy()) for k, v in list(ck["state_dict"].items())[::40]}
+    out["cases"].append(dict(files=["ckpt.0.pth", "ckpt.3.pth"], newest="ckpt.3.pth", epochs=4,
+                             result=list(ct.CommonTrainer.resume_dagger(me))))
+    time.sleep(0.05)
+    ct.CommonTrainer.save_checkpoint(me, "ckpt.1.pth", extra_state={"dagger_it": 5})   # newest by mtime, not by name
+    out["cases"].append(dict(files=["ckpt.0.pth", "ckpt.3.pth", "ckpt.1.pth"], newest="ckpt.1.pth", epochs=4,
+                             result=list(ct.CommonTrainer.resume_dagger(me))))
+    # load-for-finetune (:71-76): keys get a 'module.' prefix and go through load_state_dict(strict=False) of the DDP wrapper
+    wrapper = torch.nn.Module()
+    wrapper.module = pol
+    sd = {"module." + k: v for k, v in ck["state_dict"].items()}
+    sd["module.not_a_key"] = torch.zeros(1)
+    del sd["module.prog_pred.bias"]
+    msg = wrapper.load_state_dict(sd, strict=False)
+    out["finetune_missing"], out["finetune_unexpected"] = list(msg.missing_keys), list(msg.unexpected_keys)
+    torch.load = real_load
+    with open(os.path.join(OUT, "g8_ckpt.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("g8", out["top_level_keys"], out["cases"], out["n_state_keys"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["shapes", "g1", "g2", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["shapes", "g1", "g2", "g3", "g4", "g5", "g8", "g9"]
     for w in which:
         globals()[w]()

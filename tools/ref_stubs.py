@@ -9,7 +9,7 @@ What is stubbed:
       - torch_scatter 2.0.6 `scatter_max`   (call site rgb_mapping.py:220-225)
       - torchvision `resnet18`              (call sites map_encoder.py:75, unet_encoder.py:34)
       - habitat-lab v0.1.5 `RNNStateEncoder`, `Net`, `CriticHead`, `Flatten`,
-        `ResNetEncoder` (shape-only; goldens always pass `depth_features`)
+        `ResNetEncoder` + `resnet.resnet50` (the GroupNorm DD-PPO depth backbone)
 """
 import sys
 import types
@@ -159,17 +159,94 @@ class RNNStateEncoder(nn.Module):
         return torch.cat(outs, 0).view(t * n, -1), h
 
 
-class ResNetEncoder(nn.Module):
-    """shape-only stand-in for the DD-PPO depth ResNet50 (3p); goldens supply
-    `depth_features`, so forward is never called."""
+# habitat-lab v0.1.5 rl/ddppo/policy/resnet.py + resnet_policy.py restated (third-party, not under /root/reference:
+# parity UNPINNED): GroupNorm ResNet, Bottleneck expansion 4, conv1 = Sequential(conv7x7 s2, GN, ReLU), layers [3,4,6,3],
+# ResNetEncoder = avg_pool2d(2) -> backbone -> compression(conv3x3 -> GroupNorm(1, C) -> ReLU).
+def _conv3x3(i, o, stride=1):
+    return nn.Conv2d(i, o, kernel_size=3, stride=stride, padding=1, bias=False)
 
-    def __init__(self, observation_space, baseplanes=32, ngroups=16, make_backbone=None,
+
+def _conv1x1(i, o, stride=1):
+    return nn.Conv2d(i, o, kernel_size=1, stride=stride, bias=False)
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, ngroups, stride=1, downsample=None):
+        super().__init__()
+        self.convs = nn.Sequential(
+            _conv1x1(inplanes, planes), nn.GroupNorm(ngroups, planes), nn.ReLU(True),
+            _conv3x3(planes, planes, stride), nn.GroupNorm(ngroups, planes), nn.ReLU(True),
+            _conv1x1(planes, planes * self.expansion), nn.GroupNorm(ngroups, planes * self.expansion))
+        self.relu = nn.ReLU(True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.convs(x)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.relu(out + identity)
+
+
+class _GNResNet(nn.Module):
+    def __init__(self, in_channels, base_planes, ngroups, block, layers):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, base_planes, kernel_size=7, stride=2, padding=3, bias=False),
+                                   nn.GroupNorm(ngroups, base_planes), nn.ReLU(True))
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.inplanes = base_planes
+        self.layer1 = self._make_layer(block, ngroups, base_planes, layers[0])
+        self.layer2 = self._make_layer(block, ngroups, base_planes * 2, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, ngroups, base_planes * 4, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, ngroups, base_planes * 8, layers[3], stride=2)
+        self.final_channels = self.inplanes
+        self.final_spatial_compress = 1.0 / (2 ** 5)
+
+    def _make_layer(self, block, ngroups, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       nn.GroupNorm(ngroups, planes * block.expansion))
+        layers = [block(self.inplanes, planes, ngroups, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, ngroups))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.conv1(x))
+        return self.layer4(self.layer3(self.layer2(self.layer1(x))))
+
+
+def resnet50(in_channels, base_planes, ngroups):
+    return _GNResNet(in_channels, base_planes, ngroups, _Bottleneck, [3, 4, 6, 3])
+
+
+class ResNetEncoder(nn.Module):
+    def __init__(self, observation_space, baseplanes=32, ngroups=32, spatial_size=128, make_backbone=None,
                  normalize_visual_inputs=False, obs_transform=None):
         super().__init__()
-        self.output_shape = (128, 4, 4)
+        assert not normalize_visual_inputs
+        self._n_input_rgb = 0
+        self._n_input_depth = observation_space.spaces["depth"].shape[2]
+        spatial_size = observation_space.spaces["depth"].shape[0] // 2
+        self.running_mean_and_var = nn.Sequential()
+        self.backbone = make_backbone(self._n_input_depth, baseplanes, ngroups)
+        final_spatial = int(spatial_size * self.backbone.final_spatial_compress)
+        after_compression_flat_size = 2048
+        num_compression_channels = int(round(after_compression_flat_size / (final_spatial ** 2)))
+        self.compression = nn.Sequential(
+            nn.Conv2d(self.backbone.final_channels, num_compression_channels, kernel_size=3, padding=1, bias=False),
+            nn.GroupNorm(1, num_compression_channels), nn.ReLU(True))
+        self.output_shape = (num_compression_channels, final_spatial, final_spatial)
 
     def forward(self, observations):
-        raise RuntimeError("depth ResNet50 is third-party; pass observations['depth_features']")
+        depth_observations = observations["depth"].permute(0, 3, 1, 2)
+        x = torch.nn.functional.avg_pool2d(depth_observations, 2)
+        x = self.running_mean_and_var(x)
+        return self.compression(self.backbone(x))
 
 
 def install():
@@ -200,7 +277,7 @@ def install():
     m.Net = Net
     m.CriticHead = CriticHead
     m = _mod("habitat_baselines.rl.ddppo.policy.resnet")
-    m.resnet50 = object()
+    m.resnet50 = resnet50
     sys.modules["habitat_baselines.rl.ddppo.policy"].resnet = m
     m = _mod("habitat_baselines.rl.ddppo.policy.resnet_policy")
     m.ResNetEncoder = ResNetEncoder

@@ -287,6 +287,7 @@ struct WgradArgsB {
   int64_t npix, chunk;
   unsigned x_bytes, dy_bytes;
   int gx, gy;   // unit tiles, co tiles (1-D grid of gx*gy*gz blocks, XCD-swizzled)
+  int dbg_skip;  // timing experiments only (WSMG_WGRAD_DBG_SKIP=1): leave the epilogue out
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   }
   const int r = lane & 31;
   const int taps = a.KH * a.KW;
+  if (a.dbg_skip) { if (acc[0][0][0] == 123.456f) a.dw[0] = 1.f; return; }
 #pragma unroll
   for (int u = 0; u < TU; ++u) {
     const int uu = u0 + wave * TU + u;
@@ -554,7 +556,8 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
                                            wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
   WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
-               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0};
+               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, 0};
+  { static int sk = -1; if (sk < 0) { const char* e = getenv("WSMG_WGRAD_DBG_SKIP"); sk = e ? atoi(e) : 0; } a.dbg_skip = sk; }
   a.units = KH * KW * (Cin / 32);
   a.npix = (int64_t)B * OH * OW;
   // tile shape (measured per layer, tools/bench_conv.py): 128 co x 8 units where both dimensions are

@@ -499,3 +499,59 @@ extern "C" int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y
   return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, beta, save_mean, save_invstd, relu,
                               rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream);
 }
+
+// ----------------------------------------------------------------------------- GroupNorm (frozen DD-PPO depth ResNet50)
+// nn.GroupNorm over NHWC bf16 activations, inference only: statistics per (sample, group) over H x W x C/G elements
+// (biased variance, eps under the root), then gamma / beta per channel, optional residual add, optional ReLU.
+// habitat-lab v0.1.5 resnet.py uses it after every convolution of the depth backbone (reference call site
+// vlnce_baselines/models/encoders/resnet_encoders.py:25-32).  One workgroup per (group, sample); the whole path is 0.7 GFLOP
+// and a few MB per frame, so the kernel is written for generality (any C/G >= 1), not for the last GB/s: two passes over
+// the group's H*W*Cg elements, float accumulation per thread, float64 across the workgroup.
+namespace {
+__global__ __launch_bounds__(256) void group_norm_nhwc_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   int HW, int C, int G, float eps, int relu, bf16_t* __restrict__ y) {
+  __shared__ double red[2][4];
+  __shared__ float stat[2];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cg = C / G;
+  const int n = HW * Cg;
+  const size_t base = (size_t)b * HW * C + (size_t)g * Cg;
+  float s = 0.f, ss = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const int p = i / Cg, c = i - p * Cg;
+    const float v = (float)x[base + (size_t)p * C + c];
+    s += v;
+    ss = fmaf(v, v, ss);
+  }
+  double ds = wave_sum_d((double)s), dss = wave_sum_d((double)ss);
+  if (lane == 0) { red[0][wave] = ds; red[1][wave] = dss; }
+  __syncthreads();
+  if (tid == 0) {
+    const double t = red[0][0] + red[0][1] + red[0][2] + red[0][3], tt = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double mean = t / n;
+    double var = tt / n - mean * mean;
+    if (var < 0) var = 0;
+    stat[0] = (float)mean;
+    stat[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const float mean = stat[0], inv = stat[1];
+  for (int i = tid; i < n; i += 256) {
+    const int p = i / Cg, c = i - p * Cg;
+    const size_t o = base + (size_t)p * C + c;
+    float v = ((float)x[o] - mean) * inv * gamma[g * Cg + c] + beta[g * Cg + c];
+    if (res) v += (float)res[o];
+    if (relu) v = v > 0.f ? v : 0.f;
+    y[o] = (bf16_t)v;
+  }
+}
+}  // namespace
+
+extern "C" int wsmg_group_norm_nhwc_bf16(const void* x, const void* residual, const float* gamma, const float* beta, int B,
+                                         int HW, int C, int G, float eps, int relu, void* y, wsmg_stream_t stream) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || B > 65535) return WSMG_EINVAL;
+  hipLaunchKernelGGL(group_norm_nhwc_bf16_kernel, dim3(G, B), dim3(256), 0, wsmg_s(stream), (const bf16_t*)x,
+                     (const bf16_t*)residual, gamma, beta, HW, C, G, eps, relu, (bf16_t*)y);
+  WSMG_RETURN_LAUNCH();
+}

@@ -500,7 +500,7 @@ static unsigned* rnn_status_dev() {
     if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return nullptr;
     *(volatile unsigned*)h = 0u;
     void* d = nullptr;
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { hipHostFree(h); return nullptr; }
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return nullptr; }
     g_status_host = (unsigned*)h;
     g_status_dev = (unsigned*)d;
   }

@@ -1,22 +1,15 @@
-"""Depth branch: learned 16 x 64 spatial embedding concatenated to the DD-PPO ResNet50
-features (reference: resnet_encoders.py:12-102).  The ResNet50 itself is third-party
-(habitat-lab `ResNetEncoder`, not vendored in the reference): callers supply
-`observations['depth_features']` (what the trajectory cache stores and what the reference's
-forward short-circuits on, resnet_encoders.py:79-80) or attach their own `visual_encoder`.
+"""Depth branch: the frozen DD-PPO ResNet50 (GroupNorm, half width) + a learned 16 x 64 spatial embedding
+(reference: vlnce_baselines/models/encoders/resnet_encoders.py:12-102).  When the trajectory cache already holds
+`depth_features` the backbone is bypassed (resnet_encoders.py:79-80) — the update path never runs it.
+
+The backbone is habitat-lab's (third-party, not vendored by the reference); `ddppo_resnet.py` restates it with the
+state_dict keys of habitat-lab v0.1.5, so the reference's checkpoint loading (:37-50: the `visual_encoder.*` entries of
+a DD-PPO checkpoint, `strict=True`) works unchanged.
 """
 import torch
 import torch.nn as nn
 
-
-class _ExternalDepthBackbone(nn.Module):
-    """Placeholder for habitat-lab's DD-PPO ResNet50 (hookable, parameter-free)."""
-
-    output_shape = (128, 4, 4)
-
-    def forward(self, observations):
-        raise RuntimeError(
-            "the DD-PPO depth ResNet50 is a third-party habitat-lab module: pass observations['depth_features'] "
-            "[B,128,4,4] or assign policy.net.depth_encoder.visual_encoder")
+from .ddppo_resnet import ResNetEncoder
 
 
 class VlnResnetDepthEncoder(nn.Module):
@@ -24,16 +17,40 @@ class VlnResnetDepthEncoder(nn.Module):
                  resnet_baseplanes=32, normalize_visual_inputs=False, trainable=False, spatial_output=True,
                  visual_encoder=None):
         super().__init__()
-        self.visual_encoder = visual_encoder if visual_encoder is not None else _ExternalDepthBackbone()
+        if visual_encoder is None:
+            if backbone != "resnet50" or normalize_visual_inputs:
+                raise ValueError("the WS-MGMap depth branch is the DD-PPO resnet50 without input normalisation "
+                                 "(config/default.py:104-108)")
+            hw, ch = 256, 1
+            spaces = getattr(observation_space, "spaces", None)
+            if spaces is not None and "depth" in spaces:
+                hw, ch = int(spaces["depth"].shape[0]), int(spaces["depth"].shape[2])
+            visual_encoder = ResNetEncoder(hw, ch, baseplanes=resnet_baseplanes, ngroups=resnet_baseplanes // 2)
+        self.visual_encoder = visual_encoder
         for p in self.visual_encoder.parameters():
             p.requires_grad_(trainable)
+        if checkpoint != "NONE":
+            ddppo = torch.load(checkpoint, map_location="cpu")
+            weights = {}
+            for k, v in ddppo["state_dict"].items():
+                parts = k.split(".")[2:]           # "actor_critic.net.visual_encoder.backbone..." -> from "visual_encoder"
+                if parts and parts[0] == "visual_encoder":
+                    weights[".".join(parts[1:])] = v
+            del ddppo
+            self.visual_encoder.load_state_dict(weights, strict=True)
         self.spatial_output = spatial_output
         c, h, w = self.visual_encoder.output_shape
-        self.spatial_embeddings = nn.Embedding(h * w, 64)
-        self.output_shape = (c + self.spatial_embeddings.embedding_dim, h, w)
+        if not spatial_output:
+            self.output_shape = (output_size,)
+            self.visual_fc = nn.Sequential(nn.Flatten(), nn.Linear(c * h * w, output_size), nn.ReLU(True))
+        else:
+            self.spatial_embeddings = nn.Embedding(h * w, 64)
+            self.output_shape = (c + self.spatial_embeddings.embedding_dim, h, w)
 
     def forward(self, observations):
         x = observations["depth_features"] if "depth_features" in observations else self.visual_encoder(observations)
+        if not self.spatial_output:
+            return self.visual_fc(x)
         b, c, h, w = x.size()
         idx = torch.arange(0, self.spatial_embeddings.num_embeddings, device=x.device, dtype=torch.long)
         spatial = self.spatial_embeddings(idx).view(1, -1, h, w).expand(b, self.spatial_embeddings.embedding_dim, h, w)

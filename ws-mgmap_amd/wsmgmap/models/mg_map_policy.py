@@ -102,6 +102,8 @@ class MGMapNet(nn.Module):
         self.compute_dtype = torch.bfloat16 if want in ("bf16", "bfloat16") else torch.float32
         if self.compute_dtype == torch.bfloat16:   # the frozen RGB UNet follows: bf16 NHWC engine on the rollout path
             self.rgb_encoder.base_model.engine_dtype = torch.bfloat16
+            if hasattr(self.depth_encoder.visual_encoder, "engine_dtype"):
+                self.depth_encoder.visual_encoder.engine_dtype = torch.bfloat16
 
         self.train()
         self.depth_encoder.eval()

@@ -445,6 +445,20 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
     return y
 
 
+@torch.no_grad()
+def group_norm_nhwc(x, gamma, beta, groups, eps, relu, residual=None):
+    """nn.GroupNorm(groups, C) [+ residual] [+ ReLU] on an NHWC bf16 activation (inference only: the frozen depth backbone)."""
+    _req(x, gamma, beta, residual)
+    _f32(gamma, beta)
+    if x.dtype != torch.bfloat16 or (residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape)):
+        raise _abi.WsmgError("group_norm_nhwc: bf16 NHWC activations (and a residual of the same shape)")
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    _abi.call("wsmg_group_norm_nhwc_bf16", _p(x), _p(residual), _p(gamma), _p(beta), B, H * W, C, int(groups), float(eps),
+              int(bool(relu)), _p(y), _stream())
+    return y
+
+
 def conv_transpose2d(x, weight_iohw, stride=2, pad=1):
     """nn.ConvTranspose2d weight is [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW."""
     return _ConvT2d.apply(x, weight_iohw, stride, pad)
