@@ -311,11 +311,12 @@ int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t* lengths, 
                   wsmg_stream_t stream);
 
 /* ============================ GroupNorm (frozen DD-PPO depth backbone, rollout path) ============================ */
-/* nn.GroupNorm(G, C) [+ residual] [+ ReLU] on NHWC bf16 activations, inference only: x, y, residual [B][HW][C]; gamma, beta
- * [C]; statistics per (sample, group) over HW x C/G elements, biased variance.  Used after every convolution of habitat-lab
- * v0.1.5's GroupNorm ResNet50 (third-party; instantiated at vlnce_baselines/models/encoders/resnet_encoders.py:25-32). */
-int wsmg_group_norm_nhwc_bf16(const void* x, const void* residual, const float* gamma, const float* beta, int B, int HW,
-                              int C, int G, float eps, int relu, void* y, wsmg_stream_t stream);
+/* nn.GroupNorm(G, C) [+ residual] [+ ReLU] on NHWC activations, inference only: x [B][HW][C] float32 (x_f32 = 1: the
+ * convolution's float32 accumulators, stored unrounded) or bf16; y, residual [B][HW][C] bf16; gamma, beta [C]; statistics
+ * per (sample, group) over HW x C/G elements, biased variance.  Used after every convolution of habitat-lab v0.1.5's
+ * GroupNorm ResNet50 (third-party; instantiated at vlnce_baselines/models/encoders/resnet_encoders.py:25-32). */
+int wsmg_group_norm_nhwc_bf16(const void* x, int x_f32, const void* residual, const float* gamma, const float* beta, int B,
+                              int HW, int C, int G, float eps, int relu, void* y, wsmg_stream_t stream);
 
 /* Status of the four persistent kernels above.  All their waits are bounded; when one times out (a cooperating
  * workgroup never became resident, e.g. CU oversubscription by another process) every workgroup leaves, the

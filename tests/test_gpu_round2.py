@@ -489,10 +489,9 @@ def test_act_from_raw_depth_vs_oracle():
 
 
 def test_frozen_encoders_on_the_bf16_engine_vs_oracle():
-    """compute_dtype = bf16: the frozen RGB ResNet-UNet and the depth ResNet50 run on the NHWC bf16 conv engine (folded
-    eval-mode BatchNorm / the group-norm kernel).  Held against the ORACLE (float32 CPU restatement of
-    unet_encoder.py:64-111 and of the third-party depth backbone) on the G4 inputs, hash-filled weights.  Written bf16 bars:
-    relative L2 error of `layer4` <= 2 %, of `proj_feat` <= 3 %, of the depth features <= 3 %; hook contract unchanged."""
+    """compute_dtype = bf16: the frozen RGB ResNet-UNet runs on the NHWC bf16 conv engine (folded eval-mode BatchNorm).  Held
+    against the ORACLE (float32 CPU restatement of unet_encoder.py:64-111) on the G4 inputs, hash-filled weights.  Written
+    bf16 bars: relative L2 error of `layer4` <= 2 %, of `proj_feat` <= 3 %; hook contract unchanged."""
     pol = _policy(num_proc=2, compute_dtype="bf16").eval()
     P = make_params(grad=False)
     for hw in (224, 256):
@@ -506,10 +505,45 @@ def test_frozen_encoders_on_the_bf16_engine_vs_oracle():
         for a, b, name, bar in ((l4, l4_ref, "layer4", 2e-2), (proj, proj_ref, "proj_feat", 3e-2)):
             rel = float((a.cpu() - b).norm() / b.norm())
             assert rel <= bar, (hw, name, rel)
+    # the depth ResNet50 stays float32 in bf16 mode (ddppo_resnet.py): same bar as the float32 mode
     depth = T(cases.act_inputs(0, B=2, tag="rawd")[0]["depth"])
     with torch.no_grad():
         f_ref = policy_ref.ddppo_resnet50(P, depth)
         f = pol.net.depth_encoder.visual_encoder({"depth": depth.cuda()})
     assert f.dtype == torch.float32 and tuple(f.shape) == (2, 128, 4, 4)
-    rel = float((f.cpu() - f_ref).norm() / f_ref.norm())
-    assert rel <= 3e-2, rel
+    assert float((f.cpu() - f_ref).abs().max()) <= 1e-4
+
+
+def test_depth_backbone_engine_path_opt_in():
+    """The opt-in NHWC bf16 engine path of the depth ResNet50 (53 convolutions with float32 output + the group-norm kernel)
+    against the module's own float32 stock path, default initialisation with non-trivial affine parameters: relative L2
+    error <= 6 % at the output (measured 3-5 %: bf16 storage compounds over 53 normalised layers, which is why the path is
+    not the default), and every group-norm + residual + ReLU stage of the first bottleneck within 1.5 %."""
+    from wsmgmap import ops
+    from wsmgmap.models.encoders.ddppo_resnet import ResNetEncoder
+    torch.manual_seed(0)
+    enc = ResNetEncoder().cuda().eval()
+    for m in enc.modules():
+        if isinstance(m, torch.nn.GroupNorm):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+    depth = torch.rand(2, 256, 256, 1, device="cuda")
+    with torch.no_grad():
+        ref = enc({"depth": depth})
+        enc.engine_dtype = torch.bfloat16
+        got = enc({"depth": depth})
+        assert got.dtype == torch.float32 and got.shape == ref.shape
+        rel = float((got - ref).norm() / ref.norm())
+        assert rel <= 6e-2, rel
+        # one stage in isolation: group norm (+ residual + ReLU) of a float32 tensor against F.group_norm
+        x = torch.randn(3, 16, 16, 128, device="cuda")
+        res = torch.randn(3, 16, 16, 128, device="cuda").to(torch.bfloat16)
+        gn = torch.nn.GroupNorm(16, 128).cuda()
+        gn.weight.data.uniform_(0.5, 1.5)
+        gn.bias.data.normal_(0, 0.2)
+        want = torch.relu(gn(x.permute(0, 3, 1, 2)) + res.float().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        y = ops.group_norm_nhwc(x.contiguous(), gn.weight, gn.bias, 16, gn.eps, True, res.contiguous())
+        assert float((y.float() - want).abs().max()) <= 2e-2      # one bf16 rounding of values up to ~4
+        y1 = ops.group_norm_nhwc(x[:1, :4, :4].contiguous().to(torch.bfloat16), gn.weight, gn.bias, 1, gn.eps, False)
+        want1 = torch.nn.functional.group_norm(x[:1, :4, :4].to(torch.bfloat16).float().permute(0, 3, 1, 2), 1, gn.weight, gn.bias, gn.eps)
+        assert float((y1.float().permute(0, 3, 1, 2) - want1).abs().max()) <= 2e-2

@@ -508,7 +508,8 @@ extern "C" int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y
 // and a few MB per frame, so the kernel is written for generality (any C/G >= 1), not for the last GB/s: two passes over
 // the group's H*W*Cg elements, float accumulation per thread, float64 across the workgroup.
 namespace {
-__global__ __launch_bounds__(256) void group_norm_nhwc_bf16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+template <class TI>
+__global__ __launch_bounds__(256) void group_norm_nhwc_bf16_kernel(const TI* __restrict__ x, const bf16_t* __restrict__ res,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    int HW, int C, int G, float eps, int relu, bf16_t* __restrict__ y) {
   __shared__ double red[2][4];
@@ -548,10 +549,14 @@ __global__ __launch_bounds__(256) void group_norm_nhwc_bf16_kernel(const bf16_t*
 }
 }  // namespace
 
-extern "C" int wsmg_group_norm_nhwc_bf16(const void* x, const void* residual, const float* gamma, const float* beta, int B,
-                                         int HW, int C, int G, float eps, int relu, void* y, wsmg_stream_t stream) {
+extern "C" int wsmg_group_norm_nhwc_bf16(const void* x, int x_f32, const void* residual, const float* gamma, const float* beta,
+                                         int B, int HW, int C, int G, float eps, int relu, void* y, wsmg_stream_t stream) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || B > 65535) return WSMG_EINVAL;
-  hipLaunchKernelGGL(group_norm_nhwc_bf16_kernel, dim3(G, B), dim3(256), 0, wsmg_s(stream), (const bf16_t*)x,
-                     (const bf16_t*)residual, gamma, beta, HW, C, G, eps, relu, (bf16_t*)y);
+  if (x_f32)
+    hipLaunchKernelGGL(group_norm_nhwc_bf16_kernel<float>, dim3(G, B), dim3(256), 0, wsmg_s(stream), (const float*)x,
+                       (const bf16_t*)residual, gamma, beta, HW, C, G, eps, relu, (bf16_t*)y);
+  else
+    hipLaunchKernelGGL(group_norm_nhwc_bf16_kernel<bf16_t>, dim3(G, B), dim3(256), 0, wsmg_s(stream), (const bf16_t*)x,
+                       (const bf16_t*)residual, gamma, beta, HW, C, G, eps, relu, (bf16_t*)y);
   WSMG_RETURN_LAUNCH();
 }

@@ -102,7 +102,9 @@ class MGMapNet(nn.Module):
         self.compute_dtype = torch.bfloat16 if want in ("bf16", "bfloat16") else torch.float32
         if self.compute_dtype == torch.bfloat16:   # the frozen RGB UNet follows: bf16 NHWC engine on the rollout path
             self.rgb_encoder.base_model.engine_dtype = torch.bfloat16
-            if hasattr(self.depth_encoder.visual_encoder, "engine_dtype"):
+            # the depth ResNet50 stays float32 by default (ddppo_resnet.py: bf16 storage compounds over its 53 GroupNorm layers)
+            import os
+            if os.environ.get("WSMG_DEPTH_ENGINE", "0") == "1" and hasattr(self.depth_encoder.visual_encoder, "engine_dtype"):
                 self.depth_encoder.visual_encoder.engine_dtype = torch.bfloat16
 
         self.train()
@@ -205,11 +207,13 @@ class MGMapNet(nn.Module):
         ops.reset_pass_state()
         entry = torch.cuda.Event()
         entry.record(torch.cuda.current_stream())
+        ops.mark("entry")
         rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)
         depth_embedding = self.depth_encoder(observations)
 
         self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
         map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
+        ops.mark("map_stack", map_tokens)
         text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
 
         state_in = []
@@ -222,7 +226,9 @@ class MGMapNet(nn.Module):
         state_in = torch.cat(state_in, dim=1)
 
         n1 = self.state_encoder.num_recurrent_layers
+        ops.mark("state_in", state_in)
         state, rnn_hidden_states[0:n1] = self.state_encoder(state_in, rnn_hidden_states[0:n1], masks)
+        ops.mark("gru1", state)
 
         # instruction attention: keys projected once per unique instruction, gathered per row
         torch.cuda.current_stream().wait_stream(side)
@@ -241,5 +247,7 @@ class MGMapNet(nn.Module):
 
         parts = [state, text_embedding] + ([map_embedding] if "map" in self._inputs else [])
         x = self.second_state_compress(torch.cat(parts, dim=1))
+        ops.mark("attention", x)
         x, rnn_hidden_states[n1:] = self.second_state_encoder(x, rnn_hidden_states[n1:], masks)
+        ops.mark("gru2", x)
         return x, rnn_hidden_states, pred_sem_map

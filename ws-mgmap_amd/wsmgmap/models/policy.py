@@ -88,9 +88,12 @@ class BasePolicy(nn.Module):
             features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
         finally:
             self.net.skip_pred_map_nchw = False
-        pred = self.action_distribution(features).mean
+        # = self.action_distribution(features).mean (policy.py:96-97) without building the Normal: its log-std / exp / expand
+        # kernels produce nothing the update path reads (logstd gets no gradient in the reference either)
+        pred = self.action_distribution.fc_mean(features)
         self.aux_prediction(features, observations, pred_map)
         aux_loss = AuxLosses.reduce((weights > 0).view(-1))
+        ops.mark("heads_aux")
         return pred, aux_loss
 
 

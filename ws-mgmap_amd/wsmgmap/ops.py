@@ -115,6 +115,41 @@ def _launch(name, flops, *args):
     _prof.setdefault(name, []).append((s, e, flops))
 
 
+# ----------------------------------------------------------------------------- section marks (diagnostics)
+# tools/section_times.py: HIP events at the stage boundaries of one update (forward marks from MGMapNet.forward, backward
+# marks from gradient hooks on the boundary tensors), to see where the critical path of an update goes without a profiler
+# attached.  Off (None) in every product run.
+_marks = None
+
+
+def marks_begin():
+    global _marks
+    _marks = []
+
+
+def marks_end():
+    global _marks
+    out, _marks = _marks, None
+    return out
+
+
+def mark(name, tensor=None):
+    """Record an event now (forward); with `tensor`, also when its gradient arrives (backward)."""
+    if _marks is None:
+        return
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _marks.append(("f:" + name, e))
+    if tensor is not None and tensor.requires_grad:
+        def hook(g, name=name):
+            if _marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                _marks.append(("b:" + name, ev))
+            return g
+        tensor.register_hook(hook)
+
+
 # ----------------------------------------------------------------------------- convolution
 def _weight_layouts(w_oihw, cin_pad, dtype, need_ihwo):
     """(OHWI, IHWO or None) of an OIHW float32 parameter in `dtype`, input channels zero-padded to cin_pad: ONE launch
@@ -429,7 +464,7 @@ def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, rel
     return _Conv2dCat.apply(weight_oihw, bias, stride, pad, bias_grad_zero, relu, *xs)
 
 
-def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
+def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False):
     """Inference-only bf16 convolution with a pre-laid-out OHWI bf16 weight, float32 bias and optional fused ReLU
     (one launch; used by the frozen encoders with eval-mode BatchNorm folded into weight and bias)."""
     _req(x, w_ohwi_bf16, bias)
@@ -439,9 +474,9 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu):
     Cout, KH, KW, Cin2 = w_ohwi_bf16.shape
     assert Cin == Cin2, (x.shape, w_ohwi_bf16.shape)
     OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
-    y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.bfloat16)
+    y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
     _launch("wsmg_conv2d_fwd_bf16", 2.0 * B * OH * OW * Cout * Cin * KH * KW, _p(x), _p(w_ohwi_bf16), _p(bias), _p(y),
-            2 if relu else 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+            (2 if relu else 0) | (1 if out_f32 else 0), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
     return y
 
 
@@ -450,12 +485,13 @@ def group_norm_nhwc(x, gamma, beta, groups, eps, relu, residual=None):
     """nn.GroupNorm(groups, C) [+ residual] [+ ReLU] on an NHWC bf16 activation (inference only: the frozen depth backbone)."""
     _req(x, gamma, beta, residual)
     _f32(gamma, beta)
-    if x.dtype != torch.bfloat16 or (residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape)):
-        raise _abi.WsmgError("group_norm_nhwc: bf16 NHWC activations (and a residual of the same shape)")
+    if x.dtype not in (torch.bfloat16, torch.float32) or (
+            residual is not None and (residual.dtype != torch.bfloat16 or residual.shape != x.shape)):
+        raise _abi.WsmgError("group_norm_nhwc: float32 / bf16 NHWC input, bf16 residual of the same shape")
     B, H, W, C = x.shape
-    y = torch.empty_like(x)
-    _abi.call("wsmg_group_norm_nhwc_bf16", _p(x), _p(residual), _p(gamma), _p(beta), B, H * W, C, int(groups), float(eps),
-              int(bool(relu)), _p(y), _stream())
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _abi.call("wsmg_group_norm_nhwc_bf16", _p(x), int(x.dtype == torch.float32), _p(residual), _p(gamma), _p(beta), B, H * W, C,
+              int(groups), float(eps), int(bool(relu)), _p(y), _stream())
     return y
 
 
