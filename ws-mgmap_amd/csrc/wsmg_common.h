@@ -68,3 +68,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // any other shape
 int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int relu, int B, int H, int W, int Cin,
                            int Cout, int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s);
+// wsmg_conv_win_wgrad.hip: weight gradient of the same layer out of an LDS-resident input window; WSMG_EINVAL for any other shape
+int wsmg_conv_win_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, int OH, int OW, hipStream_t s);

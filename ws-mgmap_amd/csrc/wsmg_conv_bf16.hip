@@ -555,6 +555,15 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
                                            int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                            wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  if (Cin == 64 && Cout == 64 && KH == 8 && KW == 8 && stride == 2 && pad == 3) {
+    // the map encoder's stem: LDS-window variant (wsmg_conv_win_wgrad.hip); WSMG_WGRAD_WIN=0 keeps the generic kernel (A/B)
+    static int use_win = -1;
+    if (use_win < 0) { const char* e = getenv("WSMG_WGRAD_WIN"); use_win = e ? atoi(e) : 1; }
+    if (use_win) {
+      int rc = wsmg_conv_win_wgrad_bf16(x, dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
+      if (rc != WSMG_EINVAL) return rc;
+    }
+  }
   WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
                (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, 0};
   { static int sk = -1; if (sk < 0) { const char* e = getenv("WSMG_WGRAD_DBG_SKIP"); sk = e ? atoi(e) : 0; } a.dbg_skip = sk; }
