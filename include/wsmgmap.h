@@ -170,6 +170,20 @@ int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, v
 int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                               wsmg_stream_t stream);
+/* The same two launches with the train-mode BatchNorm statistics of their output taken in the epilogue (every convolution of
+ * the map stack feeds a BatchNorm2d: map_encoder.py:10-12,21-28,94-112, mg_map_policy.py:80-85): stats [nslab][2][C] float64,
+ * ACCUMULATED INTO (sum, sum of squares of the bf16-rounded outputs per output channel; the m-tile index picks the slab).
+ * wsmg_bn_act_fwd_bf16_pre consumes and clears them, so the separate statistics pass over y never runs.  bf16 output,
+ * no accumulate flag. */
+int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, double* stats,
+                               int nslab, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
+                               int OW, wsmg_stream_t stream);
+int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
+                                    int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                    wsmg_stream_t stream);
+int wsmg_bn_act_fwd_bf16_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, int relu, int64_t rows, int C, void* y,
+                             float* save_mean, float* save_invstd, double* stats, int nslab, wsmg_stream_t stream);
 int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin,
                                 int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                 wsmg_stream_t stream);

@@ -66,8 +66,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // wsmg_conv_win.hip: direct convolution with an LDS-resident input window (64 -> 64 channels, k8 s2 p3); WSMG_EINVAL for
 // any other shape
-int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int relu, int B, int H, int W, int Cin,
-                           int Cout, int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s);
+int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int relu, double* stats, int nslab, int B,
+                           int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s);
 // wsmg_conv_win_wgrad.hip: weight gradient of the same layer out of an LDS-resident input window; WSMG_EINVAL for any other shape
 int wsmg_conv_win_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, int OH, int OW, hipStream_t s);

@@ -51,6 +51,8 @@ struct ConvArgsB {
   int mtiles, ntiles;
   int out_f32;
   unsigned src_bytes, wt_bytes;
+  double* stats;   // or null: [nslab][2][N] float64 sums / sums of squares of the (bf16-rounded) output, accumulated into
+  int nslab;
 };
 
 // PF = k-steps of global loads kept in flight in registers (a bf16 k-step is only 256-512 MFMA
@@ -112,9 +114,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
       py = ty * a.stride - a.pad;
       px = tx * a.stride - a.pad;
     }
-    unsigned ym = 0, xm = 0;
-    for (int t = 0; t < KHc; ++t) { int sy = py + sg * t; if (sy >= 0 && sy < a.SH) ym |= 1u << t; }
-    for (int t = 0; t < KWc; ++t) { int sx = px + sg * t; if (sx >= 0 && sx < a.SW) xm |= 1u << t; }
+    // taps t with 0 <= p + sg t < S form one interval [lo, hi]: closed form (the tap loops compiled to a chain of
+    // data-dependent branches, run 2 x APASS times by every workgroup: a noticeable prologue for the 9-k-step launches)
+    auto tapmask = [&](int p, int S_, int n) -> unsigned {
+      int lo = BWD ? p - (S_ - 1) : -p, hi = BWD ? p : S_ - 1 - p;
+      lo = lo < 0 ? 0 : lo;
+      hi = hi > n - 1 ? n - 1 : hi;
+      return hi >= lo ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;
+    };
+    const unsigned ym = tapmask(py, a.SH, KHc), xm = tapmask(px, a.SW, KWc);
     ymask[i] = pv ? ym : 0u;
     xmask[i] = xm;
     roff[i] = ((b * a.SH + py) * a.SW + px) * a.Kc + seg * 8;
@@ -236,6 +244,28 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
         if (dp < 0 || n >= a.N) continue;
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)dp * a.N + n) * 2) =
             *reinterpret_cast<const u32x4*>(smem + row * OP + ch * 16);
+      }
+      if (a.stats) {
+        // Train-mode BatchNorm statistics of THIS output (map_encoder.py:10-12: every conv of the map stack feeds one):
+        // per-channel sum and sum of squares of the tile, taken from the bf16 values just staged in LDS, added to one of
+        // `nslab` float64 slabs (slab = m-tile mod nslab: 72 adders per address instead of 4608) — the separate
+        // statistics pass over y (one full read of every conv output) disappears.
+        constexpr int PARTS = 256 / BN, RPP2 = BM / PARTS;
+        const int col = tid % BN, part = tid / BN;
+        float sv = 0.f, qv = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < RPP2; ++rr) {
+          const int row = part * RPP2 + rr;
+          const float v = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(smem + row * OP + col * 2) << 16);
+          const float m = dpix[row] >= 0 ? 1.f : 0.f;
+          sv = fmaf(m, v, sv);
+          qv = fmaf(m * v, v, qv);
+        }
+        if (n0 + col < a.N) {
+          double* st = a.stats + (size_t)((logical / a.ntiles) % a.nslab) * 2 * a.N + n0 + col;
+          atomicAdd(st, (double)sv);
+          atomicAdd(st + a.N, (double)qv);
+        }
       }
       return;
     }
@@ -515,32 +545,40 @@ void launch_igemm(ConvArgsB& a, int64_t mrows, int classes, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, int B,
-                                    int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
-                                    int OW, wsmg_stream_t stream) {
+extern "C" int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32,
+                                          double* stats, int nslab, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                          int stride, int pad, int OH, int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  if (stats && (nslab <= 0 || (out_f32 & 5) != 0 || (Cout & 7) != 0)) return WSMG_EINVAL;   // statistics: bf16 output, no accumulate
   if (Cin == 64 && Cout == 64 && KH == 8 && KW == 8 && stride == 2 && pad == 3 && (out_f32 & 5) == 0) {
     // the map encoder's stem: direct convolution out of an LDS-resident input window (wsmg_conv_win.hip); WSMG_CONV_WIN=0
     // keeps the implicit-GEMM kernel (A/B)
     static int use_win = -1;
     if (use_win < 0) { const char* e = getenv("WSMG_CONV_WIN"); use_win = e ? atoi(e) : 1; }
     if (use_win) {
-      int rc = wsmg_conv_win_fwd_bf16(x, w_ohwi, bias, y, (out_f32 & 2) != 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
+      int rc = wsmg_conv_win_fwd_bf16(x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
     }
   }
   ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32,
-              (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2)};
+              (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
   launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream));
   WSMG_RETURN_LAUNCH();
 }
 
-extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
-                                         int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
-                                         wsmg_stream_t stream) {
+extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, int B,
+                                    int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
+                                    int OW, wsmg_stream_t stream) {
+  return wsmg_conv2d_fwd_bf16_stats(x, w_ohwi, bias, y, out_f32, nullptr, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
+}
+
+extern "C" int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab,
+                                               int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                               int OH, int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  if (stats && (nslab <= 0 || (out_f32 & 5) != 0 || (Cin & 7) != 0)) return WSMG_EINVAL;
   ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32,
-              (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2)};
+              (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
   int classes = 1;
   int64_t mmax = (int64_t)B * H * W;
   if (stride == 2) {
@@ -549,6 +587,12 @@ extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, voi
   }
   launch_igemm<true>(a, mmax, classes, wsmg_s(stream));
   WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
+                                         int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                         wsmg_stream_t stream) {
+  return wsmg_conv2d_bwd_data_bf16_stats(dy, w_ihwo, dx, out_f32, nullptr, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
 }
 
 extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin,

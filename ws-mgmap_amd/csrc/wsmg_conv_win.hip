@@ -33,6 +33,8 @@ struct WinArgs {
   bf16_t* y;          // [B][OH][OW][64]
   int B, H, W, OH, OW, tiles_y, tiles_x, relu;
   unsigned x_bytes, w_bytes;
+  double* stats;   // or null: [nslab][2][64] float64 batch-norm sums of the output (see conv_igemm_bf16_kernel)
+  int nslab;
 };
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nb) {
@@ -211,6 +213,22 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(win + qq * PITCH + ch * 16);
     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.y) + (((size_t)(b * a.OH + oy) * a.OW + ox) * CO) * 2 + ch * 16) = v;
   }
+  if (a.stats) {   // train-mode BatchNorm sums of this tile's valid pixels, from the staged bf16 values
+    const int col = tid & 63, part = tid >> 6;
+    float sv = 0.f, qv = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 32; ++rr) {
+      const int qq = part * 32 + rr;
+      const bool ok = qq < TH * TW && oy0 + qq / TW < a.OH && ox0 + qq % TW < a.OW;
+      const float v = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(win + qq * PITCH + col * 2) << 16);
+      const float m = ok ? 1.f : 0.f;
+      sv = fmaf(m, v, sv);
+      qv = fmaf(m * v, v, qv);
+    }
+    double* st = a.stats + (size_t)(logical % a.nslab) * 2 * CO + col;
+    atomicAdd(st, (double)sv);
+    atomicAdd(st + CO, (double)qv);
+  }
   __syncthreads();   // the output tile has left LDS before the next window is written over it
   }
 }
@@ -219,13 +237,13 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
 
 // Forward of a 64 -> 64 channel k8 s2 p3 convolution on bf16 NHWC; returns WSMG_EINVAL for any other shape (the
 // caller then uses the implicit-GEMM kernel).  relu: fused ReLU after the bias.
-int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int relu, int B, int H, int W, int Cin,
-                           int Cout, int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s) {
+int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int relu, double* stats, int nslab, int B,
+                           int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s) {
   if (Cin != 64 || Cout != 64 || KH != 8 || KW != 8 || stride != 2 || pad != 3) return WSMG_EINVAL;
   if ((size_t)B * H * W * 128 >= (1ull << 31)) return WSMG_EINVAL;
   constexpr int TH = 5, TW = 25;
   WinArgs a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, (bf16_t*)y, B, H, W, OH, OW, (OH + TH - 1) / TH, (OW + TW - 1) / TW, relu,
-            (unsigned)((size_t)B * H * W * 128), (unsigned)(64u * 8 * 8 * 64 * 2)};
+            (unsigned)((size_t)B * H * W * 128), (unsigned)(64u * 8 * 8 * 64 * 2), stats, nslab};
   auto kern = conv_win_fwd_kernel<8, 2, 3, TH, TW>;
   constexpr int LDS = (((TH - 1) * 2 + 8) * 2 * (((TW - 1) * 2 + 8) / 2) + 3 * 64) * 144;
   static bool attr = false;

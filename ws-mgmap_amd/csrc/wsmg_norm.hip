@@ -142,13 +142,15 @@ __global__ __launch_bounds__(64) void sum_finalize_kernel(const double* part, in
   if (threadIdx.x == 0) out[c] = (float)s;
 }
 
-__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* part, int nblk, int C, int64_t rows,
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(double* part, int nblk, int C, int64_t rows,
                                                                float momentum, float eps, float* running_mean,
                                                                float* running_var, float* save_mean,
-                                                               float* save_invstd) {
+                                                               float* save_invstd, int clear) {
   const int c = blockIdx.x;
   double s, q;
   reduce_partials(part, nblk, C, c, s, q);
+  if (clear)   // slabs filled by a convolution's epilogue: hand them back zeroed for the next forward pass
+    for (int b = threadIdx.x; b < nblk; b += WSMG_WAVE) { part[((size_t)b * 2 + 0) * C + c] = 0.0; part[((size_t)b * 2 + 1) * C + c] = 0.0; }
   if (threadIdx.x != 0) return;
   double n = (double)rows;
   double mean = s / n;
@@ -412,7 +414,7 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
     hipLaunchKernelGGL((col_reduce_kernel<1, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, (const T*)nullptr,
                        (const T*)nullptr, nullptr, nullptr, nullptr, nullptr, 0, rows, C, workspace);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, rows, momentum, eps,
-                       running_mean, running_var, save_mean, save_invstd);
+                       running_mean, running_var, save_mean, save_invstd, 0);
   } else {
     hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((unsigned)wsmg_cdiv(C, 256)), dim3(256), 0, s, running_mean, running_var, eps, C,
                        save_mean, save_invstd);
@@ -454,6 +456,25 @@ int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const 
 }
 
 }  // namespace
+
+// BatchNorm (train) + residual + ReLU of a bf16 tensor whose per-channel sums were already accumulated by the producing
+// convolution's epilogue (wsmg_conv2d_fwd_bf16_stats): finalize (+ clear the slabs) and apply — no statistics pass over x.
+extern "C" int wsmg_bn_act_fwd_bf16_pre(const void* x, const void* residual, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float momentum, float eps, int relu,
+                                        int64_t rows, int C, void* y, float* save_mean, float* save_invstd, double* stats,
+                                        int nslab, wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0 || !stats || nslab <= 0) return WSMG_EINVAL;
+  hipStream_t s = wsmg_s(stream);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, stats, nslab, C, rows, momentum, eps, running_mean,
+                     running_var, save_mean, save_invstd, 1);
+  if (bn_vec8())
+    hipLaunchKernelGGL(bn_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual, gamma,
+                       beta, save_mean, save_invstd, relu, rows, C, (bf16_t*)y);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(stream_grid(rows, C)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)residual,
+                       gamma, beta, save_mean, save_invstd, relu, rows, C, (bf16_t*)y);
+  WSMG_RETURN_LAUNCH();
+}
 
 extern "C" int64_t wsmg_channel_reduce_workspace_bytes(int64_t rows, int C) {
   if (!chan_ok(C)) return 0;

@@ -49,11 +49,22 @@ def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True,
     """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
     # (if x carries zero-padded channels, ops.conv2d pads the weight's input channels to match)
     if isinstance(x, (list, tuple)):   # convolution over a channel concatenation, run part by part (no torch.cat)
-        y = ops.conv2d_cat(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
-    else:
-        y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
+        if len(x) == 2 and not (x[0].dtype == torch.bfloat16 and os.environ.get("WSMG_CONV_CAT", "0") == "1"):
+            x = ops.cat_channels(x[0], x[1])
+        else:
+            y = ops.conv2d_cat(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
+            bump(bn, train)
+            return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
+    # bf16 training: the convolution's epilogue accumulates the BatchNorm sums of its output (no statistics pass over y)
+    stats = None
+    if train and x.dtype == torch.bfloat16 and conv.out_channels % 8 == 0:
+        stats = ops.bn_stats_slabs(id(bn), conv.out_channels, x.device)
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train, stats=stats)
     bump(bn, train)
-    return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
+    out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps, stats)
+    if stats is not None:
+        ops.bn_stats_done(id(bn), conv.out_channels, x.device)
+    return out
 
 
 def convrelu(in_channels, out_channels, kernel, padding):

@@ -160,12 +160,18 @@ class MGMapNet(nn.Module):
         dec = self.map_decoder(enc)
         c = self.map_classfier
         from .encoders.map_encoder import bump
-        y = ops.conv_transpose2d(dec, c[0].weight, 2, 1)
+        fused = train and dec.dtype == torch.bfloat16
+        st1 = ops.bn_stats_slabs(id(c[1]), 32, dec.device) if fused else None
+        y = ops.conv_transpose2d(dec, c[0].weight, 2, 1, st1)
         bump(c[1], train)
-        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps)
-        y = ops.conv2d(y, c[3].weight, None, 1, 1)
+        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps, st1)
+        st4 = ops.bn_stats_slabs(id(c[4]), 32, dec.device) if fused else None
+        y = ops.conv2d(y, c[3].weight, None, 1, 1, stats=st4)
         bump(c[4], train)
-        y = ops.bn_act(y, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var, train, True, None, c[4].momentum, c[4].eps)
+        y = ops.bn_act(y, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var, train, True, None, c[4].momentum, c[4].eps, st4)
+        if fused:
+            ops.bn_stats_done(id(c[1]), 32, dec.device)
+            ops.bn_stats_done(id(c[4]), 32, dec.device)
         pad_o = SEM_PAD - SEM_CLASSES
         w6 = torch.nn.functional.pad(c[6].weight, (0, 0, 0, 0, 0, 0, 0, pad_o))   # [32,32,1,1]
         b6 = torch.nn.functional.pad(c[6].bias, (0, pad_o))

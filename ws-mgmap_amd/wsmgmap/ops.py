@@ -71,6 +71,8 @@ def _conv_out(h, k, s, p):
 _prof = None
 
 KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trace names it)
+    "wsmg_conv2d_fwd_bf16_stats": "conv_igemm_bf16_kernel<false, *>",
+    "wsmg_conv2d_bwd_data_bf16_stats": "conv_igemm_bf16_kernel<true, *>",
     "wsmg_conv2d_fwd": "conv_igemm_kernel<false, false>",
     "wsmg_conv2d_bwd_data": "conv_igemm_kernel<true, false>",
     "wsmg_conv2d_bwd_weight": "conv_wgrad_kernel<false>",
@@ -259,7 +261,7 @@ class _Conv2d(torch.autograd.Function):
     channels than w (the engine pads activations to multiples of 32) the weight is zero-padded to match."""
 
     @staticmethod
-    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False):
+    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None):
         _req(x, w_oihw, bias)
         _f32(w_oihw, bias)
         sfx = _sfx(x)
@@ -271,7 +273,10 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         dims = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)
-        if sfx:   # ReLU, when asked for, runs in the conv epilogue (flag bit 1)
+        if sfx and stats is not None:   # + the output's BatchNorm sums in the epilogue (see bn_stats_slabs)
+            _launch("wsmg_conv2d_fwd_bf16_stats", fl, _p(x), _p(w), _p(bias), _p(y), 2 if relu else 0, _p(stats), stats.shape[0],
+                    *dims, _stream())
+        elif sfx:   # ReLU, when asked for, runs in the conv epilogue (flag bit 1)
             _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias), _p(y), 2 if relu else 0, *dims, _stream())
         else:
             _launch("wsmg_conv2d_fwd", fl, _p(x), _p(w), _p(bias), _p(y), *dims, _stream())
@@ -323,7 +328,7 @@ class _Conv2d(torch.autograd.Function):
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
             db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _ConvT2d(torch.autograd.Function):
@@ -331,7 +336,7 @@ class _ConvT2d(torch.autograd.Function):
     parameter [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW weight (O = Cin_t channels on the small grid)."""
 
     @staticmethod
-    def forward(ctx, x, w_iohw, stride, pad):
+    def forward(ctx, x, w_iohw, stride, pad, stats=None):
         _req(x, w_iohw)
         _f32(w_iohw)
         sfx = _sfx(x)
@@ -343,7 +348,9 @@ class _ConvT2d(torch.autograd.Function):
         y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=x.dtype)
         fl = 2.0 * B * Hs * Ws * O * I * KH * KW
         dims = (B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws)
-        if sfx:
+        if sfx and stats is not None:
+            _launch("wsmg_conv2d_bwd_data_bf16_stats", fl, _p(x), _p(w_ihwo), _p(y), 0, _p(stats), stats.shape[0], *dims, _stream())
+        elif sfx:
             _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(x), _p(w_ihwo), _p(y), 0, *dims, _stream())
         else:
             _launch("wsmg_conv2d_bwd_data", fl, _p(x), _p(w_ihwo), _p(y), *dims, _stream())
@@ -369,15 +376,15 @@ class _ConvT2d(torch.autograd.Function):
             dw_ohwi = _zeros_f32((O, KH, KW, I), x.device)
             _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(dy), _p(x), _p(dw_ohwi), *dims, _stream())
             dw = _weight_grad_oihw(dw_ohwi, I)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
-def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False):
+def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None):
     """x NHWC; weight = the reference's OIHW parameter (laid out for the engine in one launch inside the autograd
     node, so the parameter's .grad comes back OIHW float32).  bias_grad_zero: the output feeds a train-mode
     BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros.  relu: y = relu(conv + bias), fused into
     the conv epilogue in bf16 mode."""
-    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats)
 
 
 class _Conv2dCat(torch.autograd.Function):
@@ -495,9 +502,9 @@ def group_norm_nhwc(x, gamma, beta, groups, eps, relu, residual=None):
     return y
 
 
-def conv_transpose2d(x, weight_iohw, stride=2, pad=1):
+def conv_transpose2d(x, weight_iohw, stride=2, pad=1, stats=None):
     """nn.ConvTranspose2d weight is [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW."""
-    return _ConvT2d.apply(x, weight_iohw, stride, pad)
+    return _ConvT2d.apply(x, weight_iohw, stride, pad, stats)
 
 
 def channel_sum(x2d):
@@ -512,7 +519,7 @@ def channel_sum(x2d):
 # ----------------------------------------------------------------------------- batch norm (+res)(+relu)
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats=None):
         _req(x, residual, gamma, beta, running_mean, running_var)
         _f32(gamma, beta, running_mean, running_var)
         sfx = _sfx(x)
@@ -523,10 +530,16 @@ class _BnAct(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         invstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        ws = _workspace(x.device)
-        _abi.call("wsmg_bn_act_fwd" + sfx, _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                  float(momentum), float(eps), int(train), int(relu), rows, C, _p(y), _p(mean), _p(invstd),
-                  _p(ws), ws.numel() * 8, _stream())
+        if stats is not None and train and sfx:
+            # the producing convolution left the sums of this tensor in `stats`: finalize (+ clear) and apply, no pass over x
+            _abi.call("wsmg_bn_act_fwd_bf16_pre", _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                      float(momentum), float(eps), int(relu), rows, C, _p(y), _p(mean), _p(invstd), _p(stats), stats.shape[0],
+                      _stream())
+        else:
+            ws = _workspace(x.device)
+            _abi.call("wsmg_bn_act_fwd" + sfx, _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                      float(momentum), float(eps), int(train), int(relu), rows, C, _p(y), _p(mean), _p(invstd),
+                      _p(ws), ws.numel() * 8, _stream())
         # without a residual the ReLU mask is recomputed from x in the backward kernels: y is neither kept nor read
         keep_y = relu and residual is not None
         ctx.save_for_backward(x, y if keep_y else None, gamma, beta, mean, invstd)
@@ -547,11 +560,38 @@ class _BnAct(torch.autograd.Function):
         ws = _workspace(x.device)
         _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
                   _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5):
-    return _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps)
+def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5, stats=None):
+    return _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats)
+
+
+BN_SLABS = 64
+_bn_slabs = {}
+
+
+def bn_stats_slabs(key, C, device):
+    """Float64 [BN_SLABS, 2, C] accumulator a convolution's epilogue adds its output's per-channel sums into and the
+    following train-mode BatchNorm consumes AND CLEARS (wsmg_bn_act_fwd_bf16_pre) — one persistent buffer per BatchNorm
+    layer, zero between uses.  Returns None when the fused statistics are off (WSMG_BN_FUSED_STATS=0) .  If a forward pass
+    died between the two launches the buffer is dirty: `in_use` catches that and it is zeroed again."""
+    if _os.environ.get("WSMG_BN_FUSED_STATS", "1") == "0":
+        return None
+    k = (key, C, device.index)
+    e = _bn_slabs.get(k)
+    if e is None:
+        e = _bn_slabs[k] = dict(buf=torch.zeros(BN_SLABS, 2, C, device=device, dtype=torch.float64), in_use=False)
+    if e["in_use"]:
+        e["buf"].zero_()
+    e["in_use"] = True
+    return e["buf"]
+
+
+def bn_stats_done(key, C, device):
+    e = _bn_slabs.get((key, C, device.index))
+    if e is not None:
+        e["in_use"] = False
 
 
 # ----------------------------------------------------------------------------- small NHWC ops
