@@ -310,16 +310,36 @@ def main():
                             frac=round(ach / peak, 4), traffic=None,
                             avg_launch_ms=round(r["ms_total"] / r["launches"], 4), launches=r["launches"],
                             alg_gflop_per_launch=round(r["flops_total"] / r["launches"] / 1e9, 3))
-            # HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes over this very
-            # command (FETCH_SIZE and WRITE_SIZE in separate runs, folded by tools/pmc_traffic.py); PMC
-            # collection cannot run inside a timed bench, so the figure is read from profiles/, not measured live
-            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_bench_bf16_hbm_traffic.json")
-            if args.dtype == "bf16" and os.path.exists(tfile):
-                tk = json.load(open(tfile)).get("kernels", {}).get(dom.replace("<*>", ""))
-                if tk:
-                    roofline["traffic"] = round(tk["hbm_bytes_per_launch"])
-                    roofline["traffic_unit"] = "HBM bytes per launch (1024*(2*FETCH_SIZE+WRITE_SIZE))"
-                    roofline["traffic_source"] = "profiles/r01_bench_bf16_hbm_traffic.json"
+            # HBM bytes per launch and MFMA-pipe utilisation of the same kernel family, from the committed rocprofv3 --pmc
+            # passes over this very command (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM counters in separate runs, folded by
+            # tools/pmc_traffic.py / tools/pmc_mfma.py; tools/refresh_profiles.sh): PMC collection cannot run inside a timed
+            # bench, so the figures are read from profiles/ (newest round), not measured live
+            fams = {"wsmg_conv2d_bwd_weight_bf16": ["conv_wgrad_bf16_kernel", "conv_win_wgrad_kernel"],
+                    "wsmg_conv2d_fwd_bf16": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel"],
+                    "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel"],
+                    "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>"]}.get(r.get("entry"), [dom.replace("<*>", "")])
+            roofline["kernels_of_family"] = fams
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            import glob
+            tfiles = sorted(glob.glob(os.path.join(pdir, "r*_bench_bf16_hbm_traffic.json")))
+            mfiles = sorted(glob.glob(os.path.join(pdir, "r*_bench_bf16_mfma_busy.json")))
+            if args.dtype == "bf16" and tfiles:
+                tk = json.load(open(tfiles[-1])).get("kernels", {})
+                hit = [tk[f] for f in fams if f in tk]
+                if hit:
+                    roofline["traffic"] = round(sum(h["hbm_bytes_per_update"] for h in hit) / sum(h["launches_per_update"] for h in hit))
+                    roofline["traffic_unit"] = "HBM bytes per launch (1024*(2*FETCH_SIZE+WRITE_SIZE)), mean over the family's launches"
+                    roofline["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
+            if args.dtype == "bf16" and mfiles:
+                mk = json.load(open(mfiles[-1])).get("kernels", {})
+                hit = [mk[f] for f in fams if f in mk]
+                if hit:
+                    w = sum(h["ms_per_update"] for h in hit)
+                    roofline["mfma_busy"] = round(sum(h["mfma_busy"] * h["ms_per_update"] for h in hit) / w, 4)
+                    roofline["eff_clock_ghz"] = round(sum(h["eff_clock_ghz"] * h["ms_per_update"] for h in hit) / w, 3)
+                    roofline["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), time-weighted over the "
+                                                 "family; achieved/peak = mfma_busy x (clock / 2.4 GHz) x (algorithmic / issued FLOPs)")
+                    roofline["mfma_busy_source"] = "profiles/" + os.path.basename(mfiles[-1])
         out = {
             "metric": "policy steps/sec (fwd+bwd), CMA batch=8 seq=64",
             "value": round(steps_per_s, 2),

@@ -102,12 +102,15 @@ def profile_end():
     out = {}
     for name, items in (rec or {}).items():
         ms = sum(s.elapsed_time(e) for s, e, _ in items)
-        out[KERNEL_OF[name]] = dict(launches=len(items), ms_total=ms, flops_total=float(sum(f for _, _, f in items)), entry=name)
+        o = out.setdefault(KERNEL_OF[name], dict(launches=0, ms_total=0.0, flops_total=0.0, entry=name.replace("_stats", "")))
+        o["launches"] += len(items)      # (the *_stats entry points launch the same kernels: one family)
+        o["ms_total"] += ms
+        o["flops_total"] += float(sum(f for _, _, f in items))
     return out
 
 
 def _launch(name, flops, *args):
-    if _prof is None or (_prof_only is not None and name not in _prof_only):
+    if _prof is None or (_prof_only is not None and name.replace("_stats", "") not in _prof_only):
         _abi.call(name, *args)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
