@@ -237,14 +237,27 @@ int wsmg_attn_shared_bwd_bf16(const float* q, const void* k_sets, const void* v_
                               const float* dattn, const int64_t* row_index, float scale, int B, int I, int C, float* dq,
                               float* dlogits, wsmg_stream_t stream);
 
-/* fp8 (OCP e4m3) text attention, BASELINE configs[4] (B=64, L=160): the k=1 Conv1d key projection of
- * mg_map_policy.py:126-127 is folded into the single query — q.(W_k x_l + b_k) = (W_k^T q).x_l + q.b_k — so
- * every token of x is read from HBM once, as bytes.  q_folded [B][C] = W_k^T q (float32), q_dot_bias [B] = q.b_k
- * or null, x_e4m3 [B][L][C] with real value = byte value * x_scale, lengths [B] (tokens >= length get the
- * reference's -1e8 additive mask, mg_map_policy.py:175) or null; out [B][C], attn [B][L] float32.  L <= 224. */
-int wsmg_attn_fp8_fused_fwd(const float* q_folded, const float* q_dot_bias, const uint8_t* x_e4m3, float x_scale,
-                            const int* lengths, float scale, int B, int L, int C, float* out, float* attn,
-                            wsmg_stream_t stream);
+/* fp8 (OCP e4m3) text attention, BASELINE configs[4] (B=64, L=160), forward and backward (csrc/wsmg_attn_fp8.hip).  The k=1
+ * Conv1d key projection of mg_map_policy.py:126-127 is folded into the single query — q.(W_k x_l + b_k) = (q W_k).x_l +
+ * q.b_k, and the last term cancels in the softmax — so every token of x is read from HBM once, as bytes:
+ *   wsmg_attn_fp8_fold   out [B][C] = in [B][C] @ W (transpose = 0: q_f = q W_k) or @ W^T (1: dq = d q_f W_k^T); W [C][C] is the
+ *                        Conv1d weight [C_out][C_in]; float32 MFMA (v_mfma_f32_16x16x4_f32), exact float32 products;
+ *   wsmg_attn_fp8_fwd    q_folded [B][C], x_e4m3 [B][L][C] with real value = byte value * *x_scale (device scalar), lengths [B]
+ *                        (tokens >= length get the reference's -1e8 additive mask, mg_map_policy.py:175) or null -> out [B][C],
+ *                        attn [B][L].  A row is split over wsmg_attn_fp8_splits(B, L) workgroups; workspace =
+ *                        wsmg_attn_fp8_workspace_bytes(B, L) bytes of scratch, ticket = B zero-initialised words that every
+ *                        launch leaves zeroed again;
+ *   wsmg_attn_fp8_bwd    saved attn, dout [B][C], dattn [B][L] or null -> dq_folded [B][C] and dx [B][L][C] (gradient of the
+ *                        de-quantised tokens, straight-through; may be null).  L <= 224.
+ *   wsmg_quantize_e4m3_dev = wsmg_quantize_e4m3 with the scale read from device memory (no host round trip for amax). */
+int wsmg_attn_fp8_fold(const float* in, const float* w, int B, int C, int transpose, float* out, wsmg_stream_t stream);
+int wsmg_attn_fp8_splits(int B, int L);
+int64_t wsmg_attn_fp8_workspace_bytes(int B, int L);
+int wsmg_attn_fp8_fwd(const float* q_folded, const uint8_t* x_e4m3, const float* x_scale, const int* lengths, float scale, int B,
+                      int L, int C, float* out, float* attn, void* workspace, unsigned* ticket, wsmg_stream_t stream);
+int wsmg_attn_fp8_bwd(const float* q_folded, const uint8_t* x_e4m3, const float* x_scale, const float* attn, const float* dout,
+                      const float* dattn, float scale, int B, int L, int C, float* dq_folded, float* dx, wsmg_stream_t stream);
+int wsmg_quantize_e4m3_dev(const float* x, int64_t n, const float* scale, uint8_t* y, wsmg_stream_t stream);
 /* y = e4m3(clamp(x * inv_scale, +-448)), round to nearest even; n a multiple of 4. */
 int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, uint8_t* y, wsmg_stream_t stream);
 

@@ -43,3 +43,23 @@ def attn_fp8(q, w_k, b_k, x_codes, x_scale, lengths, scale):
     attn = e / e.sum(axis=1, keepdims=True)
     out = np.einsum("bl,blc->bc", attn, x)
     return out, attn
+
+
+def attn_fp8_grads(q, w_k, b_k, x_codes, x_scale, lengths, scale, dout, dattn=None):
+    """Gradients of <out, dout> (+ <attn, dattn>) w.r.t. q, W_k, b_k and the DE-QUANTISED tokens x, by float64 autograd over the
+    reference formula (the product path's straight-through gradient of x is this dx).  Returns (dq, dW_k, db_k, dx)."""
+    x = torch.from_numpy(dequantize_e4m3(x_codes, x_scale)).requires_grad_(True)
+    qt = torch.from_numpy(q.astype(np.float64)).requires_grad_(True)
+    wt = torch.from_numpy(w_k.astype(np.float64)).requires_grad_(True)
+    bt = torch.from_numpy(b_k.astype(np.float64)).requires_grad_(True)
+    k = x @ wt.T + bt
+    logits = torch.einsum("bc,blc->bl", qt, k)
+    L = x.shape[1]
+    mask = torch.from_numpy((np.arange(L)[None, :] >= np.asarray(lengths)[:, None]).astype(np.float64))
+    a = torch.softmax((logits - 1e8 * mask) * scale, dim=1)
+    out = torch.einsum("bl,blc->bc", a, x)
+    obj = (out * torch.from_numpy(dout.astype(np.float64))).sum()
+    if dattn is not None:
+        obj = obj + (a * torch.from_numpy(dattn.astype(np.float64))).sum()
+    obj.backward()
+    return qt.grad.numpy(), wt.grad.numpy(), bt.grad.numpy(), x.grad.numpy()

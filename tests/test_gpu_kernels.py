@@ -605,6 +605,38 @@ def test_attn_fp8_fused_cfg5(ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,L", [(64, 160), (3, 37), (300, 80), (17, 200)])
+def test_attn_fp8_forward_backward_vs_oracle(ops, B, L):
+    """configs[4] forward + backward through the trainable op (device-side amax / 448 scale, e4m3 bytes, row split over
+    workgroups, float32-MFMA query fold): out / attn within 2e-5, dq, dW_k, dx within 2e-5 of max|.| of the float64 autograd
+    of the reference formula on the same de-quantised tokens; db_k is exactly zero (it cancels in the softmax: the oracle's
+    is ~1e-17); ragged lengths incl. 1 and L, B not a multiple of 16, L not a multiple of the chunk."""
+    from oracle import attn_fp8_ref as ar
+    q, w, b, x, lengths = _cfg5_inputs(B=B, L=L, seed=B + L)
+    rng = np.random.RandomState(9)
+    dout = rng.randn(B, 256).astype(np.float32)
+    dattn = (rng.randn(B, L) * 0.3).astype(np.float32)
+    # the op's per-tensor scale: amax / 448 as the device computes it (a reciprocal multiply: 1 ulp from numpy's division)
+    x_scale = float(T(x).cuda().abs().amax() / 448.0)
+    codes = ar.quantize_e4m3(x, x_scale)
+    out_ref, attn_ref = ar.attn_fp8(q, w, b, codes, x_scale, lengths, 1.0 / 16)
+    dq_r, dw_r, db_r, dx_r = ar.attn_fp8_grads(q, w, b, codes, x_scale, lengths, 1.0 / 16, dout, dattn)
+    qt, wt, bt, xt = [T(a).cuda().requires_grad_(True) for a in (q, w.reshape(256, 256, 1), b, x)]
+    out, attn = ops.attention_fp8(qt, wt, bt, xt, torch.from_numpy(lengths).cuda(), 1.0 / 16)
+    ((out * T(dout).cuda()).sum() + (attn * T(dattn).cuda()).sum()).backward()
+    assert np.abs(attn.detach().cpu().numpy() - attn_ref).max() <= 2e-5
+    assert np.abs(out.detach().cpu().numpy() - out_ref).max() <= 2e-5 * np.abs(out_ref).max()
+    for got, want, name in ((qt.grad, dq_r, "dq"), (wt.grad.reshape(256, 256), dw_r, "dW_k"), (xt.grad, dx_r, "dx")):
+        err = np.abs(got.cpu().numpy() - want).max() / np.abs(want).max()
+        assert err <= 2e-5, (name, err)
+    assert float(bt.grad.abs().max()) == 0.0 and np.abs(db_r).max() <= 1e-9
+    assert all(float(attn[i, lengths[i]:].abs().sum()) == 0.0 for i in range(B))
+    # a second launch on the same stream: the ticket words were handed back zeroed
+    out2, attn2 = ops.attention_fp8(qt.detach(), wt.detach(), bt.detach(), xt.detach(), torch.from_numpy(lengths).cuda(), 1.0 / 16)
+    assert torch.equal(attn2, attn.detach()) or float((attn2 - attn.detach()).abs().max()) <= 1e-7
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("masked", [False, True])
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_attention_with_folded_key_projection(ops, dt, masked):

@@ -7,7 +7,18 @@ sys.path.insert(0, os.path.join(ROOT, "ws-mgmap_amd"))
 import torch
 from wsmgmap import ops, _abi
 P = ops._p; st = ops._stream
-for B, L in ((64, 160), (512, 80), (4096, 160)):
+def _floor():
+    t = torch.zeros(256, device="cuda")
+    f = lambda: _abi.call("wsmg_relu_fwd", P(t), P(t), 256, st())
+    for _ in range(20): f()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(200): f()
+    e.record(); torch.cuda.synchronize()
+    return a.elapsed_time(e) / 200 * 1e3
+print(f"launch floor of this loop (a 256-element ReLU launched back to back through the same ctypes path): {_floor():.1f} us per launch")
+for B, L in ((64, 160), (512, 80), (4096, 160), (16384, 160)):
     C = 256
     torch.manual_seed(0)
     q = torch.randn(B, C, device="cuda"); w = torch.randn(C, C, device="cuda") / 16; b = torch.randn(C, device="cuda") * 0.1
@@ -15,12 +26,17 @@ for B, L in ((64, 160), (512, 80), (4096, 160)):
     xs = float(x.abs().max() / 448.0)
     codes = ops.quantize_e4m3(x, xs)
     lengths = torch.full((B,), L, dtype=torch.int32, device="cuda")
-    qf = (q @ w).contiguous(); qb = (q @ b).contiguous()
+    qf = (q @ w).contiguous()
     out = torch.empty(B, C, device="cuda"); attn = torch.empty(B, L, device="cuda")
-    def kern(): _abi.call("wsmg_attn_fp8_fused_fwd", P(qf), P(qb), P(codes), xs, P(lengths), 1 / 16, B, L, C, P(out), P(attn), st())
-    def whole(): ops.attn_fp8_fused(q, w, b, codes, xs, lengths, 1 / 16)
+    xs_t = torch.full((1,), xs, device="cuda")
+    ws, ticket = ops._fp8_scratch(B, L, q.device)
+    dout = torch.randn(B, C, device="cuda"); dqf = torch.empty(B, C, device="cuda"); dx = torch.empty(B, L, C, device="cuda")
+    def kern(): _abi.call("wsmg_attn_fp8_fwd", P(qf), P(codes), P(xs_t), P(lengths), 1 / 16, B, L, C, P(out), P(attn), P(ws), P(ticket), st())
+    def whole(): ops.attn_fp8_fused(q, w, b, codes, xs_t, lengths, 1 / 16)
+    def bwd(): _abi.call("wsmg_attn_fp8_bwd", P(qf), P(codes), P(xs_t), P(attn), P(dout), None, 1 / 16, B, L, C, P(dqf), P(dx), st())
+    def fold(): _abi.call("wsmg_attn_fp8_fold", P(q), P(w), B, C, 0, P(qf), st())
     res = []
-    for f in (kern, whole):
+    for f in (kern, whole, bwd, fold):
         for _ in range(5): f()
         torch.cuda.synchronize()
         a = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
@@ -29,4 +45,7 @@ for B, L in ((64, 160), (512, 80), (4096, 160)):
         e.record(); torch.cuda.synchronize()
         res.append(a.elapsed_time(e) / 50 * 1e3)
     by = B * (C * L + C * 4 + (C + L) * 4)
-    print(f"B={B} L={L}: fused kernel {res[0]:.1f} us = {by / res[0] / 1e3:.0f} GB/s ({by / res[0] / 1e3 / 8000 * 100:.1f} % of 8 TB/s); with the query fold GEMMs {res[1]:.1f} us")
+    byb = B * (C * L + 2 * C * 4 + L * 4 + C * 4 + L * C * 4)   # backward: bytes in, q_f, dout, attn -> d q_f, dx (float32)
+    print(f"B={B} L={L} ({_abi.lib().wsmg_attn_fp8_splits(B, L)} workgroups per row): forward {res[0]:.1f} us = {by / res[0] / 1e3:.0f} GB/s "
+          f"({by / res[0] / 1e3 / 8000 * 100:.1f} % of 8 TB/s); with the MFMA query fold {res[1]:.1f} us (fold alone {res[3]:.1f}); "
+          f"backward {res[2]:.1f} us = {byb / res[2] / 1e3:.0f} GB/s ({byb / res[2] / 1e3 / 8000 * 100:.1f} %)")

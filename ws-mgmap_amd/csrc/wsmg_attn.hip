@@ -417,79 +417,7 @@ __global__ __launch_bounds__(NW * 64) void attn_same_bwd_kernel(const float* __r
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// fp8 (OCP e4m3) text attention with the key projection folded into the query (BASELINE configs[4]).
-// The reference computes k = W_k x + b_k per token and logits = q . k (mg_map_policy.py:126-132,173-178):
-// 2*256*256 FLOP per token, 99 % of the attention FLOPs, for ONE query per row.  Because there is a single
-// query, q . (W_k x_l + b_k) = (W_k^T q) . x_l + q . b_k: the caller folds W_k into the query (a [B,256] x
-// [256,256] product) and this kernel reads every token of x exactly once — into LDS as bytes — for the
-// logits and again from LDS for the weighted sum: 256 L bytes of HBM per row instead of 2 * 256 L * 4.
-// x is e4m3 with one float scale; accumulation, softmax and outputs are float32.
-constexpr int F8_MAX_L = 224;   // 224 * 256 B = 56 KiB of LDS for the token tile
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 cvt4_e4m3(unsigned w) {
-  auto lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
-  auto hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
-  return f32x4{lo[0], lo[1], hi[0], hi[1]};
-}
-
-__global__ __launch_bounds__(256) void attn_fp8_fused_fwd_kernel(const float* __restrict__ qf, const float* __restrict__ qb,
-                                                                 const uint8_t* __restrict__ x, float x_scale,
-                                                                 const int* __restrict__ lengths, float scale, int L,
-                                                                 float* __restrict__ out, float* __restrict__ attn) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t xs[];   // L * 256 token bytes (sized per launch: more rows per CU)
-  __shared__ float lg[F8_MAX_L];
-  __shared__ float red[AWAVES];
-  __shared__ __attribute__((aligned(16))) float part[AWAVES][AC];
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int len = lengths ? lengths[b] : L;
-  // the only HBM read of the tokens: 16 bytes per thread and trip, fully coalesced
-  const u32x4* src = reinterpret_cast<const u32x4*>(x + (size_t)b * L * AC);
-  for (int i = tid; i < L * AC / 16; i += 256) reinterpret_cast<u32x4*>(xs)[i] = src[i];
-  const f32x4 qv = reinterpret_cast<const f32x4*>(qf + (size_t)b * AC)[lane];
-  const float bias = qb ? qb[b] : 0.f;
-  __syncthreads();
-  for (int i = wave; i < L; i += AWAVES) {
-    const f32x4 kv = cvt4_e4m3(reinterpret_cast<const unsigned*>(xs + (size_t)i * AC)[lane]);
-    float d = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
-    d = wave_sum(d);
-    if (lane == 0) {
-      d = d * x_scale + bias;
-      if (i >= len) d = d - 1e8f;   // the reference's additive mask (mg_map_policy.py:175)
-      lg[i] = d * scale;
-    }
-  }
-  __syncthreads();
-  float mx = -INFINITY;
-  for (int i = tid; i < L; i += 256) mx = fmaxf(mx, lg[i]);
-  mx = block_reduce_max(mx, red, wave, lane);
-  float sm = 0.f;
-  for (int i = tid; i < L; i += 256) {
-    float e = expf(lg[i] - mx);
-    lg[i] = e;
-    sm += e;
-  }
-  sm = block_reduce_sum(sm, red, wave, lane);
-  const float inv = 1.f / sm;
-  for (int i = tid; i < L; i += 256) {
-    float a = lg[i] * inv;
-    lg[i] = a;
-    attn[(size_t)b * L + i] = a;
-  }
-  __syncthreads();
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int i = wave; i < L; i += AWAVES) {
-    const float a = lg[i];
-    const f32x4 vv = cvt4_e4m3(reinterpret_cast<const unsigned*>(xs + (size_t)i * AC)[lane]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += a * vv[j];
-  }
-  reinterpret_cast<f32x4*>(&part[wave][0])[lane] = acc;
-  __syncthreads();
-  out[(size_t)b * AC + tid] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * x_scale;
-}
 
 // float32 -> e4m3 (round to nearest even, saturating at +-448), 4 values per thread
 __global__ __launch_bounds__(256) void quantize_e4m3_kernel(const float* __restrict__ x, int64_t n4, float inv_scale,
@@ -553,15 +481,6 @@ extern "C" int wsmg_attn_bwd_bf16(const float* q, const void* k, const void* v, 
   }
   hipLaunchKernelGGL(attn_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, wsmg_s(stream), q, (const bf16_t*)k,
                      (const bf16_t*)v, attn, dout, dattn, scale, I, dq, (bf16_t*)dk, (bf16_t*)dv, (const int64_t*)nullptr, (float*)nullptr);
-  WSMG_RETURN_LAUNCH();
-}
-
-extern "C" int wsmg_attn_fp8_fused_fwd(const float* q_folded, const float* q_dot_bias, const uint8_t* x_e4m3, float x_scale,
-                                       const int* lengths, float scale, int B, int L, int C, float* out, float* attn,
-                                       wsmg_stream_t stream) {
-  if (C != AC || B <= 0 || L <= 0 || L > F8_MAX_L) return WSMG_EINVAL;
-  hipLaunchKernelGGL(attn_fp8_fused_fwd_kernel, dim3(B), dim3(256), (size_t)L * AC, wsmg_s(stream), q_folded, q_dot_bias, x_e4m3, x_scale,
-                     lengths, scale, L, out, attn);
   WSMG_RETURN_LAUNCH();
 }
 

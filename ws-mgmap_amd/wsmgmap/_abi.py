@@ -64,7 +64,12 @@ _SIG["wsmg_attn_shared_fwd"] = [c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p
 _SIG["wsmg_attn_shared_bwd"] = [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_attn_shared_fwd_bf16"] = list(_SIG["wsmg_attn_shared_fwd"])
 _SIG["wsmg_attn_shared_bwd_bf16"] = list(_SIG["wsmg_attn_shared_bwd"])
-_SIG["wsmg_attn_fp8_fused_fwd"] = [c_p, c_p, c_p, c_f, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p]
+_SIG["wsmg_attn_fp8_fold"] = [c_p, c_p, c_i, c_i, c_i, c_p, c_p]
+_SIG["wsmg_attn_fp8_splits"] = [c_i, c_i]
+_SIG["wsmg_attn_fp8_workspace_bytes"] = [c_i, c_i]
+_SIG["wsmg_attn_fp8_fwd"] = [c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p]
+_SIG["wsmg_attn_fp8_bwd"] = [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p]
+_SIG["wsmg_quantize_e4m3_dev"] = [c_p, c_l, c_p, c_p, c_p]
 _SIG["wsmg_quantize_e4m3"] = [c_p, c_l, c_f, c_p, c_p]
 _SIG["wsmg_weight_relayout"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_weight_relayout_bf16"] = list(_SIG["wsmg_weight_relayout"])
@@ -84,7 +89,7 @@ _SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
 _SIG["wsmg_group_norm_nhwc_bf16"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]
 _SIG["wsmg_rnn_status"] = [c_i]
 _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
-_RESTYPE = {"wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
+_RESTYPE = {"wsmg_attn_fp8_workspace_bytes": c_l, "wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
 
 _lib = None
 

@@ -954,23 +954,92 @@ def quantize_e4m3(x, scale):
     return y
 
 
+_fp8_tickets = {}
+
+
+def _fp8_scratch(B, L, device):
+    """(workspace, ticket) of the split-row fp8 attention: the ticket words must be zero before a launch and every launch
+    leaves them zero, so one zero-initialised buffer per (stream, B) serves all calls."""
+    L_ = _abi.lib()
+    ws = torch.empty(int(L_.wsmg_attn_fp8_workspace_bytes(B, L)) // 4, device=device, dtype=torch.float32)
+    key = (device.index, torch.cuda.current_stream().cuda_stream, B)
+    t = _fp8_tickets.get(key)
+    if t is None:
+        t = _fp8_tickets[key] = torch.zeros(B, device=device, dtype=torch.int32)
+    return ws, t
+
+
+def _fp8_fold(x, w, transpose):
+    B, C = x.shape
+    out = torch.empty(B, C, device=x.device, dtype=torch.float32)
+    _abi.call("wsmg_attn_fp8_fold", _p(x), _p(w), B, C, int(transpose), _p(out), _stream())
+    return out
+
+
+def _fp8_forward(q, w2d, x_q, xs_t, lengths, scale):
+    B, L, C = x_q.shape
+    qf = _fp8_fold(q, w2d, False)                       # q W_k on the matrix cores (float32 MFMA)
+    out = torch.empty(B, C, device=q.device, dtype=torch.float32)
+    attn = torch.empty(B, L, device=q.device, dtype=torch.float32)
+    ws, ticket = _fp8_scratch(B, L, q.device)
+    _abi.call("wsmg_attn_fp8_fwd", _p(qf), _p(x_q), _p(xs_t), _p(lengths), float(scale), B, L, C, _p(out), _p(attn), _p(ws),
+              _p(ticket), _stream())
+    return qf, out, attn
+
+
 def attn_fp8_fused(q, w_k, b_k, x_q, x_scale, lengths, scale):
-    """Text attention of BASELINE configs[4] (no autograd): q [B,C] float32, w_k [C,C] / b_k [C] the k=1 Conv1d key
-    projection (mg_map_policy.py:126-127), x_q [B,L,C] uint8 e4m3 codes of the instruction embedding / x_scale,
-    lengths [B] int32.  Returns (out [B,C], attn [B,L]) = softmax((q.(W_k x + b_k) - 1e8 mask) * scale) applied
-    to x, with W_k folded into the query so x is read once."""
+    """Text attention of BASELINE configs[4] on pre-quantised tokens (no autograd): q [B,C] float32, w_k [C,C] / b_k [C] the
+    k=1 Conv1d key projection (mg_map_policy.py:126-127; b_k cancels in the softmax and is not read), x_q [B,L,C] uint8
+    e4m3 codes of the instruction embedding / x_scale (float or device scalar), lengths [B] int32.  Returns
+    (out [B,C], attn [B,L]) = softmax((q.(W_k x + b_k) - 1e8 mask) * scale) applied to x."""
     _req(q, x_q, lengths)
     _f32(q)
     if x_q.dtype != torch.uint8 or (lengths is not None and lengths.dtype != torch.int32):
         raise _abi.WsmgError("attn_fp8_fused: x_q must be uint8 (e4m3 codes), lengths int32")
-    B, L, C = x_q.shape
-    qf = (q @ w_k.float()).contiguous()                      # W_k^T q  (w_k is [C_out, C_in])
-    qb = None if b_k is None else (q @ b_k.float()).contiguous()
-    out = torch.empty(B, C, device=q.device, dtype=torch.float32)
-    attn = torch.empty(B, L, device=q.device, dtype=torch.float32)
-    _abi.call("wsmg_attn_fp8_fused_fwd", _p(qf), _p(qb), _p(x_q), float(x_scale), _p(lengths), float(scale), B, L, C,
-              _p(out), _p(attn), _stream())
+    xs_t = x_scale if torch.is_tensor(x_scale) else torch.full((1,), float(x_scale), device=q.device, dtype=torch.float32)
+    w2d = w_k.reshape(w_k.shape[0], -1).float().contiguous()
+    _, out, attn = _fp8_forward(q.contiguous(), w2d, x_q.contiguous(), xs_t, lengths, scale)
     return out, attn
+
+
+class _AttnFp8(torch.autograd.Function):
+    """Trainable form: x float32 [B,L,C] is quantised to e4m3 with one per-tensor scale (amax / 448, computed on the device),
+    forward and backward read the BYTES; the gradient of x is the straight-through gradient of the de-quantised tokens."""
+
+    @staticmethod
+    def forward(ctx, q, w_k, b_k, x, lengths, scale):
+        _req(q, x, lengths)
+        _f32(q, x)
+        B, L, C = x.shape
+        xs_t = (x.detach().abs().amax() / 448.0).clamp_min(1e-30).reshape(1).float()
+        x_q = torch.empty(B, L, C, device=x.device, dtype=torch.uint8)
+        _abi.call("wsmg_quantize_e4m3_dev", _p(x), x.numel(), _p(xs_t), _p(x_q), _stream())
+        w2d = w_k.reshape(w_k.shape[0], -1).float().contiguous()
+        qf, out, attn = _fp8_forward(q.contiguous(), w2d, x_q, xs_t, lengths, scale)
+        ctx.save_for_backward(q, w2d, qf, x_q, xs_t, attn)
+        ctx.scale, ctx.wshape, ctx.has_b = float(scale), w_k.shape, b_k is not None
+        ctx.set_materialize_grads(False)
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, dout, dattn):
+        q, w2d, qf, x_q, xs_t, attn = ctx.saved_tensors
+        B, L, C = x_q.shape
+        dout = torch.zeros_like(q) if dout is None else dout.contiguous().float()
+        dattn = None if dattn is None else dattn.contiguous().float()
+        dqf = torch.empty_like(qf)
+        dx = torch.empty(B, L, C, device=q.device, dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        _abi.call("wsmg_attn_fp8_bwd", _p(qf), _p(x_q), _p(xs_t), _p(attn), _p(dout), _p(dattn), ctx.scale, B, L, C, _p(dqf), _p(dx),
+                  _stream())
+        dq = _fp8_fold(dqf, w2d, True) if ctx.needs_input_grad[0] else None          # d q_f W_k^T, same MFMA kernel
+        dw = (q.t() @ dqf).reshape(ctx.wshape) if ctx.needs_input_grad[1] else None   # [C_out, C_in] = q^T d q_f
+        db = torch.zeros(ctx.wshape[0], device=q.device, dtype=torch.float32) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dq, dw, db, dx, None, None
+
+
+def attention_fp8(q, w_k, b_k, x, lengths, scale=1.0 / 16):
+    """(context [B,C], weights [B,L]) of the state -> instruction attention with e4m3 token storage; differentiable in q, W_k, x."""
+    return _AttnFp8.apply(q, w_k, b_k, x.contiguous(), lengths, scale)
 
 
 def _rnn_workspace(nbytes, device):
