@@ -121,6 +121,9 @@ int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float
  *   upsample2x:  nn.Upsample(bilinear, align_corners=True) (map_encoder.py:84)
  *   avgpool2:    F.avg_pool2d(2,2)           (mg_map_policy.py:197) */
 int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t stream);
+/* dx [B][I][C] (in place) = (dx + g [B][C] / I) * (x > 0 if relu): the attention's gradient of the map tokens merged with the
+ * broadcast gradient of their mean (mg_map_policy.py:217) and masked by the ReLU of map_cated_linear (:99-100) in one pass. */
+int wsmg_token_grad_merge(float* dx, const float* x, const float* g, int B, int I, int C, int relu, wsmg_stream_t stream);
 int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t stream);
 int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW,
                           wsmg_stream_t stream);
@@ -198,6 +201,7 @@ int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y, const flo
                          void* dx, void* dresidual, float* dgamma, float* dbeta, double* workspace,
                          int64_t workspace_bytes, wsmg_stream_t stream);
 int wsmg_relu_fwd_bf16(const void* x, void* y, int64_t n, wsmg_stream_t stream);
+int wsmg_token_grad_merge_bf16(void* dx, const void* x, const float* g, int B, int I, int C, int relu, wsmg_stream_t stream);
 int wsmg_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, wsmg_stream_t stream);
 int wsmg_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW,
                                wsmg_stream_t stream);

@@ -403,6 +403,37 @@ __global__ void relu_bwd8_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* 
   }
 }
 
+// dx[b][i][c] = (dx[b][i][c] + g[b][c] * inv_I) * (x[b][i][c] > 0), in place: the gradient of the map tokens from the attention
+// (already in dx) merged with the broadcast gradient of their token mean (mg_map_policy.py:217: AdaptiveAvgPool1d over the 576
+// tokens) and masked by the fused ReLU of the convolution that produced the tokens (map_cated_linear, :99-100) — one pass
+// instead of an add launch over a materialised broadcast plus a ReLU-mask launch.
+template <class T>
+__global__ void token_grad_merge_kernel(T* __restrict__ dx, const T* __restrict__ x, const float* __restrict__ g, int I, int C,
+                                        float inv_I, int relu, int64_t n4) {
+  const int C4 = C / 4;
+  GRID_STRIDE(i, n4) {
+    const int c = (int)(i % C4) * 4;
+    const int64_t b = i / ((int64_t)C4 * I);
+    f32x4 d = ld4(dx + i * 4);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + b * C + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = fmaf(gv[j], inv_I, d[j]);
+    if (relu) {
+      const f32x4 xv = ld4(x + i * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = xv[j] > 0.f ? d[j] : 0.f;
+    }
+    st4(dx + i * 4, d);
+  }
+}
+template <class T>
+int token_grad_merge_t(T* dx, const T* x, const float* g, int B, int I, int C, int relu, wsmg_stream_t stream) {
+  if (B <= 0 || I <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  const int64_t n4 = (int64_t)B * I * C / 4;
+  hipLaunchKernelGGL(token_grad_merge_kernel<T>, dim3(sgrid(n4)), dim3(256), 0, wsmg_s(stream), dx, x, g, I, C, 1.0f / (float)I, relu, n4);
+  WSMG_RETURN_LAUNCH();
+}
+
 template <class T>
 int relu_fwd_t(const T* x, T* y, int64_t n, wsmg_stream_t stream) {
   if (n <= 0 || n % 4) return WSMG_EINVAL;
@@ -500,6 +531,12 @@ extern "C" int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t 
 }
 extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<float>(x, y, n, s); }
 extern "C" int wsmg_relu_fwd_bf16(const void* x, void* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<bf16_t>(CB16(x), B16(y), n, s); }
+extern "C" int wsmg_token_grad_merge(float* dx, const float* x, const float* g, int B, int I, int C, int relu, wsmg_stream_t s) {
+  return token_grad_merge_t<float>(dx, x, g, B, I, C, relu, s);
+}
+extern "C" int wsmg_token_grad_merge_bf16(void* dx, const void* x, const float* g, int B, int I, int C, int relu, wsmg_stream_t s) {
+  return token_grad_merge_t<bf16_t>(B16(dx), CB16(x), g, B, I, C, relu, s);
+}
 extern "C" int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<float>(dy, y, dx, n, s); }
 extern "C" int wsmg_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<bf16_t>(CB16(dy), CB16(y), B16(dx), n, s); }
 extern "C" int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<float>(x, y, B, H, W, C, OH, OW, s); }

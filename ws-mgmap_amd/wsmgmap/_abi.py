@@ -38,6 +38,7 @@ _SIG = {
     "wsmg_bn_act_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_p],
     "wsmg_relu_fwd": [c_p, c_p, c_l, c_p],
     "wsmg_relu_bwd": [c_p, c_p, c_p, c_l, c_p],
+    "wsmg_token_grad_merge": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "wsmg_maxpool3x3s2_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "wsmg_maxpool3x3s2_bwd": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p],
     "wsmg_upsample2x_fwd": [c_p, c_p, c_i, c_i, c_i, c_i, c_p],
@@ -50,7 +51,7 @@ _SIG = {
     "wsmg_attn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
 }
 # bf16 storage variants: identical argument lists except the convs' extra `out_f32` int
-for _n in ["wsmg_channel_sum", "wsmg_bn_act_fwd", "wsmg_bn_act_bwd", "wsmg_relu_fwd", "wsmg_relu_bwd",
+for _n in ["wsmg_token_grad_merge", "wsmg_channel_sum", "wsmg_bn_act_fwd", "wsmg_bn_act_bwd", "wsmg_relu_fwd", "wsmg_relu_bwd",
            "wsmg_maxpool3x3s2_fwd", "wsmg_maxpool3x3s2_bwd", "wsmg_upsample2x_fwd", "wsmg_upsample2x_bwd",
            "wsmg_avgpool2_fwd", "wsmg_avgpool2_bwd", "wsmg_nchw_to_nhwc", "wsmg_nhwc_to_nchw", "wsmg_attn_fwd",
            "wsmg_attn_bwd", "wsmg_conv2d_bwd_weight"]:

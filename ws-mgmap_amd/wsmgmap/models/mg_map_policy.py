@@ -145,6 +145,8 @@ class MGMapNet(nn.Module):
             return nhwc_view.to(self.compute_dtype)
         return ops.to_nhwc(ego_map.contiguous(), cpad, dtype=self.compute_dtype)
 
+    _token_sink = None
+
     def map_stack(self, ego_map):
         """ego map [B,C,E,E] -> (map tokens [B, S*S, 256] token-major, pred_sem_map [B,27,2S,2S])."""
         from .encoders.map_encoder import batched_bumps
@@ -182,7 +184,8 @@ class MGMapNet(nn.Module):
         pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
         # (27 -> 32 input channels: ops.conv2d zero-pads the weight to the activation's channel count)
         cls_proj = ops.conv2d(ops.avgpool2(sem), self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True)
-        emb = ops.conv2d_cat([enc_proj, cls_proj], self.map_cated_linear[0].weight, self.map_cated_linear[0].bias, 1, 1, relu=True)
+        emb = ops.conv2d_cat([enc_proj, cls_proj], self.map_cated_linear[0].weight, self.map_cated_linear[0].bias, 1, 1, relu=True,
+                             relu_sink=self._token_sink)
         b, s1, s2, ch = emb.shape
         return emb.view(b, s1 * s2, ch), pred_sem_map
 
@@ -218,7 +221,13 @@ class MGMapNet(nn.Module):
         depth_embedding = self.depth_encoder(observations)
 
         self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
+        # the map tokens feed their mean (state input) and the map attention: one merged, ReLU-masked gradient pass (TokenGradSink)
+        import os
+        self._token_sink = ops.TokenGradSink() if (torch.is_grad_enabled() and "map" in self._inputs
+                                                   and os.environ.get("WSMG_TOKEN_SINK", "1") != "0") else None
+        sink = self._token_sink
         map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
+        self._token_sink = None
         ops.mark("map_stack", map_tokens)
         text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
 
@@ -228,7 +237,7 @@ class MGMapNet(nn.Module):
         if "depth" in self._inputs:
             state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
         if "map" in self._inputs:
-            state_in.append(self.map_linear[3](self.map_linear[2](ops.token_mean(map_tokens))))
+            state_in.append(self.map_linear[3](self.map_linear[2](ops.token_mean(map_tokens, sink))))
         state_in = torch.cat(state_in, dim=1)
 
         n1 = self.state_encoder.num_recurrent_layers
@@ -249,7 +258,7 @@ class MGMapNet(nn.Module):
         # keys and values, and no projected key tensor exists
         map_embedding, self.att_map_t_m = ops.attention_folded(
             self.text_map_q_layer(text_embedding).contiguous(), self.text_map_k_layer.weight, self.text_map_k_layer.bias,
-            map_tokens.contiguous(), None, self._scale_f)
+            map_tokens.contiguous(), None, self._scale_f, sink)
 
         parts = [state, text_embedding] + ([map_embedding] if "map" in self._inputs else [])
         x = self.second_state_compress(torch.cat(parts, dim=1))

@@ -185,6 +185,7 @@ def reset_pass_state():
     join the weight-gradient side stream do not run when backward() raises (a WsmgError from a kernel, OOM): without
     this reset one failed backward would leave them 'armed' for ever — every later request would fall back to a
     torch.zeros launch and, with WSMG_WGRAD_STREAM=1, optimizer.step could race the side-stream weight gradients."""
+    TokenGradSink.check_none_pending()
     if any(z["armed"] for z in _zero_pool.values()):
         _zero_pool_retire()
     if _side_join_armed:
@@ -258,13 +259,46 @@ def _join_side_at_end(main, side):
         main.wait_stream(side)
 
 
+class TokenGradSink:
+    """Links the backward passes around the map tokens (mg_map_policy.py:99-100,217,233-235): the tokens are the output of a
+    convolution with a fused ReLU and feed (a) their token mean and (b) the map attention.  Autograd would add the two
+    gradients (materialising the mean's broadcast) and the convolution would then mask the sum with a third pass.  With a
+    sink, the attention's backward PARKS its gradient here and returns nothing; the token mean's backward — which data
+    dependence puts later (its gradient comes through GRU 1, which needs the attention's query gradient first) — merges its
+    broadcast row into the parked tensor and applies the ReLU mask in the same pass (wsmg_token_grad_merge), and the
+    convolution sees `masked` and skips its own mask.  One object per forward pass."""
+    _pending = []
+
+    def __init__(self):
+        self.dx = None        # the attention's gradient of the tokens, parked
+        self.relu = False     # set by the producing convolution: the tokens are relu(conv)
+        self.masked = False   # set by the merge: the gradient handed to the convolution is already masked
+
+    def park(self, dx):
+        self.dx = dx
+        TokenGradSink._pending.append(self)
+
+    def take(self):
+        dx, self.dx = self.dx, None
+        if self in TokenGradSink._pending:
+            TokenGradSink._pending.remove(self)
+        return dx
+
+    @staticmethod
+    def check_none_pending():
+        if TokenGradSink._pending:
+            TokenGradSink._pending.clear()
+            raise _abi.WsmgError("a map-token gradient parked by the attention's backward was never merged (the token mean's "
+                                 "backward did not run): gradients of the previous pass are incomplete")
+
+
 class _Conv2d(torch.autograd.Function):
     """y = conv2d(x, w) + b on NHWC x; w is the reference's OIHW float32 parameter (its .grad comes back OIHW
     float32).  x float32 -> f32 MFMA engine; x bf16 -> bf16 operands, float32 accumulation and dW.  If x has more
     channels than w (the engine pads activations to multiples of 32) the weight is zero-padded to match."""
 
     @staticmethod
-    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None):
+    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None, relu_sink=None):
         _req(x, w_oihw, bias)
         _f32(w_oihw, bias)
         sfx = _sfx(x)
@@ -288,6 +322,9 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w_ihwo, y if relu else None)
         ctx.cfg = dims + (bias is not None, sfx, Cin_w)
         ctx.bias_grad_zero = bool(bias_grad_zero)
+        ctx.relu_sink = relu_sink if relu else None
+        if ctx.relu_sink is not None:
+            relu_sink.relu = True
         return y
 
     @staticmethod
@@ -296,6 +333,8 @@ class _Conv2d(torch.autograd.Function):
         *dims, has_bias, sfx, Cin_w = ctx.cfg
         B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
         dy = dy.contiguous()
+        if ctx.relu_sink is not None and ctx.relu_sink.masked:
+            y_relu = None        # the token-gradient merge applied the ReLU mask already (TokenGradSink)
         if y_relu is not None:   # fused ReLU: mask the incoming gradient with the saved output first
             masked = torch.empty_like(dy)
             _abi.call("wsmg_relu_bwd" + sfx, _p(dy), _p(y_relu), _p(masked), dy.numel(), _stream())
@@ -331,7 +370,7 @@ class _Conv2d(torch.autograd.Function):
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
             db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class _ConvT2d(torch.autograd.Function):
@@ -382,12 +421,12 @@ class _ConvT2d(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None):
+def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None, relu_sink=None):
     """x NHWC; weight = the reference's OIHW parameter (laid out for the engine in one launch inside the autograd
     node, so the parameter's .grad comes back OIHW float32).  bias_grad_zero: the output feeds a train-mode
     BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros.  relu: y = relu(conv + bias), fused into
     the conv epilogue in bf16 mode."""
-    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats)
+    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats, relu_sink)
 
 
 class _Conv2dCat(torch.autograd.Function):
@@ -459,18 +498,18 @@ class _Conv2dCat(torch.autograd.Function):
         return (dw, db, None, None, None, None, *dxs)
 
 
-def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False):
+def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, relu_sink=None):
     """conv2d over the channel concatenation of the NHWC tensors `xs` (see _Conv2dCat); float32 activations take the
     plain route (torch.cat + conv2d)."""
     xs = list(xs)
     if len(xs) == 1:
-        return conv2d(xs[0], weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+        return conv2d(xs[0], weight_oihw, bias, stride, pad, bias_grad_zero, relu, relu_sink=relu_sink)
     # measured on the T=64 x N=8 update: 15.30-15.39 ms with the part-by-part route against 15.14 ms with torch.cat + one
     # conv — two shorter reductions, two epilogues (the second re-reads y) and twice the weight-gradient launches cost
     # more than the 0.35 ms of concatenation and slice copies they remove — so the part-by-part route is opt-in
     if xs[0].dtype != torch.bfloat16 or _os.environ.get("WSMG_CONV_CAT", "0") != "1":
         x = cat_channels(xs[0], xs[1]) if len(xs) == 2 else torch.cat(xs, dim=-1)
-        return conv2d(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu)
+        return conv2d(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, relu_sink=relu_sink)
     return _Conv2dCat.apply(weight_oihw, bias, stride, pad, bias_grad_zero, relu, *xs)
 
 
@@ -855,10 +894,11 @@ class _AttnFolded(torch.autograd.Function):
     keys and values; no key tensor is ever materialised."""
 
     @staticmethod
-    def forward(ctx, q, w, b, x, mask, scale):
+    def forward(ctx, q, w, b, x, mask, scale, sink=None):
         _req(q, x, mask)
         _f32(q)
         B, I, C = x.shape
+        ctx.sink = sink
         if mask is not None:
             mask = mask.to(torch.uint8).contiguous()
         wf = w.reshape(w.shape[0], -1).float()
@@ -885,12 +925,15 @@ class _AttnFolded(torch.autograd.Function):
         dq = dqf @ wf.t()
         dw = (q.t() @ dqf).reshape(ctx.wshape)
         db = torch.zeros(ctx.wshape[0], device=q.device, dtype=torch.float32) if ctx.has_b else None   # exactly zero
-        return dq, dw, db, dx, None, None
+        if ctx.sink is not None:     # parked: the token mean's backward merges its row in and returns the sum (TokenGradSink)
+            ctx.sink.park(dx)
+            dx = None
+        return dq, dw, db, dx, None, None, None
 
 
-def attention_folded(q, w, b, x, mask, scale):
+def attention_folded(q, w, b, x, mask, scale, sink=None):
     """(context [B,C], weights [B,I]) of softmax(scale * (q . (W x_i + b) - 1e8 mask_i)) over x [B,I,C]."""
-    return _AttnFolded.apply(q, w, b, x, mask, scale)
+    return _AttnFolded.apply(q, w, b, x, mask, scale, sink)
 
 
 class _CatChannels(torch.autograd.Function):
@@ -930,17 +973,29 @@ class _TokenMean(torch.autograd.Function):
     and the add (div 112 us + copy 92 us + add 73 us at B=512, I=576, C=256)."""
 
     @staticmethod
-    def forward(ctx, x):
-        ctx.shape, ctx.dtype = x.shape, x.dtype
+    def forward(ctx, x, sink=None):
+        ctx.shape, ctx.dtype, ctx.sink = x.shape, x.dtype, sink
+        if sink is not None:
+            ctx.save_for_backward(x)
         return x.mean(dim=1, dtype=torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        return (g * (1.0 / ctx.shape[1])).to(ctx.dtype).unsqueeze(1).expand(ctx.shape)
+        sink = ctx.sink
+        dx = sink.take() if sink is not None else None
+        if dx is not None:       # the attention's gradient is parked: merge the broadcast row and the ReLU mask in one pass
+            (x,) = ctx.saved_tensors
+            B, I, C = ctx.shape
+            g = g.contiguous().float()
+            _req(dx, x, g)
+            _abi.call("wsmg_token_grad_merge" + _sfx(dx), _p(dx), _p(x), _p(g), B, I, C, int(sink.relu), _stream())
+            sink.masked = bool(sink.relu)
+            return dx, None
+        return (g * (1.0 / ctx.shape[1])).to(ctx.dtype).unsqueeze(1).expand(ctx.shape), None
 
 
-def token_mean(x):
-    return _TokenMean.apply(x)
+def token_mean(x, sink=None):
+    return _TokenMean.apply(x, sink)
 
 
 def quantize_e4m3(x, scale):
