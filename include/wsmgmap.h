@@ -265,6 +265,17 @@ int wsmg_quantize_e4m3_dev(const float* x, int64_t n, const float* scale, uint8_
 /* y = e4m3(clamp(x * inv_scale, +-448)), round to nearest even; n a multiple of 4. */
 int wsmg_quantize_e4m3(const float* x, int64_t n, float inv_scale, uint8_t* y, wsmg_stream_t stream);
 
+/* wsmg_weight_relayout for n parameters in one launch per WSMG_RELAYOUT_MAX of them (descs is a HOST array, copied into the
+ * kernel arguments; bf16 != 0: bf16 operands, else float32).  The 20 convolutions of the map stack (map_encoder.py:19-29,
+ * 94-112, mg_map_policy.py:78-100) get their operands laid out at the start of a forward pass. */
+#define WSMG_RELAYOUT_MAX 32
+typedef struct {
+  const float* w_oihw;   /* [O][I][KH][KW] float32 parameter */
+  void* w_ohwi;          /* [O][KH][KW][I_pad] out */
+  void* w_ihwo;          /* [I_pad][KH][KW][O] out, or NULL */
+  int O, I, KH, KW, I_pad, reserved;
+} WsmgRelayoutDesc;
+int wsmg_weight_relayout_multi(const WsmgRelayoutDesc* descs, int n, int bf16, wsmg_stream_t stream);
 /* Conv weight layouts of one layer in one launch: the reference's OIHW float32 parameter (checkpoint layout) ->
  * OHWI (operand of wsmg_conv2d_fwd / _bwd_weight) and, if w_ihwo != NULL, IHWO (operand of _bwd_data), input
  * channels zero-padded to I_pad; wsmg_weight_grad_to_oihw brings the OHWI float32 weight gradient back to OIHW. */

@@ -351,6 +351,28 @@ __global__ __launch_bounds__(256) void weight_relayout_kernel(const float* __res
     if (ihwo) stf(ihwo + (((int64_t)i * KH + kh) * KW + kw) * O + o, v);
   }
 }
+// the same for up to WSMG_RELAYOUT_MAX parameters in ONE launch (blockIdx.y = parameter): the map stack has 20 convolutions,
+// and 20 five-microsecond launches in front of them were 0.1 ms of the forward pass's critical path
+struct RelayoutBatch { WsmgRelayoutDesc d[WSMG_RELAYOUT_MAX]; };
+template <class T>
+__global__ __launch_bounds__(256) void weight_relayout_multi_kernel(RelayoutBatch b) {
+  const WsmgRelayoutDesc& d = b.d[blockIdx.y];
+  const int O = d.O, I = d.I, KH = d.KH, KW = d.KW, I_pad = d.I_pad;
+  const float* __restrict__ w = d.w_oihw;
+  T* __restrict__ ohwi = (T*)d.w_ohwi;
+  T* __restrict__ ihwo = (T*)d.w_ihwo;
+  const int64_t n = (int64_t)O * KH * KW * I_pad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx % I_pad);
+    int64_t r = idx / I_pad;
+    const int kw = (int)(r % KW); r /= KW;
+    const int kh = (int)(r % KH);
+    const int o = (int)(r / KH);
+    const float v = i < I ? w[(((int64_t)o * I + i) * KH + kh) * KW + kw] : 0.f;
+    stf(ohwi + idx, v);
+    if (ihwo) stf(ihwo + (((int64_t)i * KH + kh) * KW + kw) * O + o, v);
+  }
+}
 // dW [O][KH][KW][I_pad] float32 -> the parameter's OIHW gradient (padded channels dropped)
 __global__ __launch_bounds__(256) void weight_grad_to_oihw_kernel(const float* __restrict__ dw, int O, int I, int KH, int KW,
                                                                   int I_pad, float* __restrict__ out) {
@@ -589,6 +611,21 @@ extern "C" int wsmg_weight_relayout_bf16(const float* w_oihw, int O, int I, int 
   if (O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || I_pad < I) return WSMG_EINVAL;
   hipLaunchKernelGGL(weight_relayout_kernel<bf16_t>, dim3(sgrid((int64_t)O * KH * KW * I_pad)), dim3(256), 0, wsmg_s(s), w_oihw, O, I,
                      KH, KW, I_pad, B16(w_ohwi), B16(w_ihwo));
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_weight_relayout_multi(const WsmgRelayoutDesc* descs, int n, int bf16, wsmg_stream_t s) {
+  if (!descs || n <= 0) return WSMG_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += WSMG_RELAYOUT_MAX) {
+    RelayoutBatch b;
+    const int m = n - i0 < WSMG_RELAYOUT_MAX ? n - i0 : WSMG_RELAYOUT_MAX;
+    for (int i = 0; i < m; ++i) {
+      b.d[i] = descs[i0 + i];
+      if (b.d[i].O <= 0 || b.d[i].I <= 0 || b.d[i].KH <= 0 || b.d[i].KW <= 0 || b.d[i].I_pad < b.d[i].I || !b.d[i].w_oihw || !b.d[i].w_ohwi)
+        return WSMG_EINVAL;
+    }
+    if (bf16) hipLaunchKernelGGL(weight_relayout_multi_kernel<bf16_t>, dim3(48, (unsigned)m), dim3(256), 0, wsmg_s(s), b);
+    else hipLaunchKernelGGL(weight_relayout_multi_kernel<float>, dim3(48, (unsigned)m), dim3(256), 0, wsmg_s(s), b);
+  }
   WSMG_RETURN_LAUNCH();
 }
 extern "C" int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW, int I_pad, float* dw_oihw, wsmg_stream_t s) {

@@ -20,6 +20,11 @@ class WsmgError(RuntimeError):
     pass
 
 
+class RelayoutDesc(ctypes.Structure):     # WsmgRelayoutDesc of include/wsmgmap.h
+    _fields_ = [("w_oihw", c_p), ("w_ohwi", c_p), ("w_ihwo", c_p), ("O", c_i), ("I", c_i), ("KH", c_i), ("KW", c_i),
+                ("I_pad", c_i), ("reserved", c_i)]
+
+
 # name -> argtypes (all return int unless listed in _RESTYPE)
 _SIG = {
     "wsmg_abi_version": [],
@@ -74,6 +79,7 @@ _SIG["wsmg_quantize_e4m3_dev"] = [c_p, c_l, c_p, c_p, c_p]
 _SIG["wsmg_quantize_e4m3"] = [c_p, c_l, c_f, c_p, c_p]
 _SIG["wsmg_weight_relayout"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_weight_relayout_bf16"] = list(_SIG["wsmg_weight_relayout"])
+_SIG["wsmg_weight_relayout_multi"] = [c_p, c_i, c_i, c_p]
 _SIG["wsmg_weight_grad_to_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
 _SIG["wsmg_cat_channels"] = [c_p, c_p, c_p, c_l, c_i, c_i, c_p]
 _SIG["wsmg_ce_nhwc_fwd"] = [c_p, c_p, c_l, c_i, c_p, c_p]

@@ -153,8 +153,20 @@ class MGMapNet(nn.Module):
         with batched_bumps():
             return self._map_stack(ego_map)
 
+    def _map_stack_conv_weights(self):
+        d, c = self.map_decoder, self.map_classfier
+        stem = d.base_model   # (its layer2-4 / fc exist for the checkpoint contract only and are never run)
+        ws = [self.map_encoder.cnn[i].weight for i in (0, 3, 6)]
+        ws += [stem.conv1.weight] + [w for blk in stem.layer1 for w in (blk.conv1.weight, blk.conv2.weight)]
+        ws += [seq[0].weight for seq in (d.layer0_1x1, d.layer1_1x1, d.conv_up0, d.conv_original_size0, d.conv_original_size1,
+                                         d.conv_original_size2)]
+        return ws + [c[0].weight, c[3].weight, self.map_encoded_linear[0].weight, self.map_classified_linear[0].weight,
+                     self.map_cated_linear[0].weight]
+
     def _map_stack(self, ego_map):
         train = self.training
+        if ego_map.is_cuda:   # operands of all the map stack's convolutions in one launch (they are on the main stream only)
+            ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
         x = self._ego_to_nhwc(ego_map)
         enc = self.map_encoder(x)
         conv = lambda t, seq, pad: ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad, relu=True)  # noqa: E731
