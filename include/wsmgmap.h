@@ -184,6 +184,11 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
+/* Tests / tools: tile of the LDS-window kernel that serves 3x3 stride-1 pad-1 layers with Cout % 128 == 0, Cin % 32 == 0, Cin >= 64 and
+ * B*H*W >= 65536 (0 = off -> implicit-GEMM kernel, 1 = tile chosen by shape, 256 or 512 pixels per workgroup; default 1 or
+ * env WSMG_CONV_WIN3).
+ * Returns the previous choice.  No reference counterpart (the reference calls torch.nn.Conv2d, map_encoder.py:29-112). */
+int wsmg_conv_debug_win3_tile(int mt);
 int wsmg_bn_act_fwd_bf16_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, int64_t rows, int C, void* y,
                              float* save_mean, float* save_invstd, double* stats, int nslab, wsmg_stream_t stream);

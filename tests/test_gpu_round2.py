@@ -547,3 +547,64 @@ def test_depth_backbone_engine_path_opt_in():
         y1 = ops.group_norm_nhwc(x[:1, :4, :4].contiguous().to(torch.bfloat16), gn.weight, gn.bias, 1, gn.eps, False)
         want1 = torch.nn.functional.group_norm(x[:1, :4, :4].to(torch.bfloat16).float().permute(0, 3, 1, 2), 1, gn.weight, gn.bias, gn.eps)
         assert float((y1.float().permute(0, 3, 1, 2) - want1).abs().max()) <= 2e-2
+
+
+# ------------------------------------------------------------------ the LDS-window kernel of the 3x3 stride-1 layers
+@pytest.mark.gpu
+@pytest.mark.parametrize("mt", [512, 256])
+@pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 64, 128), (29, 48, 32, 128)], ids=["cated", "ragged", "48x48"])
+def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
+    """wsmg_conv_win3.hip (zero-padded LDS pixel window, fwd + backward-data, bias / ReLU / BatchNorm sums) against a float64
+    convolution of the same bf16 operands, through the public entry points at sizes that reach it (B*H*W >= 65536):
+    tiles that cross image rows and images, a last tile that is not full (ragged), and a second image geometry.  The same
+    calls with the window kernel switched off (implicit-GEMM kernel) must agree to the bf16 rounding of the output."""
+    import ctypes
+    import torch.nn.functional as F
+    from wsmgmap import _abi
+    B, H, Cin, Cout = shape
+    torch.manual_seed(mt + B)
+    x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * (2.0 / (9 * Cin) ** 0.5)).bfloat16()
+    bias = torch.randn(Cout, device="cuda")
+    gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous()
+    w_ihwo = w.permute(1, 2, 3, 0).contiguous()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nslab = 8
+
+    def run(tile):
+        prev = _abi.lib().wsmg_conv_debug_win3_tile(tile)
+        try:
+            y = torch.empty(B, H, H, Cout, device="cuda", dtype=torch.bfloat16)
+            stats = torch.zeros(nslab, 2, Cout, device="cuda", dtype=torch.float64)
+            _abi.call("wsmg_conv2d_fwd_bf16_stats", P(x), P(w_ohwi), P(bias), P(y), 2, P(stats), nslab, B, H, H, Cin, Cout, 3, 3, 1, 1,
+                      H, H, st)
+            dx = torch.empty(B, H, H, Cin, device="cuda", dtype=torch.bfloat16)
+            dstats = torch.zeros(nslab, 2, Cin, device="cuda", dtype=torch.float64)
+            _abi.call("wsmg_conv2d_bwd_data_bf16_stats", P(gy), P(w_ihwo), P(dx), 0, P(dstats), nslab, B, H, H, Cin, Cout, 3, 3, 1, 1,
+                      H, H, st)
+            torch.cuda.synchronize()
+            return y, stats.sum(0), dx, dstats.sum(0)
+        finally:
+            _abi.lib().wsmg_conv_debug_win3_tile(prev)
+
+    y, s, dx, ds = run(mt)
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    yr = F.conv2d(xr, w.double(), bias.double(), padding=1)
+    yr.backward(gy.permute(0, 3, 1, 2).double())
+    yref = torch.relu(yr.detach()).permute(0, 2, 3, 1)
+    dxref = xr.grad.permute(0, 2, 3, 1)
+    eps = 2.0 ** -8
+    assert float(((y.double() - yref).abs() - eps * yref.abs()).max()) <= 1e-3
+    assert float(((dx.double() - dxref).abs() - eps * dxref.abs()).max()) <= 1e-3
+    # BatchNorm sums are taken of the bf16-ROUNDED outputs (what the normalisation kernel will read)
+    yb, dxb = y.double().reshape(-1, Cout), dx.double().reshape(-1, Cin)
+    assert float((s[0] - yb.sum(0)).abs().max()) <= 1e-4 * float(yb.abs().sum(0).max())
+    assert float((s[1] - (yb * yb).sum(0)).abs().max()) <= 1e-4 * float((yb * yb).sum(0).max())
+    assert float((ds[0] - dxb.sum(0)).abs().max()) <= 1e-4 * float(dxb.abs().sum(0).max())
+    assert float((ds[1] - (dxb * dxb).sum(0)).abs().max()) <= 1e-4 * float((dxb * dxb).sum(0).max())
+    y0, s0, dx0, ds0 = run(0)
+    assert float(((y.double() - y0.double()).abs() - 2 * eps * y0.double().abs()).max()) <= 1e-3
+    assert float(((dx.double() - dx0.double()).abs() - 2 * eps * dx0.double().abs()).max()) <= 1e-3
+

@@ -29,8 +29,14 @@ LAYERS = [
     ("mapk_1x1", 256, 256, 1, 1, 0, 24, True),
 ]
 
-def timeit(fn, reps):
+def timeit(fn, reps, warm_s=0.25):
+    # a cold GPU runs its first kernels of a process at a lower clock (cated_k3 forward: 0.44 ms cold, 0.36 ms warm): spin first
+    import time
     fn(); torch.cuda.synchronize()
+    t0 = time.time()
+    while time.time() - t0 < warm_s:
+        for _ in range(10): fn()
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps): fn()

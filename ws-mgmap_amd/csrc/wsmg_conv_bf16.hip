@@ -515,6 +515,22 @@ int conv_prefetch(int dflt) {
   return v > 0 ? v : dflt;
 }
 
+int g_win3_tile = -1;
+int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 256 = that many pixels per workgroup
+  if (g_win3_tile < 0) { const char* e = getenv("WSMG_CONV_WIN3"); g_win3_tile = e ? atoi(e) : 1; }
+  return g_win3_tile;
+}
+// The LDS-window kernel (wsmg_conv_win3.hip) for a 3 x 3 / stride 1 / pad 1 layer of M pixels, Kc reduction channels and N output
+// channels: 0 = no (implicit-GEMM kernel), else pixels per workgroup.  Measured at B = 512 (tools/ab_win3.sh): at Kc = 32 (9
+// k-steps) its prologue costs more than the window saves; 512-pixel tiles move half the weight bytes per MFMA of 256-pixel
+// ones but need >= 4 rounds of workgroups over the 256 CUs to keep the last round's idle CUs cheap (N = 128 layers: 256).
+int win3_choice(int64_t M, int Kc, int N) {
+  const int t = win3_tile();
+  if (t == 0 || M < 256 * 256 || Kc < 64 || Kc % 32 || N % 128) return 0;
+  if (t != 1) return t;
+  return ((M + 511) / 512) * (N / 128) >= 1024 ? 512 : 256;
+}
+
 template <bool BWD, int PF>
 void launch_igemm_pf(ConvArgsB& a, dim3 grid, bool bk64, bool bn128, hipStream_t s) {
   if (bk64 && bn128)
@@ -560,10 +576,23 @@ extern "C" int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, con
       if (rc != WSMG_EINVAL) return rc;
     }
   }
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 5) == 0) {
+    if (const int mt = win3_choice((int64_t)B * OH * OW, Cin, Cout)) {
+      int rc = wsmg_conv_win3_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, mt, wsmg_s(stream));
+      if (rc != WSMG_EINVAL) return rc;
+    }
+  }
   ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32,
               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
   launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream));
   WSMG_RETURN_LAUNCH();
+}
+
+// tests / tools: choose the window kernel's tile (0 = off, 1 = by shape, 256, 512) for the calls that follow; returns the previous choice
+extern "C" int wsmg_conv_debug_win3_tile(int mt) {
+  const int old = win3_tile();
+  if (mt == 0 || mt == 1 || mt == 256 || mt == 512) g_win3_tile = mt;
+  return old;
 }
 
 extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, int B,
@@ -577,6 +606,12 @@ extern "C" int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihw
                                                int OH, int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
   if (stats && (nslab <= 0 || (out_f32 & 5) != 0 || (Cin & 7) != 0)) return WSMG_EINVAL;
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 7) == 0) {
+    if (const int mt = win3_choice((int64_t)B * H * W, Cout, Cin)) {
+      int rc = wsmg_conv_win3_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cout, Cin, mt, wsmg_s(stream));
+      if (rc != WSMG_EINVAL) return rc;
+    }
+  }
   ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32,
               (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
   int classes = 1;
