@@ -138,7 +138,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     policy.train()
     policy.net.depth_encoder.eval()
     policy.net.rgb_encoder.eval()
-    opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
+    # the reference's torch.optim.Adam (common_trainer.py:67-69) as one multi-tensor HIP launch per 48 tensors; WSMG_STOCK_ADAM=1: stock
+    from wsmgmap.optim import Adam as WsmgAdam
+    opt = (torch.optim.Adam if os.environ.get("WSMG_STOCK_ADAM") == "1" else WsmgAdam)(policy.parameters(), lr=2.5e-4)
     reducer = GradAllReducer(policy.parameters()) if world > 1 else None
     if reducer:
         reducer.broadcast_parameters(policy)

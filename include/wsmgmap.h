@@ -184,6 +184,20 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
+/* One Adam step over a list of float32 parameter tensors (amsgrad = False, maximize = False; weight_decay is the L2 form
+ * added to the gradient), arithmetic in torch.optim.Adam's order.  Replaces the optimizer step of the reference's update
+ * (torch.optim.Adam built at common_trainer.py:67-69, stepped at dagger_trainer.py:540-541): 3 launches for the policy's 102
+ * live tensors instead of 15.  descs is a HOST array; bias_correction{1,2} = 1 - beta{1,2}^step, computed by the caller. */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  long long n;
+} WsmgAdamDesc;
+int wsmg_adam_step_multi(const WsmgAdamDesc* descs, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         double bias_correction1, double bias_correction2, wsmg_stream_t stream);
+
 /* Tests / tools: tile of the LDS-window kernel that serves 3x3 stride-1 pad-1 layers with Cout % 128 == 0, Cin % 32 == 0, Cin >= 64 and
  * B*H*W >= 65536 (0 = off -> implicit-GEMM kernel, 1 = tile chosen by shape, 256 or 512 pixels per workgroup; default 1 or
  * env WSMG_CONV_WIN3).

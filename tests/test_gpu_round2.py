@@ -608,3 +608,67 @@ def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
     assert float(((y.double() - y0.double()).abs() - 2 * eps * y0.double().abs()).max()) <= 1e-3
     assert float(((dx.double() - dx0.double()).abs() - 2 * eps * dx0.double().abs()).max()) <= 1e-3
 
+
+
+# ------------------------------------------------------------------ multi-tensor Adam
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adam_multi_tensor_matches_torch_adam(wd):
+    """wsmgmap.optim.Adam (csrc/wsmg_optim.hip) against torch.optim.Adam, the reference's optimizer (common_trainer.py:67-69):
+    ragged sizes, an empty tensor, a parameter whose storage is not 16-byte aligned, more tensors than one launch's table
+    holds, 6 steps; then each optimizer continues from the OTHER's state_dict()."""
+    from wsmgmap import optim
+    torch.manual_seed(5)
+    shapes = [(7,), (4096,), (4097,), (3, 5, 7), (0,), (130001,), (64, 64, 3, 3)] + [(33 + i,) for i in range(60)]
+
+    def make():
+        torch.manual_seed(6)
+        ps = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+        base = torch.randn(1001, device="cuda")
+        ps.append(torch.nn.Parameter(base[1:]))           # data_ptr() % 16 == 4: scalar path
+        return ps
+    pa, pb = make(), make()
+    assert pa[-1].data_ptr() % 16 != 0
+    oa = optim.Adam(pa, lr=2.5e-4, weight_decay=wd)
+    ob = torch.optim.Adam(pb, lr=2.5e-4, weight_decay=wd)
+
+    def step(k):
+        torch.manual_seed(100 + k)
+        for x, y in zip(pa, pb):
+            g = torch.randn_like(x) * (0.1 + k)
+            x.grad, y.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for k in range(6):
+        step(k)
+    for x, y in zip(pa, pb):
+        torch.testing.assert_close(x, y, rtol=2e-6, atol=1e-7)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys() and set(sa["state"][1]) == set(sb["state"][1])
+    oa.load_state_dict(sb); ob.load_state_dict(sa)
+    for k in range(6, 9):
+        step(k)
+    for x, y in zip(pa, pb):
+        torch.testing.assert_close(x, y, rtol=4e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_adam_multi_tensor_on_the_policy_update():
+    """One T=4 x N=2 update of the policy stepped by wsmgmap.optim.Adam and by torch.optim.Adam from the same gradients."""
+    from wsmgmap import optim
+    from wsmgmap.common.aux_losses import AuxLosses
+    obs_np, prev, masks, weights = cases.update_inputs(4, 2, n_tok=(80, 37), tag="adam")
+    policy = _train_mode(_policy(num_proc=2, compute_dtype="bf16"))
+    AuxLosses.activate(); AuxLosses.clear()
+    obs = _cuda(obs_np)
+    pred, aux = policy(obs, torch.zeros(2, 2, 512, device="cuda"), T(prev).cuda(), T(masks).cuda(), T(weights).cuda())
+    loss = (pred ** 2).mean() + aux
+    loss.backward()
+    AuxLosses.deactivate()
+    live = [p for p in policy.parameters() if p.grad is not None]
+    twins = [torch.nn.Parameter(p.detach().clone()) for p in live]
+    for t, p in zip(twins, live):
+        t.grad = p.grad.clone()
+    optim.Adam(live, lr=2.5e-4).step()
+    torch.optim.Adam(twins, lr=2.5e-4).step()
+    for t, p in zip(twins, live):
+        torch.testing.assert_close(p.detach(), t.detach(), rtol=2e-6, atol=1e-8)

@@ -307,3 +307,22 @@ def test_depth_encoder_oracle_and_module_vs_golden():
     assert tuple(out.shape) == (2, 192, 4, 4)
     assert float((out[:, :128] - T(g["feat"])).abs().max()) <= 1e-5
     assert float((out[:, ::7] - T(g["out_sample"])).abs().max()) <= 1e-5
+
+
+def test_adam_refuses_anything_but_float32_cuda_parameters():
+    """wsmgmap.optim.Adam has no CPU path: stepping a CPU parameter raises (the product never falls back), unsupported
+    variants are refused at construction, and its state_dict has torch.optim.Adam's layout."""
+    import torch
+    from wsmgmap import _abi, optim
+    p = torch.nn.Parameter(torch.zeros(5))
+    opt = optim.Adam([p], lr=1e-3)
+    p.grad = torch.ones(5)
+    with pytest.raises(_abi.WsmgError):
+        opt.step()
+    with pytest.raises(ValueError):
+        optim.Adam([p], amsgrad=True)
+    with pytest.raises(ValueError):
+        optim.Adam([p], lr=-1.0)
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(5))], lr=1e-3).state_dict()
+    mine = opt.state_dict()["param_groups"][0]
+    assert set(mine) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"} and set(mine) <= set(ref["param_groups"][0])
