@@ -610,6 +610,40 @@ def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
 
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 128, 256), (120, 24, 64, 128), (150, 20, 128, 128)],
+                         ids=["cated", "ragged-enc6", "64-in", "20x20"])
+def test_conv_window_weight_gradient_3x3(shape):
+    """wsmg_conv_win3_wgrad.hip (zero-padded LDS window; an image count that does not divide into the workgroups' ranges, an image size whose padded rows do not fill the last k-step) against a float64 weight gradient of
+    the same bf16 operands, and against the generic kernel (window kernels switched off)."""
+    import ctypes
+    import torch.nn.functional as F
+    from wsmgmap import _abi
+    B, H, Cin, Cout = shape
+    torch.manual_seed(B + Cin)
+    x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+    gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(tile):
+        prev = _abi.lib().wsmg_conv_debug_win3_tile(tile)
+        try:
+            dw = torch.zeros(Cout, 3, 3, Cin, device="cuda")
+            _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(gy), P(dw), B, H, H, Cin, Cout, 3, 3, 1, 1, H, H, st)
+            torch.cuda.synchronize()
+            return dw
+        finally:
+            _abi.lib().wsmg_conv_debug_win3_tile(prev)
+    dw = run(1)
+    w = torch.zeros(Cout, Cin, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double(), w, padding=1).backward(gy.permute(0, 3, 1, 2).double())
+    ref = w.grad.permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((dw.double() - ref).abs().max()) <= 2e-5 * scale
+    assert float((dw - run(0)).abs().max()) <= 2e-5 * scale
+
+
 # ------------------------------------------------------------------ multi-tensor Adam
 @pytest.mark.gpu
 @pytest.mark.parametrize("wd", [0.0, 0.01])

@@ -75,3 +75,6 @@ int wsmg_conv_win_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, int 
 // Kc % 32 == 0, mt = 512 or 256 pixels per workgroup; WSMG_EINVAL otherwise
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
                         int B, int H, int W, int Kc, int N, int mt, hipStream_t s);
+// wsmg_conv_win3_wgrad.hip: weight gradient of a 3 x 3 / stride 1 / pad 1 layer out of a zero-padded LDS window (W <= 24, channel
+// multiples of 64 / 128); WSMG_EINVAL otherwise
+int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin, int Cout, hipStream_t s);

@@ -643,6 +643,14 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
       if (rc != WSMG_EINVAL) return rc;
     }
   }
+  static int use_w3w = -1;
+  if (use_w3w < 0) { const char* e = getenv("WSMG_WGRAD_WIN3"); use_w3w = e ? atoi(e) : 1; }
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && use_w3w && win3_tile() && (int64_t)B * H * W >= 256 * 256) {
+    // 3 x 3 stride-1 layers: zero-padded LDS window (wsmg_conv_win3_wgrad.hip); WSMG_WGRAD_WIN3=0 (or the tests' tile switch = 0)
+    // keeps the generic kernel (A/B)
+    int rc = wsmg_conv_win3_wgrad_bf16(x, dy, dw_ohwi, B, H, W, Cin, Cout, wsmg_s(stream));
+    if (rc != WSMG_EINVAL) return rc;
+  }
   WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
                (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, 0};
   { static int sk = -1; if (sk < 0) { const char* e = getenv("WSMG_WGRAD_DBG_SKIP"); sk = e ? atoi(e) : 0; } a.dbg_skip = sk; }
