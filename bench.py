@@ -316,10 +316,10 @@ def main():
             # passes over this very command (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM counters in separate runs, folded by
             # tools/pmc_traffic.py / tools/pmc_mfma.py; tools/refresh_profiles.sh): PMC collection cannot run inside a timed
             # bench, so the figures are read from profiles/ (newest round), not measured live
-            fams = {"wsmg_conv2d_bwd_weight_bf16": ["conv_wgrad_bf16_kernel", "conv_win_wgrad_kernel"],
-                    "wsmg_conv2d_fwd_bf16": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel"],
-                    "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel"],
-                    "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>"]}.get(r.get("entry"), [dom.replace("<*>", "")])
+            fams = {"wsmg_conv2d_bwd_weight_bf16": ["conv_wgrad_bf16_kernel", "conv_win_wgrad_kernel", "conv_win3_wgrad_kernel"],
+                    "wsmg_conv2d_fwd_bf16": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel"],
+                    "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel"],
+                    "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>", "conv_win3_kernel"]}.get(r.get("entry"), [dom.replace("<*>", "")])
             roofline["kernels_of_family"] = fams
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
             import glob

@@ -19,7 +19,8 @@ torch.manual_seed(0)
 policy = BasePolicy(None, bench._Box(), default_model_config(num_proc=1, gpu_id=0, compute_dtype=mode))
 policy.net.instruction_encoder.embedding_layer.weight.requires_grad_(False)
 policy = policy.to(dev); policy.train(); policy.net.depth_encoder.eval(); policy.net.rgb_encoder.eval()
-opt = torch.optim.Adam(policy.parameters(), lr=2.5e-4)
+from wsmgmap.optim import Adam as WsmgAdam
+opt = WsmgAdam(policy.parameters(), lr=2.5e-4)
 obs, prev, masks, weights = bench.synth_batch(T, N, dev, 1000)
 AuxLosses.activate()
 
