@@ -46,11 +46,12 @@ class Adam(torch.optim.Optimizer):
                     g.record_stream(torch.cuda.current_stream(p.device))   # the copy must outlive the launch queued below
                 st = self.state[p]
                 if not st:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["step"] = 0    # a Python int while training (102 CPU-tensor increments per step cost 1 ms of host time);
+                    #                   state_dict() / load_state_dict() convert from / to torch.optim.Adam's float32 tensor
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                by_step.setdefault(float(st["step"]), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                by_step.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             b1, b2 = group["betas"]
             for step, items in by_step.items():
                 descs = (_AdamDesc * len(items))()
@@ -61,3 +62,15 @@ class Adam(torch.optim.Optimizer):
                     _abi.call("wsmg_adam_step_multi", descs, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                               float(group["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, stream)
         return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["state"] = {k: {**v, "step": torch.tensor(float(v["step"]), dtype=torch.float32)} if "step" in v else v
+                       for k, v in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = int(round(float(st["step"])))
