@@ -215,6 +215,34 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.detach())
+    # The same update captured into ONE HIP graph and replayed (wsmgmap.graph.GraphedUpdate): reported beside the eager figure,
+    # never as `value` — the roofline object is measured with HIP events around eager launches inside the timed region, which
+    # a graph replay has none of.  One process only; WSMG_BENCH_GRAPH=0 skips it.
+    measure.graphed = None
+    if world == 1 and dtype == "bf16" and os.environ.get("WSMG_BENCH_GRAPH", "1") != "0":
+        from wsmgmap.graph import GraphedUpdate
+        del loss                    # the last eager update's autograd graph (and its AccumulateGrad nodes) must be gone before a capture
+        opt.zero_grad(set_to_none=True)
+        gopt = WsmgAdam(policy.parameters(), lr=2.5e-4, capturable=True)
+        gu = GraphedUpdate(policy, gopt, lambda pred, aux, o, w: dagger_loss(pred, aux, o["waypoint"], w), eager_calls=2)
+        hs = torch.zeros(policy.net.num_recurrent_layers, N, 512, device=dev)
+
+        def gupdate():
+            hs.zero_()
+            return gu(obs, hs, prev, masks, weights)
+        for _ in range(4):          # 2 eager, capture + first replay, one more replay
+            gupdate()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        for _ in range(steps):
+            gloss = gupdate()
+        torch.cuda.synchronize()
+        gdt = time.perf_counter() - g0
+        ops.check_rnn_status()
+        measure.graphed = dict(ms_per_step=round(gdt / steps * 1e3, 3), value=round(T * N * steps / gdt, 2), unit="policy steps/s", steps=steps,
+                               loss=round(float(gloss), 5),
+                               note="the same update (zero_grad + forward + loss + backward + Adam) as one captured HIP graph per "
+                                    "input signature, replayed; only the instruction dedup stays eager")
     del policy, opt, obs
     torch.cuda.empty_cache()
     return dt, prof, final_loss, state_cpu
@@ -284,6 +312,7 @@ def main():
     T, N = args.T, args.N
     dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)
     dp_info = measure.dp_info
+    graphed = getattr(measure, "graphed", None)
     parity = None
     if args.dtype == "bf16" and not args.no_f32:
         k32 = max(2, args.steps // 2)
@@ -362,6 +391,7 @@ def main():
             "whole_update_tflops": round(ALG_GFLOP_PER_STEP * steps_per_s / 1e3 / world, 2),
             "loss": round(final_loss, 5),
             "f32_parity_mode": parity,
+            "graphed_update": graphed,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
         }

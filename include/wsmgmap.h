@@ -197,6 +197,10 @@ typedef struct {
 } WsmgAdamDesc;
 int wsmg_adam_step_multi(const WsmgAdamDesc* descs, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
                          double bias_correction1, double bias_correction2, wsmg_stream_t stream);
+/* The same step with the step count (already incremented, one float32) read from DEVICE memory and the bias corrections computed
+ * in the kernel: the form a captured HIP graph can replay (torch.optim.Adam(capturable=True) is the stock counterpart). */
+int wsmg_adam_step_multi_dev(const WsmgAdamDesc* descs, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             const float* step_dev, wsmg_stream_t stream);
 
 /* Tests / tools: tile of the LDS-window kernel that serves 3x3 stride-1 pad-1 layers with Cout % 128 == 0, Cin % 32 == 0, Cin >= 64 and
  * B*H*W >= 65536 (0 = off -> implicit-GEMM kernel, 1 = tile chosen by shape, 256 or 512 pixels per workgroup; default 1 or

@@ -706,3 +706,55 @@ def test_adam_multi_tensor_on_the_policy_update():
     torch.optim.Adam(twins, lr=2.5e-4).step()
     for t, p in zip(twins, live):
         torch.testing.assert_close(p.detach(), t.detach(), rtol=2e-6, atol=1e-8)
+
+
+# ------------------------------------------------------------------ the update as one HIP graph
+@pytest.mark.gpu
+def test_graphed_update_matches_eager_updates():
+    """wsmgmap.graph.GraphedUpdate: five updates of a T=4 x N=2 batch — two eager, then capture + replay — leave the same
+    parameters and losses as five eager updates of a twin policy with the same optimizer class (float32 mode; what differs
+    is the order of float atomics, 1e-5), the optimizer's step counts agree, and new instructions of another length
+    (another signature) get their own graph."""
+    from wsmgmap import optim
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.graph import GraphedUpdate
+    obs_np, prev, masks, weights = cases.update_inputs(4, 2, n_tok=(80, 37), tag="graph")
+    obs = _cuda(obs_np)
+    prev, masks, weights = T(prev).cuda(), T(masks).cuda(), T(weights).cuda()
+    AuxLosses.activate()
+
+    def loss_fn(pred, aux, o, w):
+        return (pred ** 2).mean() + aux
+    pa, pb = _train_mode(_policy(num_proc=2)), _train_mode(_policy(num_proc=2))
+    # lr = 1e-5: Adam's first steps move a parameter by ± lr whatever its gradient's size, so where a gradient is float-atomic
+    # noise around zero the two trajectories differ by 2 lr per step
+    oa = optim.Adam(pa.parameters(), lr=1e-5, capturable=True)
+    ob = optim.Adam(pb.parameters(), lr=1e-5)
+    gu = GraphedUpdate(pa, oa, loss_fn, eager_calls=2)
+    la, lb = [], []
+    for k in range(5):
+        h = torch.zeros(2, 2, 512, device="cuda")
+        la.append(float(gu(obs, h, prev, masks, weights)))
+        ob.zero_grad(set_to_none=True)
+        AuxLosses.clear()
+        hb = torch.zeros(2, 2, 512, device="cuda")
+        pred, aux = pb(dict(obs), hb, prev, masks, weights)
+        loss = loss_fn(pred, aux, obs, weights)
+        loss.backward()
+        ob.step()
+        lb.append(float(loss))
+        assert float((h - hb).abs().max()) <= 2e-3
+    assert len(gu._graphs) == 1
+    np.testing.assert_allclose(la, lb, rtol=2e-4, atol=1e-5)
+    for (n, x), y in zip(pa.named_parameters(), pb.parameters()):
+        assert float((x - y).abs().max()) <= 2e-4 * max(1.0, float(y.abs().max())), n
+    assert {int(v["step"]) for v in oa.state.values()} == {int(v["step"]) for v in ob.state.values()} == {5}
+    obs2_np, _, _, _ = cases.update_inputs(4, 2, n_tok=(61, 12), tag="graph2")
+    obs2 = dict(obs)
+    obs2["instruction"] = T(obs2_np["instruction"]).cuda()
+    h = torch.zeros(2, 2, 512, device="cuda")
+    l2 = float(gu(obs2, h, prev, masks, weights))
+    assert len(gu._graphs) == 2 and np.isfinite(l2)
+    AuxLosses.deactivate()
+    from wsmgmap import ops
+    ops.check_rnn_status()

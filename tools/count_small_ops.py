@@ -11,7 +11,7 @@ from wsmgmap.config import default_model_config
 from wsmgmap.models.policy import BasePolicy
 from wsmgmap.optim import Adam
 
-T, N = 64, 8
+T, N = int(os.environ.get("T", 64)), int(os.environ.get("N", 8))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 policy = BasePolicy(None, bench._Box(), default_model_config(num_proc=1, gpu_id=0, compute_dtype="bf16"))
@@ -39,7 +39,7 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=True) as prof:
     update()
     torch.cuda.synchronize()
-want = ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::cat", "aten::sum", "aten::mul", "aten::clone", "aten::contiguous",
+want = ("aten::gather", "aten::scatter", "aten::scatter_", "aten::scatter_add_", "aten::take_along_dim", "aten::index_add_", "aten::gather_backward", "aten::value_selecting_reduction_backward", "aten::max", "aten::min", "aten::sort", "aten::topk", "aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::cat", "aten::sum", "aten::mul", "aten::clone", "aten::contiguous",
         "aten::zeros", "aten::index_select", "aten::_to_copy")
 cnt = collections.Counter()
 for e in prof.events():

@@ -74,12 +74,20 @@ class InstructionEncoder(nn.Module):
             InstructionEncoder._diag_memo = ((B, L), U, host, inverse)
         return uniq, inverse, host[1:], lengths
 
-    def encode_unique(self, instruction, stock=False):
+    def dedup(self, instruction):
+        """The data-dependent part of the encoder, callable on its own: (unique rows [U, L], inverse [B], lengths on the host,
+        lengths on the device).  `wsmgmap.graph.GraphedUpdate` runs it eagerly in front of a captured update and hands the
+        result back through `observations["instruction_dedup"]` (U and the longest length fix the shapes the graph was captured
+        for)."""
+        return self._dedup(instruction.long())
+
+    def encode_unique(self, instruction, stock=False, dedup=None):
         """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows.
         stock=False: persistent HIP bi-LSTM (csrc/wsmg_rnn.hip); stock=True: nn.LSTM on a packed
-        sequence (MIOpen / CPU), kept for comparison in tests."""
+        sequence (MIOpen / CPU), kept for comparison in tests.  dedup: the result of `dedup()` for these tokens, if the caller
+        already has it (no host read-back here then)."""
         tokens = instruction.long()
-        uniq, inverse, len_host, len_dev = self._dedup(tokens)
+        uniq, inverse, len_host, len_dev = self._dedup(tokens) if dedup is None else dedup
         if stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
             embedded = self.embedding_layer(uniq)
             packed = nn.utils.rnn.pack_padded_sequence(embedded, len_host, batch_first=True, enforce_sorted=False)

@@ -218,7 +218,8 @@ class MGMapNet(nn.Module):
         side = self._side_stream
         side.wait_event(entry)
         with torch.cuda.stream(side):
-            instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"])
+            instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"],
+                                                                             dedup=observations.get("instruction_dedup"))
             text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
             # the B rows attend over the U unique sets in place (ops.attention_shared): no per-row copies
             text = (text_k_u.contiguous(), instr_u.contiguous(), mask_u.to(torch.uint8).contiguous(), inverse.contiguous())

@@ -18,7 +18,13 @@ class _AdamDesc(ctypes.Structure):
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, maximize=False,
+                 capturable=False):
+        """capturable=True: the step count also lives in a device scalar (one per parameter group, incremented on the device)
+        and the kernel computes the bias corrections from it — the form `wsmgmap.graph.GraphedUpdate` captures into a HIP graph
+        (kernel arguments are frozen at capture).  All stepped parameters of a group must then share one step count."""
+        self._capturable = bool(capturable)
+        self._step_dev = {}
         if amsgrad or maximize:
             raise ValueError("wsmgmap.optim.Adam implements amsgrad=False, maximize=False (what the reference trains with)")
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
@@ -53,15 +59,34 @@ class Adam(torch.optim.Optimizer):
                 st["step"] += 1
                 by_step.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             b1, b2 = group["betas"]
+            if self._capturable and len(by_step) > 1:
+                raise _abi.WsmgError("wsmgmap.optim.Adam(capturable=True): the stepped parameters of a group must share one step count")
             for step, items in by_step.items():
                 descs = (_AdamDesc * len(items))()
                 for d, (p, g, m, v) in zip(descs, items):
                     d.param, d.grad, d.exp_avg, d.exp_avg_sq, d.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
-                stream = ctypes.c_void_p(torch.cuda.current_stream(items[0][0].device).cuda_stream)
-                with torch.cuda.device(items[0][0].device):
-                    _abi.call("wsmg_adam_step_multi", descs, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                              float(group["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, stream)
+                dev = items[0][0].device
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                with torch.cuda.device(dev):
+                    if self._capturable:
+                        key = id(group)
+                        if key not in self._step_dev:
+                            self._step_dev[key] = torch.full((), float(step - 1), device=dev, dtype=torch.float32)
+                        sd = self._step_dev[key]
+                        sd.add_(1.0)      # on the device: a replayed graph advances it without the host
+                        _abi.call("wsmg_adam_step_multi_dev", descs, len(items), float(group["lr"]), float(b1), float(b2),
+                                  float(group["eps"]), float(group["weight_decay"]), ctypes.c_void_p(sd.data_ptr()), stream)
+                    else:
+                        _abi.call("wsmg_adam_step_multi", descs, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                  float(group["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, stream)
         return loss
+
+    def note_replayed_steps(self, n=1):
+        """A captured graph that contains this optimizer's step was replayed n times: advance the host-side step counts (the
+        device counters advanced inside the graph)."""
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] += n
 
     def state_dict(self):
         sd = super().state_dict()
@@ -74,3 +99,4 @@ class Adam(torch.optim.Optimizer):
         for st in self.state.values():
             if "step" in st:
                 st["step"] = int(round(float(st["step"])))
+        self._step_dev = {}       # re-created from the loaded step counts at the next capturable step
