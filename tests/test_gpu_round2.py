@@ -758,3 +758,46 @@ def test_graphed_update_matches_eager_updates():
     AuxLosses.deactivate()
     from wsmgmap import ops
     ops.check_rnn_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_graphed_act_matches_eager_act(mode):
+    """wsmgmap.graph.GraphedAct: seven rollout steps from raw RGB-D with moving pose, a mask reset and new instructions —
+    two eager, then capture + replay — give the values, actions, log-probabilities, hidden states, progress estimates and
+    global maps of a twin policy stepped eagerly; the trainer's re-assignment of the map state between steps is adopted."""
+    from wsmgmap.graph import GraphedAct
+    B = 2
+    pa, pb = _policy(num_proc=B, compute_dtype=mode).eval(), _policy(num_proc=B, compute_dtype=mode).eval()
+    ga = GraphedAct(pa, eager_calls=2)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    ha, hb = torch.zeros(2, B, 512, device="cuda"), torch.zeros(2, B, 512, device="cuda")
+    prev = torch.zeros(B, 2, device="cuda")
+    ins = torch.zeros(B, 200, dtype=torch.int64, device="cuda")
+    ins[0, :80] = torch.randint(1, 2504, (80,), device="cuda", generator=gen)
+    ins[1, :37] = torch.randint(1, 2504, (37,), device="cuda", generator=gen)
+    tol = 2e-4 if mode == "f32" else 0.0      # the graph replays the SAME kernels on the same data: bf16 mode bit for bit too
+    for k in range(7):
+        obs = {"rgb": torch.randint(0, 256, (B, 224, 224, 3), device="cuda", generator=gen).float(),
+               "depth": torch.rand(B, 256, 256, 1, device="cuda", generator=gen),
+               "depth_features": torch.randn(B, 128, 4, 4, device="cuda", generator=gen),
+               "instruction": ins.clone(),
+               "gps": (torch.rand(B, 2, device="cuda", generator=gen) - 0.5) * 4,
+               "compass": (torch.rand(B, 1, device="cuda", generator=gen) - 0.5) * 6.28}
+        masks = torch.ones(B, 1, device="cuda")
+        if k in (0, 4):
+            masks[k % B] = 0.0
+        if k == 5:                                   # what dagger_trainer.py:668-678 does when environments finish
+            mm = pa.net.rgb_mapping_module
+            mm.full_global_map = mm.full_global_map.clone()
+        with torch.no_grad():
+            vb, ab, lb, hb = pb.act(dict(obs), hb, prev, masks, deterministic=True)
+        va, aa, la, hn = ga(obs, ha, prev, masks, deterministic=True)
+        ha = hn.clone()
+        for name, x, y in (("value", va, vb), ("action", aa, ab), ("logp", la, lb), ("h", ha, hb), ("prog", pa.prog, pb.prog),
+                           ("map", pa.net.rgb_mapping_module.full_global_map, pb.net.rgb_mapping_module.full_global_map)):
+            assert float((x - y).abs().max()) <= tol * max(1.0, float(y.abs().max())) + (0 if tol else 0), (k, name)
+        prev = ab.clone()
+    assert len(ga._graphs) == 1
+    from wsmgmap import ops
+    ops.check_rnn_status()

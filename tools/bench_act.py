@@ -48,5 +48,10 @@ for B, mode in ((1, "f32"), (1, "bf16"), (8, "f32"), (8, "bf16")):
         t_rgb = timed(lambda: pol.net.rgb_encoder(obs))
         emb, proj = pol.net.rgb_encoder(obs)
         t_bev = timed(lambda: pol.net.rgb_mapping_module(proj, dict(obs), masks))
+    from wsmgmap.graph import GraphedAct
+    ga = GraphedAct(pol)
+    hg = h.clone()
+    t_graph = timed(lambda: ga(obs, hg, prev, masks, deterministic=True))
+    print(f"B={B} {mode}: act() as one HIP graph (wsmgmap.graph.GraphedAct) {t_graph:.2f} ms per env-step ({B / t_graph * 1e3:.0f} env-steps/s)")
     print(f"B={B} {mode}: act() {t_act:.2f} ms per env-step ({B / t_act * 1e3:.0f} env-steps/s) | frozen RGB ResNet-UNet {t_rgb:.2f} ms | "
           f"BEV operator (index, scatter, rotate, fuse, retrieve, rotate) {t_bev:.3f} ms | rest {t_act - t_rgb - t_bev:.2f} ms")

@@ -19,6 +19,97 @@ from . import _abi, ops
 from .common.aux_losses import AuxLosses
 
 
+def _eager_dedup(owner, enc, tokens, first_call):
+    """The instruction dedup on its own stream (its host read-back must not wait for the previous replay); the result tensors
+    are handed to the caller's stream."""
+    if owner._dd_stream is None:
+        owner._dd_stream = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    if first_call:
+        owner._dd_stream.wait_stream(cur)        # the caller's tensors are complete there (first call only: later calls assume the
+    with torch.cuda.stream(owner._dd_stream):    # tokens were written before the previous call returned)
+        dd = enc.dedup(tokens)
+    cur.wait_stream(owner._dd_stream)
+    for t in dd:
+        if t.is_cuda:
+            t.record_stream(cur)    # consumed on the caller's stream (copied into the captured tensors, behind the previous
+            #                         replay): the allocator must not hand its memory to the NEXT call's dedup before that
+    return dd
+
+
+class GraphedAct:
+    """One rollout step — `BasePolicy.act` (policy.py:34-56 of the reference: network forward from raw RGB-D, progress head,
+    action distribution, critic) — as a HIP graph.  At B = 1 the step is ≈300 launches of a few microseconds: 3.75 ms eagerly
+    (bf16 mode) of which 1 ms is GPU work.  Inputs are copied into the captured tensors every call (1 MB per environment); the
+    map state (`net.rgb_mapping_module.full_global_map`, which trainers slice and re-assign between steps) is adopted: a
+    re-assigned map of the same shape is copied into the captured one, another shape gets its own graph.  Outputs are owned by
+    the graph (valid until the next call)."""
+
+    def __init__(self, policy, eager_calls=2):
+        self.policy = policy
+        self.eager_calls = max(1, int(eager_calls))
+        self.calls = 0
+        self._graphs = {}
+        self._dd_stream = None
+        self._stream = None
+
+    def __call__(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False):
+        self.calls += 1
+        pol = self.policy
+        dd = _eager_dedup(self, pol.net.instruction_encoder, observations["instruction"], self.calls == 1)
+        if self.calls <= self.eager_calls:
+            obs = dict(observations)
+            obs["instruction_dedup"] = dd
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            cur = torch.cuda.current_stream()
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream), torch.no_grad():
+                out = pol.act(obs, rnn_hidden_states, prev_actions, masks, deterministic=deterministic)
+            cur.wait_stream(self._stream)
+            return out
+        mm = pol.net.rgb_mapping_module
+
+        def sig(t):
+            return (tuple(t.shape), t.dtype)
+        key = (tuple(sorted((k, sig(v)) for k, v in observations.items() if torch.is_tensor(v))), sig(rnn_hidden_states), sig(prev_actions),
+               sig(masks), bool(deterministic), int(dd[0].shape[0]), int(dd[2].max()), sig(mm.full_global_map))
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._capture(observations, rnn_hidden_states, prev_actions, masks, deterministic, dd)
+            self._graphs[key] = g
+        for k, s in g["obs"].items():
+            s.copy_(observations[k])
+        g["h_in"].copy_(rnn_hidden_states)
+        g["prev"].copy_(prev_actions)
+        g["masks"].copy_(masks)
+        for i in (0, 1, 3):
+            g["dd"][i].copy_(dd[i])
+        if mm.full_global_map.data_ptr() != g["map"].data_ptr():     # re-assigned by the trainer (episode bookkeeping)
+            g["map"].copy_(mm.full_global_map)
+            mm.full_global_map = g["map"]
+        g["graph"].replay()
+        return g["out"]
+
+    def _capture(self, observations, rnn_hidden_states, prev_actions, masks, deterministic, dd):
+        pol = self.policy
+        mm = pol.net.rgb_mapping_module
+        obs_s = {k: v.clone() for k, v in observations.items() if torch.is_tensor(v)}
+        dd_s = tuple(t.clone() for t in dd)
+        h_in, prev_s, masks_s = rnn_hidden_states.clone(), prev_actions.clone(), masks.clone()
+        map_s = mm.full_global_map
+        obs_c = dict(obs_s)
+        obs_c["instruction_dedup"] = dd_s
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            value, action, logp, h = pol.act(obs_c, h_in.clone(), prev_s, masks_s, deterministic=deterministic)
+        if mm.full_global_map.data_ptr() != map_s.data_ptr():
+            raise _abi.WsmgError("GraphedAct: the map state was re-allocated inside act(); the graph cannot adopt it")
+        ops.check_rnn_status()
+        return dict(graph=graph, obs=obs_s, dd=dd_s, h_in=h_in, prev=prev_s, masks=masks_s, map=map_s, out=(value, action, logp, h))
+
+
 class GraphedUpdate:
     def __init__(self, policy, optimizer, loss_fn, eager_calls=3):
         """loss_fn(pred, aux_loss, observations, weights) -> scalar loss tensor.  The first `eager_calls` updates run eagerly
@@ -79,21 +170,9 @@ class GraphedUpdate:
         """-> loss (a tensor owned by the graph: valid until the next call).  rnn_hidden_states is overwritten with the final
         hidden state, as `BasePolicy.forward` does."""
         self.calls += 1
-        enc = self.policy.net.instruction_encoder
         # eager, on its own stream: the dedup's host read-back must not wait for the previous replay (it depends on the
         # instruction tokens only), or the GPU idles while the host prepares the next one
-        if self._dd_stream is None:
-            self._dd_stream = torch.cuda.Stream()
-        cur0 = torch.cuda.current_stream()
-        if self.calls == 1:
-            self._dd_stream.wait_stream(cur0)            # the caller's tensors are complete there (first call only: later calls
-        with torch.cuda.stream(self._dd_stream):         # assume the tokens were written before the previous update returned)
-            dd = enc.dedup(observations["instruction"])
-        cur0.wait_stream(self._dd_stream)
-        for t in dd:
-            if t.is_cuda:
-                t.record_stream(cur0)    # consumed on the caller's stream (copied into the captured tensors, behind the previous
-                #                          replay): the allocator must not hand its memory to the NEXT call's dedup before that
+        dd = _eager_dedup(self, self.policy.net.instruction_encoder, observations["instruction"], self.calls == 1)
         if self.calls <= self.eager_calls:
             obs = dict(observations)
             obs["instruction_dedup"] = dd
