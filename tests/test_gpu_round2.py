@@ -552,7 +552,8 @@ def test_depth_backbone_engine_path_opt_in():
 # ------------------------------------------------------------------ the LDS-window kernel of the 3x3 stride-1 layers
 @pytest.mark.gpu
 @pytest.mark.parametrize("mt", [512, 256])
-@pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 64, 128), (29, 48, 32, 128)], ids=["cated", "ragged", "48x48"])
+@pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 64, 128), (29, 48, 32, 128), (131, (18, 31), 96, 128)],
+                         ids=["cated", "ragged", "48x48", "18x31"])
 def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
     """wsmg_conv_win3.hip (zero-padded LDS pixel window, fwd + backward-data, bias / ReLU / BatchNorm sums) against a float64
     convolution of the same bf16 operands, through the public entry points at sizes that reach it (B*H*W >= 65536):
@@ -562,11 +563,12 @@ def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
     import torch.nn.functional as F
     from wsmgmap import _abi
     B, H, Cin, Cout = shape
+    H, W = H if isinstance(H, tuple) else (H, H)      # one rectangular image: rows and columns must not be mixed up anywhere
     torch.manual_seed(mt + B)
-    x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
     w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * (2.0 / (9 * Cin) ** 0.5)).bfloat16()
     bias = torch.randn(Cout, device="cuda")
-    gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
+    gy = torch.randn(B, H, W, Cout, device="cuda").bfloat16()
     w_ohwi = w.permute(0, 2, 3, 1).contiguous()
     w_ihwo = w.permute(1, 2, 3, 0).contiguous()
     P = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -576,14 +578,14 @@ def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
     def run(tile):
         prev = _abi.lib().wsmg_conv_debug_win3_tile(tile)
         try:
-            y = torch.empty(B, H, H, Cout, device="cuda", dtype=torch.bfloat16)
+            y = torch.empty(B, H, W, Cout, device="cuda", dtype=torch.bfloat16)
             stats = torch.zeros(nslab, 2, Cout, device="cuda", dtype=torch.float64)
-            _abi.call("wsmg_conv2d_fwd_bf16_stats", P(x), P(w_ohwi), P(bias), P(y), 2, P(stats), nslab, B, H, H, Cin, Cout, 3, 3, 1, 1,
-                      H, H, st)
-            dx = torch.empty(B, H, H, Cin, device="cuda", dtype=torch.bfloat16)
+            _abi.call("wsmg_conv2d_fwd_bf16_stats", P(x), P(w_ohwi), P(bias), P(y), 2, P(stats), nslab, B, H, W, Cin, Cout, 3, 3, 1, 1,
+                      H, W, st)
+            dx = torch.empty(B, H, W, Cin, device="cuda", dtype=torch.bfloat16)
             dstats = torch.zeros(nslab, 2, Cin, device="cuda", dtype=torch.float64)
-            _abi.call("wsmg_conv2d_bwd_data_bf16_stats", P(gy), P(w_ihwo), P(dx), 0, P(dstats), nslab, B, H, H, Cin, Cout, 3, 3, 1, 1,
-                      H, H, st)
+            _abi.call("wsmg_conv2d_bwd_data_bf16_stats", P(gy), P(w_ihwo), P(dx), 0, P(dstats), nslab, B, H, W, Cin, Cout, 3, 3, 1, 1,
+                      H, W, st)
             torch.cuda.synchronize()
             return y, stats.sum(0), dx, dstats.sum(0)
         finally:
@@ -611,8 +613,8 @@ def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 128, 256), (120, 24, 64, 128), (150, 20, 128, 128)],
-                         ids=["cated", "ragged-enc6", "64-in", "20x20"])
+@pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 128, 256), (120, 24, 64, 128), (150, 20, 128, 128), (123, (29, 19), 64, 128)],
+                         ids=["cated", "ragged-enc6", "64-in", "20x20", "29x19"])
 def test_conv_window_weight_gradient_3x3(shape):
     """wsmg_conv_win3_wgrad.hip (zero-padded LDS window; an image count that does not divide into the workgroups' ranges, an image size whose padded rows do not fill the last k-step) against a float64 weight gradient of
     the same bf16 operands, and against the generic kernel (window kernels switched off)."""
@@ -620,9 +622,10 @@ def test_conv_window_weight_gradient_3x3(shape):
     import torch.nn.functional as F
     from wsmgmap import _abi
     B, H, Cin, Cout = shape
+    H, W = H if isinstance(H, tuple) else (H, H)
     torch.manual_seed(B + Cin)
-    x = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
-    gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
+    x = torch.randn(B, H, W, Cin, device="cuda").bfloat16()
+    gy = torch.randn(B, H, W, Cout, device="cuda").bfloat16()
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -630,7 +633,7 @@ def test_conv_window_weight_gradient_3x3(shape):
         prev = _abi.lib().wsmg_conv_debug_win3_tile(tile)
         try:
             dw = torch.zeros(Cout, 3, 3, Cin, device="cuda")
-            _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(gy), P(dw), B, H, H, Cin, Cout, 3, 3, 1, 1, H, H, st)
+            _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(gy), P(dw), B, H, W, Cin, Cout, 3, 3, 1, 1, H, W, st)
             torch.cuda.synchronize()
             return dw
         finally:

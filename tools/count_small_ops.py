@@ -39,7 +39,7 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=True) as prof:
     update()
     torch.cuda.synchronize()
-want = ("aten::gather", "aten::scatter", "aten::scatter_", "aten::scatter_add_", "aten::take_along_dim", "aten::index_add_", "aten::gather_backward", "aten::value_selecting_reduction_backward", "aten::max", "aten::min", "aten::sort", "aten::topk", "aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::cat", "aten::sum", "aten::mul", "aten::clone", "aten::contiguous",
+want = ("aten::zeros_like", "aten::new_zeros", "aten::full", "aten::full_like", "aten::new_full", "aten::ones_like", "aten::gather", "aten::scatter", "aten::scatter_", "aten::scatter_add_", "aten::take_along_dim", "aten::index_add_", "aten::gather_backward", "aten::value_selecting_reduction_backward", "aten::max", "aten::min", "aten::sort", "aten::topk", "aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::cat", "aten::sum", "aten::mul", "aten::clone", "aten::contiguous",
         "aten::zeros", "aten::index_select", "aten::_to_copy")
 cnt = collections.Counter()
 for e in prof.events():
@@ -47,10 +47,14 @@ for e in prof.events():
         continue
     frame = ""
     for s in (e.stack or []):
-        if "wsmgmap" in s or "bench.py" in s:
+        if "wsmgmap" in s or "bench.py" in s or "count_small_ops" in s:
             frame = s.split("ws-mgmap_amd/")[-1][:90]
             break
+    if not frame and e.stack:
+        frame = "| " + e.stack[0][-80:]
     shapes = str(e.input_shapes)[:60]
     cnt[(e.name, frame, shapes)] += 1
-for (name, frame, shapes), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:70]:
+only = os.environ.get("ONLY")
+for (name, frame, shapes), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:200]:
+    if only and only not in name: continue
     print(f"{c:4d} {name:18s} {shapes:60s} {frame}")
