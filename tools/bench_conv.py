@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--B", type=int, default=512)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--data", default="randn", choices=["randn", "relu"],
+                    help="relu: x and dy half zeros, as the update's post-ReLU activations and masked gradients are (the kernels' clock, "
+                         "and with it their ranking, depends on the data)")
     a = ap.parse_args()
     B = a.B
     st = ops._stream
@@ -58,11 +61,15 @@ def main():
         if a.only and a.only not in name: continue
         OH = (H + 2 * p - k) // s + 1
         dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-        x = torch.randn(B, H, H, Cin, device="cuda").to(dt)
+        x = torch.randn(B, H, H, Cin, device="cuda")
+        if a.data == "relu": x = torch.relu(x)
+        x = x.to(dt)
         w = (torch.randn(Cout, k, k, Cin, device="cuda") * 0.05).to(dt)
         wi = w.permute(3, 1, 2, 0).contiguous()
         y = torch.empty(B, OH, OH, Cout, device="cuda", dtype=dt)
-        dy = torch.randn(B, OH, OH, Cout, device="cuda").to(dt)
+        dy = torch.randn(B, OH, OH, Cout, device="cuda")
+        if a.data == "relu": dy = dy * (torch.rand_like(dy) < 0.5)
+        dy = dy.to(dt)
         dx = torch.empty_like(x)
         dw = torch.zeros(Cout, k, k, Cin, device="cuda")
         P = ops._p

@@ -528,6 +528,7 @@ int win3_choice(int64_t M, int Kc, int N) {
   const int t = win3_tile();
   if (t == 0 || M < 256 * 256 || Kc < 64 || Kc % 32 || N % 128) return 0;
   if (t != 1) return t;
+  if (M < 2 * 256 * 256) return 0;   // 12 x 12 maps at B = 512 (73 728 pixels, 128 -> 128): 0.035 vs 0.033 ms
   return ((M + 511) / 512) * (N / 128) >= 1024 ? 512 : 256;
 }
 
