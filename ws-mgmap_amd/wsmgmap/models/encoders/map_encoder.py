@@ -136,11 +136,16 @@ class MapDecoder(nn.Module):
         # on its forward stream.  WSMG_DECODER_STREAMS=0: one stream.
         side = None
         multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-        # (single-process only: with a process group the collective library brings its own stream, and two ranks sharing one
-        # GPU for the functional test went from 49 ms to 4.3 s per update with this third stream per process — hardware-queue
-        # oversubscription; not verifiable on a multi-GPU node from here, so the data-parallel path keeps two streams)
-        mode = os.environ.get("WSMG_DECODER_STREAMS", "1")   # "2": also under a process group (experiments)
-        if x.is_cuda and mode != "0" and (not multi or mode == "2"):
+        # Under a process group the side stream is used when every rank of this node has a GPU to itself — the launcher's
+        # LOCAL_WORLD_SIZE <= visible GPUs, the only configuration of the target (one process per GPU, README.md:80-84 of the
+        # reference).  Two ranks SHARING one GPU (the functional test on a 1-GPU box) went from 49 ms to 4.3 s per update with
+        # this third stream per process beside the collective library's own: hardware-queue oversubscription between two
+        # processes' persistent RNN kernels; there the decoder stays on one stream.  The stream is worth 0.25 ms per update
+        # (12.36 vs 12.62 ms, single process, one run).
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+        shared = multi and not (0 < lws <= torch.cuda.device_count())
+        mode = os.environ.get("WSMG_DECODER_STREAMS", "1")   # "0": one stream; "2": side stream even when ranks share a GPU (experiments)
+        if x.is_cuda and mode != "0" and (not shared or mode == "2"):
             if self._side is None:
                 self._side = torch.cuda.Stream()
             side, main = self._side, torch.cuda.current_stream()
