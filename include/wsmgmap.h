@@ -184,6 +184,14 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
+/* Contrastive-monitor auxiliary loss (policy.py:72-82 of the reference): kl[b] = mean_j tg_j (log tg_j - log att_j) with
+ * tg = softmax(area_resize((hi - dis) / (hi - lo), S x S) / tau); dis = gt_path [B][H][W] float32, lo / hi = device scalars (its
+ * batch-global min / max), att [B][S*S].  target [B][S*S] is written for the backward call, which returns d att (the only input
+ * that receives a gradient): d att_j = - gkl[b] tg_j / att_j / (S*S).  One launch each instead of 13 / 8 torch launches. */
+int wsmg_path_kl_fwd(const float* dis, const float* lo, const float* hi, const float* att, int B, int H, int W, int S, float tau,
+                     float* target, float* kl, wsmg_stream_t stream);
+int wsmg_path_kl_bwd(const float* gkl, const float* target, const float* att, int B, int n, float* datt, wsmg_stream_t stream);
+
 /* One Adam step over a list of float32 parameter tensors (amsgrad = False, maximize = False; weight_decay is the L2 form
  * added to the gradient), arithmetic in torch.optim.Adam's order.  Replaces the optimizer step of the reference's update
  * (torch.optim.Adam built at common_trainer.py:67-69, stepped at dagger_trainer.py:540-541): 3 launches for the policy's 102

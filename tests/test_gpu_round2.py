@@ -804,3 +804,30 @@ def test_graphed_act_matches_eager_act(mode):
     assert len(ga._graphs) == 1
     from wsmgmap import ops
     ops.check_rnn_status()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(8, 100, 24), (3, 196, 49), (5, 57, 10)], ids=["E100", "E196", "odd"])
+def test_path_kl_matches_torch_formula(geom):
+    """ops.path_kl (csrc/wsmg_loss.hip) against the reference's contrastive-monitor arithmetic written in torch ops
+    (policy.py:72-82: batch-global min-max normalisation, area resize, softmax / tau, kl_div of the log attention), value and
+    gradient w.r.t. the attention row; bins of the area resize that do not divide the map evenly (100 -> 24, 57 -> 10)."""
+    import torch.nn.functional as F
+    from wsmgmap import ops
+    B, E, S = geom
+    torch.manual_seed(E)
+    dis = (torch.rand(B, E, E, device="cuda") * 50).contiguous()
+    dis[0, :5] = 0.0
+    att = torch.softmax(torch.randn(B, S * S, device="cuda") * 2, dim=1).requires_grad_(True)
+    g = torch.rand(B, device="cuda")
+    kl = ops.path_kl(dis, att, S, 0.07)
+    kl.backward(g)
+    ar = att.detach().double().requires_grad_(True)
+    d = dis.double()
+    lo, hi = d.min(), d.max()
+    tg = F.interpolate(((hi - d) / (hi - lo)).unsqueeze(1), size=[S, S], mode="area").squeeze(1)
+    tg = F.softmax(tg.reshape(B, -1) / 0.07, dim=1)
+    ref = F.kl_div(torch.log(ar), tg, reduction="none").mean(-1)
+    ref.backward(g.double())
+    assert float((kl.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((att.grad.double() - ar.grad).abs().max()) <= 2e-5 * float(ar.grad.abs().max())

@@ -97,6 +97,8 @@ _SIG["wsmg_group_norm_nhwc_bf16"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i
 _SIG["wsmg_rnn_status"] = [c_i]
 _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
 _SIG["wsmg_conv_debug_win3_tile"] = [c_i]
+_SIG["wsmg_path_kl_fwd"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]
+_SIG["wsmg_path_kl_bwd"] = [c_p, c_p, c_p, c_i, c_i, c_p, c_p]
 _SIG["wsmg_adam_step_multi"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_double, ctypes.c_double, c_p]
 _SIG["wsmg_adam_step_multi_dev"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
 _RESTYPE = {"wsmg_attn_fp8_workspace_bytes": c_l, "wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}

@@ -72,10 +72,14 @@ class BasePolicy(nn.Module):
         if cfg.CONTRASTIVE_MONITOR.use:
             size = self.net.map_encoder.output_shape[-1]
             dis = observations["gt_path"] if "gt_path" in observations.keys() else observations["waypoint_distribution"]
-            lo, hi = torch.aminmax(dis)  # batch-global normalisation, as the reference does (dis.max(), dis.min()) in one pass
-            target = F.interpolate(((hi - dis) / (hi - lo)).unsqueeze(1), size=[size, size], mode="area").squeeze(1)
-            target = F.softmax(target.reshape(target.shape[0], -1) / cfg.CONTRASTIVE_MONITOR.target_tau, dim=1)
-            kl = F.kl_div(torch.log(self.net.att_map_t_m), target, reduction="none").mean(-1)
+            att = self.net.att_map_t_m
+            if dis.is_cuda and dis.dtype == torch.float32 and att.dtype == torch.float32 and os.environ.get("WSMG_FUSED_KL", "1") != "0":
+                kl = ops.path_kl(dis, att, size, cfg.CONTRASTIVE_MONITOR.target_tau)      # one launch per direction
+            else:
+                lo, hi = torch.aminmax(dis)  # batch-global normalisation, as the reference does (dis.max(), dis.min()) in one pass
+                target = F.interpolate(((hi - dis) / (hi - lo)).unsqueeze(1), size=[size, size], mode="area").squeeze(1)
+                target = F.softmax(target.reshape(target.shape[0], -1) / cfg.CONTRASTIVE_MONITOR.target_tau, dim=1)
+                kl = F.kl_div(torch.log(att), target, reduction="none").mean(-1)
             AuxLosses.register_loss("contrastive_monitor", kl, cfg.CONTRASTIVE_MONITOR.alpha)
         if cfg.PROGRESS_MONITOR.use:
             loss = F.mse_loss(self.prog, observations["progress"], reduction="none").mean(-1)

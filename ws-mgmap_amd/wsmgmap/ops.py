@@ -871,6 +871,38 @@ def cross_entropy_nhwc(logits, target, classes):
     return _CrossEntropyNHWC.apply(logits.contiguous(), target.contiguous(), classes)
 
 
+class _PathKL(torch.autograd.Function):
+    """kl[b] of the contrastive monitor (policy.py:72-82 of the reference) in one launch per direction (csrc/wsmg_loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, dis, att, size, tau):
+        _req(dis, att)
+        _f32(dis, att)
+        B, H, W = dis.shape
+        if att.shape != (B, size * size):
+            raise _abi.WsmgError(f"path_kl: attention {tuple(att.shape)} does not match {B} x {size}^2")
+        lo, hi = torch.aminmax(dis)      # batch-global normalisation, as the reference does (dis.max(), dis.min())
+        target = torch.empty(B, size * size, device=dis.device, dtype=torch.float32)
+        kl = torch.empty(B, device=dis.device, dtype=torch.float32)
+        _abi.call("wsmg_path_kl_fwd", _p(dis), _p(lo), _p(hi), _p(att), B, H, W, size, float(tau), _p(target), _p(kl), _stream())
+        ctx.save_for_backward(target, att)
+        return kl
+
+    @staticmethod
+    def backward(ctx, gkl):
+        target, att = ctx.saved_tensors
+        B, n = target.shape
+        datt = torch.empty_like(att)
+        _abi.call("wsmg_path_kl_bwd", _p(gkl.contiguous().float()), _p(target), _p(att), B, n, _p(datt), _stream())
+        return None, datt, None, None
+
+
+def path_kl(dis, att, size, tau):
+    """F.kl_div(log(att), softmax(area_resize((hi - dis) / (hi - lo), size) / tau), reduction='none').mean(-1) with lo, hi the
+    batch-global extremes of dis [B, H, W]; att [B, size*size] (a probability row); -> [B]."""
+    return _PathKL.apply(dis.contiguous(), att.contiguous(), int(size), float(tau))
+
+
 class _AttnShared(torch.autograd.Function):
     """Single-query attention of B rows over U << B shared key / value sets (row b uses set inverse[b]): the update path
     repeats every instruction T times; the reference (and `attention` above) would need per-row copies of the
