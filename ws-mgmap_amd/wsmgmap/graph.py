@@ -142,7 +142,23 @@ class GraphedUpdate:
         # the capture: say so instead
         import gc
         gc.collect()
+        mine = {id(p) for p in self.policy.parameters()}
+        seen = set()
+
+        def reaches_policy(fn):      # does this autograd graph end in one of THIS policy's parameters?
+            stack = [fn]
+            while stack:
+                f = stack.pop()
+                if f is None or id(f) in seen:
+                    continue
+                seen.add(id(f))
+                v = getattr(f, "variable", None)      # AccumulateGrad
+                if v is not None and id(v) in mine:
+                    return True
+                stack.extend(nf for nf, _ in f.next_functions)
+            return False
         left = [o for o in gc.get_objects() if torch.is_tensor(o) and o.is_cuda and o.grad_fn is not None]
+        left = [t for t in left if reaches_policy(t.grad_fn)]
         if left:
             what = ", ".join(f"{tuple(t.shape)} <- {type(t.grad_fn).__name__}" for t in left[:6])
             raise _abi.WsmgError(f"GraphedUpdate: {len(left)} tensor(s) of an earlier autograd graph are still referenced ({what}); "

@@ -81,11 +81,12 @@ class InstructionEncoder(nn.Module):
         for)."""
         return self._dedup(instruction.long())
 
-    def encode_unique(self, instruction, stock=False, dedup=None):
+    def encode_unique(self, instruction, stock=False, dedup=None, lstm_after=None):
         """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows.
         stock=False: persistent HIP bi-LSTM (csrc/wsmg_rnn.hip); stock=True: nn.LSTM on a packed
         sequence (MIOpen / CPU), kept for comparison in tests.  dedup: the result of `dedup()` for these tokens, if the caller
-        already has it (no host read-back here then)."""
+        already has it (no host read-back here then).  lstm_after: an event the persistent LSTM launch waits for (the dedup, the
+        embedding and the input projection do not)."""
         tokens = instruction.long()
         uniq, inverse, len_host, len_dev = self._dedup(tokens) if dedup is None else dedup
         if stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
@@ -105,6 +106,8 @@ class InstructionEncoder(nn.Module):
             w_hh = torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse])
             b_hh = torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse])
             lens = len_dev.to(torch.int32)
+            if lstm_after is not None:
+                torch.cuda.current_stream().wait_event(lstm_after)
             parts = [ops.bilstm(gi[c:c + 8], w_hh, b_hh, lens[c:c + 8]) for c in range(0, U, 8)]
             hidden = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         mask = (hidden == 0.0).all(dim=2)

@@ -169,6 +169,13 @@ class MGMapNet(nn.Module):
             ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
         x = self._ego_to_nhwc(ego_map)
         enc = self.map_encoder(x)
+        # the stem's forward is a PERSISTENT kernel, one workgroup per CU: the instruction branch's persistent LSTM (16 workgroups
+        # that claim their CUs) must not start beside it, or 16 of the stem's workgroups wait for the LSTM to finish and then
+        # do their whole share alone (_encode_instruction waits for this event before the LSTM launch)
+        self._encoder_done = None
+        if ego_map.is_cuda:
+            self._encoder_done = torch.cuda.Event()
+            self._encoder_done.record(torch.cuda.current_stream())
         conv = lambda t, seq, pad: ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad, relu=True)  # noqa: E731
         enc_proj = conv(enc, self.map_encoded_linear, 1)
         dec = self.map_decoder(enc)
@@ -218,8 +225,10 @@ class MGMapNet(nn.Module):
         side = self._side_stream
         side.wait_event(entry)
         with torch.cuda.stream(side):
+            import os
+            after = getattr(self, "_encoder_done", None) if os.environ.get("WSMG_LSTM_AFTER_STEM", "1") != "0" else None
             instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"],
-                                                                             dedup=observations.get("instruction_dedup"))
+                                                                             dedup=observations.get("instruction_dedup"), lstm_after=after)
             text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
             # the B rows attend over the U unique sets in place (ops.attention_shared): no per-row copies
             text = (text_k_u.contiguous(), instr_u.contiguous(), mask_u.to(torch.uint8).contiguous(), inverse.contiguous())
