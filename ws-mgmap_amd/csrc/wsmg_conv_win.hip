@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
   const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   // persistent: one workgroup per CU walks a contiguous run of tiles (neighbouring tiles share halo rows in this XCD's L2)
   const int first = xcd_swizzle(blockIdx.x, gridDim.x) * per;
+  // BatchNorm sums of this workgroup's whole run of tiles (one flush at the end: per tile it was 512 float64 atomics — 5.2 M per
+  // launch at B = 512, 0.07 ms of the layer)
+  double st_s[2] = {0.0, 0.0}, st_q[2] = {0.0, 0.0};   // this lane's two channels (32 f + r), the rows of its half-wave
   for (int logical = first; logical < first + per && logical < ntiles; ++logical) {
   const int b = logical / tpi, t = logical - b * tpi;
   const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
@@ -190,17 +193,35 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
   // (g & 3) + 8 (g >> 2) + 4 h — is scattered into a [pixel][64 channels] tile (144-byte pitch), which then leaves as
   // 16-byte stores, 8 lanes per pixel (the direct route was 32 two-byte stores per lane: 0.2 ms of the layer)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  unsigned okmask = 0;   // bit g: this lane's row g of the tile is an output pixel (the BatchNorm sums leave the others out)
+  if (a.stats) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int qq = wave * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      const bool ok = qq < TH * TW && oy0 + qq / TW < a.OH && ox0 + qq % TW < a.OW;
+      okmask |= ok ? 1u << g : 0u;
+    }
+  }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int co = 32 * f + r;
     const float bv = a.bias ? a.bias[co] : 0.f;
+    float sv = 0.f, qv = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int row = (g & 3) + 8 * (g >> 2) + 4 * h;
       float v = acc[f][g] + bv;
       if (a.relu) v = v > 0.f ? v : 0.f;
-      *reinterpret_cast<unsigned short*>(win + (wave * 32 + row) * PITCH + co * 2) = f2bf_bits(v);
+      const unsigned short o = f2bf_bits(v);
+      *reinterpret_cast<unsigned short*>(win + (wave * 32 + row) * PITCH + co * 2) = o;
+      // train-mode BatchNorm sums of the ROUNDED value, straight from the registers (a second pass over the staged tile
+      // — 32 two-byte LDS reads per thread — cost 0.07 ms of the layer)
+      const float vr = (okmask >> g) & 1u ? __uint_as_float((unsigned)o << 16) : 0.f;
+      sv += vr;
+      qv = fmaf(vr, vr, qv);
     }
+    st_s[f] += (double)sv;
+    st_q[f] += (double)qv;
   }
   __syncthreads();
 #pragma unroll
@@ -213,23 +234,19 @@ __global__ __launch_bounds__(256) void conv_win_fwd_kernel(WinArgs a) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(win + qq * PITCH + ch * 16);
     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.y) + (((size_t)(b * a.OH + oy) * a.OW + ox) * CO) * 2 + ch * 16) = v;
   }
-  if (a.stats) {   // train-mode BatchNorm sums of this tile's valid pixels, from the staged bf16 values
-    const int col = tid & 63, part = tid >> 6;
-    float sv = 0.f, qv = 0.f;
-#pragma unroll 8
-    for (int rr = 0; rr < 32; ++rr) {
-      const int qq = part * 32 + rr;
-      const bool ok = qq < TH * TW && oy0 + qq / TW < a.OH && ox0 + qq % TW < a.OW;
-      const float v = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(win + qq * PITCH + col * 2) << 16);
-      const float m = ok ? 1.f : 0.f;
-      sv = fmaf(m, v, sv);
-      qv = fmaf(m * v, v, qv);
-    }
-    double* st = a.stats + (size_t)(logical % a.nslab) * 2 * CO + col;
-    atomicAdd(st, (double)sv);
-    atomicAdd(st + CO, (double)qv);
-  }
   __syncthreads();   // the output tile has left LDS before the next window is written over it
+  }
+  if (a.stats) {   // one flush per workgroup run: the two half-waves of a lane pair hold different rows of the same channels
+    const int r = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const double s2 = st_s[f] + __shfl_xor(st_s[f], 32, 64), q2 = st_q[f] + __shfl_xor(st_q[f], 32, 64);
+      if (h == 0) {
+        double* st = a.stats + (size_t)(blockIdx.x % a.nslab) * 2 * CO + 32 * f + r;
+        atomicAdd(st, s2);
+        atomicAdd(st + CO, q2);
+      }
+    }
   }
 }
 
