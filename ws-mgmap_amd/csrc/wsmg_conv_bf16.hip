@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
       for (int u = 0; u < NT; ++u) {
         const int col = wn + 32 * u + r;
         const float bv = (a.bias && n0 + col < a.N) ? a.bias[n0 + col] : 0.f;
+        float sv = 0.f, qv = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -230,8 +231,28 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
             const int row = wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
             float v = acc[t][u][g] + bv;
             if (a.out_f32 & 2) v = v > 0.f ? v : 0.f;
-            *reinterpret_cast<unsigned short*>(smem + row * OP + col * 2) = f2bf_bits(v);
+            const unsigned short o = f2bf_bits(v);
+            *reinterpret_cast<unsigned short*>(smem + row * OP + col * 2) = o;
+            if (a.stats) {   // (rows past the last pixel of the class are the only invalid ones: dpix[row] < 0 <=> m0 + row >= Mc)
+              const float vr = m0 + row < Mc ? __uint_as_float((unsigned)o << 16) : 0.f;
+              sv += vr;
+              qv = fmaf(vr, vr, qv);
+            }
           }
+        if (a.stats) {
+          // Train-mode BatchNorm statistics of THIS output (map_encoder.py:10-12: every conv of the map stack feeds one):
+          // per-channel sum and sum of squares of the bf16-ROUNDED values, taken from the registers while the tile is
+          // staged (a second pass over the staged tile was 32-64 two-byte LDS reads per thread), added to one of `nslab`
+          // float64 slabs (slab = m-tile mod nslab: 72 adders per address instead of 4608) — the separate statistics pass
+          // over y (one full read of every conv output) disappears.
+          sv += __shfl_xor(sv, 32, 64);
+          qv += __shfl_xor(qv, 32, 64);
+          if (h == 0 && n0 + col < a.N) {
+            double* st = a.stats + (size_t)((logical / a.ntiles) % a.nslab) * 2 * a.N + n0 + col;
+            atomicAdd(st, (double)sv);
+            atomicAdd(st + a.N, (double)qv);
+          }
+        }
       }
       __syncthreads();
       constexpr int CPR = BN / 8;   // 16-byte pieces per row
@@ -244,28 +265,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
         if (dp < 0 || n >= a.N) continue;
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)dp * a.N + n) * 2) =
             *reinterpret_cast<const u32x4*>(smem + row * OP + ch * 16);
-      }
-      if (a.stats) {
-        // Train-mode BatchNorm statistics of THIS output (map_encoder.py:10-12: every conv of the map stack feeds one):
-        // per-channel sum and sum of squares of the tile, taken from the bf16 values just staged in LDS, added to one of
-        // `nslab` float64 slabs (slab = m-tile mod nslab: 72 adders per address instead of 4608) — the separate
-        // statistics pass over y (one full read of every conv output) disappears.
-        constexpr int PARTS = 256 / BN, RPP2 = BM / PARTS;
-        const int col = tid % BN, part = tid / BN;
-        float sv = 0.f, qv = 0.f;
-#pragma unroll 8
-        for (int rr = 0; rr < RPP2; ++rr) {
-          const int row = part * RPP2 + rr;
-          const float v = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(smem + row * OP + col * 2) << 16);
-          const float m = dpix[row] >= 0 ? 1.f : 0.f;
-          sv = fmaf(m, v, sv);
-          qv = fmaf(m * v, v, qv);
-        }
-        if (n0 + col < a.N) {
-          double* st = a.stats + (size_t)((logical / a.ntiles) % a.nslab) * 2 * a.N + n0 + col;
-          atomicAdd(st, (double)sv);
-          atomicAdd(st + a.N, (double)qv);
-        }
       }
       return;
     }

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   for (int u = 0; u < 2; ++u) {
     const int scol = (wave >> 2) * 32 + r;                  // column in the staged half
     const float bv = a.bias ? a.bias[n0 + wn + 32 * u + r] : 0.f;
+    float sv = 0.f, qv = 0.f;
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
@@ -239,8 +240,23 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
         const int row = wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
         float v = acc[t][u][g] + bv;
         if (a.relu) v = v > 0.f ? v : 0.f;
-        *reinterpret_cast<unsigned short*>(smem + row * OPITCH + scol * 2) = f2bf3(v);
+        const unsigned short o = f2bf3(v);
+        *reinterpret_cast<unsigned short*>(smem + row * OPITCH + scol * 2) = o;
+        if (a.stats) {   // train-mode BatchNorm sums of the ROUNDED values, from the registers (see conv_igemm_bf16_kernel)
+          const float vr = m0 + row < Mtot ? __uint_as_float((unsigned)o << 16) : 0.f;
+          sv += vr;
+          qv = fmaf(vr, vr, qv);
+        }
       }
+    if (a.stats) {
+      sv += __shfl_xor(sv, 32, 64);
+      qv += __shfl_xor(qv, 32, 64);
+      if (h == 0) {
+        double* st = a.stats + (size_t)((logical / a.ntiles) % a.nslab) * 2 * a.N + n0 + wn + 32 * u + r;
+        atomicAdd(st, (double)sv);
+        atomicAdd(st + a.N, (double)qv);
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < MT * 8 / 512; ++j) {
@@ -250,22 +266,6 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
       if (m0 + row >= Mtot) continue;
       *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)(m0 + row) * a.N + n) * 2) =
           *reinterpret_cast<const u32x4*>(smem + row * OPITCH + ch * 16);
-    }
-    if (a.stats) {   // train-mode BatchNorm sums of the staged half (see conv_igemm_bf16_kernel)
-      const int sc = tid & 63, part = tid >> 6;
-      float sv = 0.f, qv = 0.f;
-#pragma unroll 8
-      for (int rr = 0; rr < MT / 8; ++rr) {
-        const int row = part * (MT / 8) + rr;
-        const float v = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(smem + row * OPITCH + sc * 2) << 16);
-        const float m = m0 + row < Mtot ? 1.f : 0.f;
-        sv = fmaf(m, v, sv);
-        qv = fmaf(m * v, v, qv);
-      }
-      const int n = n0 + (sc >> 5) * 64 + 32 * u + (sc & 31);
-      double* st = a.stats + (size_t)((logical / a.ntiles) % a.nslab) * 2 * a.N + n;
-      atomicAdd(st, (double)sv);
-      atomicAdd(st + a.N, (double)qv);
     }
     __syncthreads();
   }
