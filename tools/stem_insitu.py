@@ -1,4 +1,5 @@
-"""In-situ duration (HIP events, no profiler) of the stem's forward and weight-gradient launches inside real updates."""
+"""In-situ duration (HIP events, no profiler) of conv launches inside real updates, grouped by entry point and FLOPs.
+usage: python tools/stem_insitu.py [min GFLOP, default 600 = the stem only]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ws-mgmap_amd"))
@@ -19,14 +20,15 @@ opt = Adam(policy.parameters(), lr=2.5e-4)
 obs, prev, masks, weights = bench.synth_batch(T, N, dev, 1000)
 AuxLosses.activate()
 rec = []
+MINF = float(sys.argv[1]) * 1e9 if len(sys.argv) > 1 else 6e11
 orig = ops._launch
 
 
 def launch(name, flops, *args):
-    if flops > 6e11 and rec is not None and launch.on:
+    if flops > MINF and rec is not None and launch.on and "conv" in name:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record(); _abi.call(name, *args); e.record()
-        rec.append((name, s, e))
+        rec.append((f"{name} {flops / 1e9:7.1f} GF", s, e))
     else:
         orig(name, flops, *args)
 
@@ -51,4 +53,8 @@ torch.cuda.synchronize()
 import collections
 acc = collections.defaultdict(list)
 for n, s, e in rec: acc[n].append(s.elapsed_time(e))
-for n, v in acc.items(): print(f"{n}: {sum(v) / len(v):.4f} ms over {len(v)} launches (min {min(v):.4f})")
+tot = 0.0
+for n, v in sorted(acc.items()):
+    print(f"{n}: {sum(v) / len(v):.4f} ms x {len(v) // 10} per update (min {min(v):.4f})")
+    tot += sum(v) / 10
+print(f"sum per update {tot:.3f} ms")
