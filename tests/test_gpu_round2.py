@@ -833,3 +833,37 @@ def test_path_kl_matches_torch_formula(geom):
     ref.backward(g.double())
     assert float((kl.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert float((att.grad.double() - ar.grad).abs().max()) <= 2e-5 * float(ar.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_graphed_act_sampling_advances_the_generator():
+    """GraphedAct with deterministic=False: the action is SAMPLED inside the captured graph — replays must draw new noise
+    (torch registers the CUDA generator with the graph and advances its Philox offset per replay), and the log-probability
+    returned must be the one of the action returned."""
+    from wsmgmap.graph import GraphedAct
+    B = 2
+    pol = _policy(num_proc=B, compute_dtype="bf16").eval()
+    ga = GraphedAct(pol, eager_calls=1)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    ins = torch.zeros(B, 200, dtype=torch.int64, device="cuda")
+    ins[:, :50] = torch.randint(1, 2504, (B, 50), device="cuda", generator=gen)
+    obs = {"rgb": torch.randint(0, 256, (B, 224, 224, 3), device="cuda", generator=gen).float(),
+           "depth": torch.rand(B, 256, 256, 1, device="cuda", generator=gen),
+           "depth_features": torch.randn(B, 128, 4, 4, device="cuda", generator=gen),
+           "instruction": ins, "gps": torch.zeros(B, 2, device="cuda"), "compass": torch.zeros(B, 1, device="cuda")}
+    h = torch.zeros(2, B, 512, device="cuda"); prev = torch.zeros(B, 2, device="cuda"); masks = torch.ones(B, 1, device="cuda")
+    acts = []
+    for k in range(5):
+        value, action, logp, hn = ga(obs, h, prev, masks, deterministic=False)
+        acts.append(action.clone())
+        assert torch.isfinite(action).all() and torch.isfinite(logp).all() and logp.shape[0] == B
+    assert len(ga._graphs) == 1
+    replays = acts[1:]                                      # call 0 was eager
+    assert all(float((replays[i] - replays[i + 1]).abs().max()) > 0 for i in range(len(replays) - 1)), "replays repeated their noise"
+    # and on the GPU, too, the draw is torch.distributions.Normal's
+    from wsmgmap.common.distributions import ActionNormal
+    loc, scale = torch.randn(64, 2, device="cuda"), torch.rand(64, 2, device="cuda") + 0.1
+    torch.manual_seed(9)
+    a = ActionNormal(loc, scale, validate_args=False).sample()
+    torch.manual_seed(9)
+    assert torch.equal(a, torch.distributions.Normal(loc, scale).sample())

@@ -326,3 +326,21 @@ def test_adam_refuses_anything_but_float32_cuda_parameters():
     ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(5))], lr=1e-3).state_dict()
     mine = opt.state_dict()["param_groups"][0]
     assert set(mine) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"} and set(mine) <= set(ref["param_groups"][0])
+
+
+def test_action_sample_equals_torch_normal_sample():
+    """ActionNormal.sample() (no host read-back, capturable) draws exactly what torch.distributions.Normal.sample() draws
+    from the same generator state (the reference samples with the stock class: distributions.py:21-29, policy.py:50-53)."""
+    import torch
+    from wsmgmap.common.distributions import ActionNormal
+    loc, scale = torch.randn(37, 2), torch.rand(37, 2) + 0.1
+    torch.manual_seed(123)
+    a = ActionNormal(loc, scale, validate_args=False).sample()
+    torch.manual_seed(123)
+    b = torch.distributions.Normal(loc, scale).sample()
+    assert torch.equal(a, b)
+    torch.manual_seed(5)
+    a3 = ActionNormal(loc, scale, validate_args=False).sample((3,))
+    torch.manual_seed(5)
+    b3 = torch.distributions.Normal(loc, scale).sample((3,))
+    assert torch.equal(a3, b3)

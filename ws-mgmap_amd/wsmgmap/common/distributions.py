@@ -9,6 +9,15 @@ class ActionNormal(torch.distributions.Normal):
     def mode(self):
         return self.mean
 
+    def sample(self, sample_shape=torch.Size()):
+        """The same draw as torch.distributions.Normal.sample() — standard normals from the current generator, times scale,
+        plus loc, in that order — without torch.normal(mean, std)'s `std.min() >= 0` check, which reads a value back to the
+        host in every rollout step and cannot be captured into a HIP graph (wsmgmap.graph.GraphedAct)."""
+        shape = self._extended_shape(sample_shape)
+        with torch.no_grad():
+            return torch.empty(shape, dtype=self.loc.dtype, device=self.loc.device).normal_(0.0, 1.0).mul_(self.scale.expand(shape)).add_(
+                self.loc.expand(shape))
+
     def log_probs(self, actions):
         return super().log_prob(actions).sum(-1, keepdim=False)
 
