@@ -170,6 +170,15 @@ int wsmg_attn_bwd(const float* q, const float* k, const float* v, const float* a
 int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, int B, int H,
                          int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                          wsmg_stream_t stream);
+/* Rollout-size forward layers (the frozen RGB UNet of unet_encoder.py:68-111 at one environment: a 7 x 7 map with 512
+ * channels is ONE 128-pixel tile and 144 serial k-steps on 8 of the 256 CUs): the reduction of a tile is split over
+ * `ksplit` workgroups that write float32 partial sums to `part` [ksplit][B*OH*OW][Cout]; a second launch adds them in
+ * split order and runs the epilogue (bias, flags as above).  wsmg_conv2d_splitk_plan: *ksplit = 1 (do not split) or the
+ * split count of this layer, *part_floats = the floats `part` must hold. */
+int wsmg_conv2d_splitk_plan(int B, int OH, int OW, int Cin, int Cout, int KH, int KW, int* ksplit, long long* part_floats);
+int wsmg_conv2d_fwd_bf16_splitk(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, int ksplit,
+                                float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                int OH, int OW, wsmg_stream_t stream);
 int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                               wsmg_stream_t stream);

@@ -867,3 +867,171 @@ def test_graphed_act_sampling_advances_the_generator():
     a = ActionNormal(loc, scale, validate_args=False).sample()
     torch.manual_seed(9)
     assert torch.equal(a, torch.distributions.Normal(loc, scale).sample())
+
+
+def _rollout_obs(B, gen):
+    ins = torch.zeros(B, 200, dtype=torch.int64, device="cuda")
+    ins[:, :60] = torch.randint(1, 2504, (B, 60), device="cuda", generator=gen)
+    return {"rgb": torch.randint(0, 256, (B, 224, 224, 3), device="cuda", generator=gen).float(),
+            "depth": torch.rand(B, 256, 256, 1, device="cuda", generator=gen),
+            "depth_features": torch.randn(B, 128, 4, 4, device="cuda", generator=gen),
+            "instruction": ins, "gps": (torch.rand(B, 2, device="cuda", generator=gen) - 0.5) * 4,
+            "compass": (torch.rand(B, 1, device="cuda", generator=gen) - 0.5) * 6.28}
+
+
+def _shake_batchnorm(policy, seed):
+    """Non-trivial running statistics and affine parameters (a fresh BatchNorm has mean 0, variance 1, gamma 1, beta 0)."""
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    with torch.no_grad():
+        for m in policy.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.num_features, device="cuda", generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, device="cuda", generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.num_features, device="cuda", generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, device="cuda", generator=g) * 0.1)
+
+
+@pytest.mark.gpu
+def test_rollout_fold_matches_unfolded_map_stack(monkeypatch):
+    """The rollout route of the map stack (eval mode, no grad, bf16: BatchNorm folded into cached OHWI operands, one launch per
+    layer) against the float32 engine on a twin policy, with non-trivial running statistics: map tokens and semantic logits
+    within 3 % relative L2 — and no further from float32 than the unfolded bf16 route (conv, then eval-mode BatchNorm) is,
+    which rounds to bf16 twice per layer (measured: 1.6 % / 1.2 % folded, 1.7 % / 1.3 % unfolded)."""
+    B = 3
+    pol, ref = _policy(num_proc=B, compute_dtype="bf16").eval(), _policy(num_proc=B, compute_dtype="f32").eval()
+    _shake_batchnorm(pol, 5)
+    _shake_batchnorm(ref, 5)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(21)
+    ego = torch.randn(B, 64, 100, 100, device="cuda", generator=gen).relu()
+    net = pol.net
+    with torch.no_grad():
+        monkeypatch.setenv("WSMG_ROLLOUT_FOLD", "0")
+        tok0, sem0 = net.map_stack(ego)
+        assert net._fold is None
+        monkeypatch.setenv("WSMG_ROLLOUT_FOLD", "1")
+        tok1, sem1 = net.map_stack(ego)
+        assert net._fold is not None and len(net._fold.entries) == 19
+        tokf, semf = ref.net.map_stack(ego)
+    for name, a, b, f in (("tokens", tok1, tok0, tokf), ("sem", sem1, sem0, semf)):
+        a, b, f = a.float(), b.float(), f.float()
+        e_fold, e_unf = float((a - f).norm() / f.norm()), float((b - f).norm() / f.norm())
+        assert e_fold <= 0.03 and e_fold <= 1.1 * e_unf + 1e-3, (name, e_fold, e_unf)
+        assert float((a - f).abs().max()) <= 0.05 * float(f.abs().max()), name
+    # under autograd, or in train mode, the unfolded route runs (the folded operands carry no gradient)
+    n = len(net._fold.entries)
+    tok2, _ = net.map_stack(ego)
+    assert tok2.requires_grad and len(net._fold.entries) == n
+
+
+@pytest.mark.gpu
+def test_graphed_act_follows_parameter_updates():
+    """A captured rollout graph reads the FOLDED convolution operands, not the parameters: after an optimizer step (and new
+    BatchNorm running statistics) GraphedAct re-folds them in place before the replay, and the replay equals an eager step of a
+    twin policy that received the same update — bit for bit (same kernels, same operands)."""
+    from wsmgmap.graph import GraphedAct
+    B = 2
+    pa, pb = _policy(num_proc=B, compute_dtype="bf16").eval(), _policy(num_proc=B, compute_dtype="bf16").eval()
+    ga = GraphedAct(pa, eager_calls=1)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4)
+    ha, hb = torch.zeros(2, B, 512, device="cuda"), torch.zeros(2, B, 512, device="cuda")
+    prev, masks = torch.zeros(B, 2, device="cuda"), torch.ones(B, 1, device="cuda")
+    for k in range(6):
+        if k == 3:      # "an update happened": every trainable parameter moves, the running statistics too
+            for pol in (pa, pb):
+                g2 = torch.Generator(device="cuda"); g2.manual_seed(77)
+                with torch.no_grad():
+                    for p in pol.parameters():
+                        if p.requires_grad:
+                            p.add_(torch.randn(p.shape, device="cuda", generator=g2) * 0.02 * float(p.abs().mean() + 1e-3))
+                _shake_batchnorm(pol, 9)
+        obs = _rollout_obs(B, gen)
+        with torch.no_grad():
+            vb, ab, lb, hb = pb.act(dict(obs), hb, prev, masks, deterministic=True)
+        va, aa, la, hn = ga(obs, ha, prev, masks, deterministic=True)
+        ha = hn.clone()
+        for name, x, y in (("value", va, vb), ("action", aa, ab), ("logp", la, lb), ("h", ha, hb),
+                           ("map", pa.net.rgb_mapping_module.full_global_map, pb.net.rgb_mapping_module.full_global_map)):
+            assert torch.equal(x, y), (k, name)
+        prev = ab.clone()
+    assert len(ga._graphs) == 1 and pa.net.refresh_folded() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [
+    (1, 7, 7, 512, 512, 3, 1, 1),      # UNet layer4 at one environment: 1 pixel tile, 72 k-steps
+    (1, 14, 14, 768, 512, 3, 1, 1),    # conv_up3
+    (2, 14, 14, 256, 512, 3, 2, 1),    # stride 2
+    (1, 100, 100, 256, 64, 3, 1, 1),   # map decoder, full resolution: 79 tiles
+    (1, 24, 24, 96, 128, 3, 1, 1),     # 32-channel k-steps
+    (3, 7, 7, 1024, 512, 1, 1, 0),     # 1 x 1: 16 k-steps
+    (1, 28, 28, 128, 96, 3, 1, 1),     # output channels not a multiple of 64
+], ids=["layer4", "up3", "stride2", "dec100", "kc96", "1x1", "n96"])
+@pytest.mark.parametrize("mode", ["relu", "add_relu", "f32out"])
+def test_splitk_conv_matches_unsplit_and_torch(geom, mode, monkeypatch):
+    """ops.conv2d_infer_bf16 on rollout-size layers runs split-K (wsmg_conv2d_fwd_bf16_splitk): same result as the unsplit
+    kernel up to float32 summation order (1 bf16 ulp after rounding), the torch float32 convolution of the same bf16 operands
+    within bf16 rounding, and bit-identical from run to run (the partials are added in split order)."""
+    from wsmgmap import ops
+    B, H, W, Cin, Cout, K, stride, pad = geom
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 1000 + H + Cin)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, K, K, Cin, device="cuda", generator=g) / (K * K * Cin) ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    OH = (H + 2 * pad - K) // stride + 1
+    res = torch.randn(B, OH, OH, Cout, device="cuda", generator=g).to(torch.bfloat16) if mode == "add_relu" else None
+    ks, floats = ops._splitk_plan(B, OH, OH, Cin, Cout, K, K)
+    assert ks > 1 and floats == ks * B * OH * OH * Cout
+
+    def run():
+        return ops.conv2d_infer_bf16(x, w, bias, stride, pad, relu=mode != "f32out", out_f32=mode == "f32out",
+                                     add_to=None if res is None else res.clone())
+    monkeypatch.setenv("WSMG_CONV_SPLITK", "1")
+    y1, y2 = run(), run()
+    monkeypatch.setenv("WSMG_CONV_SPLITK", "0")
+    y0 = run()
+    assert torch.equal(y1, y2)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride, pad).permute(0, 2, 3, 1)
+    if res is not None:
+        ref = ref + res.float()
+    if mode != "f32out":
+        ref = ref.relu()
+    scale = float(ref.abs().max())
+    tol = 1e-4 if mode == "f32out" else 2.0 ** -7     # bf16: one unit in the last place at the largest magnitude
+    assert float((y1.float() - ref).abs().max()) <= tol * scale + 1e-6
+    assert float((y1.float() - y0.float()).abs().max()) <= tol * scale + 1e-6
+
+
+@pytest.mark.gpu
+def test_splitk_plan_leaves_training_size_layers_alone():
+    """Layers that fill the chip are never split: every 3 x 3 layer of the map stack at the bench size, and the first UNet levels."""
+    from wsmgmap import ops
+    for geom in ((512, 100, 100, 256, 64, 3, 3), (512, 24, 24, 256, 256, 3, 3), (512, 12, 12, 128, 128, 3, 3), (16, 112, 112, 32, 64, 7, 7),
+                 (1, 224, 224, 64, 64, 3, 3), (64, 24, 24, 256, 128, 3, 3)):
+        assert ops._splitk_plan(*geom)[0] == 1, geom
+
+
+@pytest.mark.gpu
+def test_instruction_dedup_reuse_follows_the_tokens():
+    """InstructionEncoder.dedup without autograd keeps the last rollout-size tokens and their dedup: equal tokens return the
+    kept tuple, different tokens (or a different batch size) a fresh one equal to the uncached computation; with autograd
+    enabled nothing is kept."""
+    pol = _policy(num_proc=4, compute_dtype="bf16").eval()
+    enc = pol.net.instruction_encoder
+    gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+    tok = torch.zeros(4, 200, dtype=torch.int64, device="cuda")
+    tok[:, :30] = torch.randint(1, 2504, (1, 30), device="cuda", generator=gen)
+    tok[2, :50] = torch.randint(1, 2504, (50,), device="cuda", generator=gen)
+    with torch.no_grad():
+        a = enc.dedup(tok)
+        b = enc.dedup(tok.clone())
+        assert a is b and a[0].shape[0] == 2
+        tok2 = tok.clone(); tok2[1, 5] += 1
+        c = enc.dedup(tok2)
+        assert c is not a and c[0].shape[0] == 3
+        fresh = enc._dedup(tok2)
+        for x, y in zip(c, fresh):
+            assert torch.equal(x, y)
+        d = enc.dedup(tok2[:3])
+        assert d[1].shape[0] == 3 and d is not c
+    e, f = enc.dedup(tok2[:3]), enc.dedup(tok2[:3])
+    assert e is not f and e is not d

@@ -53,11 +53,21 @@ struct ConvArgsB {
   unsigned src_bytes, wt_bytes;
   double* stats;   // or null: [nslab][2][N] float64 sums / sums of squares of the (bf16-rounded) output, accumulated into
   int nslab;
+  // split-K launches (SPLIT kernels only): `ksplit` workgroups share one output tile, each over a contiguous run of k-steps
+  int ksplit;
+  float* part;      // [ksplit][pixels][N] float32 partial sums; splitk_finish_kernel adds them and runs the epilogue
 };
 
 // PF = k-steps of global loads kept in flight in registers (a bf16 k-step is only 256-512 MFMA
 // cycles, far less than the L2/HBM latency, so one step of look-ahead leaves the loads exposed).
-template <bool BWD, int BN, int BK, int PF>
+//
+// SPLIT (rollout-size layers: a 7 x 7 map with 512 channels is ONE 128-pixel tile and 144 serial k-steps on 8 of the 256
+// CUs): the k-steps of a tile are divided over `ksplit` workgroups; each leaves its float32 accumulators in `part`, and
+// splitk_finish_kernel adds the partials in split order and runs the epilogue.  (One launch with a ticket per tile — the
+// workgroup that arrives last reduces — was tried first: the device-scope fences around the ticket write back the whole L2
+// and the last workgroup reads all the partials alone; 52 instead of 58 us for the 7 x 7 layer, 21 instead of 10 us for a
+// 2-way split.)
+template <bool BWD, int BN, int BK, int PF, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   constexpr int LDB = BK * 2 + 16;           // LDS row stride in bytes
   constexpr int SEGS = BK / 8;               // 16-B segments per row (8 bf16 each)
@@ -73,7 +83,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   __shared__ int dpix[BM];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int logical = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int tiles = a.mtiles * a.ntiles;
+  const int swz = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int split = SPLIT ? swz / tiles : 0;
+  const int logical = SPLIT ? swz - split * tiles : swz;
   const int m0 = (logical / a.ntiles) * BM, n0 = (logical % a.ntiles) * BN;
   const int seg = tid % SEGS;
   const int lrow = tid / SEGS;
@@ -136,20 +149,32 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
     woff[i] = n < a.N ? n * taps * a.Kc + seg * 8 : -0x40000000;  // far out of range -> zeros
   }
   const int kchunks = a.Kc / BK;
-  const int steps = KHc * KWc * kchunks;
+  const int all_steps = KHc * KWc * kchunks;
+  const int per_split = SPLIT ? (all_steps + a.ksplit - 1) / a.ksplit : all_steps;
+  const int step_begin = split * per_split;
+  const int steps = SPLIT ? (all_steps - step_begin < per_split ? all_steps - step_begin : per_split) : all_steps;
   const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(a.src, a.src_bytes);
   const __amdgpu_buffer_rsrc_t rs_wt = make_rsrc(a.wt, a.wt_bytes);
 
   // uniform k-step iterator: channel chunk outermost, taps innermost (consecutive steps re-read the
   // same pixels shifted by one tap: L1-friendly); advanced once per gload call, never divided.
-  int it_ch = 0, it_ay = 0, it_ax = 0;
+  int it_ch = 0, it_ay = 0, it_ax = 0, it_left = steps;
+  if (SPLIT) {   // the iterator starts at this workgroup's first k-step
+    const int tp = KHc * KWc;
+    it_ch = step_begin / tp;
+    const int rem = step_begin - it_ch * tp;
+    it_ay = rem / KWc;
+    it_ax = rem - it_ay * KWc;
+  }
   u32x4 ra[PF][APASS], rb[PF][BPASS];
   auto gload = [&](u32x4 (&ra)[APASS], u32x4 (&rb)[BPASS]) {
     const int ky = BWD ? cy + it_ay * tstep : it_ay, kx = BWD ? cx + it_ax * tstep : it_ax;
     const int sdelta = sg * (it_ay * a.SW + it_ax) * a.Kc + it_ch * BK;
     // past the last k-step (the loop runs a multiple of PF steps) every piece is out of range -> zeros
-    const int wdelta = it_ch < kchunks ? (ky * a.KW + kx) * a.Kc + it_ch * BK : -0x20000000;
-    const unsigned live = it_ch < kchunks ? 1u : 0u;
+    const bool more = SPLIT ? it_left > 0 : it_ch < kchunks;
+    if (SPLIT) --it_left;
+    const int wdelta = more ? (ky * a.KW + kx) * a.Kc + it_ch * BK : -0x20000000;
+    const unsigned live = more ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       bool ok = ((ymask[i] >> it_ay) & (xmask[i] >> it_ax) & live) != 0;
@@ -216,9 +241,29 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   // stores, 8 channels per lane — the C layout of the 32x32 MFMA (a lane holds ONE channel of 16 rows) made the direct
   // route 16 two-byte stores per accumulator tile and lane, which was a third of the short-reduction launches
   // (backward-data of the 64-channel layers: 9 k-steps per tile)
+  if (SPLIT) {
+    float* const mine = a.part + (size_t)split * Mc * a.N;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int n = n0 + wn + 32 * u + r;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int m = m0 + wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (m < Mc) mine[(size_t)m * a.N + n] = acc[t][u][g];     // (forward, one class: pixel index = row index)
+        }
+    }
+    return;
+  }
+
   constexpr int OP = OPITCH;
   {
-    if ((a.out_f32 & 5) == 0 && (a.N & 7) == 0) {
+    if ((a.out_f32 & 1) == 0 && (a.N & 7) == 0) {
+      // (flag 4, add to the existing output: the sum and the ReLU run in the 16-byte store loop below, on the bf16-rounded
+      //  tile — the arithmetic of conv -> bf16, then a separate add + ReLU pass, without that pass)
+      const bool relu_here = (a.out_f32 & 6) == 2;
 #pragma unroll
       for (int u = 0; u < NT; ++u) {
         const int col = wn + 32 * u + r;
@@ -230,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
           for (int g = 0; g < 16; ++g) {
             const int row = wm + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
             float v = acc[t][u][g] + bv;
-            if (a.out_f32 & 2) v = v > 0.f ? v : 0.f;
+            if (relu_here) v = v > 0.f ? v : 0.f;
             const unsigned short o = f2bf_bits(v);
             *reinterpret_cast<unsigned short*>(smem + row * OP + col * 2) = o;
             if (a.stats) {   // (rows past the last pixel of the class are the only invalid ones: dpix[row] < 0 <=> m0 + row >= Mc)
@@ -263,8 +308,19 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
         const int dp = dpix[row];
         const int n = n0 + ch * 8;
         if (dp < 0 || n >= a.N) continue;
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)dp * a.N + n) * 2) =
-            *reinterpret_cast<const u32x4*>(smem + row * OP + ch * 16);
+        u32x4* const out = reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)dp * a.N + n) * 2);
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * OP + ch * 16);
+        if (a.out_f32 & 4) {
+          const u32x4 old = *out;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float lo = __uint_as_float(v[q] << 16) + __uint_as_float(old[q] << 16);
+            float hi = __uint_as_float(v[q] & 0xffff0000u) + __uint_as_float(old[q] & 0xffff0000u);
+            if (a.out_f32 & 2) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+            v[q] = (unsigned)f2bf_bits(lo) | ((unsigned)f2bf_bits(hi) << 16);
+          }
+        }
+        *out = v;
       }
       return;
     }
@@ -559,7 +615,109 @@ void launch_igemm(ConvArgsB& a, int64_t mrows, int classes, hipStream_t s) {
   }
 }
 
+// split-K plan of a forward layer: 1 = none.  Only layers that leave most of the chip idle (fewer than 128 tiles of 128 pixels
+// x 64 channels) with a long reduction (>= 16 k-steps) are split, and every split keeps at least 4 k-steps: the finishing
+// launch costs about what 10 k-steps do.
+int splitk_plan(int64_t M, int Kc, int N, int KH, int KW) {
+  const int bk = (Kc % 64) == 0 ? 64 : 32;
+  const int steps = KH * KW * (Kc / bk);
+  const int tiles = (int)(wsmg_cdiv(M, BM) * wsmg_cdiv(N, 64));
+  if (tiles >= 128 || steps < 16 || (N & 7)) return 1;
+  int ks = (int)wsmg_cdiv(256, tiles);
+  if (ks > steps / 4) ks = steps / 4;
+  if (ks > 32) ks = 32;
+  if (ks < 2) return 1;
+  const int per = (int)wsmg_cdiv(steps, ks);
+  return (int)wsmg_cdiv(steps, per);     // no empty split
+}
+
+// y[m][n..n+7] = epilogue(sum over splits of part[s][m][n..n+7]): bias, + the existing y (flag 4), ReLU (flag 2), bf16 or
+// float32 (flag 1) — one thread per 8 channels.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                            void* __restrict__ y, int64_t MN8, int N, int ksplit, int flags) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= MN8) return;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  const int n = (int)((i * 8) % N);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  const f32x4v* p = reinterpret_cast<const f32x4v*>(part) + i * 2;
+  for (int s = 0; s < ksplit; ++s, p += MN8 * 2) {
+    const f32x4v a0 = p[0], a1 = p[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
+  }
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bias[n + j];
+  }
+  if (flags & 1) {
+    f32x4v* o = reinterpret_cast<f32x4v*>(y) + i * 2;
+    if (flags & 4) {
+      const f32x4v a0 = o[0], a1 = o[1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += a0[j]; v[4 + j] += a1[j]; }
+    }
+    if (flags & 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    o[0] = f32x4v{v[0], v[1], v[2], v[3]};
+    o[1] = f32x4v{v[4], v[5], v[6], v[7]};
+  } else {
+    u32x4* o = reinterpret_cast<u32x4*>(y) + i;
+    if (flags & 4) {
+      const u32x4 old = *o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[2 * j] += __uint_as_float(old[j] << 16);
+        v[2 * j + 1] += __uint_as_float(old[j] & 0xffff0000u);
+      }
+    }
+    u32x4 out;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = v[2 * j], hi = v[2 * j + 1];
+      if (flags & 2) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+      out[j] = (unsigned)f2bf_bits(lo) | ((unsigned)f2bf_bits(hi) << 16);
+    }
+    *o = out;
+  }
+}
+
 }  // namespace
+
+extern "C" int wsmg_conv2d_splitk_plan(int B, int OH, int OW, int Cin, int Cout, int KH, int KW, int* ksplit,
+                                       long long* part_floats) {
+  if (!ksplit || !part_floats) return WSMG_EINVAL;
+  *ksplit = splitk_plan((int64_t)B * OH * OW, Cin, Cout, KH, KW);
+  *part_floats = (long long)*ksplit * B * OH * OW * Cout;
+  return 0;
+}
+
+// Forward convolution with the reduction split over `ksplit` workgroups per tile (wsmg_conv2d_splitk_plan gives ksplit and the
+// size of `part`), two launches: partial sums, then sum + epilogue.  flags as wsmg_conv2d_fwd_bf16.
+extern "C" int wsmg_conv2d_fwd_bf16_splitk(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, int ksplit,
+                                           float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                           int stride, int pad, int OH, int OW, wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  const int64_t M = (int64_t)B * OH * OW;
+  if (ksplit < 2 || ksplit != splitk_plan(M, Cin, Cout, KH, KW) || !part || (flags & ~7)) return WSMG_EINVAL;
+  ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, nullptr, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, flags,
+              (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), nullptr, 0, ksplit, part};
+  a.mtiles = (int)wsmg_cdiv(M, BM);
+  a.ntiles = (int)wsmg_cdiv(Cout, 64);
+  dim3 grid((unsigned)(a.mtiles * a.ntiles * ksplit));
+  if (Cin % 64 == 0)
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 64, 64, 1, true>), grid, dim3(256), 0, wsmg_s(stream), a);
+  else
+    hipLaunchKernelGGL((conv_igemm_bf16_kernel<false, 64, 32, 1, true>), grid, dim3(256), 0, wsmg_s(stream), a);
+  const int64_t mn8 = M * Cout / 8;
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)wsmg_cdiv(mn8, 256)), dim3(256), 0, wsmg_s(stream), part, bias, y, mn8,
+                     Cout, ksplit, flags);
+  WSMG_RETURN_LAUNCH();
+}
 
 extern "C" int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32,
                                           double* stats, int nslab, int B, int H, int W, int Cin, int Cout, int KH, int KW,

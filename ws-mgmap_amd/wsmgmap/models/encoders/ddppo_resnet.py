@@ -99,17 +99,12 @@ class ResNetEncoder(nn.Module):
     _wcache = None
 
     def _w(self, conv, cin_pad):
-        """OHWI bf16 weight of a frozen conv, input channels zero-padded to the activation's; cached by parameter version."""
+        """OHWI bf16 weight of a frozen conv, input channels zero-padded to the activation's; cached by parameter version,
+        re-laid out in place when it changes (map_encoder.FoldCache)."""
         if self._wcache is None:
-            self._wcache = {}
-        hit = self._wcache.get(id(conv))
-        if hit is None or hit[0] != (conv.weight._version, cin_pad):
-            w = conv.weight.detach().float()
-            if cin_pad > w.shape[1]:
-                w = F.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
-            hit = ((conv.weight._version, cin_pad), w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16))
-            self._wcache[id(conv)] = hit
-        return hit[1]
+            from .map_encoder import FoldCache
+            self._wcache = FoldCache()
+        return self._wcache.get(conv.weight, None, None, cin_pad)[0]
 
     def _conv_gn(self, x, conv, gn, relu, residual=None):
         # the convolution's float32 accumulators go to the group norm unrounded: one bf16 rounding per layer, not two

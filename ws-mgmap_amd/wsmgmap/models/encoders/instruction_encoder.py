@@ -74,12 +74,33 @@ class InstructionEncoder(nn.Module):
             InstructionEncoder._diag_memo = ((B, L), U, host, inverse)
         return uniq, inverse, host[1:], lengths
 
-    def dedup(self, instruction):
+    _kept = None     # (tokens, dedup of them) of the last rollout-size call
+
+    def dedup(self, instruction, reuse=None):
         """The data-dependent part of the encoder, callable on its own: (unique rows [U, L], inverse [B], lengths on the host,
         lengths on the device).  `wsmgmap.graph.GraphedUpdate` runs it eagerly in front of a captured update and hands the
         result back through `observations["instruction_dedup"]` (U and the longest length fix the shapes the graph was captured
-        for)."""
-        return self._dedup(instruction.long())
+        for).
+        reuse (default: without autograd, up to 64 rows — the rollout): the last tokens and their result are kept, and equal
+        tokens (one compare + one host read-back, instead of the ~30 launches of hash / unique / gather and theirs) return the
+        kept result: a rollout's instructions change at episode boundaries only.  WSMG_DEDUP_REUSE=0 turns it off."""
+        tokens = instruction.long()
+        if reuse is None:
+            reuse = not torch.is_grad_enabled()
+        if not (reuse and tokens.is_cuda and tokens.shape[0] <= 64 and os.environ.get("WSMG_DEDUP_REUSE", "1") != "0"):
+            return self._dedup(tokens)
+        kept = self._kept
+        if kept is not None and kept[0].shape == tokens.shape and torch.equal(kept[0], tokens):
+            from ... import ops
+            ops.check_rnn_status()     # (the compare's read-back is this pass's host synchronisation point, as _dedup's is)
+            cur = torch.cuda.current_stream()
+            for t in kept[1]:
+                if t.is_cuda:
+                    t.record_stream(cur)
+            return kept[1]
+        dd = self._dedup(tokens)
+        self._kept = (tokens.clone(), dd)
+        return dd
 
     def encode_unique(self, instruction, stock=False, dedup=None, lstm_after=None):
         """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows.
@@ -88,7 +109,7 @@ class InstructionEncoder(nn.Module):
         already has it (no host read-back here then).  lstm_after: an event the persistent LSTM launch waits for (the dedup, the
         embedding and the input projection do not)."""
         tokens = instruction.long()
-        uniq, inverse, len_host, len_dev = self._dedup(tokens) if dedup is None else dedup
+        uniq, inverse, len_host, len_dev = self.dedup(tokens) if dedup is None else dedup
         if stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
             embedded = self.embedding_layer(uniq)
             packed = nn.utils.rnn.pack_padded_sequence(embedded, len_host, batch_first=True, enforce_sorted=False)

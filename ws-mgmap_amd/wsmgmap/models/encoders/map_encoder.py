@@ -67,6 +67,84 @@ def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True,
     return out
 
 
+class FoldCache:
+    """Rollout (eval mode, no grad, bf16): the engine operands of a convolution — OHWI bf16 weight, float32 bias — with the
+    eval-mode BatchNorm that follows it folded in, kept while the parameters and running statistics keep their versions.
+    A stale entry is refreshed IN PLACE: a captured rollout graph (graph.GraphedAct) reads the same addresses at every
+    replay, and `refresh()` before a replay is all it takes to follow an optimizer step.  Per rollout step this removes the
+    weight re-layout launch and the two BatchNorm launches per layer of the unfolded route."""
+
+    def __init__(self):
+        self.entries = {}
+
+    @staticmethod
+    def _versions(weight, bias, bn):
+        v = (weight._version, -1 if bias is None else bias._version)
+        if bn is not None:
+            v += (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+        return v
+
+    @staticmethod
+    @torch.no_grad()
+    def _fold(weight, bias, bn, cin_pad, cout_pad):
+        w = weight.float()
+        b = None if bias is None else bias.float()
+        if bn is not None:
+            scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            w = w * scale.view(-1, 1, 1, 1)
+            b = bn.bias.float() - bn.running_mean.float() * scale + (0 if b is None else b * scale)
+        pad_i, pad_o = max(cin_pad - w.shape[1], 0), max(cout_pad - w.shape[0], 0)
+        if pad_i or pad_o:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad_i, 0, pad_o))
+            if b is not None and pad_o:
+                b = torch.nn.functional.pad(b, (0, pad_o))
+        if b is not None and bias is not None and b.data_ptr() == bias.data_ptr():
+            b = b.clone()          # (a float32 bias without BatchNorm or padding would otherwise BE the parameter)
+        return w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16), None if b is None else b.contiguous()
+
+    def get(self, weight, bias, bn, cin_pad, cout_pad=0):
+        key = (id(weight), cin_pad, cout_pad)
+        ver = self._versions(weight, bias, bn)
+        e = self.entries.get(key)
+        if e is None:
+            w, b = self._fold(weight, bias, bn, cin_pad, cout_pad)
+            e = self.entries[key] = [ver, w, b, (weight, bias, bn, cin_pad, cout_pad)]
+        elif e[0] != ver:
+            self._refresh(e, ver)
+        return e[1], e[2]
+
+    @torch.no_grad()
+    def _refresh(self, e, ver):
+        w, b = self._fold(*e[3])
+        e[1].copy_(w)
+        if b is not None:
+            e[2].copy_(b)
+        e[0] = ver
+
+    def refresh(self):
+        """Bring every entry up to date with its parameters (same storage).  Returns the number of entries re-folded."""
+        n = 0
+        for e in self.entries.values():
+            ver = self._versions(*e[3][:3])
+            if e[0] != ver:
+                self._refresh(e, ver)
+                n += 1
+        return n
+
+
+def conv_infer(x, cache: FoldCache, conv, bn=None, relu=True, residual=None, weight=None, bias=None, cout_pad=0, pad=None):
+    """One launch: conv (+ folded eval-mode BatchNorm) (+ ReLU) on a bf16 NHWC activation, operands from `cache`.
+    With `residual`: relu(conv_bn(x) + residual) is written INTO `residual` by the convolution's epilogue (and returned)."""
+    if isinstance(x, (list, tuple)):
+        x = ops.cat_channels(x[0], x[1])
+    weight = conv.weight if weight is None else weight
+    bias = (conv.bias if conv is not None else None) if bias is None else bias
+    w, b = cache.get(weight, bias, bn, x.shape[-1], cout_pad)
+    stride = conv.stride[0] if isinstance(conv, nn.Conv2d) else 1
+    pad = (conv.padding[0] if isinstance(conv, nn.Conv2d) else 0) if pad is None else pad
+    return ops.conv2d_infer_bf16(x, w, b, stride, pad, relu, add_to=residual)
+
+
 def convrelu(in_channels, out_channels, kernel, padding):
     return nn.Sequential(
         nn.Conv2d(in_channels, out_channels, kernel, padding=padding),
@@ -94,10 +172,14 @@ class MapEncoder(nn.Module):
             d = _out_dim(d, k, s, p)
         self.output_shape = [output_channel, d, d]
 
-    def forward(self, x_nhwc):
+    def forward(self, x_nhwc, fold=None):
+        """fold: a FoldCache => the rollout route (eval-mode BatchNorm folded into the convolutions, one launch a layer)."""
         train = self.training
         for i in (0, 3, 6):
-            x_nhwc = conv_bn_relu(x_nhwc, self.cnn[i], self.cnn[i + 1], train)
+            if fold is not None:
+                x_nhwc = conv_infer(x_nhwc, fold, self.cnn[i], self.cnn[i + 1])
+            else:
+                x_nhwc = conv_bn_relu(x_nhwc, self.cnn[i], self.cnn[i + 1], train)
         return x_nhwc
 
 
@@ -122,14 +204,19 @@ class MapDecoder(nn.Module):
         self.output_shape = [64, 100, 100]
         self._side = None
 
-    def _block(self, x, blk, train):
+    def _block(self, x, blk, train, fold=None):
+        if fold is not None:
+            return conv_infer(conv_infer(x, fold, blk.conv1, blk.bn1), fold, blk.conv2, blk.bn2, residual=x)
         y = conv_bn_relu(x, blk.conv1, blk.bn1, train)
         return conv_bn_relu(y, blk.conv2, blk.bn2, train, relu=True, residual=x)
 
-    def forward(self, x):
+    def forward(self, x, fold=None):
         import torch
         train = self.training
-        cr = lambda t, seq: conv_bn_relu(t, seq[0], seq[1], train)  # noqa: E731
+        if fold is not None:
+            cr = lambda t, seq: conv_infer(t, fold, seq[0], seq[1])  # noqa: E731
+        else:
+            cr = lambda t, seq: conv_bn_relu(t, seq[0], seq[1], train)  # noqa: E731
         # The full-resolution branch (two 3x3 convs) is independent of the resnet branch until the last concatenation, and
         # the resnet branch is mostly launch-latency-bound (6x6 and 12x12 maps: ~15 us kernels that leave the chip idle):
         # the full-resolution branch runs on a side stream beside it — in backward too, where autograd replays every node
@@ -156,10 +243,10 @@ class MapDecoder(nn.Module):
         else:
             x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
         stem = self.base_model
-        layer0 = conv_bn_relu(x, stem.conv1, stem.bn1, train)
+        layer0 = cr(x, (stem.conv1, stem.bn1))
         layer1 = ops.maxpool3x3s2(layer0)
         for blk in stem.layer1:
-            layer1 = self._block(layer1, blk, train)
+            layer1 = self._block(layer1, blk, train, fold)
         up = ops.upsample2x(cr(layer1, self.layer1_1x1))
         up = cr([up, cr(layer0, self.layer0_1x1)], self.conv_up0)        # torch.cat(dim=1) of the reference, folded into the conv
         up = ops.upsample2x(up)

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from .map_encoder import convrelu
+from .map_encoder import FoldCache, convrelu
 from .resnet18 import ResNet18
 
 
@@ -47,31 +47,20 @@ class ResNetUNet(nn.Module):
 
     def _folded(self, conv, bn, cin_pad=None):
         """(OHWI bf16 weight, float32 bias) of conv followed by eval-mode bn, folded; cached while the parameters and
-        running statistics keep their versions (the encoder is frozen, so this is computed once)."""
-        key = id(conv)
-        ver = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
-        hit = self._fold_cache.get(key)
-        if hit is None or hit[0] != ver:
-            scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
-            w = conv.weight.float() * scale.view(-1, 1, 1, 1)
-            b = bn.bias.float() - bn.running_mean.float() * scale
-            if conv.bias is not None:
-                b = b + conv.bias.float() * scale
-            if cin_pad is not None and cin_pad > w.shape[1]:
-                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
-            hit = (ver, w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16), b.contiguous())
-            self._fold_cache[key] = hit
-        return hit[1], hit[2]
+        running statistics keep their versions (the encoder is frozen, so this is computed once) and re-folded in place
+        otherwise (map_encoder.FoldCache)."""
+        return self._fold_cache.get(conv.weight, conv.bias, bn, cin_pad or 0)
 
-    def _cbr(self, x, conv, bn, relu=True):
+    def _cbr(self, x, conv, bn, relu=True, add_to=None):
         w, b = self._folded(conv, bn, x.shape[-1])
-        return ops.conv2d_infer_bf16(x, w, b, conv.stride[0], conv.padding[0], relu)
+        return ops.conv2d_infer_bf16(x, w, b, conv.stride[0], conv.padding[0], relu, add_to=add_to)
 
     def _block(self, x, blk):
+        """BasicBlock; relu(bn2(conv2) + identity) leaves the second convolution's epilogue, written over the identity tensor
+        (the block's input, or the downsampled copy of it: neither is read again — the skips are stage OUTPUTS)."""
         identity = x if blk.downsample is None else self._cbr(x, blk.downsample[0], blk.downsample[1], relu=False)
         y = self._cbr(x, blk.conv1, blk.bn1)
-        y = self._cbr(y, blk.conv2, blk.bn2, relu=False)
-        return torch.relu_(y.add_(identity))
+        return self._cbr(y, blk.conv2, blk.bn2, add_to=identity)
 
     def _forward_engine(self, rgb_nhwc):
         """rgb [B,H,W,3] float -> (layer4 [B,512,H/32,W/32] f32 NCHW, proj_feat [B,64,H,W] f32 NCHW).  Inside: NHWC bf16,
@@ -101,7 +90,7 @@ class ResNetUNet(nn.Module):
             return observations["rgb_features"], None
         if self.engine_dtype is not None and observations["rgb"].is_cuda and not torch.is_grad_enabled():
             if self._fold_cache is None:
-                self._fold_cache = {}
+                self._fold_cache = FoldCache()
             return self._forward_engine(observations["rgb"])
         x = observations["rgb"].permute(0, 3, 1, 2)
         full = self.conv_original_size1(self.conv_original_size0(x))

@@ -163,8 +163,50 @@ class MGMapNet(nn.Module):
         return ws + [c[0].weight, c[3].weight, self.map_encoded_linear[0].weight, self.map_classified_linear[0].weight,
                      self.map_cated_linear[0].weight]
 
+    _fold = None   # FoldCache of the rollout route, created on first use
+
+    def refresh_folded(self):
+        """Re-fold (in place) the rollout route's cached convolution operands whose parameters changed; GraphedAct calls
+        this before every replay.  Returns the number of layers re-folded."""
+        n = 0
+        for cache in (self._fold, getattr(getattr(self.rgb_encoder, "base_model", None), "_fold_cache", None),
+                      getattr(getattr(self.depth_encoder, "visual_encoder", None), "_wcache", None)):
+            if cache is not None:
+                n += cache.refresh()
+        return n
+
+    def _map_stack_rollout(self, ego_map):
+        """The map stack in eval mode without autograd (the rollout step), bf16: every convolution takes cached, BatchNorm-
+        folded OHWI operands (encoders.map_encoder.FoldCache) — one launch per conv + BN + ReLU, no per-step weight
+        re-layout.  Same arithmetic as _map_stack up to the bf16 rounding of the folded weights."""
+        from .encoders.map_encoder import FoldCache, conv_infer
+        if self._fold is None:
+            self._fold = FoldCache()
+        f = self._fold
+        x = self._ego_to_nhwc(ego_map)
+        enc = self.map_encoder(x, fold=f)
+        self._encoder_done = torch.cuda.Event()
+        self._encoder_done.record(torch.cuda.current_stream())
+        enc_proj = conv_infer(enc, f, self.map_encoded_linear[0])
+        dec = self.map_decoder(enc, fold=f)
+        c = self.map_classfier
+        y = ops.conv_transpose2d(dec, c[0].weight, 2, 1, None)
+        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, False, True, None, c[1].momentum, c[1].eps, None)
+        y = conv_infer(y, f, c[3], c[4])
+        sem = conv_infer(y, f, c[6], relu=False, cout_pad=SEM_PAD)                   # [B,2S,2S,32], channels 27.. are 0
+        self.sem_logits_nhwc = sem
+        pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
+        cls_proj = conv_infer(ops.avgpool2(sem), f, self.map_classified_linear[0])
+        emb = conv_infer([enc_proj, cls_proj], f, self.map_cated_linear[0])
+        b, s1, s2, ch = emb.shape
+        return emb.view(b, s1 * s2, ch), pred_sem_map
+
     def _map_stack(self, ego_map):
         train = self.training
+        import os
+        if (not train and not torch.is_grad_enabled() and ego_map.is_cuda and self.compute_dtype == torch.bfloat16
+                and os.environ.get("WSMG_ROLLOUT_FOLD", "1") != "0"):
+            return self._map_stack_rollout(ego_map)
         if ego_map.is_cuda:   # operands of all the map stack's convolutions in one launch (they are on the main stream only)
             ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
         x = self._ego_to_nhwc(ego_map)
@@ -239,19 +281,28 @@ class MGMapNet(nn.Module):
         entry = torch.cuda.Event()
         entry.record(torch.cuda.current_stream())
         ops.mark("entry")
+        import os
+        # Rollout (no autograd, RGB encoded from pixels): the instruction branch is queued FIRST and runs beside the frozen
+        # RGB encoder — in a captured step (graph.GraphedAct) it otherwise lands behind the map decoder's side branch and the
+        # main stream idles through the whole 0.45 ms LSTM (B = 1).  Training keeps the order described in _encode_instruction.
+        early = (not torch.is_grad_enabled() and "rgb_features" not in observations and observations["instruction"].is_cuda
+                 and os.environ.get("WSMG_ROLLOUT_TEXT_FIRST", "1") != "0")
+        if early:
+            self._encoder_done = None
+            text, side = self._encode_instruction(observations, entry)
         rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)
         depth_embedding = self.depth_encoder(observations)
 
         self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
         # the map tokens feed their mean (state input) and the map attention: one merged, ReLU-masked gradient pass (TokenGradSink)
-        import os
         self._token_sink = ops.TokenGradSink() if (torch.is_grad_enabled() and "map" in self._inputs
                                                    and os.environ.get("WSMG_TOKEN_SINK", "1") != "0") else None
         sink = self._token_sink
         map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
         self._token_sink = None
         ops.mark("map_stack", map_tokens)
-        text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
+        if not early:
+            text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
 
         state_in = []
         if "rgb" in self._inputs:

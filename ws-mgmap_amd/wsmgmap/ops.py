@@ -77,6 +77,7 @@ KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trac
     "wsmg_conv2d_bwd_data": "conv_igemm_kernel<true, false>",
     "wsmg_conv2d_bwd_weight": "conv_wgrad_kernel<false>",
     "wsmg_conv2d_fwd_bf16": "conv_igemm_bf16_kernel<false, *>",
+    "wsmg_conv2d_fwd_bf16_splitk": "conv_igemm_bf16_kernel<false, 64, *, 1, true>",
     "wsmg_conv2d_bwd_data_bf16": "conv_igemm_bf16_kernel<true, *>",
     "wsmg_conv2d_bwd_weight_bf16": "conv_wgrad_bf16_kernel",
 }
@@ -545,19 +546,49 @@ def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, rel
     return _Conv2dCat.apply(weight_oihw, bias, stride, pad, bias_grad_zero, relu, *xs)
 
 
-def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False):
+_splitk_plans = {}    # layer geometry -> (ksplit, partial floats) from wsmg_conv2d_splitk_plan
+
+
+def _splitk_plan(B, OH, OW, Cin, Cout, KH, KW):
+    key = (B, OH, OW, Cin, Cout, KH, KW)
+    plan = _splitk_plans.get(key)
+    if plan is None:
+        ks, floats = ctypes.c_int(0), ctypes.c_longlong(0)
+        _abi.call("wsmg_conv2d_splitk_plan", B, OH, OW, Cin, Cout, KH, KW, ctypes.cast(ctypes.byref(ks), ctypes.c_void_p),
+                  ctypes.cast(ctypes.byref(floats), ctypes.c_void_p))
+        plan = _splitk_plans[key] = (ks.value, floats.value)
+    return plan
+
+
+def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False, add_to=None):
     """Inference-only bf16 convolution with a pre-laid-out OHWI bf16 weight, float32 bias and optional fused ReLU
-    (one launch; used by the frozen encoders with eval-mode BatchNorm folded into weight and bias)."""
-    _req(x, w_ohwi_bf16, bias)
+    (one launch; used by the frozen encoders with eval-mode BatchNorm folded into weight and bias).
+    add_to: a tensor of the output's shape and type that the result is ADDED to, in place, before the ReLU (the identity branch
+    of a residual block) — it is returned.  Layers too small to fill the chip run split-K (wsmg_conv2d_fwd_bf16_splitk);
+    WSMG_CONV_SPLITK=0 turns that off."""
+    _req(x, w_ohwi_bf16, bias, add_to)
     if x.dtype != torch.bfloat16 or w_ohwi_bf16.dtype != torch.bfloat16:
         raise _abi.WsmgError("conv2d_infer_bf16 needs bf16 activations and weights")
     B, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w_ohwi_bf16.shape
     assert Cin == Cin2, (x.shape, w_ohwi_bf16.shape)
     OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
-    y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-    _launch("wsmg_conv2d_fwd_bf16", 2.0 * B * OH * OW * Cout * Cin * KH * KW, _p(x), _p(w_ohwi_bf16), _p(bias), _p(y),
-            (2 if relu else 0) | (1 if out_f32 else 0), B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, _stream())
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    if add_to is not None:
+        if add_to.shape != (B, OH, OW, Cout) or add_to.dtype != odt or add_to.device != x.device:
+            raise _abi.WsmgError("conv2d_infer_bf16: add_to must have the output's shape, type and device")
+        y = add_to
+    else:
+        y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=odt)
+    flags = (2 if relu else 0) | (1 if out_f32 else 0) | (4 if add_to is not None else 0)
+    fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
+    dims = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)
+    ks, floats = _splitk_plan(B, OH, OW, Cin, Cout, KH, KW) if _os.environ.get("WSMG_CONV_SPLITK", "1") != "0" else (1, 0)
+    if ks > 1:
+        part = torch.empty(floats, device=x.device, dtype=torch.float32)
+        _launch("wsmg_conv2d_fwd_bf16_splitk", fl, _p(x), _p(w_ohwi_bf16), _p(bias), _p(y), flags, ks, _p(part), *dims, _stream())
+    else:
+        _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w_ohwi_bf16), _p(bias), _p(y), flags, *dims, _stream())
     return y
 
 
