@@ -193,6 +193,18 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
+/* Rollout-size dense layers, one row per environment (the nn.Linear calls of mg_map_policy.py:150-197 at 1-16 rows):
+ * y[r][o] = act(sum_k x[r][k] w[o][k] + bias[o]) in ONE launch (a GEMM library call is bias copy + GEMM + activation);
+ * x [B][K] (pool = 1) or [B][K][pool] whose mean over the last axis is the layer's input (rgb_linear's AdaptiveAvgPool1d(1) +
+ * Flatten); w [O][K] as nn.Linear stores it; act 0 none, 1 ReLU, 2 tanh; float32 throughout. */
+int wsmg_linear_rows(const float* x, const float* w, const float* bias, float* y, int B, int K, int O, int act, int pool,
+                     wsmg_stream_t stream);
+/* The heads of one rollout step (policy.py:34-56, common/distributions.py:21-29,58-71) in one launch: prog = tanh(prog_pred(f)),
+ * value = critic(f), mean = fc_mean(f), action = mean (noise == NULL: the mode) or noise * exp(logstd) + mean (noise [B][A]
+ * standard normals: Normal.sample()'s arithmetic), logp = sum_j Normal(mean, exp(logstd)).log_prob(action).  f [B][K]. */
+int wsmg_act_heads(const float* feat, int B, int K, const float* w_prog, const float* b_prog, const float* w_mean,
+                   const float* b_mean, const float* logstd, int A, const float* w_crit, const float* b_crit, const float* noise,
+                   float* prog, float* value, float* action, float* logp, wsmg_stream_t stream);
 /* Contrastive-monitor auxiliary loss (policy.py:72-82 of the reference): kl[b] = mean_j tg_j (log tg_j - log att_j) with
  * tg = softmax(area_resize((hi - dis) / (hi - lo), S x S) / tau); dis = gt_path [B][H][W] float32, lo / hi = device scalars (its
  * batch-global min / max), att [B][S*S].  target [B][S*S] is written for the backward call, which returns d att (the only input
@@ -330,6 +342,10 @@ int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW,
  * projections mg_map_policy.py:99) on NHWC storage: y[p] = a[p] ++ b[p] for `rows` pixels; a pixel's channel run is
  * bytes_a / bytes_b bytes (multiples of 16; any element type), 16-byte aligned pointers. */
 int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t rows, int bytes_a, int bytes_b, wsmg_stream_t stream);
+/* y [B][2H][2W][Ca+Cb] = cat([bilinear 2x upsample (align_corners) of a [B][H][W][Ca], b [B][2H][2W][Cb]], channels), bf16, in one
+ * pass: the decoder step `torch.cat([self.upsample(x), skip], dim=1)` of unet_encoder.py:95-109 / map_encoder.py:103-110 on the
+ * rollout route (no gradient).  Ca, Cb multiples of 8. */
+int wsmg_upsample2x_cat_bf16(const void* a, const void* b, void* y, int B, int H, int W, int Ca, int Cb, wsmg_stream_t stream);
 
 /* per-pixel cross-entropy of the semantic-hallucination head straight from the NHWC logits (policy.py:61-66:
  * F.cross_entropy(pred_sem_map, target, reduction='none')): logits [rows][32] (classes <= 32 valid channels, the rest

@@ -1035,3 +1035,68 @@ def test_instruction_dedup_reuse_follows_the_tokens():
         assert d[1].shape[0] == 3 and d is not c
     e, f = enc.dedup(tok2[:3]), enc.dedup(tok2[:3])
     assert e is not f and e is not d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(1, 512, 256, 1), (3, 2048, 128, 1), (8, 512, 256, 49), (11, 1024, 512, 1), (16, 130, 7, 1), (2, 33, 5, 3)],
+                         ids=["b1", "depth", "rgbpool", "two_passes", "k130", "odd"])
+@pytest.mark.parametrize("act", [None, "relu", "tanh"])
+def test_linear_rows_matches_torch(geom, act):
+    """ops.linear_rows (wsmg_linear_rows: one launch per rollout-size dense layer) against float64 torch: x @ W.T + b with the
+    optional mean over a trailing axis (rgb_linear's pooling) and activation; float32 dot products of up to 2048 terms: 2e-6
+    of the output scale."""
+    from wsmgmap import ops
+    B, K, O, pool = geom
+    g = torch.Generator(device="cuda"); g.manual_seed(K + O)
+    x = torch.randn(*( (B, K) if pool == 1 else (B, K, pool)), device="cuda", generator=g)
+    w, b = torch.randn(O, K, device="cuda", generator=g) / K ** 0.5, torch.randn(O, device="cuda", generator=g)
+    with torch.no_grad():
+        y = ops.linear_rows(x, w, b, act, pool=pool)
+        y0 = ops.linear_rows(x, w, None, act, pool=pool)
+    xin = x.double() if pool == 1 else x.double().mean(-1)
+    ref, ref0 = xin @ w.double().t() + b.double(), xin @ w.double().t()
+    f = {None: lambda t: t, "relu": torch.relu, "tanh": torch.tanh}[act]
+    assert float((y.double() - f(ref)).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert float((y0.double() - f(ref0)).abs().max()) <= 2e-6 * max(1.0, float(ref0.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_act_heads_match_the_module_heads(deterministic, monkeypatch):
+    """BasePolicy.act in rollout (no autograd, <= 16 rows) takes its heads in one launch (wsmg_act_heads) and its dense layers
+    through linear_rows: value, action, log-probability, progress estimate and hidden state equal the module route
+    (WSMG_ROWS_LINEAR=0: nn.Linear, torch.distributions.Normal) to float32 rounding, and a sampled action draws the same noise."""
+    B = 3
+    pa, pb = _policy(num_proc=B, compute_dtype="f32").eval(), _policy(num_proc=B, compute_dtype="f32").eval()
+    with torch.no_grad():
+        for pol in (pa, pb):
+            pol.action_distribution.logstd._bias.copy_(torch.tensor([[-0.3], [0.2]], device="cuda"))
+    gen = torch.Generator(device="cuda"); gen.manual_seed(31)
+    obs = _rollout_obs(B, gen)
+    h = torch.randn(2, B, 512, device="cuda", generator=gen) * 0.1
+    prev, masks = torch.zeros(B, 2, device="cuda"), torch.ones(B, 1, device="cuda")
+    with torch.no_grad():
+        torch.manual_seed(5)
+        va, aa, la, ha = pa.act(dict(obs), h.clone(), prev, masks, deterministic=deterministic)
+        monkeypatch.setenv("WSMG_ROWS_LINEAR", "0")
+        torch.manual_seed(5)
+        vb, ab, lb, hb = pb.act(dict(obs), h.clone(), prev, masks, deterministic=deterministic)
+    for name, x, y in (("value", va, vb), ("action", aa, ab), ("logp", la, lb), ("h", ha, hb), ("prog", pa.prog, pb.prog)):
+        assert x.shape == y.shape, name
+        assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max())), name
+    assert aa.shape == (B, 2) and la.shape == (B,) and va.shape == (B, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(1, 7, 7, 512, 256), (2, 12, 12, 64, 64), (1, 50, 50, 128, 64), (3, 5, 9, 8, 24)], ids=["unet", "dec", "dec100", "odd"])
+def test_upsample_cat_equals_upsample_then_cat(geom):
+    """ops.upsample2x_cat (one launch, rollout route) is bit-identical to ops.upsample2x followed by the channel concatenation."""
+    from wsmgmap import ops
+    B, H, W, Ca, Cb = geom
+    g = torch.Generator(device="cuda"); g.manual_seed(H * W + Ca)
+    a = torch.randn(B, H, W, Ca, device="cuda", generator=g).to(torch.bfloat16)
+    b = torch.randn(B, 2 * H, 2 * W, Cb, device="cuda", generator=g).to(torch.bfloat16)
+    with torch.no_grad():
+        y = ops.upsample2x_cat(a, b)
+        ref = torch.cat([ops.upsample2x(a), b], dim=-1)
+    assert y.shape == ref.shape and torch.equal(y, ref)

@@ -401,6 +401,48 @@ __global__ void cat_channels_kernel(const u32x4_t* __restrict__ a, const u32x4_t
   }
 }
 
+// Rollout route of the UNet decoders (unet_encoder.py:95-109, map_encoder.py:103-110): cat([upsample2x(a), b], channels) in one
+// pass, bf16 — the upsampled tensor is never written (and read back by the concatenation); 8 channels per thread, the
+// interpolation arithmetic of upsample_fwd_kernel.
+__global__ void upsample_cat_bf16_kernel(const bf16_t* __restrict__ a, const u32x4_t* __restrict__ b, u32x4_t* __restrict__ y, int B,
+                                         int H, int W, int ca8, int cb8) {
+  const int OH = 2 * H, OW = 2 * W, cy = ca8 + cb8, C = ca8 * 8;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const int64_t n = (int64_t)B * OH * OW * cy;
+  GRID_STRIDE(i, n) {
+    const int64_t p = i / cy;
+    const int c = (int)(i - p * cy);
+    if (c >= ca8) {
+      y[i] = b[p * cb8 + (c - ca8)];
+      continue;
+    }
+    const int ox = (int)(p % OW);
+    const int64_t q = p / OW;
+    const int oy = (int)(q % OH), bb = (int)(q / OH);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    up_src(oy, H, sh, y0, y1, hy0, hy1);
+    up_src(ox, W, sw, x0, x1, wx0, wx1);
+    const bf16_t* xb = a + (size_t)bb * H * W * C + c * 8;
+    u32x4_t o;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      const f32x4 v00 = ld4(xb + ((size_t)y0 * W + x0) * C + 4 * hlf), v01 = ld4(xb + ((size_t)y0 * W + x1) * C + 4 * hlf);
+      const f32x4 v10 = ld4(xb + ((size_t)y1 * W + x0) * C + 4 * hlf), v11 = ld4(xb + ((size_t)y1 * W + x1) * C + 4 * hlf);
+      unsigned short r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16_t v = (bf16_t)(hy0 * (wx0 * v00[j] + wx1 * v01[j]) + hy1 * (wx0 * v10[j] + wx1 * v11[j]));
+        r[j] = __builtin_bit_cast(unsigned short, v);
+      }
+      o[2 * hlf] = (unsigned)r[0] | ((unsigned)r[1] << 16);
+      o[2 * hlf + 1] = (unsigned)r[2] | ((unsigned)r[3] << 16);
+    }
+    y[i] = o;
+  }
+}
+
 // bf16: 8 values (one 16-byte access) per thread
 __device__ __forceinline__ unsigned relu2(unsigned v) {   // two packed bf16: x > 0 ? x : 0 (NaN -> 0, like the float compare)
   const float lo = __uint_as_float(v << 16), hi = __uint_as_float(v & 0xffff0000u);
@@ -549,6 +591,13 @@ extern "C" int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t 
   const int ca = bytes_a / 16, cb = bytes_b / 16;
   hipLaunchKernelGGL(cat_channels_kernel, dim3(sgrid(rows * (ca + cb))), dim3(256), 0, wsmg_s(s), (const u32x4_t*)a, (const u32x4_t*)b,
                      (u32x4_t*)y, rows, ca, cb);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_upsample2x_cat_bf16(const void* a, const void* b, void* y, int B, int H, int W, int Ca, int Cb, wsmg_stream_t s) {
+  if (B <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 7) || (Cb & 7)) return WSMG_EINVAL;
+  if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) return WSMG_EINVAL;
+  hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3(sgrid((int64_t)B * 4 * H * W * (Ca + Cb) / 8)), dim3(256), 0, wsmg_s(s), CB16(a),
+                     (const u32x4_t*)b, (u32x4_t*)y, B, H, W, Ca / 8, Cb / 8);
   WSMG_RETURN_LAUNCH();
 }
 extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<float>(x, y, n, s); }

@@ -84,6 +84,7 @@ _SIG["wsmg_weight_relayout_bf16"] = list(_SIG["wsmg_weight_relayout"])
 _SIG["wsmg_weight_relayout_multi"] = [c_p, c_i, c_i, c_p]
 _SIG["wsmg_weight_grad_to_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
 _SIG["wsmg_cat_channels"] = [c_p, c_p, c_p, c_l, c_i, c_i, c_p]
+_SIG["wsmg_upsample2x_cat_bf16"] = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]
 _SIG["wsmg_ce_nhwc_fwd"] = [c_p, c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_ce_nhwc_bwd"] = [c_p, c_p, c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_ce_nhwc_fwd_bf16"] = list(_SIG["wsmg_ce_nhwc_fwd"])
@@ -99,6 +100,8 @@ _SIG["wsmg_group_norm_nhwc_bf16"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i
 _SIG["wsmg_rnn_status"] = [c_i]
 _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
 _SIG["wsmg_conv_debug_win3_tile"] = [c_i]
+_SIG["wsmg_linear_rows"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]
+_SIG["wsmg_act_heads"] = [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
 _SIG["wsmg_path_kl_fwd"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]
 _SIG["wsmg_path_kl_bwd"] = [c_p, c_p, c_p, c_i, c_i, c_p, c_p]
 _SIG["wsmg_adam_step_multi"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_double, ctypes.c_double, c_p]

@@ -102,6 +102,31 @@ class InstructionEncoder(nn.Module):
         self._kept = (tokens.clone(), dd)
         return dd
 
+    _packed = None
+
+    @torch.no_grad()
+    def packed_lstm_weights(self, refresh_only=False):
+        """Without autograd: the two directions' LSTM parameters concatenated / stacked as the kernels take them, kept while the
+        parameters keep their versions and rewritten IN PLACE otherwise (a captured rollout step reads these addresses;
+        MGMapNet.refresh_folded calls this with refresh_only before a replay).  Four launches per step otherwise."""
+        if self._packed is None and refresh_only:
+            return 0
+        r = self.encoder_rnn
+        src = (r.weight_ih_l0, r.weight_ih_l0_reverse, r.bias_ih_l0, r.bias_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse,
+               r.bias_hh_l0, r.bias_hh_l0_reverse)
+        ver = tuple(p._version for p in src)
+        if self._packed is None:
+            self._packed = [None, torch.cat(src[0:2], dim=0), torch.cat(src[2:4], dim=0), torch.stack(src[4:6]), torch.stack(src[6:8])]
+        elif self._packed[0] != ver:
+            self._packed[1].copy_(torch.cat(src[0:2], dim=0))
+            self._packed[2].copy_(torch.cat(src[2:4], dim=0))
+            self._packed[3].copy_(torch.stack(src[4:6]))
+            self._packed[4].copy_(torch.stack(src[6:8]))
+        elif refresh_only:
+            return 0
+        self._packed[0] = ver
+        return 1 if refresh_only else tuple(self._packed[1:])
+
     def encode_unique(self, instruction, stock=False, dedup=None, lstm_after=None):
         """-> (hidden [U, L, D] token-major, pad mask [U, L] bool, inverse [B]) with U unique rows.
         stock=False: persistent HIP bi-LSTM (csrc/wsmg_rnn.hip); stock=True: nn.LSTM on a packed
@@ -120,12 +145,15 @@ class InstructionEncoder(nn.Module):
             r = self.encoder_rnn
             lmax = int(len_host.max())
             embedded = self.embedding_layer(uniq[:, :lmax])                     # [U, L, E]
-            w_ih = torch.cat([r.weight_ih_l0, r.weight_ih_l0_reverse], dim=0)   # [2*4H, E]
-            b_ih = torch.cat([r.bias_ih_l0, r.bias_ih_l0_reverse], dim=0)
+            if torch.is_grad_enabled():
+                w_ih = torch.cat([r.weight_ih_l0, r.weight_ih_l0_reverse], dim=0)   # [2*4H, E]
+                b_ih = torch.cat([r.bias_ih_l0, r.bias_ih_l0_reverse], dim=0)
+                w_hh = torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse])
+                b_hh = torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse])
+            else:
+                w_ih, b_ih, w_hh, b_hh = self.packed_lstm_weights()
             U = uniq.shape[0]
             gi = torch.addmm(b_ih, embedded.reshape(U * lmax, -1), w_ih.t()).view(U, lmax, 2, -1)
-            w_hh = torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse])
-            b_hh = torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse])
             lens = len_dev.to(torch.int32)
             if lstm_after is not None:
                 torch.cuda.current_stream().wait_event(lstm_after)

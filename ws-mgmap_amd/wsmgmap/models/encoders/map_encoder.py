@@ -247,6 +247,12 @@ class MapDecoder(nn.Module):
         layer1 = ops.maxpool3x3s2(layer0)
         for blk in stem.layer1:
             layer1 = self._block(layer1, blk, train, fold)
+        if fold is not None:   # rollout: upsample + concatenation in one launch
+            up = cr(ops.upsample2x_cat(cr(layer1, self.layer1_1x1), cr(layer0, self.layer0_1x1)), self.conv_up0)
+            if side is not None:
+                main.wait_stream(side)
+                x_original.record_stream(main)
+            return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2)
         up = ops.upsample2x(cr(layer1, self.layer1_1x1))
         up = cr([up, cr(layer0, self.layer0_1x1)], self.conv_up0)        # torch.cat(dim=1) of the reference, folded into the conv
         up = ops.upsample2x(up)

@@ -81,8 +81,8 @@ class ResNetUNet(nn.Module):
         y = ops.to_nhwc(layer4.contiguous(), 512, dtype=dt)
         for skip, lateral, fuse in ((skips[3], self.layer3_1x1, self.conv_up3), (skips[2], self.layer2_1x1, self.conv_up2),
                                     (skips[1], self.layer1_1x1, self.conv_up1), (skips[0], self.layer0_1x1, self.conv_up0)):
-            y = cr(torch.cat([ops.upsample2x(y), cr(skip, lateral)], dim=-1), fuse)
-        proj = cr(torch.cat([ops.upsample2x(y), full], dim=-1), self.conv_original_size2)
+            y = cr(ops.upsample2x_cat(y, cr(skip, lateral)), fuse)
+        proj = cr(ops.upsample2x_cat(y, full), self.conv_original_size2)
         return layer4, ops.to_nchw(proj, 64)
 
     def forward(self, observations):

@@ -173,7 +173,7 @@ class MGMapNet(nn.Module):
                       getattr(getattr(self.depth_encoder, "visual_encoder", None), "_wcache", None)):
             if cache is not None:
                 n += cache.refresh()
-        return n
+        return n + self.instruction_encoder.packed_lstm_weights(refresh_only=True)
 
     def _map_stack_rollout(self, ego_map):
         """The map stack in eval mode without autograd (the rollout step), bf16: every convolution takes cached, BatchNorm-
@@ -304,13 +304,24 @@ class MGMapNet(nn.Module):
         if not early:
             text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
 
+        rows = ops.rows_route(rgb_embedding.float())   # rollout: every dense layer below is one launch (ops.linear_rows)
+        lin = lambda m, x, act=None: ops.linear_rows(x, m.weight, m.bias, act) if rows else m(x)  # noqa: E731
         state_in = []
         if "rgb" in self._inputs:
-            state_in.append(self.rgb_linear(torch.flatten(rgb_embedding.float(), 2)))
+            if rows:   # AdaptiveAvgPool1d(1) + Flatten + Linear + ReLU
+                b, c = rgb_embedding.shape[:2]
+                state_in.append(ops.linear_rows(rgb_embedding.float().reshape(b, c, -1), self.rgb_linear[2].weight, self.rgb_linear[2].bias,
+                                                "relu", pool=int(np.prod(rgb_embedding.shape[2:]))))
+            else:
+                state_in.append(self.rgb_linear(torch.flatten(rgb_embedding.float(), 2)))
         if "depth" in self._inputs:
-            state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
+            if rows:   # Flatten + Linear + ReLU
+                state_in.append(lin(self.depth_linear[1], torch.flatten(depth_embedding.float(), 1), "relu"))
+            else:
+                state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
         if "map" in self._inputs:
-            state_in.append(self.map_linear[3](self.map_linear[2](ops.token_mean(map_tokens, sink))))
+            tm = ops.token_mean(map_tokens, sink)
+            state_in.append(lin(self.map_linear[2], tm, "relu") if rows else self.map_linear[3](self.map_linear[2](tm)))
         state_in = torch.cat(state_in, dim=1)
 
         n1 = self.state_encoder.num_recurrent_layers
@@ -323,18 +334,19 @@ class MGMapNet(nn.Module):
         text_k_u, text_v_u, text_mask_u, inverse = text
         for t in text:
             t.record_stream(torch.cuda.current_stream())
-        text_embedding, _ = ops.attention_shared(self.state_text_q_layer(state).contiguous(), text_k_u, text_v_u, text_mask_u,
+        text_embedding, _ = ops.attention_shared(lin(self.state_text_q_layer, state).contiguous(), text_k_u, text_v_u, text_mask_u,
                                                  inverse, self._scale_f)
 
         # map attention
         # text_map_k_layer is folded into the query (ops._AttnFolded): the 576 map tokens are read once, as
         # keys and values, and no projected key tensor exists
         map_embedding, self.att_map_t_m = ops.attention_folded(
-            self.text_map_q_layer(text_embedding).contiguous(), self.text_map_k_layer.weight, self.text_map_k_layer.bias,
+            lin(self.text_map_q_layer, text_embedding).contiguous(), self.text_map_k_layer.weight, self.text_map_k_layer.bias,
             map_tokens.contiguous(), None, self._scale_f, sink)
 
         parts = [state, text_embedding] + ([map_embedding] if "map" in self._inputs else [])
-        x = self.second_state_compress(torch.cat(parts, dim=1))
+        x = torch.cat(parts, dim=1)
+        x = lin(self.second_state_compress[0], x, "relu") if rows else self.second_state_compress(x)
         ops.mark("attention", x)
         x, rnn_hidden_states[n1:] = self.second_state_encoder(x, rnn_hidden_states[n1:], masks)
         ops.mark("gru2", x)

@@ -49,6 +49,14 @@ class BasePolicy(nn.Module):
 
     def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False):
         features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
+        if ops.rows_route(features) and os.environ.get("WSMG_FUSED_HEADS", "1") != "0":
+            # rollout: progress, critic, action mean, mode / sample and log-probability in one launch (≈20 otherwise); the
+            # noise of a sampled action is Normal.sample()'s own draw (same generator, same shape)
+            ad = self.action_distribution
+            noise = None if deterministic else torch.empty(features.shape[0], ad.fc_mean.out_features, device=features.device).normal_()
+            prog, value, action, logp = ops.act_heads(features, self.prog_pred, ad.fc_mean, ad.logstd._bias, self.critic.fc, noise)
+            self.aux_prediction(features, observations, pred_map, prog=prog)
+            return value, action, logp, rnn_hidden_states
         self.aux_prediction(features, observations, pred_map)
         distribution = self.action_distribution(features)
         value = self.critic(features)
@@ -56,9 +64,9 @@ class BasePolicy(nn.Module):
         return value, action, distribution.log_probs(action), rnn_hidden_states
 
     # -- auxiliary heads -------------------------------------------------------------
-    def aux_prediction(self, features, observations, pred_map):
+    def aux_prediction(self, features, observations, pred_map, prog=None):
         cfg = self.model_config
-        self.prog = torch.tanh(self.prog_pred(features))
+        self.prog = torch.tanh(self.prog_pred(features)) if prog is None else prog
         if not AuxLosses.is_active():
             return
         if cfg.PREDICTION_MONITOR.use:

@@ -39,7 +39,10 @@ class RNNStateEncoder(nn.Module):
         r = self.rnn
         n = hidden_states.size(1)
         t = x.size(0) // n
-        gi = torch.addmm(r.bias_ih_l0, x, r.weight_ih_l0.t()).view(t, n, -1)
+        if ops.rows_route(x):      # rollout: the input projection of a few rows in one launch
+            gi = ops.linear_rows(x, r.weight_ih_l0, r.bias_ih_l0).view(t, n, -1)
+        else:
+            gi = torch.addmm(r.bias_ih_l0, x, r.weight_ih_l0.t()).view(t, n, -1)
         m = masks.reshape(t, n).float()
         h0 = hidden_states[0].clone()  # the caller overwrites hidden_states in place (reference contract)
         if n <= MAX_BATCH:

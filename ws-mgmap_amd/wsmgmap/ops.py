@@ -592,6 +592,54 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False, ad
     return y
 
 
+ROWS_MAX = 16     # rollout-size dense layers: up to this many rows go through linear_rows / act_heads
+
+
+def rows_route(x):
+    """True when a dense layer on x [B, ...] should take the one-launch rollout route: no autograd, float32 on the GPU, at most
+    ROWS_MAX rows.  WSMG_ROWS_LINEAR=0 turns it off (the nn.Linear modules run)."""
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROWS_MAX
+            and _os.environ.get("WSMG_ROWS_LINEAR", "1") != "0")
+
+
+@torch.no_grad()
+def linear_rows(x, weight, bias, act=None, pool=1):
+    """act(x @ weight.T + bias) for a few rows in one launch (wsmg_linear_rows).  x [B, K] — or [B, K, pool], averaged over its
+    last axis first; weight [O, K]; act None / "relu" / "tanh"."""
+    x = x.contiguous()
+    _req(x, weight, bias)
+    _f32(x, weight, bias)
+    B = x.shape[0]
+    O, K = weight.shape
+    if x.numel() != B * K * pool or (bias is not None and bias.numel() != O):
+        raise _abi.WsmgError(f"linear_rows: x {tuple(x.shape)} does not fit weight {tuple(weight.shape)} (pool {pool})")
+    y = torch.empty(B, O, device=x.device, dtype=torch.float32)
+    _abi.call("wsmg_linear_rows", _p(x), _p(weight), _p(bias), _p(y), B, K, O, {None: 0, "relu": 1, "tanh": 2}[act], int(pool), _stream())
+    return y
+
+
+@torch.no_grad()
+def act_heads(features, prog_pred, fc_mean, logstd, critic_fc, noise=None):
+    """(prog [B,1], value [B,1], action [B,A], log-probability [B]) of one rollout step in one launch (wsmg_act_heads).
+    prog_pred / fc_mean / critic_fc: nn.Linear modules; logstd: the [A, 1] parameter of DiagGaussian.logstd; noise: [B, A]
+    standard normals for a sampled action, None for the mode."""
+    features = features.contiguous()
+    B, K = features.shape
+    A = fc_mean.weight.shape[0]
+    ls = logstd.reshape(-1)
+    _req(features, prog_pred.weight, prog_pred.bias, fc_mean.weight, fc_mean.bias, ls, critic_fc.weight, critic_fc.bias, noise)
+    _f32(features, prog_pred.weight, prog_pred.bias, fc_mean.weight, fc_mean.bias, ls, critic_fc.weight, critic_fc.bias, noise)
+    if prog_pred.weight.shape != (1, K) or critic_fc.weight.shape != (1, K) or fc_mean.weight.shape[1] != K or ls.numel() != A or (
+            noise is not None and noise.shape != (B, A)):
+        raise _abi.WsmgError("act_heads: head shapes do not fit the features")
+    dev = features.device
+    prog, value = torch.empty(B, 1, device=dev), torch.empty(B, 1, device=dev)
+    action, logp = torch.empty(B, A, device=dev), torch.empty(B, device=dev)
+    _abi.call("wsmg_act_heads", _p(features), B, K, _p(prog_pred.weight), _p(prog_pred.bias), _p(fc_mean.weight), _p(fc_mean.bias),
+              _p(ls), A, _p(critic_fc.weight), _p(critic_fc.bias), _p(noise), _p(prog), _p(value), _p(action), _p(logp), _stream())
+    return prog, value, action, logp
+
+
 @torch.no_grad()
 def group_norm_nhwc(x, gamma, beta, groups, eps, relu, residual=None):
     """nn.GroupNorm(groups, C) [+ residual] [+ ReLU] on an NHWC bf16 activation (inference only: the frozen depth backbone)."""
@@ -1050,6 +1098,23 @@ class _CatChannels(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return dy[..., :ctx.ca], dy[..., ctx.ca:]
+
+
+@torch.no_grad()
+def upsample2x_cat(a, b):
+    """cat([upsample2x(a), b], channels) of bf16 NHWC activations in one launch (wsmg_upsample2x_cat_bf16; inference only: the
+    upsampled tensor is never materialised).  Other types / channel counts: the two separate operators."""
+    if (a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.shape[-1] % 8 or b.shape[-1] % 8
+            or _os.environ.get("WSMG_UPCAT", "1") == "0"):
+        return cat_channels(upsample2x(a), b)
+    _req(a, b)
+    B, H, W, Ca = a.shape
+    Cb = b.shape[-1]
+    if b.shape[:3] != (B, 2 * H, 2 * W):
+        raise _abi.WsmgError(f"upsample2x_cat: {tuple(b.shape)} is not twice the size of {tuple(a.shape)}")
+    y = torch.empty(B, 2 * H, 2 * W, Ca + Cb, device=a.device, dtype=torch.bfloat16)
+    _abi.call("wsmg_upsample2x_cat_bf16", _p(a), _p(b), _p(y), B, H, W, Ca, Cb, _stream())
+    return y
 
 
 def cat_channels(a, b):
