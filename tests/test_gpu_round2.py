@@ -159,6 +159,42 @@ def test_rollout_b1_vs_oracle(hw):
     assert float((gm.cpu() - ref.mapper.full_global_map).abs().max()) <= 2e-4
 
 
+def test_rollout_b1_bf16_route_vs_oracle():
+    """configs[0] in bf16 mode — the rollout route: frozen UNet on the bf16 engine with split-K layers, BatchNorm-folded map
+    stack, one-launch dense layers and heads, eagerly and replayed as one HIP graph — against the float32 oracle on the host.
+    Written bf16 bars: action 3e-2, value 3e-2, progress estimate 3e-2, hidden state 5e-2, ego map
+    3 % relative L2, log-probability of the mode exact to 1e-5 (it does not depend on the features)."""
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.graph import GraphedAct
+    AuxLosses.deactivate()
+    pol, polg = _policy(num_proc=1, compute_dtype="bf16").eval(), _policy(num_proc=1, compute_dtype="bf16").eval()
+    ga = GraphedAct(polg, eager_calls=1)
+    ref = policy_ref.PolicyRef(make_params(grad=False), num_proc=1)
+    ref.train_mode = False
+    h, hg, hr = torch.zeros(2, 1, 512, device="cuda"), torch.zeros(2, 1, 512, device="cuda"), torch.zeros(2, 1, 512)
+    prev = torch.zeros(1, 2, device="cuda")
+    worst = {}
+    with torch.no_grad():
+        for step in range(4):
+            obs_np, masks = cases.act_inputs(step, B=1, rgb_hw=256, tag="b1", n_tok=(63,))
+            obs, oc = _cuda(obs_np), {k: T(v) for k, v in obs_np.items()}
+            m = T(masks).cuda()
+            vg, ag, lg, hg2 = ga(dict(obs), hg, prev, m, deterministic=True)
+            hg = hg2.clone()
+            value, action, logp, h = pol.act(obs, h, prev, m, deterministic=True)
+            vr, ar, lpr, hr = ref.act(oc, hr, None, T(masks))
+            for name, x, y in (("value", vg, value), ("action", ag, action), ("logp", lg, logp), ("h", hg, h)):
+                assert torch.equal(x, y), (step, name)       # the replay IS the eager step
+            for name, x, y, bar in (("action", action, ar, 3e-2), ("value", value, vr, 3e-2), ("prog", pol.prog, ref.prog, 3e-2),
+                                    ("h", h, hr, 5e-2), ("logp", logp, lpr, 1e-5)):
+                err = float((x.cpu() - y).abs().max())
+                worst[name] = max(worst.get(name, 0.0), err)
+                assert err <= bar, (step, name, err)
+            ego, ego_r = obs["rgb_ego_map"].cpu(), oc["rgb_ego_map"]
+            assert float((ego - ego_r).norm() / ego_r.norm()) <= 3e-2, step
+            prev = action
+
+
 def test_update_b1_with_aux_losses():
     """T=1 x N=1 teacher-forcing row with the auxiliary losses active.  The reference's `.squeeze()` (policy.py:64) drops
     the batch axis at B=1 and F.cross_entropy rejects the shapes; this implementation squeezes the channel axis only, so
