@@ -341,6 +341,17 @@ int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW,
 /* torch.cat([a, b], dim=1) of the reference's NCHW tensors (UNet skip connections map_encoder.py:104,110, map
  * projections mg_map_policy.py:99) on NHWC storage: y[p] = a[p] ++ b[p] for `rows` pixels; a pixel's channel run is
  * bytes_a / bytes_b bytes (multiples of 16; any element type), 16-byte aligned pointers. */
+/* Gradient of a channel concatenation read in place: `dy` rows are `ld_dy` elements apart (>= C, a multiple of 8, 16-byte aligned
+ * base) — autograd returns the halves of torch.cat(..., dim=1)'s gradient (map_encoder.py:104,110, mg_map_policy.py:99) as views,
+ * and the consumers below take them without a contiguous copy.  Otherwise as wsmg_bn_act_bwd / wsmg_relu_bwd. */
+int wsmg_bn_act_bwd_ld(const float* dy, int64_t ld_dy, const float* x, const float* y, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, float* dx, float* dresidual,
+                       float* dgamma, float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream);
+int wsmg_bn_act_bwd_ld_bf16(const void* dy, int64_t ld_dy, const void* x, const void* y, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, void* dx,
+                            void* dresidual, float* dgamma, float* dbeta, double* workspace, int64_t workspace_bytes,
+                            wsmg_stream_t stream);
+int wsmg_relu_bwd_rows_bf16(const void* dy, int64_t ld_dy, const void* y, void* dx, int64_t rows, int C, wsmg_stream_t stream);
 int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t rows, int bytes_a, int bytes_b, wsmg_stream_t stream);
 /* y [B][2H][2W][Ca+Cb] = cat([bilinear 2x upsample (align_corners) of a [B][H][W][Ca], b [B][2H][2W][Cb]], channels), bf16, in one
  * pass: the decoder step `torch.cat([self.upsample(x), skip], dim=1)` of unet_encoder.py:95-109 / map_encoder.py:103-110 on the

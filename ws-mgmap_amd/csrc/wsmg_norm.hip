@@ -38,8 +38,10 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
                                                                  const float* __restrict__ invstd,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, int relu,
-                                                                 int64_t rows, int C, double* __restrict__ part) {
+                                                                 int64_t rows, int C, double* __restrict__ part,
+                                                                 int64_t ld_dy = 0) {   // row stride of dy (0: C)
   __shared__ double sh[2][4][RED_THREADS];
+  const int64_t ldg = ld_dy ? ld_dy : C;
   const int tid = threadIdx.x;
   const int C4 = C >> 2;
   const int c = (tid % C4) * 4;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
     for (int u = 0; u < 4; ++u) {
       const size_t o = (size_t)(r + u * S) * C + c;
       xa[u] = ld4(x + o);
-      ga[u] = MODE == 2 ? ld4(dy + o) : zero4;
+      ga[u] = MODE == 2 ? ld4(dy + (size_t)(r + u * S) * ldg + c) : zero4;
       ya[u] = (MODE == 2 && relu && y) ? ld4(y + o) : zero4;
     }
 #pragma unroll
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(RED_THREADS) void col_reduce_kernel(const T* __rest
   }
   for (; r < rows; r += S) {
     const size_t o = (size_t)r * C + c;
-    accumulate(ld4(x + o), MODE == 2 ? ld4(dy + o) : zero4, (MODE == 2 && relu && y) ? ld4(y + o) : zero4);
+    accumulate(ld4(x + o), MODE == 2 ? ld4(dy + (size_t)r * ldg + c) : zero4, (MODE == 2 && relu && y) ? ld4(y + o) : zero4);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { sh[0][j][tid] = s0[j]; sh[1][j][tid] = s1[j]; }
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, int relu, float inv_n,
                                                            int64_t rows, int C, T* __restrict__ dx,
-                                                           T* __restrict__ dres) {
+                                                           T* __restrict__ dres, int64_t ld_dy) {
   const int C4 = C >> 2;
   const int c = (threadIdx.x % C4) * 4;
   const int rl = threadIdx.x / C4;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   for (int j = 0; j < 4; ++j) { k0[j] = gm[j] * is[j]; k1[j] = db[j] * inv_n; k2[j] = dg[j] * inv_n; }
   for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
     const size_t o = (size_t)r * C + c;
-    f32x4 g = ld4(dy + o);
+    f32x4 g = ld4(dy + (size_t)r * ld_dy + c);
     f32x4 xv = ld4(x + o);
     if (relu) {
       if (y) {
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
                                                             const float* __restrict__ beta, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ dgamma,
                                                             const float* __restrict__ dbeta, int relu, float inv_n, int64_t rows,
-                                                            int C, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres) {
+                                                            int C, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
+                                                            int64_t ld_dy) {
   const int C8 = C >> 3;
   const int c = (threadIdx.x % C8) * 8;
   const int rl = threadIdx.x / C8;
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
   for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
     const size_t o = (size_t)r * C + c;
     f32x4 g[2], xv[2], yv[2], out[2];
-    unpack8(*reinterpret_cast<const u32x4n*>(dy + o), g[0], g[1]);
+    unpack8(*reinterpret_cast<const u32x4n*>(dy + (size_t)r * ld_dy + c), g[0], g[1]);
     unpack8(*reinterpret_cast<const u32x4n*>(x + o), xv[0], xv[1]);
     if (relu && y) unpack8(*reinterpret_cast<const u32x4n*>(y + o), yv[0], yv[1]);
 #pragma unroll
@@ -434,24 +437,26 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
 template <class T>
 int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, int relu, int64_t rows, int C, T* dx, T* dresidual, float* dgamma,
-                 float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream) {
+                 float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream, int64_t ld_dy = 0) {
   if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
+  if (ld_dy == 0) ld_dy = C;
+  if (ld_dy < C || (ld_dy & 7) || ((uintptr_t)dy & 15)) return WSMG_EINVAL;
   if (relu && !y && (!beta || dresidual)) return WSMG_EINVAL;   // the mask can only be recomputed without a residual
   if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
   hipStream_t s = wsmg_s(stream);
   int nb = red_blocks(rows, C);
   hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
-                     gamma, beta, relu, rows, C, workspace);
+                     gamma, beta, relu, rows, C, workspace, ld_dy);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (bn_vec8()) {
       hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
-                         save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual);
+                         save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual, ld_dy);
       WSMG_RETURN_LAUNCH();
     }
   }
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
-                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual);
+                     save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual, ld_dy);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -519,6 +524,23 @@ extern "C" int wsmg_bn_act_bwd_bf16(const void* dy, const void* x, const void* y
                                     int64_t workspace_bytes, wsmg_stream_t stream) {
   return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, beta, save_mean, save_invstd, relu,
                               rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+// dy with a row stride (`ld_dy` elements, a multiple of 8, >= C): the channel slice of a concatenation's gradient is read in
+// place (the decoders' `torch.cat(..., dim=1)` of map_encoder.py:104,110: autograd hands the two halves back as views)
+extern "C" int wsmg_bn_act_bwd_ld(const float* dy, int64_t ld_dy, const float* x, const float* y, const float* gamma, const float* beta,
+                                  const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, float* dx,
+                                  float* dresidual, float* dgamma, float* dbeta, double* workspace, int64_t workspace_bytes,
+                                  wsmg_stream_t stream) {
+  return bn_act_bwd_t<float>(dy, x, y, gamma, beta, save_mean, save_invstd, relu, rows, C, dx, dresidual, dgamma, dbeta,
+                             workspace, workspace_bytes, stream, ld_dy);
+}
+extern "C" int wsmg_bn_act_bwd_ld_bf16(const void* dy, int64_t ld_dy, const void* x, const void* y, const float* gamma,
+                                       const float* beta, const float* save_mean, const float* save_invstd, int relu, int64_t rows,
+                                       int C, void* dx, void* dresidual, float* dgamma, float* dbeta, double* workspace,
+                                       int64_t workspace_bytes, wsmg_stream_t stream) {
+  return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, beta, save_mean, save_invstd, relu,
+                              rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream, ld_dy);
 }
 
 // ----------------------------------------------------------------------------- GroupNorm (frozen DD-PPO depth ResNet50)

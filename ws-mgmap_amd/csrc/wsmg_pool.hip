@@ -467,6 +467,17 @@ __global__ void relu_bwd8_kernel(const u32x4_t* __restrict__ dy, const u32x4_t* 
   }
 }
 
+// the same with a row stride on dy (rows of C8 16-byte pieces, `ld8` pieces apart): a channel slice of a wider gradient read in place
+__global__ void relu_bwd8_rows_kernel(const u32x4_t* __restrict__ dy, int64_t ld8, const u32x4_t* __restrict__ y, u32x4_t* __restrict__ dx,
+                                      int C8, int64_t n8) {
+  GRID_STRIDE(i, n8) {
+    const int64_t r = i / C8;
+    const u32x4_t g = dy[r * ld8 + (i - r * C8)], v = y[i];
+    u32x4_t o = {mask2(g[0], v[0]), mask2(g[1], v[1]), mask2(g[2], v[2]), mask2(g[3], v[3])};
+    dx[i] = o;
+  }
+}
+
 // dx[b][i][c] = (dx[b][i][c] + g[b][c] * inv_I) * (x[b][i][c] > 0), in place: the gradient of the map tokens from the attention
 // (already in dx) merged with the broadcast gradient of their token mean (mg_map_policy.py:217: AdaptiveAvgPool1d over the 576
 // tokens) and masked by the fused ReLU of the convolution that produced the tokens (map_cated_linear, :99-100) — one pass
@@ -610,6 +621,12 @@ extern "C" int wsmg_token_grad_merge_bf16(void* dx, const void* x, const float* 
 }
 extern "C" int wsmg_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<float>(dy, y, dx, n, s); }
 extern "C" int wsmg_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t n, wsmg_stream_t s) { return relu_bwd_t<bf16_t>(CB16(dy), CB16(y), B16(dx), n, s); }
+extern "C" int wsmg_relu_bwd_rows_bf16(const void* dy, int64_t ld_dy, const void* y, void* dx, int64_t rows, int C, wsmg_stream_t s) {
+  if (rows <= 0 || C <= 0 || (C & 7) || ld_dy < C || (ld_dy & 7) || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dx) & 15)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(relu_bwd8_rows_kernel, dim3(sgrid(rows * C / 8)), dim3(256), 0, wsmg_s(s), (const u32x4_t*)dy, ld_dy / 8,
+                     (const u32x4_t*)y, (u32x4_t*)dx, C / 8, rows * C / 8);
+  WSMG_RETURN_LAUNCH();
+}
 extern "C" int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<float>(x, y, B, H, W, C, OH, OW, s); }
 extern "C" int wsmg_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, OH, OW, s); }
 extern "C" int wsmg_maxpool3x3s2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_bwd_t<float>(dy, x, dx, B, H, W, C, OH, OW, s); }

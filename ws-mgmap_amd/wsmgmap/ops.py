@@ -61,6 +61,19 @@ def _workspace(device):
     return ws
 
 
+def _rows_of(dy, C):
+    """(tensor, row stride in elements) for a kernel that reads `dy` as rows of C channels: contiguous tensors as they are; a
+    channel slice of a contiguous wider tensor — what autograd returns for the halves of a concatenation's gradient — in
+    place, when rows stay 16-byte aligned; anything else through one contiguous copy."""
+    if dy.is_contiguous():
+        return dy, C
+    ld = dy.stride(-2) if dy.dim() >= 2 else 0
+    ok = (dy.stride(-1) == 1 and ld >= C and ld % 8 == 0 and dy.data_ptr() % 16 == 0 and C % 8 == 0
+          and all(dy.stride(i) == dy.stride(i + 1) * dy.shape[i + 1] for i in range(dy.dim() - 2))
+          and _os.environ.get("WSMG_STRIDED_GRADS", "1") != "0")
+    return (dy, ld) if ok else (dy.contiguous(), C)
+
+
 def _conv_out(h, k, s, p):
     return (h + 2 * p - k) // s + 1
 
@@ -365,13 +378,18 @@ class _Conv2d(torch.autograd.Function):
         x, w_ihwo, y_relu = ctx.saved_tensors
         *dims, has_bias, sfx, Cin_w = ctx.cfg
         B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
-        dy = dy.contiguous()
         if ctx.relu_sink is not None and ctx.relu_sink.masked:
             y_relu = None        # the token-gradient merge applied the ReLU mask already (TokenGradSink)
         if y_relu is not None:   # fused ReLU: mask the incoming gradient with the saved output first
-            masked = torch.empty_like(dy)
-            _abi.call("wsmg_relu_bwd" + sfx, _p(dy), _p(y_relu), _p(masked), dy.numel(), _stream())
+            masked = torch.empty_like(y_relu)
+            dy, ld = _rows_of(dy, Cout) if sfx else (dy.contiguous(), Cout)
+            if ld != Cout:       # a channel slice of a concatenation's gradient, read in place
+                _abi.call("wsmg_relu_bwd_rows_bf16", _p(dy), ld, _p(y_relu), _p(masked), dy.numel() // Cout, Cout, _stream())
+            else:
+                _abi.call("wsmg_relu_bwd" + sfx, _p(dy), _p(y_relu), _p(masked), dy.numel(), _stream())
             dy = masked
+        else:
+            dy = dy.contiguous()
         dx = dw = db = None
         fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
         if ctx.needs_input_grad[0]:
@@ -705,14 +723,18 @@ class _BnAct(torch.autograd.Function):
         rows, C, relu, has_res, train, sfx = ctx.cfg
         if not train:
             raise _abi.WsmgError("backward through eval-mode BatchNorm is not part of the reference's path")
-        dy = dy.contiguous()
+        dy, ld = _rows_of(dy, C)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         ws = _workspace(x.device)
-        _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
-                  _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
+        if ld != C:     # a channel slice of a concatenation's gradient, read in place
+            _abi.call("wsmg_bn_act_bwd_ld" + sfx, _p(dy), ld, _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
+                      _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
+        else:
+            _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
+                      _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
         return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
