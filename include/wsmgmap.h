@@ -352,6 +352,8 @@ int wsmg_bn_act_bwd_ld_bf16(const void* dy, int64_t ld_dy, const void* x, const 
                             void* dresidual, float* dgamma, float* dbeta, double* workspace, int64_t workspace_bytes,
                             wsmg_stream_t stream);
 int wsmg_relu_bwd_rows_bf16(const void* dy, int64_t ld_dy, const void* y, void* dx, int64_t rows, int C, wsmg_stream_t stream);
+int wsmg_upsample2x_bwd_ld(const float* dy, int64_t ld_dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream);
+int wsmg_upsample2x_bwd_ld_bf16(const void* dy, int64_t ld_dy, void* dx, int B, int H, int W, int C, wsmg_stream_t stream);
 int wsmg_cat_channels(const void* a, const void* b, void* y, int64_t rows, int bytes_a, int bytes_b, wsmg_stream_t stream);
 /* y [B][2H][2W][Ca+Cb] = cat([bilinear 2x upsample (align_corners) of a [B][H][W][Ca], b [B][2H][2W][Cb]], channels), bf16, in one
  * pass: the decoder step `torch.cat([self.upsample(x), skip], dim=1)` of unet_encoder.py:95-109 / map_encoder.py:103-110 on the

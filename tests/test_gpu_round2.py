@@ -1142,7 +1142,8 @@ def test_upsample_cat_equals_upsample_then_cat(geom):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_concatenation_gradient_halves_are_read_in_place(dtype, monkeypatch):
     """The halves of a channel concatenation's gradient reach their consumers as strided views: train-mode BatchNorm backward
-    (wsmg_bn_act_bwd_ld) and the fused-ReLU convolution backward (wsmg_relu_bwd_rows_bf16) read them in place.  Every gradient
+    (wsmg_bn_act_bwd_ld), the fused-ReLU convolution backward (wsmg_relu_bwd_rows_bf16) and the upsample backward
+    (wsmg_upsample2x_bwd_ld) read them in place — slices of slices included.  Every gradient
     is bit-identical to the route through contiguous copies (WSMG_STRIDED_GRADS=0) — the weight gradient, summed with float32
     atomics, to 1e-5."""
     from wsmgmap import ops
@@ -1153,22 +1154,24 @@ def test_concatenation_gradient_halves_are_read_in_place(dtype, monkeypatch):
     w0 = torch.randn(C2, 32, 3, 3, device="cuda", generator=g) * 0.1
     bias0 = torch.randn(C2, device="cuda", generator=g) * 0.1
     gamma0, beta0 = torch.rand(C1, device="cuda", generator=g) + 0.5, torch.randn(C1, device="cuda", generator=g) * 0.1
-    wout = torch.randn(B, H, H, C1 + C2, device="cuda", generator=g).to(dtype)
+    xu0 = torch.randn(B, H // 2, H // 2, 32, device="cuda", generator=g).to(dtype)
+    wout = torch.randn(B, H, H, C1 + C2 + 32, device="cuda", generator=g).to(dtype)
 
     def grads():
         xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
         w, bias, gamma, beta = (t.clone().requires_grad_(True) for t in (w0, bias0, gamma0, beta0))
         rm, rv = torch.zeros(C1, device="cuda"), torch.ones(C1, device="cuda")
+        xu = xu0.clone().requires_grad_(True)
         a = ops.bn_act(xa, gamma, beta, rm, rv, True, True)
         b = ops.conv2d(xb, w, bias, 1, 1, relu=True)
-        y = ops.cat_channels(a, b)
+        y = ops.cat_channels(ops.cat_channels(a, b), ops.upsample2x(xu))
         (y.float() * wout.float()).sum().backward()
-        return [t.grad.clone() for t in (xa, xb, w, bias, gamma, beta)]
+        return [t.grad.clone() for t in (xa, xb, w, bias, gamma, beta, xu)]
     monkeypatch.setenv("WSMG_STRIDED_GRADS", "1")
     g1 = grads()
     monkeypatch.setenv("WSMG_STRIDED_GRADS", "0")
     g0 = grads()
-    for name, x, y in zip(("xa", "xb", "w", "bias", "gamma", "beta"), g1, g0):
+    for name, x, y in zip(("xa", "xb", "w", "bias", "gamma", "beta", "xu"), g1, g0):
         if name == "w":      # float32 atomics: the summation order differs from run to run
             assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()), name
         else:

@@ -148,7 +148,7 @@ __global__ void upsample_fwd_kernel(const T* x, T* y, int B, int H, int W, int C
 }
 
 template <class T>
-__global__ void upsample_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int C) {
+__global__ void upsample_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int C, int64_t ld_dy) {   // ld_dy: pixel stride of dy
   const int OH = 2 * H, OW = 2 * W, C4 = C / 4;
   const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
   const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
@@ -170,7 +170,7 @@ __global__ void upsample_bwd_kernel(const T* dy, T* dx, int B, int H, int W, int
         up_src(ox, W, sw, x0, x1, wx0, wx1);
         float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
         if (wx == 0.f) continue;
-        const f32x4 d = ld4(dy + (((size_t)b * OH + oy) * OW + ox) * C + c);
+        const f32x4 d = ld4(dy + (((size_t)b * OH + oy) * OW + ox) * ld_dy + c);
         const float wgt = wy * wx;
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] += wgt * d[j];
@@ -556,10 +556,12 @@ int upsample_fwd_t(const T* x, T* y, int B, int H, int W, int C, wsmg_stream_t s
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
-int upsample_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t stream) {
+int upsample_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t stream, int64_t ld_dy = 0) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  if (ld_dy == 0) ld_dy = C;
+  if (ld_dy < C || (ld_dy & 7) || ((uintptr_t)dy & 15)) return WSMG_EINVAL;
   hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), dy, dx,
-                     B, H, W, C);
+                     B, H, W, C, ld_dy);
   WSMG_RETURN_LAUNCH();
 }
 template <class T>
@@ -635,6 +637,8 @@ extern "C" int wsmg_upsample2x_fwd(const float* x, float* y, int B, int H, int W
 extern "C" int wsmg_upsample2x_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, s); }
 extern "C" int wsmg_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_bwd_t<float>(dy, dx, B, H, W, C, s); }
 extern "C" int wsmg_upsample2x_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_bwd_t<bf16_t>(CB16(dy), B16(dx), B, H, W, C, s); }
+extern "C" int wsmg_upsample2x_bwd_ld(const float* dy, int64_t ld_dy, float* dx, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_bwd_t<float>(dy, dx, B, H, W, C, s, ld_dy); }
+extern "C" int wsmg_upsample2x_bwd_ld_bf16(const void* dy, int64_t ld_dy, void* dx, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_bwd_t<bf16_t>(CB16(dy), B16(dx), B, H, W, C, s, ld_dy); }
 extern "C" int wsmg_avgpool2_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_fwd_t<float>(x, y, B, H, W, C, s); }
 extern "C" int wsmg_avgpool2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, s); }
 extern "C" int wsmg_avgpool2_bwd(const float* dy, float* dx, int B, int H, int W, int C, wsmg_stream_t s) { return avgpool_bwd_t<float>(dy, dx, B, H, W, C, s); }

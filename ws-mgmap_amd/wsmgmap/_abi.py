@@ -85,6 +85,8 @@ _SIG["wsmg_weight_relayout_multi"] = [c_p, c_i, c_i, c_p]
 _SIG["wsmg_weight_grad_to_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
 _SIG["wsmg_bn_act_bwd_ld"] = [c_p, c_l] + _SIG["wsmg_bn_act_bwd"][1:]
 _SIG["wsmg_bn_act_bwd_ld_bf16"] = list(_SIG["wsmg_bn_act_bwd_ld"])
+_SIG["wsmg_upsample2x_bwd_ld"] = [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p]
+_SIG["wsmg_upsample2x_bwd_ld_bf16"] = list(_SIG["wsmg_upsample2x_bwd_ld"])
 _SIG["wsmg_relu_bwd_rows_bf16"] = [c_p, c_l, c_p, c_p, c_l, c_i, c_p]
 _SIG["wsmg_cat_channels"] = [c_p, c_p, c_p, c_l, c_i, c_i, c_p]
 _SIG["wsmg_upsample2x_cat_bf16"] = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]

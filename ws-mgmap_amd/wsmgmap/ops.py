@@ -822,9 +822,12 @@ class _Up2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, H, W, C = ctx.shape
-        dy = dy.contiguous()
+        dy, ld = _rows_of(dy, C)
         dx = torch.empty(B, H, W, C, device=dy.device, dtype=dy.dtype)
-        _abi.call("wsmg_upsample2x_bwd" + _sfx(dy), _p(dy), _p(dx), B, H, W, C, _stream())
+        if ld != C:      # a channel slice of a concatenation's gradient, read in place
+            _abi.call("wsmg_upsample2x_bwd_ld" + _sfx(dy), _p(dy), ld, _p(dx), B, H, W, C, _stream())
+        else:
+            _abi.call("wsmg_upsample2x_bwd" + _sfx(dy), _p(dy), _p(dx), B, H, W, C, _stream())
         return dx
 
 
