@@ -193,6 +193,14 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
+/* A list of device-to-device copies (non-overlapping) in one launch: the inputs of a captured rollout step handed into its
+ * static tensors (wsmgmap.graph.GraphedAct).  Any alignment, any byte count. */
+typedef struct {
+  void* dst;
+  const void* src;
+  long long bytes;
+} WsmgCopyDesc;
+int wsmg_copy_multi(const WsmgCopyDesc* descs, int n, wsmg_stream_t stream);
 /* Rollout-size dense layers, one row per environment (the nn.Linear calls of mg_map_policy.py:150-197 at 1-16 rows):
  * y[r][o] = act(sum_k x[r][k] w[o][k] + bias[o]) in ONE launch (a GEMM library call is bias copy + GEMM + activation);
  * x [B][K] (pool = 1) or [B][K][pool] whose mean over the last axis is the layer's input (rgb_linear's AdaptiveAvgPool1d(1) +

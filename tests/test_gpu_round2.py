@@ -1177,3 +1177,22 @@ def test_concatenation_gradient_halves_are_read_in_place(dtype, monkeypatch):
         else:
             assert torch.equal(x, y), name
     assert float(g1[0].abs().max()) > 0 and float(g1[1].abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_copy_multi_copies_every_pair():
+    """ops.copy_multi (wsmg_copy_multi): a list of copies of 4 bytes to 3 MB, mixed dtypes, one unaligned pair and one
+    non-contiguous pair (torch fallback) — every destination equals its source afterwards, nothing else is touched."""
+    from wsmgmap import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    srcs = [torch.randn(256, 256, 3, device="cuda", generator=g), torch.randint(0, 9, (3, 200), device="cuda", generator=g),
+            torch.randn(1, device="cuda", generator=g), torch.randn(2, 8, 512, device="cuda", generator=g).to(torch.bfloat16),
+            torch.randn(1001, device="cuda", generator=g)[1:], torch.randn(64, 64, device="cuda", generator=g).t(),
+            torch.randn(786432, device="cuda", generator=g), torch.empty(0, device="cuda")]
+    guard = torch.full((4096,), 7.0, device="cuda")
+    dsts = [torch.zeros_like(s) if s.is_contiguous() else torch.zeros(s.shape, device="cuda") for s in srcs]
+    dsts[4] = torch.zeros(1003, device="cuda")[3:]           # 4-byte aligned only
+    ops.copy_multi(dsts, srcs)
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0

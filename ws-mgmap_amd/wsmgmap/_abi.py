@@ -20,6 +20,10 @@ class WsmgError(RuntimeError):
     pass
 
 
+class CopyDesc(ctypes.Structure):         # WsmgCopyDesc of include/wsmgmap.h
+    _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("bytes", ctypes.c_longlong)]
+
+
 class RelayoutDesc(ctypes.Structure):     # WsmgRelayoutDesc of include/wsmgmap.h
     _fields_ = [("w_oihw", c_p), ("w_ohwi", c_p), ("w_ihwo", c_p), ("O", c_i), ("I", c_i), ("KH", c_i), ("KW", c_i),
                 ("I_pad", c_i), ("reserved", c_i)]
@@ -105,6 +109,7 @@ _SIG["wsmg_group_norm_nhwc_bf16"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i
 _SIG["wsmg_rnn_status"] = [c_i]
 _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
 _SIG["wsmg_conv_debug_win3_tile"] = [c_i]
+_SIG["wsmg_copy_multi"] = [c_p, c_i, c_p]
 _SIG["wsmg_linear_rows"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]
 _SIG["wsmg_act_heads"] = [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
 _SIG["wsmg_path_kl_fwd"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]

@@ -610,6 +610,26 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False, ad
     return y
 
 
+@torch.no_grad()
+def copy_multi(dsts, srcs):
+    """dst.copy_(src) for a list of GPU tensor pairs in ONE launch (wsmg_copy_multi) — same shape, dtype and device per pair, both
+    contiguous; anything else falls back to torch's copy for that pair."""
+    pairs = []
+    for d, s in zip(dsts, srcs):
+        if (d.is_cuda and s.is_cuda and d.device == s.device and d.dtype == s.dtype and d.shape == s.shape and d.is_contiguous()
+                and s.is_contiguous()):
+            if d.numel():
+                pairs.append((d, s))
+        else:
+            d.copy_(s)
+    if not pairs:
+        return
+    arr = (_abi.CopyDesc * len(pairs))()
+    for i, (d, s) in enumerate(pairs):
+        arr[i].dst, arr[i].src, arr[i].bytes = d.data_ptr(), s.data_ptr(), d.numel() * d.element_size()
+    _abi.call("wsmg_copy_multi", ctypes.cast(arr, ctypes.c_void_p), len(pairs), _stream())
+
+
 ROWS_MAX = 16     # rollout-size dense layers: up to this many rows go through linear_rows / act_heads
 
 
