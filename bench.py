@@ -253,8 +253,8 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--T", type=int, default=64)
     ap.add_argument("--N", type=int, default=8)
     ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],

@@ -622,9 +622,15 @@ int splitk_plan(int64_t M, int Kc, int N, int KH, int KW) {
   const int bk = (Kc % 64) == 0 ? 64 : 32;
   const int steps = KH * KW * (Kc / bk);
   const int tiles = (int)(wsmg_cdiv(M, BM) * wsmg_cdiv(N, 64));
-  if (tiles >= 128 || steps < 16 || (N & 7)) return 1;
-  int ks = (int)wsmg_cdiv(256, tiles);
-  if (ks > steps / 4) ks = steps / 4;
+  static int target = 0, minsteps = 0, maxtiles = 0;   // experiments: WSMG_SPLITK_TARGET / _MINSTEPS / _MAXTILES
+  if (!target) {
+    const char* e = getenv("WSMG_SPLITK_TARGET"); target = e && atoi(e) > 0 ? atoi(e) : 256;
+    e = getenv("WSMG_SPLITK_MINSTEPS"); minsteps = e && atoi(e) > 0 ? atoi(e) : 4;
+    e = getenv("WSMG_SPLITK_MAXTILES"); maxtiles = e && atoi(e) > 0 ? atoi(e) : 128;
+  }
+  if (tiles >= maxtiles || steps < 4 * minsteps || (N & 7)) return 1;
+  int ks = (int)wsmg_cdiv(target, tiles);
+  if (ks > steps / minsteps) ks = steps / minsteps;
   if (ks > 32) ks = 32;
   if (ks < 2) return 1;
   const int per = (int)wsmg_cdiv(steps, ks);
