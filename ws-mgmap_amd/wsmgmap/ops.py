@@ -277,10 +277,12 @@ _wgrad_side = {}
 _side_join_armed = set()
 
 
-def _wgrad_side_stream():
-    """Side stream of the weight-gradient launches (WSMG_WGRAD_STREAM=1; not with a process group: the gradient
-    all-reduce hooks read p.grad on the main stream as soon as it is accumulated)."""
-    if _os.environ.get("WSMG_WGRAD_STREAM", "0") != "1":
+def _wgrad_side_stream(flops=0.0):
+    """Side stream of the weight-gradient launches (WSMG_WGRAD_STREAM=1: all of them; =2: only the layers below 60 GFLOP,
+    which cannot fill the chip on their own; not with a process group: the gradient all-reduce hooks read p.grad on the main
+    stream as soon as it is accumulated)."""
+    mode = _os.environ.get("WSMG_WGRAD_STREAM", "0")
+    if mode not in ("1", "2") or (mode == "2" and flops >= 60e9):
         return None
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         return None
@@ -399,7 +401,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            side = _wgrad_side_stream()
+            side = _wgrad_side_stream(fl)
             if side is None:
                 dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
                 _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
