@@ -102,15 +102,20 @@ class FoldCache:
             b = b.clone()          # (a float32 bias without BatchNorm or padding would otherwise BE the parameter)
         return w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16), None if b is None else b.contiguous()
 
-    def get(self, weight, bias, bn, cin_pad, cout_pad=0):
-        key = (id(weight), cin_pad, cout_pad)
-        ver = self._versions(weight, bias, bn)
+    def get(self, weight, bias, bn, cin_pad, cout_pad=0, owner=None):
+        """owner: the module the parameters belong to — keys the entry, so a hit costs no parameter lookups on the module."""
+        key = (id(weight) if owner is None else id(owner), cin_pad, cout_pad)
         e = self.entries.get(key)
         if e is None:
+            if weight is None:
+                weight, bias = owner.weight, owner.bias
             w, b = self._fold(weight, bias, bn, cin_pad, cout_pad)
-            e = self.entries[key] = [ver, w, b, (weight, bias, bn, cin_pad, cout_pad)]
-        elif e[0] != ver:
-            self._refresh(e, ver)
+            e = self.entries[key] = [self._versions(weight, bias, bn), w, b, (weight, bias, bn, cin_pad, cout_pad)]
+        else:
+            src = e[3]
+            ver = self._versions(src[0], src[1], src[2])
+            if e[0] != ver:
+                self._refresh(e, ver)
         return e[1], e[2]
 
     @torch.no_grad()
@@ -132,17 +137,13 @@ class FoldCache:
         return n
 
 
-def conv_infer(x, cache: FoldCache, conv, bn=None, relu=True, residual=None, weight=None, bias=None, cout_pad=0, pad=None):
+def conv_infer(x, cache: FoldCache, conv, bn=None, relu=True, residual=None, cout_pad=0):
     """One launch: conv (+ folded eval-mode BatchNorm) (+ ReLU) on a bf16 NHWC activation, operands from `cache`.
     With `residual`: relu(conv_bn(x) + residual) is written INTO `residual` by the convolution's epilogue (and returned)."""
     if isinstance(x, (list, tuple)):
         x = ops.cat_channels(x[0], x[1])
-    weight = conv.weight if weight is None else weight
-    bias = (conv.bias if conv is not None else None) if bias is None else bias
-    w, b = cache.get(weight, bias, bn, x.shape[-1], cout_pad)
-    stride = conv.stride[0] if isinstance(conv, nn.Conv2d) else 1
-    pad = (conv.padding[0] if isinstance(conv, nn.Conv2d) else 0) if pad is None else pad
-    return ops.conv2d_infer_bf16(x, w, b, stride, pad, relu, add_to=residual)
+    w, b = cache.get(None, None, bn, x.shape[-1], cout_pad, owner=conv)
+    return ops.conv2d_infer_bf16(x, w, b, conv.stride[0], conv.padding[0], relu, add_to=residual)
 
 
 def convrelu(in_channels, out_channels, kernel, padding):

@@ -49,7 +49,7 @@ class ResNetUNet(nn.Module):
         """(OHWI bf16 weight, float32 bias) of conv followed by eval-mode bn, folded; cached while the parameters and
         running statistics keep their versions (the encoder is frozen, so this is computed once) and re-folded in place
         otherwise (map_encoder.FoldCache)."""
-        return self._fold_cache.get(conv.weight, conv.bias, bn, cin_pad or 0)
+        return self._fold_cache.get(None, None, bn, cin_pad or 0, owner=conv)
 
     def _cbr(self, x, conv, bn, relu=True, add_to=None):
         w, b = self._folded(conv, bn, x.shape[-1])
