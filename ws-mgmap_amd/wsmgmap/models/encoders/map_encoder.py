@@ -110,7 +110,8 @@ class FoldCache:
             if weight is None:
                 weight, bias = owner.weight, owner.bias
             w, b = self._fold(weight, bias, bn, cin_pad, cout_pad)
-            e = self.entries[key] = [self._versions(weight, bias, bn), w, b, (weight, bias, bn, cin_pad, cout_pad)]
+            # (the entry keeps `owner` alive: its id, the key, cannot be handed to another module while the entry exists)
+            e = self.entries[key] = [self._versions(weight, bias, bn), w, b, (weight, bias, bn, cin_pad, cout_pad), owner]
         else:
             src = e[3]
             ver = self._versions(src[0], src[1], src[2])

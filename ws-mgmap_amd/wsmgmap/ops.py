@@ -20,10 +20,14 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _raw_stream():
-    """The current HIP stream of the current device as an integer handle (two C calls: torch.cuda.current_stream() walks
-    five Python frames per call, ≈100 times per rollout step — a fifth of the step's host time)."""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+if hasattr(torch._C, "_cuda_getCurrentRawStream") and hasattr(torch._C, "_cuda_getDevice"):
+    def _raw_stream():
+        """The current HIP stream of the current device as an integer handle (two C calls: torch.cuda.current_stream() walks
+        five Python frames per call, ≈100 times per rollout step — a fifth of the step's host time)."""
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+else:   # a torch build without the two entry points: the public route
+    def _raw_stream():
+        return torch.cuda.current_stream().cuda_stream
 
 
 def _stream():
