@@ -179,6 +179,11 @@ int wsmg_conv2d_splitk_plan(int B, int OH, int OW, int Cin, int Cout, int KH, in
 int wsmg_conv2d_fwd_bf16_splitk(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, int ksplit,
                                 float* part, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                 int OH, int OW, wsmg_stream_t stream);
+/* nn.ConvTranspose2d forward without a gradient (the semantic classifier's first layer, mg_map_policy.py:59-61, on the rollout
+ * route): backward-data of the adjoint convolution with an epilogue bias over the Cin output channels (eval-mode BatchNorm folded
+ * into weight and bias) and flags bit 0 (float32 output) / bit 1 (ReLU).  x [B][OH][OW][Cout] -> y [B][H][W][Cin], w as IHWO. */
+int wsmg_conv_transpose2d_infer_bf16(const void* x, const void* w_ihwo, const float* bias, void* y, int flags, int B, int H, int W,
+                                     int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, wsmg_stream_t stream);
 int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
                               int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                               wsmg_stream_t stream);

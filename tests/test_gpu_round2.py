@@ -291,7 +291,7 @@ def test_high_res_e196_c40_bf16_rollout_route_vs_oracle():
             ego, ego_r = obs["rgb_ego_map"].cpu(), oc["rgb_ego_map"]
             assert tuple(ego.shape) == (2, 40, 196, 196)
             assert float((ego - ego_r).norm() / ego_r.norm()) <= 3e-2
-    assert pol.net._fold is not None and len(pol.net._fold.entries) == 19
+    assert pol.net._fold is not None and len(pol.net._fold.entries) == 20
 
 
 # ----------------------------------------------------------------------------- error paths
@@ -975,7 +975,7 @@ def test_rollout_fold_matches_unfolded_map_stack(monkeypatch):
         assert net._fold is None
         monkeypatch.setenv("WSMG_ROLLOUT_FOLD", "1")
         tok1, sem1 = net.map_stack(ego)
-        assert net._fold is not None and len(net._fold.entries) == 19
+        assert net._fold is not None and len(net._fold.entries) == 20
         tokf, semf = ref.net.map_stack(ego)
     for name, a, b, f in (("tokens", tok1, tok0, tokf), ("sem", sem1, sem0, semf)):
         a, b, f = a.float(), b.float(), f.float()
@@ -1225,3 +1225,32 @@ def test_copy_multi_copies_every_pair():
     for d, s in zip(dsts, srcs):
         assert torch.equal(d, s)
     assert float(guard.min()) == 7.0 and float(guard.max()) == 7.0
+
+
+@pytest.mark.gpu
+def test_conv_transpose_infer_with_folded_batchnorm():
+    """encoders.map_encoder.conv_transpose_infer (wsmg_conv_transpose2d_infer_bf16): ConvTranspose2d(k4, s2, p1) + eval-mode
+    BatchNorm + ReLU in one launch against the stock modules in float32 on the same bf16 input: 1.5 % of the output scale
+    (bf16 weights and output), exact zeros where ReLU clips."""
+    from wsmgmap.models.encoders.map_encoder import FoldCache, conv_transpose_infer
+    torch.manual_seed(2)
+    ct = torch.nn.ConvTranspose2d(64, 32, kernel_size=4, stride=2, padding=1, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(32).cuda().eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    x = torch.randn(3, 24, 24, 64, device="cuda").to(torch.bfloat16)
+    cache = FoldCache()
+    with torch.no_grad():
+        y = conv_transpose_infer(x, cache, ct, bn)
+        ref = torch.relu(bn(ct(x.float().permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (3, 48, 48, 32) and y.dtype == torch.bfloat16
+    assert float((y.float() - ref).abs().max()) <= 1.5e-2 * float(ref.abs().max())
+    assert float(y.float().min()) == 0.0
+    with torch.no_grad():       # the entry follows the parameters, in place
+        ptr = cache.get(None, None, bn, FoldCache.TRANSPOSED, 0, owner=ct)[0].data_ptr()
+        ct.weight.mul_(0.5)
+        assert cache.refresh() == 1
+        y2 = conv_transpose_infer(x, cache, ct, bn)
+        ref2 = torch.relu(bn(ct(x.float().permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
+    assert cache.get(None, None, bn, FoldCache.TRANSPOSED, 0, owner=ct)[0].data_ptr() == ptr
+    assert float((y2.float() - ref2).abs().max()) <= 1.5e-2 * float(ref2.abs().max())

@@ -788,6 +788,26 @@ extern "C" int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihw
   WSMG_RETURN_LAUNCH();
 }
 
+// ConvTranspose2d forward of the rollout route (the semantic classifier's first layer, mg_map_policy.py:59-61): the
+// backward-data kernel of the adjoint convolution WITH an epilogue bias over the Cin output channels (the folded eval-mode
+// BatchNorm shift) and the flag word's ReLU bit.  x = dy [B][OH][OW][Cout], y = dx [B][H][W][Cin].
+extern "C" int wsmg_conv_transpose2d_infer_bf16(const void* x, const void* w_ihwo, const float* bias, void* y, int flags, int B,
+                                                int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
+                                                int OW, wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  if (flags & ~3) return WSMG_EINVAL;
+  ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ihwo, bias, y, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, flags,
+              (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), nullptr, 0};
+  int classes = 1;
+  int64_t mmax = (int64_t)B * H * W;
+  if (stride == 2) {
+    classes = 4;
+    mmax = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  }
+  launch_igemm<true>(a, mmax, classes, wsmg_s(stream));
+  WSMG_RETURN_LAUNCH();
+}
+
 extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, void* dx, int out_f32, int B, int H, int W,
                                          int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                          wsmg_stream_t stream) {

@@ -67,6 +67,7 @@ for _n in ["wsmg_token_grad_merge", "wsmg_channel_sum", "wsmg_bn_act_fwd", "wsmg
     _SIG[_n + "_bf16"] = list(_SIG[_n])
 _SIG["wsmg_conv2d_fwd_bf16"] = [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
 _SIG["wsmg_conv2d_bwd_data_bf16"] = [c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
+_SIG["wsmg_conv_transpose2d_infer_bf16"] = [c_p, c_p, c_p, c_p, c_i] + [c_i] * 11 + [c_p]
 _SIG["wsmg_conv2d_splitk_plan"] = [c_i] * 7 + [c_p, c_p]
 _SIG["wsmg_conv2d_fwd_bf16_splitk"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_p] + [c_i] * 11 + [c_p]
 _SIG["wsmg_conv2d_fwd_bf16_stats"] = [c_p, c_p, c_p, c_p, c_i, c_p, c_i] + [c_i] * 11 + [c_p]

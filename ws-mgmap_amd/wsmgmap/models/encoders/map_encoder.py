@@ -74,6 +74,8 @@ class FoldCache:
     replay, and `refresh()` before a replay is all it takes to follow an optimizer step.  Per rollout step this removes the
     weight re-layout launch and the two BatchNorm launches per layer of the unfolded route."""
 
+    TRANSPOSED = -1     # `cin_pad` value that asks for the operands of an nn.ConvTranspose2d (conv_transpose_infer)
+
     def __init__(self):
         self.entries = {}
 
@@ -87,6 +89,16 @@ class FoldCache:
     @staticmethod
     @torch.no_grad()
     def _fold(weight, bias, bn, cin_pad, cout_pad):
+        if cin_pad == FoldCache.TRANSPOSED:     # nn.ConvTranspose2d parameter [Cin_t, Cout_t, KH, KW] -> IHWO = [Cout_t, KH, KW, Cin_t]
+            w = weight.float()
+            b = None if bias is None else bias.float()
+            if bn is not None:
+                scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                w = w * scale.view(1, -1, 1, 1)
+                b = bn.bias.float() - bn.running_mean.float() * scale + (0 if b is None else b * scale)
+            if b is not None and bias is not None and b.data_ptr() == bias.data_ptr():
+                b = b.clone()
+            return w.permute(1, 2, 3, 0).contiguous().to(torch.bfloat16), None if b is None else b.contiguous()
         w = weight.float()
         b = None if bias is None else bias.float()
         if bn is not None:
@@ -145,6 +157,12 @@ def conv_infer(x, cache: FoldCache, conv, bn=None, relu=True, residual=None, cou
         x = ops.cat_channels(x[0], x[1])
     w, b = cache.get(None, None, bn, x.shape[-1], cout_pad, owner=conv)
     return ops.conv2d_infer_bf16(x, w, b, conv.stride[0], conv.padding[0], relu, add_to=residual)
+
+
+def conv_transpose_infer(x, cache: FoldCache, convt: nn.ConvTranspose2d, bn=None, relu=True):
+    """One launch: ConvTranspose2d (+ folded eval-mode BatchNorm) (+ ReLU) on a bf16 NHWC activation, operands from `cache`."""
+    w, b = cache.get(None, None, bn, FoldCache.TRANSPOSED, 0, owner=convt)
+    return ops.conv_transpose2d_infer_bf16(x, w, b, convt.stride[0], convt.padding[0], relu)
 
 
 def convrelu(in_channels, out_channels, kernel, padding):

@@ -179,7 +179,7 @@ class MGMapNet(nn.Module):
         """The map stack in eval mode without autograd (the rollout step), bf16: every convolution takes cached, BatchNorm-
         folded OHWI operands (encoders.map_encoder.FoldCache) — one launch per conv + BN + ReLU, no per-step weight
         re-layout.  Same arithmetic as _map_stack up to the bf16 rounding of the folded weights."""
-        from .encoders.map_encoder import FoldCache, conv_infer
+        from .encoders.map_encoder import FoldCache, conv_infer, conv_transpose_infer
         if self._fold is None:
             self._fold = FoldCache()
         f = self._fold
@@ -190,8 +190,7 @@ class MGMapNet(nn.Module):
         enc_proj = conv_infer(enc, f, self.map_encoded_linear[0])
         dec = self.map_decoder(enc, fold=f)
         c = self.map_classfier
-        y = ops.conv_transpose2d(dec, c[0].weight, 2, 1, None)
-        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, False, True, None, c[1].momentum, c[1].eps, None)
+        y = conv_transpose_infer(dec, f, c[0], c[1])
         y = conv_infer(y, f, c[3], c[4])
         sem = conv_infer(y, f, c[6], relu=False, cout_pad=SEM_PAD)                   # [B,2S,2S,32], channels 27.. are 0
         self.sem_logits_nhwc = sem

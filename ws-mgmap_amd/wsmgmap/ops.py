@@ -642,6 +642,23 @@ def copy_multi(dsts, srcs):
     _abi.call("wsmg_copy_multi", ctypes.cast(arr, ctypes.c_void_p), len(pairs), _stream())
 
 
+def conv_transpose2d_infer_bf16(x, w_ihwo_bf16, bias, stride, pad, relu):
+    """Inference-only nn.ConvTranspose2d on a bf16 NHWC activation with a pre-laid-out IHWO bf16 weight ([Cout_t, KH, KW, Cin_t]
+    of the module's [Cin_t, Cout_t, KH, KW] parameter), float32 bias and optional fused ReLU — one launch
+    (wsmg_conv_transpose2d_infer_bf16; eval-mode BatchNorm folded into weight and bias by FoldCache)."""
+    _req(x, w_ihwo_bf16, bias)
+    if x.dtype != torch.bfloat16 or w_ihwo_bf16.dtype != torch.bfloat16:
+        raise _abi.WsmgError("conv_transpose2d_infer_bf16 needs bf16 activations and weights")
+    B, Hs, Ws, Ct_in = x.shape
+    I, KH, KW, O = w_ihwo_bf16.shape
+    assert O == Ct_in, (x.shape, w_ihwo_bf16.shape)
+    Hb, Wb = (Hs - 1) * stride - 2 * pad + KH, (Ws - 1) * stride - 2 * pad + KW
+    y = torch.empty(B, Hb, Wb, I, device=x.device, dtype=torch.bfloat16)
+    _launch("wsmg_conv_transpose2d_infer_bf16", 2.0 * B * Hs * Ws * O * I * KH * KW, _p(x), _p(w_ihwo_bf16), _p(bias), _p(y),
+            2 if relu else 0, B, Hb, Wb, I, O, KH, KW, stride, pad, Hs, Ws, _stream())
+    return y
+
+
 ROWS_MAX = 16     # rollout-size dense layers: up to this many rows go through linear_rows / act_heads
 
 
