@@ -52,6 +52,11 @@ class VlnResnetDepthEncoder(nn.Module):
         if not self.spatial_output:
             return self.visual_fc(x)
         b, c, h, w = x.size()
-        idx = torch.arange(0, self.spatial_embeddings.num_embeddings, device=x.device, dtype=torch.long)
-        spatial = self.spatial_embeddings(idx).view(1, -1, h, w).expand(b, self.spatial_embeddings.embedding_dim, h, w)
+        # the reference looks up ALL rows in order (embedding(arange(h * w)), resnet_encoders.py:86-98): that is the weight itself
+        # — same values, same gradient (every row is hit exactly once), no arange / gather launches and no sort-based
+        # embedding backward in the update
+        emb = self.spatial_embeddings
+        if emb.num_embeddings != h * w:
+            raise ValueError(f"spatial embedding table has {emb.num_embeddings} rows for a {h} x {w} feature map")
+        spatial = emb.weight.view(1, -1, h, w).expand(b, emb.embedding_dim, h, w)
         return torch.cat([x, spatial], dim=1)
