@@ -70,10 +70,39 @@ def dagger_loss(pred, aux_loss, waypoint, weights):
     return al + aux_loss
 
 
-def cpu_baseline(state, T_full, N, budget_s=20.0):
-    """The oracle's update step (fwd + loss + bwd + Adam, PyTorch CPU fp32) on the host cores.
-    Sample: the same workload at the largest T (<= T_full) expected to fit `budget_s`."""
+def host_cpu_info():
+    """(model string, physical cores, logical CPUs) of this host, from /proc/cpuinfo."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name" and model == "unknown":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None and cid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or logical or os.cpu_count() or 1), (logical or os.cpu_count() or 1)
+
+
+def cpu_baseline(state, T_full, N, budget_s=90.0):
+    """The oracle's update step (fwd + loss + bwd + Adam, PyTorch CPU fp32) on the host cores (one thread per
+    physical core, >= 1 warm-up + >= 2 timed updates, CPU model and core count in the report).
+    Sample: the same workload at the largest T in {T_full, 32, 16, ...} whose TWO timed updates are expected to fit `budget_s`."""
     from oracle import policy_ref
+    model, phys, logical = host_cpu_info()
+    torch.set_num_threads(max(1, phys))
     cores = torch.get_num_threads()
 
     def make_P():
@@ -109,17 +138,22 @@ def cpu_baseline(state, T_full, N, budget_s=20.0):
     # SURVEY.md 8d / BASELINE.md 3: the same cfg2 shapes (T=64, B=512) when the host does them within the budget, else
     # T=16 (B=128) scaled linearly, stated in `sample`; smaller only if even that does not fit.  The time per policy step
     # falls with the batch (BatchNorm / conv efficiency), so the estimate from T=4 is an upper bound.
-    if per_t * T_full <= budget_s:
-        T = T_full
-    elif per_t * 16 <= budget_s:
-        T = min(16, T_full)
-    else:
-        T = int(max(2, min(T_full, budget_s / max(per_t, 1e-3))))
-    dt = run(T)
+    reps = 2
+    T = None
+    for cand in (T_full, 32, 16, 8):
+        if cand <= T_full and per_t * cand * reps <= budget_s:
+            T = cand
+            break
+    if T is None:
+        T = int(max(2, min(T_full, budget_s / reps / max(per_t, 1e-3))))
+    dts = [run(T) for _ in range(reps)]
+    dt = sum(dts) / len(dts)
     scaled = "" if T == T_full else f" — T={T} instead of {T_full}: policy steps/s assumed linear in T"
-    return dict(value=T * N / dt, unit="policy steps/s", cores=cores, kind="port",
-                sample=f"1 update of T={T} x N={N} ({T * N} policy steps, {dt:.1f} s) of the oracle (PyTorch-CPU fp32 port "
-                       f"of the reference update: fwd+loss+bwd+Adam), {cores} threads{scaled}")
+    return dict(value=T * N / dt, unit="policy steps/s", cores=cores, kind="port", cpu_model=model, physical_cores=phys,
+                logical_cpus=logical, timed_updates=len(dts), seconds_per_update=[round(d, 2) for d in dts],
+                sample=f"{len(dts)} updates of T={T} x N={N} ({T * N} policy steps each; {', '.join('%.1f s' % d for d in dts)}; mean) "
+                       f"of the oracle (PyTorch-CPU fp32 port of the reference update: fwd+loss+bwd+Adam) after a warm-up, "
+                       f"{cores} threads = physical cores of {model}{scaled}")
 
 
 def measure(args, dtype, steps, warmup, rank, world, local, dev):
@@ -187,13 +221,32 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_begin(only=[dom_entry] if dom_entry else None)
+    WIN = 50                     # --steps >= 200: an event every 50 updates, for the `sustained` sub-object (no synchronisation)
+    marks = []
     t0 = time.perf_counter()
     host = 0.0
-    for _ in range(steps):
+    for i in range(steps):
+        if steps >= 200 and i % WIN == 0:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
         h0 = time.perf_counter()
         loss = update()
         host += time.perf_counter() - h0
+    if marks:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append(ev)
     torch.cuda.synchronize()
+    measure.sustained = None
+    if len(marks) >= 3:
+        spans = [(min(WIN, steps - j * WIN), marks[j].elapsed_time(marks[j + 1])) for j in range(len(marks) - 1)]
+        per = [ms / n for n, ms in spans if n > 0]
+        tail = per[len(per) // 2:]
+        measure.sustained = dict(updates=steps, window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
+                                 ms_per_update_first_window=round(per[0], 3),
+                                 ms_per_update_second_half=round(sum(tail) / len(tail), 3),
+                                 note="HIP-event time of consecutive 50-update windows inside the same timed region")
     if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
         print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
     if world > 1:
@@ -227,6 +280,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         opt.zero_grad(set_to_none=True)
         gopt = WsmgAdam(policy.parameters(), lr=2.5e-4, capturable=True)
         gu = GraphedUpdate(policy, gopt, lambda pred, aux, o, w: dagger_loss(pred, aux, o["waypoint"], w), eager_calls=2)
+        gu.register_static_inputs(obs, prev, masks, weights)   # the bench refills nothing: the graph reads the batch in place
         hs = torch.zeros(policy.net.num_recurrent_layers, N, 512, device=dev)
 
         def gupdate():
@@ -261,8 +315,8 @@ def main():
                     help="storage/MFMA type of the map stack: bf16 = BASELINE configs[1] (default); f32 = parity mode (1e-4 vs reference)")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra float32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=75.0,
-                    help="seconds the host may spend on the timed CPU-baseline update: T=64 if it fits, else T=16")
+    ap.add_argument("--cpu-budget", type=float, default=90.0,
+                    help="seconds the host may spend on the TWO timed CPU-baseline updates: T=64 if they fit, else T=32 / 16")
     args = ap.parse_args()
 
     share = os.environ.get("WSMG_BENCH_SHARE_GPU") == "1"
@@ -315,6 +369,7 @@ def main():
     dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)
     dp_info = measure.dp_info
     graphed = getattr(measure, "graphed", None)
+    sustained = getattr(measure, "sustained", None)
     parity = None
     if args.dtype == "bf16" and not args.no_f32:
         k32 = max(2, args.steps // 2)
@@ -394,6 +449,7 @@ def main():
             "loss": round(final_loss, 5),
             "f32_parity_mode": parity,
             "graphed_update": graphed,
+            "sustained": sustained,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
         }

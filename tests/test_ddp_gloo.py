@@ -101,3 +101,126 @@ def test_grad_allreduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+class Deep(torch.nn.Module):
+    """Five layers -> with 300-byte buckets at least four buckets, filled in reverse layer order."""
+
+    def __init__(self):
+        super().__init__()
+        self.l = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(5)])
+        self.extra = torch.nn.Linear(8, 8)      # live on some ranks only in the set-mismatch case
+
+    def forward(self, x, skip=None, extra=False):
+        for i, m in enumerate(self.l):
+            if i != skip:
+                x = torch.tanh(m(x))
+        if extra:
+            x = x + self.extra(x)
+        return x
+
+
+def _worker_order(rank, world, port, q):
+    """Layout agreement and the error paths of the in-order bucket issue (ADVICE r2 / VERDICT r2 item 3, reference contract:
+    DDP verifies parameter order and shapes across ranks at construction, common_trainer.py:60-66)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "ws-mgmap_amd"))
+    from wsmgmap.parallel import GradAllReducer, GradExchangeError
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    net = Deep()
+    torch.manual_seed(11)
+    data = torch.randn(world * 4, 8)
+    xs = data[rank * 4:(rank + 1) * 4]
+    ok = True
+
+    def want_grads(skip=None):
+        ref = Deep()
+        ref.load_state_dict(net.state_dict())
+        (ref(data, skip=skip) ** 2).mean().backward()
+        return [None if p.grad is None else p.grad.clone() for p in ref.parameters()]
+
+    # (1) one rank's discovery ORDER differs (injected): the layout is rank 0's everywhere and the averages are right
+    red = GradAllReducer(net.parameters(), bucket_bytes=300)
+    net.zero_grad(set_to_none=True)
+    (net(xs) ** 2).mean().backward()
+    if rank == 1:
+        red._order.reverse()
+    red.finish()
+    layout = [[red._index[id(p)] for p in b["params"]] for b in red._buckets]
+    got = [torch.tensor(sum(layout, []))]
+    gathered = [torch.zeros_like(got[0]) for _ in range(world)]
+    dist.all_gather(gathered, got[0])
+    ok = ok and all(torch.equal(gathered[0], g) for g in gathered) and len(red._buckets) >= 3
+    want = want_grads()
+    for it in range(2):     # hook / overlap path on the agreed layout
+        net.zero_grad(set_to_none=True)
+        (net(xs) ** 2).mean().backward()
+        red.finish()
+        ok = ok and all(torch.allclose(p.grad, w, atol=1e-6) for p, w in zip(net.parameters(), want) if w is not None)
+    # (2) rank 1 misses the gradients of a MIDDLE bucket (layer 2 skipped): every collective still pairs up (in-order issue),
+    #     the update's gradients are zeros on BOTH ranks (so an optimizer step cannot diverge them), both raise at the next finish()
+    net.zero_grad(set_to_none=True)
+    (net(xs, skip=2 if rank == 1 else None) ** 2).mean().backward()
+    red.finish()
+    zeros = all(float(p.grad.abs().max()) == 0.0 for p in net.l.parameters())
+    ok = ok and zeros
+    raised = False
+    try:
+        red.check()
+    except GradExchangeError as e:
+        raised = "1 of 2 ranks" in str(e) and (("no gradient" in str(e)) == (rank == 1))
+    ok = ok and raised and red._buckets is None
+    # ... and check_now=True raises inside the same finish(), before an optimizer could step
+    net.zero_grad(set_to_none=True)
+    (net(xs) ** 2).mean().backward()
+    red.finish()                                  # re-discovery
+    net.zero_grad(set_to_none=True)
+    (net(xs, skip=1 if rank == 0 else None) ** 2).mean().backward()
+    raised = False
+    try:
+        red.finish(check_now=True)
+    except GradExchangeError:
+        raised = True
+    ok = ok and raised
+    # (3) the ranks' live SETS differ in the discovery pass: both refuse
+    net.zero_grad(set_to_none=True)
+    (net(xs, extra=(rank == 1)) ** 2).mean().backward()
+    raised = False
+    try:
+        red.finish()
+    except GradExchangeError as e:
+        raised = "different parameter sets" in str(e)
+    ok = ok and raised
+    # (4) resync + statistics
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(float(rank))               # diverge the ranks on purpose
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    red.resync(net, opt)
+    w0 = net.l[0].weight.detach().clone()
+    gathered = [torch.zeros_like(w0) for _ in range(world)]
+    dist.all_gather(gathered, w0)
+    ok = ok and all(torch.equal(gathered[0], g) for g in gathered)
+    net.zero_grad(set_to_none=True)
+    (net(xs) ** 2).mean().backward()
+    red.finish()
+    st = red.stats()
+    ok = ok and st["updates"] >= 5 and st["buckets"] >= 3 and st["live_gradient_bytes"] == 5 * (64 + 8) * 4 and st["host_ms_in_finish"] > 0
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_layout_agreement_and_inorder_error_paths():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_order, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)], res

@@ -282,6 +282,16 @@ def test_checkpoint_with_unimportable_config_class_still_loads(tmp_path):
     d = ck.load_checkpoint(str(tmp_path / "c.pth"))
     assert torch.equal(d["state_dict"]["w"], torch.arange(3.0)) and d["extra_state"]["dagger_it"] == 1
     assert d["config"]["LR"] == 1e-3
+    # the full unpickler is a caller's choice, and only the safe loader's REJECTION leads to it
+    with pytest.raises(pickle.UnpicklingError):
+        ck.load_checkpoint(str(tmp_path / "c.pth"), allow_pickle=False)
+    (tmp_path / "corrupt.pth").write_bytes(b"this is not a checkpoint")
+    with pytest.raises(Exception) as ei:
+        ck.load_checkpoint(str(tmp_path / "corrupt.pth"))
+    assert not isinstance(ei.value, AttributeError)
+    # a stand-in created through REDUCE (called with constructor arguments) keeps them instead of failing obscurely
+    o = ck._LenientUnpickler.find_class(ck._LenientUnpickler.__new__(ck._LenientUnpickler), "no_such_pkg_xyz", "Thing")(1, 2, key=3)
+    assert o["__args__"] == (1, 2) and o["__kwargs__"] == {"key": 3}
 
 
 # ----------------------------------------------------------------------------- depth branch from raw depth

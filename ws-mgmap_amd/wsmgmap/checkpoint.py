@@ -40,6 +40,14 @@ def save_checkpoint(policy, checkpoint_folder, file_name, config=None, extra_sta
 class _Opaque(dict):
     """Stand-in for a pickled object whose class cannot be imported (e.g. yacs CfgNode without yacs installed)."""
 
+    def __init__(self, *args, **kwargs):
+        # (a class that pickle re-creates through REDUCE is CALLED with its constructor arguments: keep them, whatever they are)
+        super().__init__()
+        if args:
+            self["__args__"] = args
+        if kwargs:
+            self["__kwargs__"] = kwargs
+
     def __setstate__(self, state):
         if isinstance(state, dict):
             self.update(state)
@@ -72,12 +80,20 @@ class _LenientPickle:
     HIGHEST_PROTOCOL = pickle.HIGHEST_PROTOCOL
 
 
-def load_checkpoint(checkpoint_path, map_location="cpu"):
-    """common_trainer.py:105-116.  Tensors-only files take torch's safe loader; files with a pickled config object (every
-    checkpoint the reference writes) need the full unpickler — load only checkpoints you trust, as with the reference."""
+def load_checkpoint(checkpoint_path, map_location="cpu", allow_pickle=True):
+    """common_trainer.py:105-116.  Tensors-only files take torch's safe loader.  Files with a pickled config object (every
+    checkpoint the reference writes) are REJECTED by it (pickle.UnpicklingError) and need the full unpickler, which can run
+    code from the file: that second attempt is made only for that rejection — a corrupt or unreadable file raises as it is —
+    only with allow_pickle=True (the default, because it is what the reference's `torch.load` does: load only checkpoints
+    you trust), and says so in a warning."""
     try:
         return torch.load(checkpoint_path, map_location=map_location, weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError as e:
+        if not allow_pickle:
+            raise
+        import warnings
+        warnings.warn(f"{checkpoint_path}: not a tensors-only file ({str(e).splitlines()[0][:120]}); loading it with the full "
+                      "unpickler, as the reference does — only do this with checkpoints you trust", RuntimeWarning, stacklevel=2)
         return torch.load(checkpoint_path, map_location=map_location, weights_only=False, pickle_module=_LenientPickle)
 
 

@@ -91,6 +91,10 @@ class GraphedAct:
         if refresh is not None:      # the rollout route's folded convolution operands follow the parameters (in place)
             refresh()
         g["graph"].replay()
+        # the reference's act() leaves the new hidden state in the caller's tensor (mg_map_policy.py:220-227,242-249 write
+        # rnn_hidden_states in place): so does the replay.  The returned tensors are owned by the graph — valid until the next
+        # call ("output lifetime").
+        rnn_hidden_states.copy_(g["out"][3])
         return g["out"]
 
     def _capture(self, observations, rnn_hidden_states, prev_actions, masks, deterministic, dd):
@@ -121,7 +125,10 @@ class GraphedUpdate:
         self.policy, self.optimizer, self.loss_fn = policy, optimizer, loss_fn
         self.eager_calls = max(1, int(eager_calls))   # at least one: the optimizer's device-side step counters are created eagerly
         self.calls = 0
-        self._graphs = {}
+        self._graphs = {}      # signature -> captured graph, least recently used first; at most `max_graphs` are kept
+        self.max_graphs = 4
+        self._static = {}      # id(tensor) -> tensor: inputs the caller registered as static buffers (adopted, never cloned)
+        self._written = None   # parameters + buffers a replay rewrites behind autograd's back (version bumps after a replay)
         self._dd_stream = None
         self._stream = None    # the eager updates run on a side stream: autograd's AccumulateGrad nodes remember the stream they
         #                        were created on, and one that lives on the default stream breaks a later capture
@@ -166,6 +173,28 @@ class GraphedUpdate:
             raise _abi.WsmgError(f"GraphedUpdate: {len(left)} tensor(s) of an earlier autograd graph are still referenced ({what}); "
                                  "drop them (del loss, predictions, ...) before the first graphed update")
 
+    def register_static_inputs(self, *tensors):
+        """Declare input tensors (observation tensors, masks, ...) as STATIC buffers: the captured graph reads them in place, so a
+        caller that refills the same buffers for every batch pays no copy (the cached ego map alone is 1.3 GB per update).  Any
+        other input tensor is cloned at capture and copied into that clone on every call — the caller's tensors are never
+        written to."""
+        for t in tensors:
+            if isinstance(t, dict):
+                self.register_static_inputs(*[v for v in t.values() if torch.is_tensor(v)])
+            elif torch.is_tensor(t):
+                self._static[id(t)] = t
+        return self
+
+    def _adopt(self, t):
+        return t if id(t) in self._static else t.clone()
+
+    def _bump_versions(self):
+        """A replay rewrote parameters (the optimizer step), BatchNorm running statistics and counters without any autograd
+        version counter noticing; caches of derived operands (FoldCache, packed LSTM weights) compare those counters."""
+        if self._written is None:
+            self._written = [p for p in self.policy.parameters()] + [b for b in self.policy.buffers()]
+        torch.autograd.graph.increment_version(self._written)
+
     # -- the update itself (what is captured) ------------------------------------------------------------------------------
     def _update(self, obs, h_in, prev_actions, masks, weights):
         self.optimizer.zero_grad(set_to_none=True)
@@ -205,11 +234,14 @@ class GraphedUpdate:
             cur.wait_stream(self._stream)
             return loss
         key = self._signature(observations, rnn_hidden_states, prev_actions, masks, weights, dd)
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
+            while len(self._graphs) >= self.max_graphs:      # every graph owns a private memory pool: evict the least recently used
+                old_key = next(iter(self._graphs))
+                self._graphs.pop(old_key)["graph"].reset()
             g = self._capture(observations, rnn_hidden_states, prev_actions, masks, weights, dd)
-            self._graphs[key] = g
-        # inputs: same storage -> nothing to do; new storage -> copy into the captured tensors
+        self._graphs[key] = g                                # (re-inserted last = most recently used)
+        # inputs: same storage (a registered static buffer) -> nothing to do; other storage -> copy into the graph's own tensors
         for k, s in g["obs"].items():
             v = observations[k]
             if v.data_ptr() != s.data_ptr():
@@ -221,11 +253,15 @@ class GraphedUpdate:
         g["graph"].replay()
         if hasattr(self.optimizer, "note_replayed_steps"):
             self.optimizer.note_replayed_steps(1)
+        self._bump_versions()
         rnn_hidden_states.copy_(g["h_out"])
         return g["loss"]
 
     def _capture(self, observations, rnn_hidden_states, prev_actions, masks, weights, dd):
-        obs_s = {k: v for k, v in observations.items() if torch.is_tensor(v)}
+        # the graph's static inputs: registered static buffers are adopted, everything else is CLONED — a later call with tensors
+        # at other addresses copies into the clones, never into a batch the caller still holds
+        obs_s = {k: self._adopt(v) for k, v in observations.items() if torch.is_tensor(v)}
+        prev_actions, masks, weights = self._adopt(prev_actions), self._adopt(masks), self._adopt(weights)
         dd_s = (dd[0].clone(), dd[1].clone(), dd[2].clone(), dd[3].clone())   # owned copies: the eager dedup returns fresh tensors
         h_in = rnn_hidden_states.clone()
         obs_c = dict(obs_s)

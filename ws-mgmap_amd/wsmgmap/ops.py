@@ -760,6 +760,9 @@ class _BnAct(torch.autograd.Function):
             _abi.call("wsmg_bn_act_fwd" + sfx, _p(x), _p(residual), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                       float(momentum), float(eps), int(train), int(relu), rows, C, _p(y), _p(mean), _p(invstd),
                       _p(ws), ws.numel() * 8, _stream())
+        if train:   # the kernel wrote the running statistics through raw pointers: tell autograd's version counters, which
+            #         the rollout route's FoldCache keys its folded operands on
+            torch.autograd.graph.increment_version([running_mean, running_var])
         # without a residual the ReLU mask is recomputed from x in the backward kernels: y is neither kept nor read
         keep_y = relu and residual is not None
         ctx.save_for_backward(x, y if keep_y else None, gamma, beta, mean, invstd)

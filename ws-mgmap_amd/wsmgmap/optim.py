@@ -79,14 +79,21 @@ class Adam(torch.optim.Optimizer):
                     else:
                         _abi.call("wsmg_adam_step_multi", descs, len(items), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                   float(group["weight_decay"]), 1.0 - b1 ** step, 1.0 - b2 ** step, stream)
+                # the kernel wrote the parameters through raw pointers: advance their autograd version counters, which is what
+                # caches of derived operands (FoldCache, InstructionEncoder.packed_lstm_weights) compare
+                torch.autograd.graph.increment_version([it[0] for it in items])
         return loss
 
     def note_replayed_steps(self, n=1):
         """A captured graph that contains this optimizer's step was replayed n times: advance the host-side step counts (the
         device counters advanced inside the graph)."""
-        for st in self.state.values():
+        stepped = []
+        for p, st in self.state.items():
             if "step" in st:
                 st["step"] += n
+                stepped.append(p)
+        if n > 0 and stepped:     # the replay rewrote them without any version counter noticing
+            torch.autograd.graph.increment_version(stepped)
 
     def state_dict(self):
         sd = super().state_dict()

@@ -10,18 +10,33 @@ resnet18 layers 2-4 / fc, critic, logstd); here the first backward discovers whi
 (8.23 M, 32.9 MB) and only those are exchanged, in buckets filled in gradient-ready order (xGMI ring
 all-reduce is per-link bound, so a few ~8 MB buckets keep every link busy while backward continues).
 
+What DDP guarantees at construction — every rank reduces the same tensors in the same order
+(common_trainer.py:60-66 → torch's `_verify_param_shape_across_processes`) — is established here after the
+discovery pass: rank 0's gradient-ready order is broadcast and becomes EVERY rank's bucket layout, and a 64-bit
+digest of each rank's live SET (parameter index, numel, dtype) is all-reduced (MIN and MAX): ranks whose backward
+passes touched different parameters raise `GradExchangeError` together instead of averaging unrelated tensors.
+Buckets are issued strictly in index order on every rank (a bucket that is ready waits for its predecessors),
+also on the error path, because NCCL/RCCL and gloo pair collectives by issue order.
+
 BatchNorm statistics stay per rank (no SyncBN), like the reference; `broadcast_buffers()` gives every rank
 rank 0's buffers (what DDP's per-forward buffer broadcast, C4 in SURVEY.md, amounts to at checkpoint time).
 
-Errors are agreed on across ranks: a rank that sees a local problem (a gradient outside the discovered live
-set, a live parameter without a gradient, a persistent-RNN timeout) still takes part in every collective of the
-update — so no peer blocks in an all-reduce — and raises a flag that is summed over the ranks by one
-extra 4-byte all-reduce per update; every rank reads the sum at the start of the NEXT `finish()` (by then the
-copy to pinned memory is long complete: no stall) and all of them raise there together, after resetting to a
-fresh discovery pass.
+Errors are agreed on across ranks BEFORE the optimizer can use the gradients: a rank that sees a local problem (a
+gradient outside the discovered live set, a live parameter without a gradient, a persistent-RNN timeout) still
+takes part in every collective of the update — so no peer blocks in an all-reduce — and raises a flag that one
+4-byte all-reduce sums inside `finish()`; the averaged gradients of ALL ranks are then replaced by zeros on the
+device (`masked_fill_(flag, 0)`: no host synchronisation), so the `optimizer.step()` that follows applies the same
+(momentum-only, finite) step everywhere and the ranks' parameters stay identical.  Every rank reads the summed
+flag at the start of the NEXT `finish()` (by then the copy to pinned memory is long complete: no stall) — or in
+this one with `finish(check_now=True)`, at the price of a host synchronisation per update — and all of them raise
+together, after resetting to a fresh discovery pass.  `resync()` re-broadcasts rank 0's parameters, buffers and
+optimizer state for callers that want to continue after such an error.
 
 Works with any torch.distributed backend (gloo on CPU for tests).
 """
+import time
+import zlib
+
 import torch
 import torch.distributed as dist
 
@@ -39,6 +54,7 @@ class GradAllReducer:
                 seen.add(id(p))
                 uniq.append(p)
         self.params = uniq
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         self.bucket_bytes = bucket_bytes
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -46,12 +62,15 @@ class GradAllReducer:
         self._buckets = None      # list of dicts: params, flat buffer, pending count
         self._where = {}          # id(param) -> (bucket index, offset)
         self._works = []
+        self._next = 0            # buckets are issued in index order: the next one to launch
         self._local_error = None  # first local problem of the running update
         self._flag = None         # device int32 [1]: this rank's error flag, summed over the ranks
         self._flag_host = None    # pinned copy of the summed flag of the previous update (+ event)
         self._flag_event = None
         self._flag_pending = False
         self._prev_error = None
+        self._timing = []         # per update: (host seconds inside finish(), event at finish() entry, event after the last wait)
+        self._stats = dict(updates=0, host_wait_ms=0.0, exposed_ms=0.0, exposed_max_ms=0.0)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     # -- setup ---------------------------------------------------------------------
@@ -61,6 +80,7 @@ class GradAllReducer:
             return
         for t in list(module.parameters()) + [b for b in module.buffers() if b.is_floating_point() or b.dtype == torch.int64]:
             dist.broadcast(t.data, src=src, group=self.group)
+            torch.autograd.graph.increment_version(t)
 
     def broadcast_buffers(self, module, src=0):
         """rank-`src` buffers (BatchNorm running statistics, counters) to every rank: the state DDP's
@@ -72,6 +92,41 @@ class GradAllReducer:
         for b in module.buffers():
             if b.is_floating_point() or b.dtype == torch.int64:
                 dist.broadcast(b.data, src=src, group=self.group)
+                torch.autograd.graph.increment_version(b)
+
+    def resync(self, module, optimizer=None, src=0):
+        """After a GradExchangeError: rank-`src` parameters, buffers and (if given) optimizer state tensors to every rank, so
+        training can continue from one consistent state (a rank whose forward pass produced NaN — a persistent-RNN timeout —
+        may hold NaN BatchNorm statistics; the zeroed gradients kept its parameters in step with the others)."""
+        self.broadcast_parameters(module, src)
+        if optimizer is not None and self.world > 1:
+            for group in optimizer.param_groups:
+                for p in group["params"]:
+                    st = optimizer.state.get(p)
+                    if not st:
+                        continue
+                    for k in sorted(st):
+                        v = st[k]
+                        if torch.is_tensor(v) and v.device == p.device:
+                            dist.broadcast(v, src=src, group=self.group)
+
+    def _agree_on_layout(self):
+        """After the discovery pass: every rank must have found the same live SET; the ORDER (bucket layout) is rank 0's."""
+        dev = self.params[0].device
+        items = sorted((self._index[id(p)], p.numel(), str(p.dtype)) for p in self._order)
+        digest = zlib.crc32(repr(items).encode()) | (len(items) << 32)          # < 2^63
+        t = torch.tensor([digest, -digest], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        hi, lo = int(t[0]), -int(t[1])
+        if hi != lo:
+            mine = len(items)
+            self.reset()
+            raise GradExchangeError(f"the ranks' backward passes produced gradients for different parameter sets (this rank: {mine} "
+                                    f"live parameters, digest {digest:#x}; over the ranks {lo:#x} .. {hi:#x}): refusing to average "
+                                    "unrelated tensors")
+        order = torch.tensor([self._index[id(p)] for p in self._order], dtype=torch.int64, device=dev)
+        dist.broadcast(order, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        self._order = [self.params[i] for i in order.tolist()]
 
     def _build_buckets(self):
         live = self._order
@@ -100,6 +155,7 @@ class GradAllReducer:
                 o2 += p.numel()
             out.append(dict(params=ps, flat=flat, views=views, pending=len(ps), total=len(ps), launched=False))
         self._buckets = out
+        self._next = 0
 
     @property
     def live_bytes(self):
@@ -136,6 +192,12 @@ class GradAllReducer:
         b["launched"] = True
         self._works.append((bi, dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
+    def _launch_ready(self):
+        """Issue every ready bucket whose predecessors have been issued: all ranks issue bucket 0, 1, 2, ... in that order."""
+        while self._next < len(self._buckets) and self._buckets[self._next]["pending"] == 0:
+            self._launch(self._next)
+            self._next += 1
+
     def _on_grad(self, p):
         if self.world == 1:
             return
@@ -156,10 +218,11 @@ class GradAllReducer:
             ev.record(torch.cuda.current_stream())
             b.setdefault("events", []).append(ev)
         if b["pending"] == 0:
-            self._launch(bi)
+            self._launch_ready()
 
     def reset(self):
         self._order, self._buckets, self._where, self._works = [], None, {}, []
+        self._next = 0
         self._local_error = None
 
     def _raise_if_flagged(self):
@@ -175,9 +238,11 @@ class GradAllReducer:
             self.reset()
             raise GradExchangeError(f"{n} of {self.world} ranks reported an error in the previous update"
                                     + (f" (this rank: {mine})" if mine else " (not this rank)")
-                                    + "; the live-gradient set will be re-discovered on the next update")
+                                    + "; that update's gradients were replaced by zeros on every rank (parameters stayed in step); "
+                                      "the live-gradient set will be re-discovered on the next update")
 
     def _exchange_flag(self, dev):
+        """-> device bool [1]: did any rank flag an error in THIS update (stream-ordered, no host synchronisation)."""
         if self._flag is None:
             self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
             self._flag_host = torch.zeros(1, dtype=torch.int32, pin_memory=dev.type == "cuda")
@@ -190,43 +255,93 @@ class GradAllReducer:
             self._flag_event.record(torch.cuda.current_stream())
         self._prev_error, self._local_error = self._local_error, None
         self._flag_pending = True
+        return self._flag > 0
 
-    def finish(self):
-        """Call after backward(): waits for the exchanges and writes averaged gradients back."""
+    def finish(self, check_now=False):
+        """Call after backward() and before optimizer.step(): waits for the exchanges (the compute stream waits, not the host)
+        and leaves the averaged gradients in `p.grad` — zeros on every rank if any rank flagged an error in this update.
+        check_now=True: read the ranks' error flag of THIS update before returning (one host synchronisation per update) and
+        raise GradExchangeError here; default: the flag is read at the start of the next finish()."""
         if self.world == 1:
             return
         self._raise_if_flagged()
+        t_host = time.perf_counter()
         dev = self.params[0].device
+        ev0 = ev1 = None
         if dev.type == "cuda":
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream())      # the backward pass ends here on the compute stream
             from . import _abi
             try:
                 _abi.check_rnn_status()
             except _abi.WsmgError as e:   # agreed on with the other ranks below: no rank may leave the collectives alone
                 self._note(str(e))
         if self._buckets is None:  # first update: discovery pass, exchange synchronously
+            self._agree_on_layout()
             self._build_buckets()
             for b in self._buckets:
                 torch._foreach_copy_(b["views"], [p.grad for p in b["params"]])
                 dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)
             done = range(len(self._buckets))
         else:
-            for bi, b in enumerate(self._buckets):
-                if not b["launched"]:
-                    self._note("a live parameter received no gradient in this update")
-                    self._launch(bi)          # with zeros for the missing ones: the peers are waiting in this all-reduce
+            if self._next < len(self._buckets):
+                # (only on an error path: a bucket never became ready.  The rest go out now, in index order — the order the
+                # peers issue theirs in — with zeros for the missing gradients.)
+                self._note("a live parameter received no gradient in this update")
+                while self._next < len(self._buckets):
+                    self._launch(self._next)
+                    self._next += 1
             for _, w in self._works:
                 w.wait()
             done = [bi for bi, _ in self._works]
+        bad = self._exchange_flag(dev)
         inv = 1.0 / self.world
         for bi in done:
             b = self._buckets[bi]
-            b["flat"].mul_(inv)                      # one kernel per bucket
+            b["flat"].mul_(inv)
+            b["flat"].masked_fill_(bad, 0.0)             # an error on any rank: the same zeros everywhere (NaN included)
             for p, v in zip(b["params"], b["views"]):
                 p.grad = v                           # the averaged gradient lives in the bucket: no copy back
             b["pending"] = b["total"]
             b["launched"] = False
         self._works = []
-        self._exchange_flag(dev)
+        self._next = 0
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream())
+        self._timing.append((time.perf_counter() - t_host, ev0, ev1))
+        if len(self._timing) > 64:
+            self._fold_timing(keep=8)
+        if check_now:
+            self._raise_if_flagged()
+
+    def _fold_timing(self, keep=0):
+        """Fold completed updates' timings into the running statistics (events of the newest `keep` updates may be in flight)."""
+        todo, self._timing = self._timing[:len(self._timing) - keep], self._timing[len(self._timing) - keep:]
+        for host_s, ev0, ev1 in todo:
+            exposed = 0.0
+            if ev0 is not None and ev1 is not None:
+                ev1.synchronize()
+                exposed = ev0.elapsed_time(ev1)
+            s = self._stats
+            s["updates"] += 1
+            s["host_wait_ms"] += host_s * 1e3
+            s["exposed_ms"] += exposed
+            s["exposed_max_ms"] = max(s["exposed_max_ms"], exposed)
+
+    def stats(self, reset=False):
+        """Per-update means since construction (or the last reset): `host_ms_in_finish` = host time spent inside finish()
+        (enqueueing the waits, the flag exchange and the scale kernels); `exposed_allreduce_ms` = time on the compute stream
+        between the end of the backward pass and the last averaged bucket — the part of the gradient exchange that backward
+        did NOT hide."""
+        self._fold_timing()
+        s = self._stats
+        n = max(1, s["updates"])
+        out = dict(updates=s["updates"], exposed_allreduce_ms=round(s["exposed_ms"] / n, 4), exposed_allreduce_max_ms=round(s["exposed_max_ms"], 4),
+                   host_ms_in_finish=round(s["host_wait_ms"] / n, 4), buckets=self.num_buckets, live_gradient_bytes=self.live_bytes)
+        if reset:
+            self._stats = dict(updates=0, host_wait_ms=0.0, exposed_ms=0.0, exposed_max_ms=0.0)
+        return out
 
     def check(self):
         """Synchronous form of the deferred error check (end of training / tests)."""
