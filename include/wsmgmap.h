@@ -351,6 +351,29 @@ int wsmg_weight_relayout_bf16(const float* w_oihw, int O, int I, int KH, int KW,
 int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW, int I_pad, float* dw_oihw,
                              wsmg_stream_t stream);
 
+/* DETERMINISTIC weight gradients (the reference sets torch.backends.cudnn.deterministic = True, run.py:107-108; the weight
+ * gradient itself is cuDNN's behind torch.nn.Conv2d / ConvTranspose2d, map_encoder.py:19-29,94-112, mg_map_policy.py:78-100).
+ * The reduction over B*OH*OW pixels is split over `nsplit` workgroup ranges; instead of adding its partial tile into dW with
+ * float atomics (arrival order: two runs differ in the last bits), every workgroup STORES it into its own slab of a workspace
+ * ws [nsplit][Cout][KH][KW][Cin] float32 — nothing to zero, every element written exactly once — and
+ * wsmg_weight_grad_reduce_oihw adds the slabs in an order that depends on nsplit only while it re-lays the result out as
+ * the parameter's OIHW gradient (input channels >= I, the engine's padding, dropped).  Three calls per layer:
+ *   1. _plan   -> nsplit and the workspace size in floats for this geometry (host only, no launch);
+ *   2. _slabs  -> the partial sums (same kernels, same tiles and rates as wsmg_conv2d_bwd_weight[_bf16]); nsplit / ws_floats
+ *                 are checked against the plan (WSMG_EINVAL);
+ *   3. wsmg_weight_grad_reduce_oihw(ws, nsplit, O = Cout, I, KH, KW, I_pad = Cin, dw_oihw).
+ * The workspace may be reused by the next layer on the same stream. */
+int wsmg_conv2d_bwd_weight_bf16_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                     int* nsplit, long long* ws_floats);
+int wsmg_conv2d_bwd_weight_bf16_slabs(const void* x, const void* dy, float* ws, int nsplit, long long ws_floats, int B, int H, int W,
+                                      int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, wsmg_stream_t stream);
+int wsmg_conv2d_bwd_weight_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                int* nsplit, long long* ws_floats);
+int wsmg_conv2d_bwd_weight_slabs(const float* x, const float* dy, float* ws, int nsplit, long long ws_floats, int B, int H, int W,
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, wsmg_stream_t stream);
+int wsmg_weight_grad_reduce_oihw(const float* ws, int nsplit, int O, int I, int KH, int KW, int I_pad, float* dw_oihw,
+                                 wsmg_stream_t stream);
+
 /* torch.cat([a, b], dim=1) of the reference's NCHW tensors (UNet skip connections map_encoder.py:104,110, map
  * projections mg_map_policy.py:99) on NHWC storage: y[p] = a[p] ++ b[p] for `rows` pixels; a pixel's channel run is
  * bytes_a / bytes_b bytes (multiples of 16; any element type), 16-byte aligned pointers. */

@@ -321,21 +321,31 @@ def test_frozen_rgb_unet_on_the_bf16_engine_tracks_the_stock_path():
             assert rel < 2e-2, (hw, name, rel)
 
 
-def test_update_gradients_repeatable_with_side_streams():
-    """The update runs parts of the graph on side streams (instruction branch, the decoder's full-resolution branch).
-    Two evaluations of the same update from the same state must give the same gradients up to the summation order of
-    the float32 atomics (cosine of the whole gradient >= 0.99999; a reduction workspace shared between streams — the bug
-    this guards — moved the loss by 10-20 % within 30 steps).  T=16 x N=8, bf16 mode, 3 repeats."""
+def test_update_gradients_repeatable_with_side_streams(monkeypatch):
+    """The update runs parts of the graph on side streams (instruction branch, the decoder's full-resolution branch), and the
+    reference asks for deterministic kernels (`torch.backends.cudnn.deterministic = True`, run.py:107-108).  Since round 3 the
+    weight gradients leave the conv kernels as per-workgroup slabs that one launch adds in a fixed order (no float atomics):
+    two evaluations of the same update from the same state give BIT-IDENTICAL logits, loss and gradients — every tensor,
+    `torch.equal`.  (A reduction workspace shared between streams — the bug this test first guarded — moved the loss by
+    10-20 % within 30 steps.)  T=16 x N=8, bf16 mode and float32 mode, 3 repeats each.  With WSMG_WGRAD_ATOMICS=1 (the
+    round-2 form, kept for A/B) the old bar holds: cosine >= 0.99999, every large tensor within 1e-2 of max|grad|."""
     from wsmgmap.config import default_model_config
     from wsmgmap.models.policy import BasePolicy
     torch.manual_seed(0)
     state = BasePolicy(None, _Box(), default_model_config()).state_dict()
-    runs = [_bench_like_update("bf16", 16, 8, state) for _ in range(3)]
+    for mode, Tn in (("bf16", 16), ("f32", 4)):
+        runs = [_bench_like_update(mode, Tn, 8, state) for _ in range(3)]
+        p0, l0, g0 = runs[0]
+        for p, l, g in runs[1:]:
+            assert torch.equal(p, p0), "forward differs between identical evaluations"
+            assert l == l0, (l, l0)
+            diff = [n for n in g0 if not torch.equal(g[n], g0[n])]
+            assert not diff, f"{mode}: {len(diff)} gradient tensors differ between two identical updates: {diff[:6]}"
+    monkeypatch.setenv("WSMG_WGRAD_ATOMICS", "1")
+    runs = [_bench_like_update("bf16", 16, 8, state) for _ in range(2)]
     p0, l0, g0 = runs[0]
     a = torch.cat([g0[n].flatten() for n in g0])
     for p, l, g in runs[1:]:
-        assert float((p - p0).abs().max()) <= 1e-5, "forward differs between identical evaluations"
-        assert abs(l - l0) <= 1e-5 * abs(l0)
         b = torch.cat([g[n].flatten() for n in g0])
         cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
         assert cos >= 0.99999, cos

@@ -1,0 +1,421 @@
+"""GPU parity, round 3 (VERDICT r02 "Next round" 2, 7 and ADVICE r02 high / medium): the BACKWARD pass at the bench size
+against the oracle's `loss.backward()`, a 20-update training trajectory in both numeric modes, checkpoint save / resume on
+CUDA policies whose rollout caches hold stale operands, and the version counters that those caches key on after writes
+that happen behind autograd's back (the multi-tensor Adam kernel, train-mode BatchNorm statistics, graph replays)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import policy_ref
+from util import NULL_GRAD
+
+import test_gpu_round2 as r2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_grads(state, obs, prev, masks, weights, N, dtype=torch.float32):
+    """The oracle's update step on the host in `dtype`: forward + DAgger loss + backward; -> (pred, loss, {state_dict key: grad})."""
+    P = {k: (v.detach().cpu().clone().to(dtype) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in state.items()}
+    for k, t in P.items():
+        if t.is_floating_point() and not k.startswith(("net.rgb_encoder", "net.instruction_encoder.embedding")) \
+                and "running_" not in k and k != "net._scale":
+            t.requires_grad_(True)
+    ref = policy_ref.PolicyRef(P, num_proc=1)
+    ref.aux_active = True
+    cast = lambda v: v.cpu().to(dtype) if v.is_floating_point() else v.cpu()   # noqa: E731
+    oc = {k: cast(v) for k, v in obs.items()}
+    torch.set_default_dtype(dtype)
+    try:
+        pred, aux, _, _ = ref.forward(oc, torch.zeros(2, N, 512, dtype=dtype), cast(prev), cast(masks), cast(weights))
+        loss, _ = policy_ref.dagger_loss(pred, aux, oc["waypoint"], cast(weights))
+        loss.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return pred.detach(), float(loss.detach()), {k: t.grad for k, t in P.items() if t.requires_grad and t.grad is not None}
+
+
+# ----------------------------------------------------------------------------- backward at the bench size vs the oracle
+def test_bench_workload_f32_backward_vs_oracle_full_size():
+    """BASELINE configs[1] exactly as bench.py builds it (T=64 x N=8 = 512 rows), float32 mode: EVERY gradient tensor of
+    the update against the oracle's `loss.backward()` evaluated on this box's host cores (models/policy.py:91-103 +
+    dagger_trainer.py:526-541 of the reference; the 30-60 s leg bench.py's cpu_baseline also runs).
+
+    Bars.  The whole gradient: cosine >= 0.99999 against the float32 oracle (measured 1.00000000), the same live set.  Per
+    tensor the asked-for bar is max|g - g_ref| <= 1e-3 max|g_ref| — which float32 arithmetic itself does not meet here: through
+    13 train-mode BatchNorms over 73 728-294 912 elements per channel, two correct float32 evaluations (this path and the
+    float32 CPU oracle) sit up to 1.6e-2 apart on the decoder stem's weight.  So the oracle is ALSO evaluated in float64
+    (the truth, ≈4x the float32 time) and every tensor must be within 1e-3 of it, or no farther from it than twice the
+    float32 CPU oracle is — the rule of test_update_path_gradients_full_tensor_vs_oracle (B = 6), tightened from 4x / 5e-3."""
+    import bench
+    from wsmgmap.common.aux_losses import AuxLosses
+    Tn, N = 64, 8
+    state = r2._default_state()
+    obs, prev, masks, weights = bench.synth_batch(Tn, N, "cuda", 77)
+    pol = r2._train_mode(r2._policy(num_proc=1, state=state))
+    AuxLosses.activate()
+    AuxLosses.clear()
+    pred, aux = pol(dict(obs), torch.zeros(2, N, 512, device="cuda"), prev, masks, weights)
+    loss = bench.dagger_loss(pred, aux, obs["waypoint"], weights)
+    loss.backward()
+    AuxLosses.deactivate()
+    got = {n: p.grad.detach().cpu() for n, p in pol.named_parameters() if p.grad is not None}
+    pr, lr, want = _oracle_grads(state, obs, prev, masks, weights, N)
+    assert float((pred.detach().cpu() - pr).abs().max()) <= 1e-4 and abs(float(loss.detach()) - lr) <= 1e-4
+    _, l64, truth = _oracle_grads(state, obs, prev, masks, weights, N, torch.float64)
+    assert abs(float(loss.detach()) - l64) <= 1e-5
+    live_ref = {k for k, g in want.items() if float(g.abs().max()) > 0}
+    live_got = {k for k, g in got.items() if float(g.abs().max()) > 0}
+    missing = sorted(k for k in live_ref - set(got) if k not in NULL_GRAD)
+    assert not missing, f"the oracle has gradients the HIP path lacks: {missing[:6]}"
+    extra = sorted(k for k in live_got - set(want))
+    assert not extra, f"the HIP path has gradients the oracle lacks: {extra[:6]}"
+    rows = []
+    for k in sorted(set(got) & set(want)):
+        if k in NULL_GRAD:
+            continue
+        t = truth[k]
+        scale = float(t.abs().max())
+        if scale == 0.0:
+            assert float(got[k].abs().max()) <= 1e-12, k
+            continue
+        e_hip = float((got[k].double() - t).abs().max()) / scale
+        e_f32 = float((want[k].double() - t).abs().max()) / scale
+        e_dir = float((got[k] - want[k]).abs().max()) / float(want[k].abs().max())
+        rows.append((e_hip, e_f32, e_dir, k))
+    a = torch.cat([got[k].flatten() for *_, k in rows]).double()
+    b = torch.cat([want[k].flatten() for *_, k in rows]).double()
+    c = torch.cat([truth[k].flatten() for *_, k in rows])
+    cos32 = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+    cos64 = float(torch.nn.functional.cosine_similarity(a, c, dim=0))
+    rows.sort(reverse=True)
+    print(f"B=512 f32 backward: {len(rows)} tensors; cosine of the whole gradient vs the float32 oracle {cos32:.8f}, vs the float64 "
+          f"oracle {cos64:.8f}; farthest from the float64 truth (HIP / float32 CPU oracle / HIP-vs-f32-oracle, relative to max|grad|): "
+          + "; ".join(f"{k} {eh:.1e} / {e3:.1e} / {ed:.1e}" for eh, e3, ed, k in rows[:5]))
+    within = sum(1 for eh, *_ in rows if eh <= 1e-3)
+    print(f"{within} of {len(rows)} tensors within 1e-3 of the float64 truth; the float32 CPU oracle: {sum(1 for _, e3, *_ in rows if e3 <= 1e-3)}")
+    bad = [(k, f"hip {eh:.2e}", f"f32 oracle {e3:.2e}") for eh, e3, _, k in rows if eh > max(1e-3, 2.0 * e3)]
+    assert not bad, f"gradient tensors farther from the float64 oracle than float32 arithmetic explains: {bad[:8]}"
+    assert cos32 >= 0.99999 and cos64 >= 0.99999, (cos32, cos64)
+
+
+def test_bf16_mode_gradient_cosines_full_size_tight():
+    """bf16 against float32 at B=512, per tensor.  The round-2 bar (cosine >= 0.95 for every tensor with >= 4096 elements) was a
+    guess; measured on MI355X (printed): whole gradient 0.999989, lowest tensors 0.9617-0.973 — the FIRST layers of the three
+    backward chains (map_encoder.cnn.0/3/6, the decoder's stem and first block), whose gradients have crossed the most bf16
+    roundings; every other tensor >= 0.975.  Bars: whole gradient >= 0.9999, every tensor >= 0.955.  A per-tensor cosine cannot
+    tell accumulated rounding noise from a structural error in a small layer (one wrong tap of nine is cosine 0.94), so the
+    error is also required to be noise-like: for every convolution weight, the cosine of EACH tap [:, :, ky, kx] must be
+    within 0.04 of the tensor's (a wrong tap would sit near 0)."""
+    import test_gpu_policy as tp
+    state = r2._default_state()
+    p32, l32, g32 = tp._bench_like_update("f32", 64, 8, state)
+    torch.cuda.empty_cache()
+    p16, l16, g16 = tp._bench_like_update("bf16", 64, 8, state)
+    torch.cuda.empty_cache()
+    cosf = lambda x, y: float(torch.nn.functional.cosine_similarity(x.flatten().double(), y.flatten().double(), dim=0))  # noqa: E731
+    rows, taps = [], []
+    for n in g32:
+        if n in NULL_GRAD or g32[n].numel() < 4096 or float(g32[n].norm()) < 1e-6:
+            continue
+        c = cosf(g32[n], g16[n])
+        rows.append((c, n))
+        if g32[n].dim() == 4 and g32[n].shape[2] * g32[n].shape[3] > 1:
+            per = [cosf(g32[n][:, :, ky, kx], g16[n][:, :, ky, kx]) for ky in range(g32[n].shape[2]) for kx in range(g32[n].shape[3])]
+            taps.append((min(per) - c, n))
+    rows.sort()
+    taps.sort()
+    a = torch.cat([g32[n].flatten() for n in g32]).double()
+    b = torch.cat([g16[n].flatten() for n in g32]).double()
+    cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+    print(f"bf16 vs f32 at B=512: global cosine {cos:.6f}; lowest per-tensor cosines: " + ", ".join(f"{n} {c:.5f}" for c, n in rows[:6])
+          + "; worst tap below its tensor: " + ", ".join(f"{n} {d:+.4f}" for d, n in taps[:3]))
+    assert cos >= 0.9999, cos
+    low = [(n, round(c, 5)) for c, n in rows if c < 0.955]
+    assert not low, low[:8]
+    odd = [(n, round(d, 4)) for d, n in taps if d < -0.04]
+    assert not odd, f"one tap of a convolution's weight gradient is far worse than the rest: {odd[:6]}"
+
+
+# ----------------------------------------------------------------------------- a training trajectory in both modes
+def _trajectory(mode, state, K, obs, prev, masks, weights, N):
+    import bench
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.optim import Adam
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype=mode, state=state))
+    opt = Adam(pol.parameters(), lr=2.5e-4)
+    AuxLosses.activate()
+    losses = []
+    for _ in range(K):
+        opt.zero_grad(set_to_none=True)
+        AuxLosses.clear()
+        pred, aux = pol(dict(obs), torch.zeros(2, N, 512, device="cuda"), prev, masks, weights)
+        loss = bench.dagger_loss(pred, aux, obs["waypoint"], weights)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    AuxLosses.deactivate()
+    params = {n: p.detach().float().cpu() for n, p in pol.named_parameters() if p.requires_grad}
+    return losses, params
+
+
+def test_bf16_training_trajectory_tracks_f32():
+    """K = 20 updates (Adam, lr 2.5e-4, the bench inputs at T=64 x N=8) from ONE initial state in the bf16 mode (the headline) and in
+    the float32 parity mode (dagger_trainer.py:526-541 around models/policy.py:91-103).  Written bars (measured on MI355X, printed: largest
+    gap 1.2e-3 at step 19, drift 0.245): the two loss curves within 0.4 % of each other at EVERY step; both fall; the parameter
+    drift between the modes after 20 updates — |p_bf16 - p_f32| relative to the distance |p_f32 - p_0| travelled, over all
+    parameters — stays below 0.30 (Adam divides by the gradient's magnitude, so the sign noise of bf16 on near-zero gradient
+    elements moves parameters at full step size: the first layers of each chain drift 0.57-0.58)."""
+    import bench
+    K, Tn, N = 20, 64, 8
+    state = r2._default_state()
+    obs, prev, masks, weights = bench.synth_batch(Tn, N, "cuda", 77)
+    l32, p32 = _trajectory("f32", state, K, obs, prev, masks, weights, N)
+    torch.cuda.empty_cache()
+    l16, p16 = _trajectory("bf16", state, K, obs, prev, masks, weights, N)
+    torch.cuda.empty_cache()
+    rel = [abs(a - b) / abs(a) for a, b in zip(l32, l16)]
+    p0 = {n: state[n].float().cpu() for n in p32}
+    moved = float(torch.sqrt(sum(((p32[n] - p0[n]) ** 2).sum() for n in p32)))
+    drift = float(torch.sqrt(sum(((p32[n] - p16[n]) ** 2).sum() for n in p32)))
+    per = sorted(((float((p32[n] - p16[n]).norm()) / max(float((p32[n] - p0[n]).norm()), 1e-12), n) for n in p32
+                  if p32[n].numel() >= 4096 and n not in NULL_GRAD), reverse=True)
+    print("loss f32 : " + " ".join(f"{v:.4f}" for v in l32))
+    print("loss bf16: " + " ".join(f"{v:.4f}" for v in l16))
+    print(f"max relative loss gap {max(rel):.3e} (step {rel.index(max(rel))}); parameter drift |p16 - p32| / |p32 - p0| = {drift / moved:.4f}; "
+          "largest per tensor: " + ", ".join(f"{n} {r:.3f}" for r, n in per[:4]))
+    assert all(np.isfinite(l16)) and all(np.isfinite(l32))
+    assert l32[-1] < l32[0] and l16[-1] < l16[0], "the loss did not fall over 20 updates"
+    assert max(rel) <= 4e-3, (max(rel), rel.index(max(rel)))
+    assert drift / moved <= 0.30, drift / moved
+
+
+# ----------------------------------------------------------------------------- version counters behind raw-pointer writes
+def test_rollout_caches_follow_adam_kernel_and_batchnorm_statistics():
+    """`wsmgmap.optim.Adam` writes the parameters, and train-mode BatchNorm its running statistics, through
+    raw pointers in HIP kernels.  The rollout route's FoldCache / packed LSTM weights key on autograd version counters, so
+    those writes must advance them.  The reference's DAgger loop (dagger_trainer.py:648-665) alternates updates with eval() +
+    no_grad act(): after real updates (WsmgAdam + train-mode forwards) between rollout steps, the policy's eager act() and
+    its GraphedAct replay — both reading caches filled BEFORE the updates — must equal, bit for bit, a twin policy that
+    loads the updated state_dict and starts with NO caches."""
+    import bench
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.graph import GraphedAct
+    from wsmgmap.optim import Adam
+    B, Tn, N = 2, 4, 2
+    st0 = r2._default_state()      # (default init: the hash-filled golden weights are deliberately ill-conditioned and do not train)
+    pa, pb = r2._policy(num_proc=B, compute_dtype="bf16", state=st0), r2._policy(num_proc=B, compute_dtype="bf16", state=st0)
+    ga = GraphedAct(pa, eager_calls=2)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    obs_u, prev_u, masks_u, weights_u = bench.synth_batch(Tn, N, "cuda", 5)
+    opt = Adam(pa.parameters(), lr=2e-3)      # a large step: stale operands must be visible
+
+    def train_updates(k):
+        r2._train_mode(pa)
+        AuxLosses.activate()
+        for _ in range(k):
+            opt.zero_grad(set_to_none=True)
+            AuxLosses.clear()
+            pred, aux = pa(dict(obs_u), torch.zeros(2, N, 512, device="cuda"), prev_u, masks_u, weights_u)
+            bench.dagger_loss(pred, aux, obs_u["waypoint"], weights_u).backward()
+            opt.step()
+        AuxLosses.deactivate()
+        AuxLosses.clear()
+        pa.eval()
+
+    def twin_follows():      # the twin gets the state through load_state_dict and forgets every derived operand
+        pb.load_state_dict(pa.state_dict())
+        pb.net._fold = None
+        pb.net.instruction_encoder._packed = None
+
+    ha, hb = torch.zeros(2, B, 512, device="cuda"), torch.zeros(2, B, 512, device="cuda")
+    prev, masks = torch.zeros(B, 2, device="cuda"), torch.ones(B, 1, device="cuda")
+    pa.eval(); pb.eval()
+    for k in range(7):
+        if k in (3, 5):      # updates between rollout steps, after the caches were filled (k = 0, 1) and the graph captured (k = 2)
+            v_before = pa.net.map_encoder.cnn[0].weight._version, pa.net.map_encoder.cnn[1].running_mean._version
+            train_updates(2)
+            assert pa.net.map_encoder.cnn[0].weight._version > v_before[0], "Adam's kernel write did not advance the version counter"
+            assert pa.net.map_encoder.cnn[1].running_mean._version > v_before[1], "BatchNorm's statistics write did not advance it"
+            twin_follows()
+        obs = r2._rollout_obs(B, gen)
+        with torch.no_grad():
+            vb, ab, lb, hb = pb.act(dict(obs), hb, prev, masks, deterministic=True)
+        va, aa, la, hn = ga(obs, ha, prev, masks, deterministic=True)
+        assert torch.isfinite(hn).all() and torch.isfinite(aa).all(), k
+        assert torch.equal(ha, hn), "GraphedAct did not leave the new hidden state in the caller's tensor"
+        for name, x, y in (("value", va, vb), ("action", aa, ab), ("logp", la, lb), ("h", hn, hb),
+                           ("map", pa.net.rgb_mapping_module.full_global_map, pb.net.rgb_mapping_module.full_global_map)):
+            assert torch.equal(x, y), (k, name, float((x.float() - y.float()).abs().max()))
+        hb = hb.clone()
+        prev = ab.clone()
+    assert len(ga._graphs) == 1
+
+
+def test_graphed_update_replays_advance_versions_and_leave_inputs_alone():
+    """GraphedUpdate adopted the caller's first batch as the graph's static inputs and later copied
+    other batches INTO it.  Now inputs are cloned at capture unless registered as static buffers; a replay advances the
+    version counters of everything it rewrote (parameters, BatchNorm statistics); the graph cache is bounded."""
+    import bench
+    from wsmgmap.graph import GraphedUpdate
+    from wsmgmap.optim import Adam
+    Tn, N = 4, 2
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+    opt = Adam(pol.parameters(), lr=2.5e-4, capturable=True)
+    gu = GraphedUpdate(pol, opt, lambda pred, aux, o, w: bench.dagger_loss(pred, aux, o["waypoint"], w), eager_calls=2)
+    from wsmgmap.common.aux_losses import AuxLosses
+    AuxLosses.activate()
+    batches = [bench.synth_batch(Tn, N, "cuda", 40 + i) for i in range(3)]
+    keep = [{k: v.clone() for k, v in b[0].items()} for b in batches]
+    w = pol.net.map_encoder.cnn[0].weight
+    rm = pol.net.map_encoder.cnn[1].running_mean
+    for it in range(8):
+        obs, prev, masks, weights = batches[it % 3]
+        v0, r0 = w._version, rm._version
+        hs = torch.zeros(2, N, 512, device="cuda")
+        loss = gu(obs, hs, prev, masks, weights)
+        assert np.isfinite(float(loss))
+        assert w._version > v0 and rm._version > r0, (it, "a graphed update left the version counters where they were")
+    AuxLosses.deactivate()
+    for b, k in zip(batches, keep):      # the caller's batches are untouched
+        for name in k:
+            assert torch.equal(b[0][name], k[name]), name
+    assert len(gu._graphs) == 1
+    gu.max_graphs = 1
+    obs2, prev2, masks2, weights2 = bench.synth_batch(6, N, "cuda", 50)     # another signature: the first graph is evicted
+    AuxLosses.activate()
+    gu(obs2, torch.zeros(2, N, 512, device="cuda"), prev2, masks2, weights2)
+    AuxLosses.deactivate()
+    assert len(gu._graphs) == 1
+
+
+# ----------------------------------------------------------------------------- checkpoint save / resume on CUDA policies
+def test_checkpoint_round_trip_on_cuda_policies_with_stale_rollout_caches(tmp_path):
+    """common_trainer.py:91-139 on the GPU: save from a CUDA policy after two bf16 updates (`save_checkpoint` through
+    `checkpoint.epoch_end`, the trainer's end-of-epoch step, dagger_trainer.py:636-655), `resume_dagger` into a FRESH CUDA
+    policy that has already run one eager act() and one GraphedAct replay — so its folded convolution operands, packed LSTM
+    weights and captured graph hold the operands of its OWN initial parameters — and require the next eager act() and the
+    next replay to be bit-identical to the saving policy's."""
+    import bench
+    from wsmgmap import checkpoint as ck
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.graph import GraphedAct
+    from wsmgmap.optim import Adam
+    B, Tn, N, EPOCHS = 2, 4, 2, 12
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    obs_u, prev_u, masks_u, weights_u = bench.synth_batch(Tn, N, "cuda", 8)
+    saver = r2._train_mode(r2._policy(num_proc=B, compute_dtype="bf16", state=r2._default_state()))
+    opt = Adam(saver.parameters(), lr=2e-3)
+    AuxLosses.activate()
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        AuxLosses.clear()
+        pred, aux = saver(dict(obs_u), torch.zeros(2, N, 512, device="cuda"), prev_u, masks_u, weights_u)
+        bench.dagger_loss(pred, aux, obs_u["waypoint"], weights_u).backward()
+        opt.step()
+    seen = {}
+
+    def on_epoch_end(policy, ckpt_path):      # the in-train evaluation hook: policy in eval mode, checkpoint on disk
+        seen["training"], seen["path"] = policy.training, ckpt_path
+        seen["encoders"] = (policy.net.depth_encoder.training, policy.net.rgb_encoder.training)
+    path = ck.epoch_end(saver, str(tmp_path), dagger_it=1, epoch=3, epochs=EPOCHS, config={"lr": 1e-2}, local_rank=0, on_epoch_end=on_epoch_end)
+    assert os.path.basename(path) == f"ckpt.{1 * EPOCHS + 3}.pth" and seen == {"training": False, "path": path, "encoders": (False, False)}
+    assert saver.training and not saver.net.depth_encoder.training and not saver.net.rgb_encoder.training and AuxLosses.is_active()
+    AuxLosses.deactivate()
+    AuxLosses.clear()
+
+    # the resuming policy: different parameters (hash-filled, then shaken), caches and graph warmed on THOSE
+    fresh = r2._policy(num_proc=B, compute_dtype="bf16").eval()
+    r2._shake_batchnorm(fresh, 21)
+    gf = GraphedAct(fresh, eager_calls=1)
+    h = torch.zeros(2, B, 512, device="cuda")
+    prev, masks = torch.zeros(B, 2, device="cuda"), torch.ones(B, 1, device="cuda")
+    warm = r2._rollout_obs(B, gen)
+    gf(warm, h, prev, masks, deterministic=True)           # eager act(): fills FoldCache + packed LSTM weights
+    gf(warm, h, prev, masks, deterministic=True)           # capture + first replay
+    assert len(gf._graphs) == 1
+    d_it, e_it, report = ck.resume_dagger(fresh, str(tmp_path), epochs=EPOCHS)
+    assert (d_it, e_it) == (1, 4) and not report.missing_keys and not report.unexpected_keys
+    for (k, a), (_, b) in zip(saver.state_dict().items(), fresh.state_dict().items()):
+        assert torch.equal(a, b) and (not a.is_floating_point() or torch.isfinite(a).all()), k
+
+    saver.eval()
+    for pol in (saver, fresh):      # same map state on both sides (the trainer re-creates it, dagger_trainer.py:668-678)
+        ck.dagger_iteration_end(pol, B, local_rank=1)
+        pol.eval()
+    hs, hf, hg = (torch.zeros(2, B, 512, device="cuda") for _ in range(3))
+    for step in range(3):
+        obs = r2._rollout_obs(B, gen)
+        with torch.no_grad():
+            out_s = saver.act(dict(obs), hs, prev, masks, deterministic=True)
+        map_s = saver.net.rgb_mapping_module.full_global_map.clone()
+        if step < 2:       # eager act() on the resumed policy
+            with torch.no_grad():
+                out_f = fresh.act(dict(obs), hf, prev, masks, deterministic=True)
+            hcmp = hf
+        else:              # and the captured graph (its map state continues from the eager steps)
+            hg.copy_(hf)
+            out_f = gf(obs, hg, prev, masks, deterministic=True)
+            hcmp = hg
+        for name, x, y in (("value", out_f[0], out_s[0]), ("action", out_f[1], out_s[1]), ("logp", out_f[2], out_s[2]), ("h", hcmp, hs),
+                           ("map", fresh.net.rgb_mapping_module.full_global_map, map_s)):
+            assert torch.equal(x, y), (step, name, float((x.float() - y.float()).abs().max()))
+        prev = out_s[1].clone()
+
+
+# ----------------------------------------------------------------------------- deterministic weight gradients (slab reduce)
+@pytest.mark.parametrize("geom", [
+    (16, 100, 100, 64, 64, 8, 2, 3, 64),     # the stem: LDS-window kernel, one slab per tile group
+    (64, 24, 24, 256, 256, 3, 1, 1, 256),    # 3 x 3 window kernel, one slab per image range
+    (32, 50, 50, 64, 128, 5, 2, 1, 64),      # generic kernel, stride 2
+    (48, 48, 48, 32, 32, 3, 1, 1, 27),       # 27 real input channels in a 32-channel activation (the padded ones are dropped)
+    (8, 24, 24, 192, 64, 3, 1, 1, 192),      # 6 channel chunks, 64 outputs
+    (3, 6, 6, 64, 64, 3, 1, 1, 64),          # fewer pixels than one split wants
+    (40, 24, 24, 256, 256, 1, 1, 0, 256),    # 1 x 1
+], ids=["stem", "win3", "k5s2", "cin27", "c192", "tiny", "1x1"])
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_weight_gradient_slabs_are_deterministic_and_match_atomics(geom, dtype, monkeypatch):
+    """wsmg_conv2d_bwd_weight[_bf16]_plan / _slabs + wsmg_weight_grad_reduce_oihw (run.py:107-108 of the reference: deterministic
+    kernels): the slab form equals the atomic form of the same kernels up to float32 summation order, equals the float64
+    torch weight gradient of the same (rounded) operands within the engine's bar, and is BIT-IDENTICAL over repeated launches;
+    the plan's workspace contract is enforced."""
+    import ctypes
+    from wsmgmap import _abi, ops
+    B, H, W, Cin, Cout, K, stride, pad, Cin_w = geom
+    if dtype == "f32" and B * H * W * Cin > 40e6:
+        B = max(2, B // 4)
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    sfx = "_bf16" if dtype == "bf16" else ""
+    OH, OW = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 7 + Cin + K)
+    x = torch.relu(torch.randn(B, H, W, Cin, device="cuda", generator=g)).to(dt)
+    if Cin_w < Cin:
+        x[..., Cin_w:] = 0
+    dy = (torch.randn(B, OH, OW, Cout, device="cuda", generator=g) * 0.1).to(dt)
+    dims = (B, H, W, Cin, Cout, K, K, stride, pad, OH, OW)
+    fl = 0.0
+    outs = [ops._weight_grad(sfx, x, dy, dims, fl, Cin_w) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert outs[0].shape == (Cout, Cin_w, K, K)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the slab-reduced weight gradient is not repeatable"
+    monkeypatch.setenv("WSMG_WGRAD_ATOMICS", "1")
+    ref_atomic = ops._weight_grad(sfx, x, dy, dims, fl, Cin_w)
+    monkeypatch.delenv("WSMG_WGRAD_ATOMICS")
+    xs = x.double().permute(0, 3, 1, 2)[:, :Cin_w]
+    dys = dy.double().permute(0, 3, 1, 2)
+    want = torch.nn.grad.conv2d_weight(xs, (Cout, Cin_w, K, K), dys, stride=stride, padding=pad)
+    scale = float(want.abs().max())
+    assert float((outs[0].double() - want).abs().max()) <= 2e-4 * scale, float((outs[0].double() - want).abs().max()) / scale
+    assert float((outs[0] - ref_atomic).abs().max()) <= 2e-4 * scale
+    # the workspace contract: a plan for another geometry / a short workspace is refused
+    ns, fl_ = ctypes.c_int(0), ctypes.c_longlong(0)
+    _abi.call("wsmg_conv2d_bwd_weight" + sfx + "_plan", *dims, ctypes.cast(ctypes.byref(ns), ctypes.c_void_p), ctypes.cast(ctypes.byref(fl_), ctypes.c_void_p))
+    assert ns.value >= 1 and fl_.value == ns.value * Cout * K * K * Cin
+    ws = torch.empty(fl_.value, device="cuda")
+    for bad_ns, bad_fl in ((ns.value + 1, fl_.value), (ns.value, fl_.value - 1)):
+        rc = getattr(_abi.lib(), "wsmg_conv2d_bwd_weight" + sfx + "_slabs")(ops._p(x), ops._p(dy), ops._p(ws), bad_ns, bad_fl, *dims, ops._stream())
+        assert rc == -1, rc      # WSMG_EINVAL

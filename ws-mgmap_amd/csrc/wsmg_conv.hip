@@ -204,6 +204,8 @@ struct WgradArgs {
   int64_t npix;      // B*OH*OW
   int64_t chunk;     // pixels per pixel-range slice (multiple of WPX)
   int gx, gy;        // unit tiles, co tiles (1-D grid of gx*gy*gz blocks, XCD-swizzled)
+  int64_t slab;      // > 0: floats per slab — `dw` is a workspace [gz][Cout][KH][KW][Cin]; the workgroup of pixel chunk z STORES its
+                     // partial tile into slab z (no atomics, nothing to zero); wsmg_weight_grad_reduce_oihw adds the slabs in order
 };
 
 template <bool DB>
@@ -320,7 +322,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       int co = co0 + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, t == 0 ? acc0[g] : acc1[g]);
+      if (co < a.Cout) {
+        float* const q = a.dw + (size_t)bz * a.slab + ((size_t)co * taps + tap) * a.Cin + ci;
+        if (a.slab) *q = t == 0 ? acc0[g] : acc1[g];
+        else atomicAdd(q, t == 0 ? acc0[g] : acc1[g]);
+      }
     }
   }
 }
@@ -382,28 +388,65 @@ extern "C" int wsmg_conv2d_bwd_data(const float* dy, const float* w_ihwo, float*
   WSMG_RETURN_LAUNCH();
 }
 
+namespace {
+// split of the pixel reduction: ~2048 workgroups in flight, >= 8 k-steps each
+void wgrad_plan_f32(int B, int OH, int OW, int Cin, int Cout, int KH, int KW, int& gx, int& gy, int64_t& chunk, int& gz_out) {
+  const int units = KH * KW * (Cin / 32);
+  const int64_t npix = (int64_t)B * OH * OW;
+  gx = (int)wsmg_cdiv(units, WUN);
+  gy = (int)wsmg_cdiv(Cout, WCO);
+  int64_t want = wsmg_cdiv(2048, (int64_t)gx * gy);
+  int64_t maxz = wsmg_cdiv(npix, WPX * 8);
+  int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);
+  if (gz < 1) gz = 1;
+  if (gz > 65535) gz = 65535;
+  chunk = wsmg_cdiv(wsmg_cdiv(npix, gz), WPX) * WPX;
+  gz_out = (int)wsmg_cdiv(npix, chunk);
+}
+
+int launch_wgrad_f32(const float* x, const float* dy, float* dw, long long slab, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                     int stride, int pad, int OH, int OW, hipStream_t stream) {
+  WgradArgs a{x, dy, dw, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0, 0, 0, (int64_t)slab};
+  a.units = KH * KW * (Cin / 32);
+  a.npix = (int64_t)B * OH * OW;
+  int gz = 1;
+  wgrad_plan_f32(B, OH, OW, Cin, Cout, KH, KW, a.gx, a.gy, a.chunk, gz);
+  dim3 grid((unsigned)((int64_t)a.gx * a.gy * gz));
+  if (conv_double_buffer())
+    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, stream, a);
+  WSMG_RETURN_LAUNCH();
+}
+}  // namespace
+
 extern "C" int wsmg_conv2d_bwd_weight(const float* x, const float* dy, float* dw_ohwi, int B, int H, int W, int Cin,
                                       int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                       wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  WgradArgs a{x, dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0, 0, 0};
-  a.units = KH * KW * (Cin / 32);
-  a.npix = (int64_t)B * OH * OW;
-  int gx = (int)wsmg_cdiv(a.units, WUN), gy = (int)wsmg_cdiv(Cout, WCO);
-  // split the pixel reduction so that ~2048 workgroups are in flight, >= 8 k-steps each
-  int64_t want = wsmg_cdiv(2048, (int64_t)gx * gy);
-  int64_t maxz = wsmg_cdiv(a.npix, WPX * 8);
-  int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);
-  if (gz < 1) gz = 1;
-  if (gz > 65535) gz = 65535;
-  a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WPX) * WPX;
-  gz = wsmg_cdiv(a.npix, a.chunk);
-  a.gx = gx;
-  a.gy = gy;
-  dim3 grid((unsigned)((int64_t)gx * gy * gz));
-  if (conv_double_buffer())
-    hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, wsmg_s(stream), a);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, wsmg_s(stream), a);
-  WSMG_RETURN_LAUNCH();
+  return launch_wgrad_f32(x, dy, dw_ohwi, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
+}
+
+// Deterministic weight gradient of the float32 engine: plan / slabs, as the bf16 pair (wsmg_conv2d_bwd_weight_bf16_plan / _slabs)
+extern "C" int wsmg_conv2d_bwd_weight_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                           int* nsplit, long long* ws_floats) {
+  if (!nsplit || !ws_floats) return WSMG_EINVAL;
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  int gx, gy, gz;
+  int64_t chunk;
+  wgrad_plan_f32(B, OH, OW, Cin, Cout, KH, KW, gx, gy, chunk, gz);
+  *nsplit = gz;
+  *ws_floats = (long long)gz * Cout * KH * KW * Cin;
+  return 0;
+}
+
+extern "C" int wsmg_conv2d_bwd_weight_slabs(const float* x, const float* dy, float* ws, int nsplit, long long ws_floats, int B, int H, int W,
+                                            int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  int gx, gy, gz;
+  int64_t chunk;
+  wgrad_plan_f32(B, OH, OW, Cin, Cout, KH, KW, gx, gy, chunk, gz);
+  const long long slab = (long long)Cout * KH * KW * Cin;
+  if (!ws || nsplit != gz || ws_floats < slab * gz) return WSMG_EINVAL;
+  return launch_wgrad_f32(x, dy, ws, slab, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
 }

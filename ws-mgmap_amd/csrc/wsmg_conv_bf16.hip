@@ -373,6 +373,10 @@ struct WgradArgsB {
   unsigned x_bytes, dy_bytes;
   int gx, gy;   // unit tiles, co tiles (1-D grid of gx*gy*gz blocks, XCD-swizzled)
   int dbg_skip;  // timing experiments only (WSMG_WGRAD_DBG_SKIP=1): leave the epilogue out
+  int64_t slab;  // > 0: floats per slab — `dw` is a workspace [gz][Cout][KH][KW][Cin] and the workgroup of pixel chunk z STORES its
+                 // partial tile into slab z (plain stores: no atomics, no zero fill — every element of every slab is written once);
+                 // wsmg_weight_grad_reduce_oihw adds the slabs in slab order, so dW is bit-reproducible (run.py:107-108 of the
+                 // reference asks for deterministic kernels).  0: float atomics into a zeroed OHWI dW
 };
 
 __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
@@ -541,7 +545,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         int co = co0 + 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (co < a.Cout) atomicAdd(a.dw + ((size_t)co * taps + tap) * a.Cin + ci, acc[t][u][g]);
+        if (co < a.Cout) {
+          float* const q = a.dw + (size_t)bz * a.slab + ((size_t)co * taps + tap) * a.Cin + ci;
+          if (a.slab) *q = acc[t][u][g];      // lanes = consecutive input channels: two 128-byte segments per instruction
+          else atomicAdd(q, acc[t][u][g]);
+        }
       }
     }
   }
@@ -814,65 +822,84 @@ extern "C" int wsmg_conv2d_bwd_data_bf16(const void* dy, const void* w_ihwo, voi
   return wsmg_conv2d_bwd_data_bf16_stats(dy, w_ihwo, dx, out_f32, nullptr, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
 }
 
-extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin,
-                                           int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
-                                           wsmg_stream_t stream) {
-  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
-  if (Cin == 64 && Cout == 64 && KH == 8 && KW == 8 && stride == 2 && pad == 3) {
-    // the map encoder's stem: LDS-window variant (wsmg_conv_win_wgrad.hip); WSMG_WGRAD_WIN=0 keeps the generic kernel (A/B)
-    static int use_win = -1;
-    if (use_win < 0) { const char* e = getenv("WSMG_WGRAD_WIN"); use_win = e ? atoi(e) : 1; }
-    if (use_win) {
-      int rc = wsmg_conv_win_wgrad_bf16(x, dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
-      if (rc != WSMG_EINVAL) return rc;
-    }
+namespace {
+// Which kernel takes the weight gradient of a layer, and over how many partial sums (pixel chunks / image ranges / tile groups) its
+// reduction is split — the number of slabs of the deterministic form.
+struct WgradPlan {
+  int kind;      // 0 generic (conv_wgrad_bf16_kernel), 1 stem window kernel, 2 3 x 3 window kernel
+  int nsplit;
+  int tc, tu, gx, gy;
+  int64_t chunk;
+};
+
+WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
+  WgradPlan p{0, 0, 0, 0, 0, 0, 0};
+  // the map encoder's stem: LDS-window variant (wsmg_conv_win_wgrad.hip); WSMG_WGRAD_WIN=0 keeps the generic kernel (A/B)
+  static int use_win = -1;
+  if (use_win < 0) { const char* e = getenv("WSMG_WGRAD_WIN"); use_win = e ? atoi(e) : 1; }
+  if (use_win) {
+    if (const int n = wsmg_conv_win_wgrad_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) { p.kind = 1; p.nsplit = n; return p; }
   }
+  // 3 x 3 stride-1 layers: zero-padded LDS window (wsmg_conv_win3_wgrad.hip); WSMG_WGRAD_WIN3=0 (or the tests' tile switch = 0)
+  // keeps the generic kernel (A/B)
   static int use_w3w = -1;
   if (use_w3w < 0) { const char* e = getenv("WSMG_WGRAD_WIN3"); use_w3w = e ? atoi(e) : 1; }
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && use_w3w && win3_tile() && (int64_t)B * H * W >= 256 * 256) {
-    // 3 x 3 stride-1 layers: zero-padded LDS window (wsmg_conv_win3_wgrad.hip); WSMG_WGRAD_WIN3=0 (or the tests' tile switch = 0)
-    // keeps the generic kernel (A/B)
-    int rc = wsmg_conv_win3_wgrad_bf16(x, dy, dw_ohwi, B, H, W, Cin, Cout, wsmg_s(stream));
-    if (rc != WSMG_EINVAL) return rc;
+    if (const int n = wsmg_conv_win3_wgrad_splits(B, H, W, Cin, Cout)) { p.kind = 2; p.nsplit = n; return p; }
   }
-  WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
-               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, 0};
-  { static int sk = -1; if (sk < 0) { const char* e = getenv("WSMG_WGRAD_DBG_SKIP"); sk = e ? atoi(e) : 0; } a.dbg_skip = sk; }
-  a.units = KH * KW * (Cin / 32);
-  a.npix = (int64_t)B * OH * OW;
+  const int units = KH * KW * (Cin / 32);
+  const int64_t npix = (int64_t)B * OH * OW;
   // tile shape (measured per layer, tools/bench_conv.py): 128 co x 8 units where both dimensions are
   // large (cated 765 vs 660 TFLOP/s), else 64 co x 4 units, which keeps 5 workgroups per CU resident
   // (the 64-channel k8 stem, 128 units of 64 input channels: 64 co x 8 units measured 0.94 vs 0.99 ms; every other
   // 64-wide layer is faster with 4 units)
-  int tc = (Cout % 128 == 0 && a.units >= 48) ? 4 : 2, tu = (tc == 4 || (Cin == 64 && a.units >= 128)) ? 2 : 1;
+  int tc = (Cout % 128 == 0 && units >= 48) ? 4 : 2, tu = (tc == 4 || (Cin == 64 && units >= 128)) ? 2 : 1;
   if (const char* e = getenv("WSMG_WGRAD_TILE")) {   // debug: "42", "21", "22"
     int v = atoi(e);
     if (v == 42 || v == 21 || v == 22) { tc = v / 10; tu = v % 10; }
   }
-  int gx = (int)wsmg_cdiv(a.units, 4 * tu), gy = (int)wsmg_cdiv(Cout, 32 * tc);
+  const int gx = (int)wsmg_cdiv(units, 4 * tu), gy = (int)wsmg_cdiv(Cout, 32 * tc);
   // workgroups over the pixel reduction (the k8 stem's 64 x 8 tile: 0.90 ms at 2048, 0.96 at 1024).  Every workgroup ends
-  // with a tile of float32 atomics, which is 40-50 % of the launch for the small layers (tools sweep, WSMG_WGRAD_WANT):
-  // below 40 GFLOP fewer, longer workgroups win (768: -0.08 ms over the six small layers of the update)
-  const double gflop = 2.0 * (double)a.npix * Cout * Cin * KH * KW * 1e-9;
+  // with its tile going to memory — float atomics, 40-50 % of the launch for the small layers, or (slab form) plain stores
+  // that the reduce launch reads back: below 40 GFLOP fewer, longer workgroups win (768: -0.08 ms over the six small
+  // layers of the update; tools sweep, WSMG_WGRAD_WANT)
+  const double gflop = 2.0 * (double)npix * Cout * Cin * KH * KW * 1e-9;
   int64_t target = tc == 4 ? 1024 : (gflop < 40.0 ? 768 : 2048);
   if (const char* e = getenv("WSMG_WGRAD_WANT")) { int v = atoi(e); if (v > 0) target = v; }
   int64_t want = wsmg_cdiv(target, (int64_t)gx * gy);
-  int64_t maxz = wsmg_cdiv(a.npix, WKP * 8);
+  int64_t maxz = wsmg_cdiv(npix, WKP * 8);
   int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);
   if (gz < 1) gz = 1;
   if (gz > 65535) gz = 65535;
-  a.chunk = wsmg_cdiv(wsmg_cdiv(a.npix, gz), WKP) * WKP;
-  gz = wsmg_cdiv(a.npix, a.chunk);
-  a.gx = gx;
-  a.gy = gy;
-  dim3 grid((unsigned)((int64_t)gx * gy * gz));
+  p.chunk = wsmg_cdiv(wsmg_cdiv(npix, gz), WKP) * WKP;
+  p.nsplit = (int)wsmg_cdiv(npix, p.chunk);
+  p.tc = tc; p.tu = tu; p.gx = gx; p.gy = gy;
+  return p;
+}
+
+// slab_floats == 0: atomics into the zeroed OHWI dW; > 0: `dw` is the slab workspace (WgradArgsB::slab)
+int launch_wgrad_bf16(const void* x, const void* dy, float* dw, long long slab_floats, int B, int H, int W, int Cin, int Cout, int KH,
+                      int KW, int stride, int pad, int OH, int OW, hipStream_t stream) {
+  const WgradPlan p = wgrad_plan_bf16(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW);
+  if (p.kind == 1) return wsmg_conv_win_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
+  if (p.kind == 2) return wsmg_conv_win3_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, stream);
+  WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
+               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, 0, (int64_t)slab_floats};
+  { static int sk = -1; if (sk < 0) { const char* e = getenv("WSMG_WGRAD_DBG_SKIP"); sk = e ? atoi(e) : 0; } a.dbg_skip = sk; }
+  a.units = KH * KW * (Cin / 32);
+  a.npix = (int64_t)B * OH * OW;
+  a.chunk = p.chunk;
+  a.gx = p.gx;
+  a.gy = p.gy;
+  const int tc = p.tc, tu = p.tu;
+  dim3 grid((unsigned)((int64_t)p.gx * p.gy * p.nsplit));
   const int pf = conv_prefetch(1) >= 2 ? 2 : 1;
   const int cch = Cin / 32, wun = 4 * tu;
   int upt = 1;
   for (int c = wun; c > 1; c >>= 1)
     if (cch % c == 0) { upt = c; break; }
 #define WSMG_WGRAD(TC_, TU_, PF_, UPT_) \
-  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TC_, TU_, PF_, UPT_>), grid, dim3(256), 0, wsmg_s(stream), a)
+  hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TC_, TU_, PF_, UPT_>), grid, dim3(256), 0, stream, a)
 #define WSMG_WGRAD_U4(TC_, TU_, PF_) \
   do { if (upt >= 4) WSMG_WGRAD(TC_, TU_, PF_, 4); else if (upt == 2) WSMG_WGRAD(TC_, TU_, PF_, 2); else WSMG_WGRAD(TC_, TU_, PF_, 1); } while (0)
 #define WSMG_WGRAD_U8(TC_, TU_, PF_) \
@@ -888,4 +915,38 @@ extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float*
 #undef WSMG_WGRAD_U4
 #undef WSMG_WGRAD
   WSMG_RETURN_LAUNCH();
+}
+}  // namespace
+
+extern "C" int wsmg_conv2d_bwd_weight_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin,
+                                           int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                           wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  return launch_wgrad_bf16(x, dy, dw_ohwi, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
+}
+
+// Deterministic weight gradient, step 1 of 2 (the plan): how many partial sums (`nsplit`) the layer's reduction is split into and
+// how many floats of workspace that takes — nsplit slabs of Cout*KH*KW*Cin floats.
+extern "C" int wsmg_conv2d_bwd_weight_bf16_plan(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
+                                                int OW, int* nsplit, long long* ws_floats) {
+  if (!nsplit || !ws_floats) return WSMG_EINVAL;
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  const WgradPlan p = wgrad_plan_bf16(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW);
+  *nsplit = p.nsplit;
+  *ws_floats = (long long)p.nsplit * Cout * KH * KW * Cin;
+  return 0;
+}
+
+// Deterministic weight gradient, step 2: the same kernels as wsmg_conv2d_bwd_weight_bf16, but every workgroup STORES its partial
+// tile into its slab of `ws` ([nsplit][Cout][KH][KW][Cin] float32, nothing to zero) instead of adding it into dW with float
+// atomics.  `nsplit` / `ws_floats` must be what the plan call returned for this geometry (checked).  Step 3 is
+// wsmg_weight_grad_reduce_oihw, which adds the slabs in slab order.
+extern "C" int wsmg_conv2d_bwd_weight_bf16_slabs(const void* x, const void* dy, float* ws, int nsplit, long long ws_floats, int B, int H,
+                                                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                                                 wsmg_stream_t stream) {
+  if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
+  const WgradPlan p = wgrad_plan_bf16(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW);
+  const long long slab = (long long)Cout * KH * KW * Cin;
+  if (!ws || nsplit != p.nsplit || ws_floats < slab * p.nsplit) return WSMG_EINVAL;
+  return launch_wgrad_bf16(x, dy, ws, slab, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
 }

@@ -42,7 +42,9 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 struct W3wArgs {
   const bf16_t* x;    // [B][H][W][Cin]
   const bf16_t* dy;   // [B][H][W][Cout]
-  float* dw;          // [Cout][3][3][Cin] float32, accumulated into
+  float* dw;          // [Cout][3][3][Cin] float32, accumulated into (slab == 0) — or the slab workspace [gz][Cout][3][3][Cin]
+  int64_t slab;       // > 0: floats per slab — the workgroup of image range z STORES its partial tile into slab z (no atomics,
+                      // no zero fill: every element of every slab is written exactly once); wsmg_weight_grad_reduce_oihw adds the slabs
   int B, H, W, Cin, Cout;
   int gco, gci, gz;   // workgroup grid: output-channel tiles, input-channel tiles, image ranges
   int imgs;           // images per range
@@ -231,6 +233,17 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
   // ---- one flush per workgroup: lane r = input channel (consecutive lanes -> 128-byte segments of an OHWI row)
   const int r = lane & 31;
   const int ci = ci0 + 32 * tci + r;
+  if (a.slab) {     // deterministic form: plain stores into this image range's slab
+    float* const dst = a.dw + (size_t)z * a.slab;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int co = co0 + 32 * tco + (g & 3) + 8 * (g >> 2) + 4 * h;
+        dst[((size_t)co * 9 + tap) * a.Cin + ci] = acc[tap][g];
+      }
+    return;
+  }
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -240,30 +253,43 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
     }
 }
 
-template <int WCO, int WCI, int NLW>
-int launch_w3w(W3wArgs& a, hipStream_t s) {
-  constexpr int LDS = NSTG * (KS * 64 * WCO + XCAP * 64 * WCI) + 1024;
-  static bool attr = false;
+int w3w_cus() {
   static int cus = 0;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_wgrad_kernel<WCO, WCI, NLW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
+  if (!cus) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
-    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    attr = true;
+    cus = 256;     // (MI355X; also the answer where no device can be asked — the plan call of a GPU-less build check)
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
   }
+  return cus;
+}
+
+// image ranges: one workgroup per CU (its LDS), every range the same number of images (no range is empty)
+template <int WCO, int WCI>
+void plan_w3w(W3wArgs& a) {
   a.gco = a.Cout / (32 * WCO);
   a.gci = a.Cin / (32 * WCI);
   const int ntile = a.gco * a.gci;
-  // image ranges: one workgroup per CU (its LDS), every range the same number of images
-  int gz = cus / ntile;
+  int gz = w3w_cus() / ntile;
   if (const char* e = getenv("WSMG_WIN3W_SPLITS")) { int v = atoi(e); if (v > 0) gz = v; }
   if (gz < 1) gz = 1;
   if (gz > a.B) gz = a.B;
   a.imgs = (a.B + gz - 1) / gz;
   a.gz = (a.B + a.imgs - 1) / a.imgs;
+}
+
+template <int WCO, int WCI, int NLW>
+int launch_w3w(W3wArgs& a, hipStream_t s) {
+  constexpr int LDS = NSTG * (KS * 64 * WCO + XCAP * 64 * WCI) + 1024;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_wgrad_kernel<WCO, WCI, NLW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  plan_w3w<WCO, WCI>(a);
+  const int ntile = a.gco * a.gci;
   hipLaunchKernelGGL((conv_win3_wgrad_kernel<WCO, WCI, NLW>), dim3((unsigned)(ntile * a.gz)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -271,16 +297,33 @@ int launch_w3w(W3wArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// dW (OHWI float32, accumulated into: the caller zeroes it) of a 3 x 3 / stride 1 / pad 1 convolution on bf16 NHWC with
-// 16 <= W <= 24, Cout % 128 == 0 and Cin % 64 == 0; WSMG_EINVAL otherwise (the caller then uses the generic kernel).
-int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
-  if (B <= 0 || H < 1 || W < 16 || KS + 2 * (W + 3) > XCAP) return WSMG_EINVAL;   // W < 16: the pad columns and the last k-step's
-                                                                                 // unused entries cost more than the window saves (12 x 12: 0.091 vs 0.052 ms)
-  if ((size_t)B * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return WSMG_EINVAL;
+// dW of a 3 x 3 / stride 1 / pad 1 convolution on bf16 NHWC with 16 <= W <= 24, Cout % 128 == 0 and Cin % 64 == 0; WSMG_EINVAL
+// otherwise (the caller then uses the generic kernel).
+static bool w3w_fits(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H < 1 || W < 16 || KS + 2 * (W + 3) > XCAP) return false;   // W < 16: the pad columns and the last k-step's
+                                                                            // unused entries cost more than the window saves (12 x 12: 0.091 vs 0.052 ms)
+  if ((size_t)B * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return false;
   const unsigned PW = (unsigned)(W + 2);
   const uint64_t nmax = (uint64_t)(H + 4) * PW + KS + XCAP;
-  if (nmax * PW >= (1ull << 32)) return WSMG_EINVAL;
-  W3wArgs a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, Cin, Cout, 0, 0, 0, 0, (unsigned)((1ull << 32) / PW + 1),
+  if (nmax * PW >= (1ull << 32)) return false;
+  return Cout % 128 == 0 && Cin % 64 == 0;
+}
+
+// image ranges (= slabs of the deterministic form) this kernel would use for the layer; 0: the layer is not this kernel's
+int wsmg_conv_win3_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
+  if (!w3w_fits(B, H, W, Cin, Cout)) return 0;
+  W3wArgs a{nullptr, nullptr, nullptr, 0, B, H, W, Cin, Cout, 0, 0, 0, 0, 0, 0, 0};
+  plan_w3w<4, 2>(a);
+  return a.gz;
+}
+
+// slab_floats == 0: dW (OHWI float32) is ACCUMULATED INTO with float atomics (the caller zeroes it); slab_floats > 0: `dw_ohwi` is a
+// workspace of wsmg_conv_win3_wgrad_splits() slabs of that many floats, every one written whole (see W3wArgs::slab).
+int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,
+                              hipStream_t s) {
+  if (!w3w_fits(B, H, W, Cin, Cout)) return WSMG_EINVAL;
+  const unsigned PW = (unsigned)(W + 2);
+  W3wArgs a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, (int64_t)slab_floats, B, H, W, Cin, Cout, 0, 0, 0, 0, (unsigned)((1ull << 32) / PW + 1),
             (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * H * W * Cout * 2)};
   // waves 0-3 load (measured at B = 512: 0.373 / 0.205 / 0.206 ms on the 256->256, 128->256 and 256->128 layers against 0.404 /
   // 0.216 / 0.216 with all eight loading, and 0.421 / 0.247 / 0.225 for the generic kernel); WSMG_WIN3W_LOADERS=8: all eight (A/B).

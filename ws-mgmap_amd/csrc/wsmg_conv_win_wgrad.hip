@@ -29,7 +29,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct WinWgradArgs {
   const bf16_t* x;    // [B][H][W][64]
   const bf16_t* dy;   // [B][OH][OW][64]
-  float* dw;          // [64][8][8][64] float32 (OHWI), accumulated into
+  float* dw;          // [64][8][8][64] float32 (OHWI), accumulated into (slab == 0) — or the slab workspace [groups][64][8][8][64]
+  int64_t slab;       // > 0: floats per slab — tile group g STORES its partial sums into slab g (its 8 roles cover the 8 kernel rows):
+                      // no atomics, no zero fill, summed in slab order by wsmg_weight_grad_reduce_oihw (bit-reproducible)
   int B, H, W, OH, OW, tiles_y, tiles_x, groups;
   unsigned x_bytes, dy_bytes;
 };
@@ -215,26 +217,41 @@ __global__ __launch_bounds__(256, 2) void conv_win_wgrad_kernel(WinWgradArgs a) 
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int co = 32 * t + (g & 3) + 8 * (g >> 2) + 4 * h;
-        atomicAdd(a.dw + ((size_t)co * (K * K) + tap) * 64 + ci, acc[t][v][g]);
+        float* const q = a.dw + (size_t)grp * a.slab + ((size_t)co * (K * K) + tap) * 64 + ci;
+        if (a.slab) *q = acc[t][v][g];
+        else atomicAdd(q, acc[t][v][g]);
       }
   }
 }
 
 }  // namespace
 
-// dW (OHWI float32, accumulated into: the caller zeroes it) of a 64 -> 64 channel k8 s2 p3 convolution on bf16 NHWC; returns
-// WSMG_EINVAL for any other shape (the caller then uses the generic kernel).
-int wsmg_conv_win_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                             int stride, int pad, int OH, int OW, hipStream_t s) {
-  if (Cin != 64 || Cout != 64 || KH != 8 || KW != 8 || stride != 2 || pad != 3) return WSMG_EINVAL;
-  if ((size_t)B * H * W * 128 >= (1ull << 31) || (size_t)B * OH * OW * 128 >= (1ull << 31)) return WSMG_EINVAL;
-  WinWgradArgs a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, B, H, W, OH, OW, (OH + TH - 1) / TH, (OW + TW - 1) / TW, 0,
-                 (unsigned)((size_t)B * H * W * 128), (unsigned)((size_t)B * OH * OW * 128)};
-  const int ntiles = B * a.tiles_y * a.tiles_x;
+// dW (OHWI float32) of a 64 -> 64 channel k8 s2 p3 convolution on bf16 NHWC — slab_floats == 0: accumulated into with float atomics
+// (the caller zeroes it); > 0: one slab per tile group, stored (WinWgradArgs::slab); returns WSMG_EINVAL for any other shape (the
+// caller then uses the generic kernel).
+static bool winw_fits(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
+  if (Cin != 64 || Cout != 64 || KH != 8 || KW != 8 || stride != 2 || pad != 3) return false;
+  return !((size_t)B * H * W * 128 >= (1ull << 31) || (size_t)B * OH * OW * 128 >= (1ull << 31));
+}
+static int winw_groups(int B, int OH, int OW) {
+  const int ntiles = B * ((OH + TH - 1) / TH) * ((OW + TW - 1) / TW);
   int groups = 64;   // 8 roles x 64 groups = 512 workgroups = 2 per CU (78 KB of LDS each)
   if (const char* e = getenv("WSMG_WIN_WGRAD_GROUPS")) { int g = atoi(e); if (g > 0) groups = g; }
   if (groups > ntiles) groups = ntiles;
-  groups = (groups + 7) / 8 * 8;   // whole XCD rounds (groups beyond the tile count find no tile and only flush zeros)
+  return (groups + 7) / 8 * 8;   // whole XCD rounds (groups beyond the tile count find no tile and only flush zeros)
+}
+
+// tile groups (= slabs of the deterministic form) this kernel would use; 0: the layer is not this kernel's
+int wsmg_conv_win_wgrad_splits(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
+  return winw_fits(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW) ? winw_groups(B, OH, OW) : 0;
+}
+
+int wsmg_conv_win_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,
+                             int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s) {
+  if (!winw_fits(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return WSMG_EINVAL;
+  WinWgradArgs a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, (int64_t)slab_floats, B, H, W, OH, OW, (OH + TH - 1) / TH, (OW + TW - 1) / TW, 0,
+                 (unsigned)((size_t)B * H * W * 128), (unsigned)((size_t)B * OH * OW * 128)};
+  const int groups = winw_groups(B, OH, OW);
   a.groups = groups;
   static bool attr = false;
   if (!attr) {

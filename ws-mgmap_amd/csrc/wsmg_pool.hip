@@ -387,6 +387,44 @@ __global__ __launch_bounds__(256) void weight_grad_to_oihw_kernel(const float* _
   }
 }
 
+// The deterministic weight gradient's last step: dW[o][i][kh][kw] (OIHW, i < I) = sum over z < nsplit of ws[z][o][kh][kw][i]
+// (OHWI slabs of I_pad channels, written whole by the weight-gradient kernels' workgroups — wsmg_conv2d_bwd_weight*_slabs).
+// The order of the additions depends on nsplit only — four z ranges summed in z order by four threads, their results added
+// in range order — so dW is bit-identical from run to run (float atomics add in arrival order).  A thread owns 4 consecutive
+// input channels (one 16-byte load per slab); the OIHW stores are 4-byte, KH*KW apart: dW is 10-40x smaller than the slabs.
+__global__ __launch_bounds__(256) void weight_grad_reduce_oihw_kernel(const float* __restrict__ ws, int nsplit, int64_t slab4, int I,
+                                                                      int KH, int KW, int I_pad, float* __restrict__ out) {
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  __shared__ f32x4v part[3][64];
+  const int ql = threadIdx.x & 63, zp = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 64 + ql;
+  const int per = (nsplit + 3) >> 2;
+  const int z0 = zp * per, z1 = z0 + per < nsplit ? z0 + per : nsplit;
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  if (q < slab4) {
+    const f32x4v* p = reinterpret_cast<const f32x4v*>(ws) + (int64_t)z0 * slab4 + q;
+    int z = z0;
+    for (; z + 4 <= z1; z += 4, p += 4 * slab4) {     // four loads in flight, added in z order
+      const f32x4v a = p[0], b = p[slab4], c = p[2 * slab4], d = p[3 * slab4];
+      acc += a; acc += b; acc += c; acc += d;
+    }
+    for (; z < z1; ++z, p += slab4) acc += p[0];
+  }
+  if (zp) part[zp - 1][ql] = acc;
+  __syncthreads();
+  if (zp || q >= slab4) return;
+  acc += part[0][ql]; acc += part[1][ql]; acc += part[2][ql];
+  const int64_t e = q * 4;                           // flat OHWI index of the first of the 4 channels
+  const int i = (int)(e % I_pad);
+  int64_t r = e / I_pad;
+  const int kw = (int)(r % KW); r /= KW;
+  const int kh = (int)(r % KH);
+  const int64_t o = r / KH;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (i + j < I) out[((o * I + i + j) * KH + kh) * KW + kw] = acc[j];
+}
+
 // ---- channel concatenation of two NHWC tensors (the UNet skip connections, map_encoder.py:104,110, and
 // mg_map_policy.py:99): out[p] = a[p] ++ b[p], one 16-byte chunk per thread, the pixel index computed once per chunk
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -696,6 +734,14 @@ extern "C" int wsmg_weight_relayout_multi(const WsmgRelayoutDesc* descs, int n, 
     if (bf16) hipLaunchKernelGGL(weight_relayout_multi_kernel<bf16_t>, dim3(48, (unsigned)m), dim3(256), 0, wsmg_s(s), b);
     else hipLaunchKernelGGL(weight_relayout_multi_kernel<float>, dim3(48, (unsigned)m), dim3(256), 0, wsmg_s(s), b);
   }
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_weight_grad_reduce_oihw(const float* ws, int nsplit, int O, int I, int KH, int KW, int I_pad, float* dw_oihw,
+                                            wsmg_stream_t s) {
+  if (!ws || !dw_oihw || nsplit <= 0 || O <= 0 || I <= 0 || KH <= 0 || KW <= 0 || I_pad < I || (I_pad & 3)) return WSMG_EINVAL;
+  const int64_t slab4 = (int64_t)O * KH * KW * I_pad / 4;
+  hipLaunchKernelGGL(weight_grad_reduce_oihw_kernel, dim3((unsigned)wsmg_cdiv(slab4, 64)), dim3(256), 0, wsmg_s(s), ws, nsplit, slab4, I,
+                     KH, KW, I_pad, dw_oihw);
   WSMG_RETURN_LAUNCH();
 }
 extern "C" int wsmg_weight_grad_to_oihw(const float* dw_ohwi, int O, int I, int KH, int KW, int I_pad, float* dw_oihw, wsmg_stream_t s) {

@@ -88,6 +88,11 @@ _SIG["wsmg_weight_relayout"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_weight_relayout_bf16"] = list(_SIG["wsmg_weight_relayout"])
 _SIG["wsmg_weight_relayout_multi"] = [c_p, c_i, c_i, c_p]
 _SIG["wsmg_weight_grad_to_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
+_SIG["wsmg_conv2d_bwd_weight_plan"] = [c_i] * 11 + [c_p, c_p]
+_SIG["wsmg_conv2d_bwd_weight_bf16_plan"] = list(_SIG["wsmg_conv2d_bwd_weight_plan"])
+_SIG["wsmg_conv2d_bwd_weight_slabs"] = [c_p, c_p, c_p, c_i, c_l] + [c_i] * 11 + [c_p]
+_SIG["wsmg_conv2d_bwd_weight_bf16_slabs"] = list(_SIG["wsmg_conv2d_bwd_weight_slabs"])
+_SIG["wsmg_weight_grad_reduce_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
 _SIG["wsmg_bn_act_bwd_ld"] = [c_p, c_l] + _SIG["wsmg_bn_act_bwd"][1:]
 _SIG["wsmg_bn_act_bwd_ld_bf16"] = list(_SIG["wsmg_bn_act_bwd_ld"])
 _SIG["wsmg_upsample2x_bwd_ld"] = [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p]

@@ -135,3 +135,74 @@ def resume_dagger(policy, checkpoint_folder, epochs, resume_ckpt=None, map_locat
         if start_epoch_it == 0:
             start_dagger_it += 1
     return start_dagger_it, start_epoch_it, report
+
+
+# ----------------------------------------------------------------------------- end-of-epoch / end-of-iteration steps of the trainer
+def _frozen_encoders_eval(policy):
+    """`.train()` followed by `.net.depth_encoder.eval(); .net.rgb_encoder.eval()` (dagger_trainer.py:650-652,663-665)."""
+    pol = _unwrap(policy)
+    policy.train()
+    pol.net.depth_encoder.eval()
+    pol.net.rgb_encoder.eval()
+
+
+def _barrier():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()
+
+
+def epoch_end(policy, checkpoint_folder, dagger_it, epoch, epochs, config=None, local_rank=0, on_epoch_end=None):
+    """What the reference's training loop does after the last batch of an epoch (dagger_trainer.py:636-655):
+
+      * rank 0 saves `ckpt.<dagger_it * EPOCHS + epoch>.pth` with `extra_state={'dagger_it': dagger_it}` (:636-640);
+      * barrier (:642);
+      * if EPOCHS > 10 (:644-655): auxiliary losses off, caches emptied, and on every third epoch rank 0 evaluates in-train:
+        `policy.eval()`, the evaluation, `policy.train()` + the two frozen encoders back to eval; barrier; losses on again.
+
+    on_epoch_end(policy, ckpt_path): the in-train evaluation hook — called where the reference calls
+    `self._eval_checkpoint('', writer, 0, training=True, training_step=epoch)` (:649), with the policy in eval mode and the
+    path of the checkpoint just written (None on ranks that did not write one).  Returns the checkpoint path (rank 0) or None."""
+    from .common.aux_losses import AuxLosses
+    path = None
+    if local_rank == 0:
+        path = save_checkpoint(policy, checkpoint_folder, f"ckpt.{dagger_it * epochs + epoch}.pth", config=config,
+                               extra_state={"dagger_it": dagger_it})
+    _barrier()
+    if epochs > 10:
+        AuxLosses.deactivate()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        if epoch % 3 == 0 and local_rank == 0 and on_epoch_end is not None:
+            policy.eval()
+            try:
+                on_epoch_end(policy, path)
+            finally:
+                _frozen_encoders_eval(policy)
+        _barrier()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        AuxLosses.activate()
+    return path
+
+
+def dagger_iteration_end(policy, num_processes, local_rank=0, on_iteration_end=None, ckpt_path=None):
+    """After the last epoch of a DAgger iteration (dagger_trainer.py:657-678): auxiliary losses off, rank 0 evaluates in
+    eval mode (`on_iteration_end(policy, ckpt_path)`, where the reference calls `_eval_checkpoint`), train mode + frozen
+    encoders back to eval, barrier, and the map state re-created as zeros for NUM_PROCESSES environments."""
+    from .common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    if local_rank == 0 and on_iteration_end is not None:
+        policy.eval()
+        try:
+            on_iteration_end(policy, ckpt_path)
+        finally:
+            _frozen_encoders_eval(policy)
+    _barrier()
+    mm = getattr(_unwrap(policy).net, "rgb_mapping_module", None)
+    if mm is not None:
+        mm.full_global_map = torch.zeros([num_processes] + list(mm.full_global_map.shape[1:]), device=mm.full_global_map.device)
+        # (same shape as the reference's zeros; kept as a broadcast view of one element per channel, as RGBMapping does)
+        _, C, G1, G2 = mm.agent_view.shape
+        mm.agent_view = torch.zeros(num_processes, C, 1, 1, device=mm.agent_view.device).expand(num_processes, C, G1, G2)

@@ -93,6 +93,12 @@ def _conv_out(h, k, s, p):
 # current stream IS the stream handed to the C ABI) to report per-kernel roofline figures.
 _prof = None
 
+def _prof_key(name):
+    """The entry points of one kernel family share a key: *_stats launch the same kernels with the statistics epilogue, *_slabs
+    the same weight-gradient kernels with stores into slabs instead of atomics."""
+    return name.replace("_stats", "").replace("_slabs", "")
+
+
 KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trace names it)
     "wsmg_conv2d_fwd_bf16_stats": "conv_igemm_bf16_kernel<false, *>",
     "wsmg_conv2d_bwd_data_bf16_stats": "conv_igemm_bf16_kernel<true, *>",
@@ -126,7 +132,7 @@ def profile_end():
     out = {}
     for name, items in (rec or {}).items():
         ms = sum(s.elapsed_time(e) for s, e, _ in items)
-        o = out.setdefault(KERNEL_OF[name], dict(launches=0, ms_total=0.0, flops_total=0.0, entry=name.replace("_stats", "")))
+        o = out.setdefault(KERNEL_OF[_prof_key(name)], dict(launches=0, ms_total=0.0, flops_total=0.0, entry=_prof_key(name)))
         o["launches"] += len(items)      # (the *_stats entry points launch the same kernels: one family)
         o["ms_total"] += ms
         o["flops_total"] += float(sum(f for _, _, f in items))
@@ -134,7 +140,7 @@ def profile_end():
 
 
 def _launch(name, flops, *args):
-    if _prof is None or (_prof_only is not None and name.replace("_stats", "") not in _prof_only):
+    if _prof is None or (_prof_only is not None and _prof_key(name) not in _prof_only):
         _abi.call(name, *args)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -283,6 +289,41 @@ def _weight_grad_oihw(dw_ohwi, I):
     return out
 
 
+# Deterministic weight gradients (C ABI: wsmg_conv2d_bwd_weight[_bf16]_plan / _slabs + wsmg_weight_grad_reduce_oihw): the
+# weight-gradient kernels' workgroups STORE their partial tiles into slabs of a workspace and one more launch adds the slabs in
+# a fixed order while it re-lays dW out as OIHW — no float atomics, no zero-fill of dW, bit-identical gradients from run to
+# run (the reference sets cudnn.deterministic, run.py:107-108).  WSMG_WGRAD_ATOMICS=1 restores the atomic form (A/B).
+_wgrad_ws = {}        # stream -> float32 workspace (launches of one stream use it one after the other)
+
+
+def _wgrad_workspace(device, floats):
+    key = (device.index, _raw_stream())
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < floats:
+        if ws is not None:
+            ws.record_stream(torch.cuda.current_stream())      # launches that still read the old one are queued on this stream
+        ws = torch.empty(max(int(floats), 1 << 24), device=device, dtype=torch.float32)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def _weight_grad(sfx, x, dy, dims, fl, Cin_w):
+    """OIHW float32 weight gradient [Cout, Cin_w, KH, KW] of the convolution `dims` from x [B,H,W,Cin] and dy [B,OH,OW,Cout]."""
+    B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
+    if _os.environ.get("WSMG_WGRAD_ATOMICS", "0") == "1":
+        dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
+        _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
+        return _weight_grad_oihw(dw_ohwi, Cin_w)
+    nsplit, floats = ctypes.c_int(0), ctypes.c_longlong(0)
+    _abi.call("wsmg_conv2d_bwd_weight" + sfx + "_plan", *dims, ctypes.cast(ctypes.byref(nsplit), ctypes.c_void_p),
+              ctypes.cast(ctypes.byref(floats), ctypes.c_void_p))
+    ws = _wgrad_workspace(x.device, floats.value)
+    _launch("wsmg_conv2d_bwd_weight" + sfx + "_slabs", fl, _p(x), _p(dy), _p(ws), nsplit.value, floats.value, *dims, _stream())
+    out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
+    _abi.call("wsmg_weight_grad_reduce_oihw", _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream())
+    return out
+
+
 _wgrad_side = {}
 _side_join_armed = set()
 
@@ -413,9 +454,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             side = _wgrad_side_stream(fl)
             if side is None:
-                dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
-                _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
-                dw = _weight_grad_oihw(dw_ohwi, Cin_w)
+                dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
             else:
                 # the weight gradient is a leaf of the backward graph: it runs on a side stream beside the backward-data
                 # chain and fills the tails of its launches (1.8-3.6 waves of workgroups each); the main stream joins the
@@ -425,9 +464,7 @@ class _Conv2d(torch.autograd.Function):
                 x.record_stream(side)
                 dy.record_stream(side)
                 with torch.cuda.stream(side):
-                    dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
-                    _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
-                    dw = _weight_grad_oihw(dw_ohwi, Cin_w)
+                    dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
                 _join_side_at_end(main, side)
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
@@ -478,9 +515,7 @@ class _ConvT2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            dw_ohwi = _zeros_f32((O, KH, KW, I), x.device)
-            _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(dy), _p(x), _p(dw_ohwi), *dims, _stream())
-            dw = _weight_grad_oihw(dw_ohwi, I)
+            dw = _weight_grad(sfx, dy, x, tuple(dims), fl, I)
         return dx, dw, None, None, None
 
 
@@ -550,9 +585,7 @@ class _Conv2dCat(torch.autograd.Function):
                 _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
             dxs.append(dx)
             if ctx.needs_input_grad[0]:
-                dw_ohwi = _zeros_f32((Cout, KH, KW, Ci), x.device)
-                _launch("wsmg_conv2d_bwd_weight_bf16", fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
-                dws.append(_weight_grad_oihw(dw_ohwi, Ci_w))
+                dws.append(_weight_grad("_bf16", x, dy, tuple(dims), fl, Ci_w))
         dw = torch.cat(dws, dim=1) if dws else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[1]:
