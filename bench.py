@@ -63,6 +63,11 @@ def synth_batch(T, N, device, seed, E=100, C=64):
 
 
 def dagger_loss(pred, aux_loss, waypoint, weights):
+    """The trainer's loss (dagger_trainer.py:526-534).  GPU: wsmgmap.losses.dagger_loss, the same arithmetic as one launch per
+    direction (WSMG_FUSED_LOSS=0: the reference's torch lines below, 11 launches each way); CPU tensors: the torch lines."""
+    if pred.is_cuda and os.environ.get("WSMG_FUSED_LOSS", "1") != "0":
+        from wsmgmap.losses import dagger_loss as fused
+        return fused(pred, aux_loss, waypoint, weights)[0]
     T, N = weights.shape
     logits = torch.tanh(pred).view(T, N, -1)
     al = F.mse_loss(logits, waypoint[:, :2].view(T, N, -1), reduction="none").sum(2)

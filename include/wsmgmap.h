@@ -476,6 +476,36 @@ int wsmg_group_norm_nhwc_bf16(const void* x, int x_f32, const void* residual, co
 int wsmg_rnn_status(int clear);
 int wsmg_rnn_debug_spin_limit(unsigned limit);
 
+/* ---- the update path's heads, auxiliary-loss reduction and trainer loss (csrc/wsmg_heads.hip) ----------------------------
+ * Replace, each as ONE launch per direction, the tail of tiny torch operators after the second recurrence:
+ *   wsmg_update_heads_*: `pred = self.action_distribution(features).mean` (models/policy.py:96-97 -> common/distributions.py:42-57,
+ *       Linear 512 -> A), `self.prog = torch.tanh(self.prog_pred(features))` (policy.py:59) and the progress monitor's per-row
+ *       squared error `F.mse_loss(self.prog, observations['progress'], reduction='none').mean(-1)` (policy.py:86-88);
+ *       x [B][K] float32 (K % 4 == 0), wm [A][K], bm [A], wp [K], bp [1], progress [B] or NULL; A <= 4.
+ *       backward: dpred [B][A] / dprog [B] / dprog_rows [B] may each be NULL (no gradient); dx, dwm, dbm, dwp, dbp are overwritten;
+ *       every sum runs in a fixed order (bit-reproducible).
+ *   wsmg_aux_reduce_*: `_AuxLosses.reduce(mask)` (common/aux_losses.py:24-35): out2[0] = sum_k alpha[k] * sum over rows with
+ *       mask[b] != 0 of rows[k][b], divided by the number of such rows (out2[1]); `rows` / `alpha` are HOST arrays of L <= 4
+ *       device pointers / factors; masked-out rows are dropped, not multiplied (a non-finite loss on a padded row stays out).
+ *       backward: drows [L][B] = mask ? daux * alpha[k] / nsel : 0.
+ *   wsmg_dagger_loss_*: the trainer's loss (dagger_trainer.py:526-534): logits = tanh(pred) viewed [T][N][A]; per episode n the
+ *       weighted mean over t of sum_j (logits - waypoint[..., :A])^2 with weights [T][N]; mean over n; + aux (NULL: none).
+ *       out2 = {loss, action_loss}; den [N] is kept for the backward, which writes dpred [T*N][A] (d aux = d loss).
+ *       waypoint rows are ld_waypoint floats apart (the reference slices `[:, :2]` of a wider tensor). */
+int wsmg_update_heads_fwd(const float* x, const float* wm, const float* bm, const float* wp, const float* bp, const float* progress,
+                          int B, int K, int A, float* pred, float* prog, float* prog_rows, wsmg_stream_t stream);
+int wsmg_update_heads_bwd(const float* x, const float* wm, const float* wp, const float* prog, const float* progress,
+                          const float* dpred, const float* dprog, const float* dprog_rows, int B, int K, int A, float* dx, float* dwm,
+                          float* dbm, float* dwp, float* dbp, wsmg_stream_t stream);
+int wsmg_aux_reduce_fwd(const float* const* rows, const float* alpha, int L, const unsigned char* mask, int B, float* out2,
+                        wsmg_stream_t stream);
+int wsmg_aux_reduce_bwd(const float* alpha, int L, const unsigned char* mask, const float* nsel, const float* daux, int B,
+                        float* drows, wsmg_stream_t stream);
+int wsmg_dagger_loss_fwd(const float* pred, const float* waypoint, int ld_waypoint, const float* weights, const float* aux, int T,
+                         int N, int A, float* out2, float* den, wsmg_stream_t stream);
+int wsmg_dagger_loss_bwd(const float* pred, const float* waypoint, int ld_waypoint, const float* weights, const float* den,
+                         const float* dloss, int T, int N, int A, float* dpred, wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,12 @@ _SIG["wsmg_conv2d_bwd_weight_bf16_plan"] = list(_SIG["wsmg_conv2d_bwd_weight_pla
 _SIG["wsmg_conv2d_bwd_weight_slabs"] = [c_p, c_p, c_p, c_i, c_l] + [c_i] * 11 + [c_p]
 _SIG["wsmg_conv2d_bwd_weight_bf16_slabs"] = list(_SIG["wsmg_conv2d_bwd_weight_slabs"])
 _SIG["wsmg_weight_grad_reduce_oihw"] = [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]
+_SIG["wsmg_update_heads_fwd"] = [c_p] * 6 + [c_i] * 3 + [c_p] * 3 + [c_p]
+_SIG["wsmg_update_heads_bwd"] = [c_p] * 8 + [c_i] * 3 + [c_p] * 5 + [c_p]
+_SIG["wsmg_aux_reduce_fwd"] = [c_p, c_p, c_i, c_p, c_i, c_p, c_p]
+_SIG["wsmg_aux_reduce_bwd"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p]
+_SIG["wsmg_dagger_loss_fwd"] = [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]
+_SIG["wsmg_dagger_loss_bwd"] = [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]
 _SIG["wsmg_bn_act_bwd_ld"] = [c_p, c_l] + _SIG["wsmg_bn_act_bwd"][1:]
 _SIG["wsmg_bn_act_bwd_ld_bf16"] = list(_SIG["wsmg_bn_act_bwd_ld"])
 _SIG["wsmg_upsample2x_bwd_ld"] = [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p]

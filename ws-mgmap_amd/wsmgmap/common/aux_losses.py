@@ -46,6 +46,11 @@ class _Registry:
                     # poison the total
                     total = total + alpha * (torch.where(mask, loss, loss.new_zeros(())).sum() / mask.sum())
             return total
+        first = entries[0][0]
+        if first.is_cuda and len(entries) <= 4 and mask.dtype == torch.bool and all(l.dtype == torch.float32 for l, _ in entries):
+            # the same sum as below in one launch per direction (csrc/wsmg_heads.hip): selected rows only, NaN for an empty selection
+            from .. import ops
+            return ops.aux_reduce([l for l, _ in entries], [a for _, a in entries], mask)
         # = sum_k alpha_k * masked_select(loss_k, mask).mean() (NaN for an empty selection, like the reference), without
         # the data-dependent output size — masked_select makes the host wait for the whole forward pass — and as ONE
         # stacked reduction: per loss the loop above is 7 tiny launches forward and as many backward, each ~5 us on the

@@ -64,7 +64,9 @@ class BasePolicy(nn.Module):
         return value, action, distribution.log_probs(action), rnn_hidden_states
 
     # -- auxiliary heads -------------------------------------------------------------
-    def aux_prediction(self, features, observations, pred_map, prog=None):
+    def aux_prediction(self, features, observations, pred_map, prog=None, prog_rows=None):
+        """prog: the progress head's output when the caller already has it (the fused heads of act / forward); prog_rows: the
+        progress monitor's per-row loss, likewise."""
         cfg = self.model_config
         self.prog = torch.tanh(self.prog_pred(features)) if prog is None else prog
         if not AuxLosses.is_active():
@@ -90,7 +92,7 @@ class BasePolicy(nn.Module):
                 kl = F.kl_div(torch.log(att), target, reduction="none").mean(-1)
             AuxLosses.register_loss("contrastive_monitor", kl, cfg.CONTRASTIVE_MONITOR.alpha)
         if cfg.PROGRESS_MONITOR.use:
-            loss = F.mse_loss(self.prog, observations["progress"], reduction="none").mean(-1)
+            loss = F.mse_loss(self.prog, observations["progress"], reduction="none").mean(-1) if prog_rows is None else prog_rows
             AuxLosses.register_loss("progress_monitor", loss, cfg.PROGRESS_MONITOR.alpha)
 
     # -- teacher forcing / DAgger update ---------------------------------------------
@@ -102,8 +104,18 @@ class BasePolicy(nn.Module):
             self.net.skip_pred_map_nchw = False
         # = self.action_distribution(features).mean (policy.py:96-97) without building the Normal: its log-std / exp / expand
         # kernels produce nothing the update path reads (logstd gets no gradient in the reference either)
-        pred = self.action_distribution.fc_mean(features)
-        self.aux_prediction(features, observations, pred_map)
+        fused = (features.is_cuda and features.dtype == torch.float32 and features.shape[1] % 4 == 0
+                 and os.environ.get("WSMG_FUSED_UPDATE_HEADS", "1") != "0")
+        if fused:
+            # action mean, tanh progress head and the progress monitor's per-row loss in one launch per direction (≈10 each way)
+            progress = observations.get("progress") if (AuxLosses.is_active() and self.model_config.PROGRESS_MONITOR.use) else None
+            if progress is not None and not (progress.is_cuda and progress.dtype == torch.float32 and progress.numel() == features.shape[0]):
+                progress = None
+            pred, prog, prog_rows = ops.update_heads(features, self.action_distribution.fc_mean, self.prog_pred, progress)
+            self.aux_prediction(features, observations, pred_map, prog=prog, prog_rows=prog_rows)
+        else:
+            pred = self.action_distribution.fc_mean(features)
+            self.aux_prediction(features, observations, pred_map)
         aux_loss = AuxLosses.reduce((weights > 0).view(-1))
         ops.mark("heads_aux")
         return pred, aux_loss

@@ -1092,6 +1092,128 @@ def path_kl(dis, att, size, tau):
     return _PathKL.apply(dis.contiguous(), att.contiguous(), int(size), float(tau))
 
 
+# ----------------------------------------------------------------------------- update-path heads, auxiliary reduction, trainer loss
+class _UpdateHeads(torch.autograd.Function):
+    """(pred [B,A], prog [B,1], progress-loss rows [B]) of the update path in one launch per direction (csrc/wsmg_heads.hip):
+    `action_distribution.fc_mean`, `tanh(prog_pred(.))` and `mse_loss(prog, progress, 'none').mean(-1)` of the reference's
+    BasePolicy.forward / aux_prediction (models/policy.py:59,86-88,96-97)."""
+
+    @staticmethod
+    def forward(ctx, x, wm, bm, wp, bp, progress):
+        _req(x, wm, bm, wp, bp, progress)
+        _f32(x, wm, bm, wp, bp, progress)
+        B, K = x.shape
+        A = wm.shape[0]
+        if wm.shape != (A, K) or wp.numel() != K or bm.numel() != A or bp.numel() != 1 or (progress is not None and progress.numel() != B):
+            raise _abi.WsmgError("update_heads: head shapes do not fit the features")
+        pred = torch.empty(B, A, device=x.device, dtype=torch.float32)
+        prog = torch.empty(B, 1, device=x.device, dtype=torch.float32)
+        rows = torch.empty(B, device=x.device, dtype=torch.float32) if progress is not None else None
+        _abi.call("wsmg_update_heads_fwd", _p(x), _p(wm), _p(bm), _p(wp), _p(bp), _p(progress), B, K, A, _p(pred), _p(prog), _p(rows), _stream())
+        ctx.save_for_backward(x, wm, wp, prog, progress)
+        ctx.set_materialize_grads(False)
+        return pred, prog, rows
+
+    @staticmethod
+    def backward(ctx, dpred, dprog, drows):
+        x, wm, wp, prog, progress = ctx.saved_tensors
+        B, K = x.shape
+        A = wm.shape[0]
+        c = lambda t: None if t is None else t.contiguous().float()   # noqa: E731
+        dpred, dprog, drows = c(dpred), c(dprog), c(drows)
+        dx = torch.empty_like(x)
+        dwm, dbm = torch.empty_like(wm), torch.empty(A, device=x.device, dtype=torch.float32)
+        dwp, dbp = torch.empty_like(wp), torch.empty(1, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_update_heads_bwd", _p(x), _p(wm), _p(wp), _p(prog), _p(progress), _p(dpred), _p(dprog), _p(drows), B, K, A,
+                  _p(dx), _p(dwm), _p(dbm), _p(dwp), _p(dbp), _stream())
+        return dx, dwm, dbm, dwp, dbp, None
+
+
+def update_heads(features, fc_mean, prog_pred, progress=None):
+    """-> (pred [B,A], prog [B,1], rows [B] or None): action mean, tanh progress head and — with `progress` [B,1] — the progress
+    monitor's per-row squared error, one launch; fc_mean / prog_pred are the nn.Linear modules."""
+    return _UpdateHeads.apply(features.contiguous(), fc_mean.weight, fc_mean.bias, prog_pred.weight, prog_pred.bias,
+                              None if progress is None else progress.contiguous())
+
+
+class _AuxReduce(torch.autograd.Function):
+    """_AuxLosses.reduce(mask) (common/aux_losses.py:24-35) over up to 4 per-row loss vectors: one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, mask, alphas, *rows):
+        _req(mask, *rows)
+        _f32(*rows)
+        B = rows[0].numel()
+        if mask.dtype != torch.bool or mask.numel() != B or any(r.numel() != B for r in rows) or not 1 <= len(rows) <= 4:
+            raise _abi.WsmgError("aux_reduce: 1-4 float32 loss vectors and a bool mask of one length")
+        L = len(rows)
+        ptrs = (ctypes.c_void_p * L)(*[r.data_ptr() for r in rows])
+        al = (ctypes.c_float * L)(*[float(a) for a in alphas])
+        out = torch.empty(2, device=mask.device, dtype=torch.float32)
+        _abi.call("wsmg_aux_reduce_fwd", ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(al, ctypes.c_void_p), L, _p(mask), B, _p(out), _stream())
+        ctx.save_for_backward(mask, out)
+        ctx.alphas, ctx.shapes = tuple(float(a) for a in alphas), [r.shape for r in rows]
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, daux):
+        mask, out = ctx.saved_tensors
+        L, B = len(ctx.alphas), mask.numel()
+        al = (ctypes.c_float * L)(*ctx.alphas)
+        drows = torch.empty(L, B, device=mask.device, dtype=torch.float32)
+        _abi.call("wsmg_aux_reduce_bwd", ctypes.cast(al, ctypes.c_void_p), L, _p(mask), _p(out[1:]), _p(daux.contiguous().float()), B, _p(drows),
+                  _stream())
+        return (None, None) + tuple(drows[k].view(shp) for k, shp in enumerate(ctx.shapes))
+
+
+def aux_reduce(rows, alphas, mask):
+    """sum_k alphas[k] * mean(rows[k][mask]) as a 0-dim tensor (rows: list of [B] float32 CUDA tensors, mask [B] bool)."""
+    return _AuxReduce.apply(mask.contiguous(), tuple(alphas), *[r.contiguous() for r in rows])
+
+
+class _DaggerLoss(torch.autograd.Function):
+    """The trainer's loss of one update (dagger_trainer.py:526-534): weighted squared error of tanh(pred) against the waypoint,
+    per-episode weight normalisation, mean over episodes, + the auxiliary loss — one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, pred, waypoint, weights, aux):
+        _req(pred, waypoint, weights, aux)
+        _f32(pred, waypoint, weights, aux)
+        T, N = weights.shape
+        A = pred.shape[-1]
+        if pred.numel() != T * N * A or waypoint.shape[0] != T * N or waypoint.shape[-1] < A or waypoint.dim() != 2:
+            raise _abi.WsmgError("dagger_loss: pred [T*N, A], waypoint [T*N, >= A], weights [T, N]")
+        out = torch.empty(2, device=pred.device, dtype=torch.float32)
+        den = torch.empty(N, device=pred.device, dtype=torch.float32)
+        _abi.call("wsmg_dagger_loss_fwd", _p(pred), _p(waypoint), waypoint.shape[-1], _p(weights), _p(aux), T, N, A, _p(out), _p(den), _stream())
+        ctx.save_for_backward(pred, waypoint, weights, den)
+        ctx.has_aux = aux is not None
+        loss, action = out[0], out[1]
+        ctx.mark_non_differentiable(action)
+        return loss, action
+
+    @staticmethod
+    def backward(ctx, dloss, _daction):
+        pred, waypoint, weights, den = ctx.saved_tensors
+        T, N = weights.shape
+        A = pred.shape[-1]
+        dloss = dloss.contiguous().float()
+        dpred = torch.empty_like(pred)
+        _abi.call("wsmg_dagger_loss_bwd", _p(pred), _p(waypoint), waypoint.shape[-1], _p(weights), _p(den), _p(dloss), T, N, A, _p(dpred), _stream())
+        return dpred, None, None, (dloss if ctx.has_aux else None)
+
+
+def dagger_loss(pred, aux_loss, waypoint, weights):
+    """-> (loss, action_loss) as 0-dim tensors; pred [T*N, A], waypoint [T*N, >= A] (its first A columns are the target),
+    weights [T, N]; aux_loss a 0-dim tensor, a Python number (added on the host side of the graph) or None."""
+    aux_t = aux_loss if torch.is_tensor(aux_loss) else None
+    loss, action = _DaggerLoss.apply(pred.contiguous(), waypoint.contiguous(), weights.contiguous(),
+                                     None if aux_t is None else aux_t.reshape(1).float())
+    if aux_t is None and aux_loss is not None:
+        loss = loss + float(aux_loss)
+    return loss, action
+
+
 class _AttnShared(torch.autograd.Function):
     """Single-query attention of B rows over U << B shared key / value sets (row b uses set inverse[b]): the update path
     repeats every instruction T times; the reference (and `attention` above) would need per-row copies of the
