@@ -202,6 +202,37 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         opt.step()
         return loss
 
+    # N > 1: the decoder's side stream beside RCCL's own streams was never run on the target (no multi-GPU box reachable from the
+    # build environment), and on a SHARED GPU a third stream per process once took updates from 49 ms to 4.3 s.  So it is
+    # measured before it is trusted: 3 updates with and 3 without it (after one untimed update each), max over ranks; more than
+    # 1.3x slower with the stream -> fall back to one stream for the run and say so in the line.
+    measure.side_stream = None
+    if world > 1 and os.environ.get("WSMG_DECODER_STREAMS") is None:
+        def timed(k):
+            update()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_ = time.perf_counter()
+            for _ in range(k):
+                update()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / k
+        update()                                   # discovery pass of the gradient exchange, allocator warm-up
+        os.environ["WSMG_DECODER_STREAMS"] = "0"
+        t_one = timed(3)
+        os.environ["WSMG_DECODER_STREAMS"] = "1"
+        t_two = timed(3)
+        keep = t_two <= 1.3 * t_one
+        if not keep:
+            os.environ["WSMG_DECODER_STREAMS"] = "0"
+        measure.side_stream = dict(ms_per_update_one_stream=round(t_one * 1e3, 3), ms_per_update_with_decoder_side_stream=round(t_two * 1e3, 3),
+                                   decoder_side_stream_used=bool(keep),
+                                   note="3 updates each, max over ranks; the side stream is dropped for the run when it is > 1.3x slower")
+        if reducer:
+            reducer.stats(reset=True)
+
     # which conv-engine kernel family dominates is learned on the warm-up updates (all six entry points timed); inside
     # the timed region only that family is bracketed with HIP events — every timed launch costs two event records on a
     # host that is within 10 % of being the bottleneck, and `value` should not pay for the other five
@@ -225,6 +256,8 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if reducer:
+        reducer.stats(reset=True)
     ops.profile_begin(only=[dom_entry] if dom_entry else None)
     WIN = 50                     # --steps >= 200: an event every 50 updates, for the `sustained` sub-object (no synchronisation)
     marks = []
@@ -262,9 +295,15 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     ops.check_rnn_status()        # a persistent-RNN timeout anywhere in the run invalidates it: fail loudly
     if reducer:
         reducer.check()
+        st = reducer.stats()
         measure.dp_info = dict(ranks_in_process_group=dist.get_world_size(), backend=dist.get_backend(),
                                live_gradient_bytes=reducer.live_bytes, buckets=reducer.num_buckets,
-                               devices_visible=torch.cuda.device_count())
+                               devices_visible=torch.cuda.device_count(),
+                               exposed_allreduce_ms=st["exposed_allreduce_ms"], exposed_allreduce_max_ms=st["exposed_allreduce_max_ms"],
+                               host_ms_in_finish=st["host_ms_in_finish"], updates_measured=st["updates"],
+                               exposed_note="HIP-event time on the compute stream between the end of backward (entry of finish()) and the "
+                                            "last averaged bucket: the part of the gradient all-reduce that backward did not hide; rank 0",
+                               side_stream_check=measure.side_stream)
     for name, r in warm_prof.items():     # the other families: per-launch figures from the warm-up updates, labelled so
         if name not in prof:
             prof[name] = dict(r, per_steps=1, phase="last warm-up update")

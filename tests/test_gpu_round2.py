@@ -440,7 +440,7 @@ def test_stock_ddp_wrap_matches_goldens():
 
 
 # ----------------------------------------------------------------------------- two data-parallel ranks, the real policy
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, mode="f32", inject=False):
     for p in (ROOT, os.path.join(ROOT, "ws-mgmap_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -465,7 +465,7 @@ def _dp_worker(rank, world, port, q):
             return pred.detach()
 
         # expected: the mean of the two ranks' single-rank gradients (BatchNorm statistics are per rank, like the reference)
-        plain = _train_mode(_policy(num_proc=2))
+        plain = _train_mode(_policy(num_proc=2, compute_dtype=mode))
         want = None
         for r in range(world):
             grads_of(plain, r)
@@ -475,12 +475,14 @@ def _dp_worker(rank, world, port, q):
                 own = g
         want = {n: v / world for n, v in want.items()}
         del plain
-        pol = _train_mode(_policy(num_proc=2))
+        pol = _train_mode(_policy(num_proc=2, compute_dtype=mode))
         red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20)
         red.broadcast_parameters(pol)
         worst = 0.0
         for it in range(3):                 # 0: discovery pass; 1, 2: hook / overlap path with side-stream event waits
             grads_of(pol, rank)
+            if it == 0 and inject and rank == 1:
+                red._order.reverse()        # an injected ORDER mismatch between the ranks: the agreed layout is rank 0's
             red.finish()
             torch.cuda.synchronize()
             got = {n: p.grad for n, p in pol.named_parameters() if p.grad is not None}
@@ -492,7 +494,9 @@ def _dp_worker(rank, world, port, q):
                 # identical arithmetic on both sides except the float32 atomics' summation order in dW
                 worst = max(worst, float((got[n] - want[n]).abs().max()) / scale)
         red.check()
-        info = dict(live_bytes=red.live_bytes, buckets=red.num_buckets, worst=worst,
+        layout = [red._index[id(p)] for b in red._buckets for p in b["params"]]
+        info = dict(live_bytes=red.live_bytes, buckets=red.num_buckets, worst=worst, mode=mode, injected_order_mismatch=bool(inject),
+                    layout_crc=__import__("zlib").crc32(repr(layout).encode()), stats=red.stats(),
                     differs_from_own=max(float((want[n] - own[n]).abs().max()) for n in want))
         q.put((rank, "ok", info))
         dist.destroy_process_group()
@@ -501,15 +505,18 @@ def _dp_worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc() + repr(e)))
 
 
-def test_data_parallel_two_ranks_real_policy():
-    """the data-parallel path on the REAL policy — two ranks (processes) on this box's GPU, gloo moving the
-    buckets between CUDA tensors, GradAllReducer's hook / overlap path incl. the cross-stream event waits: the exchanged
-    gradients equal the mean of the two ranks' single-rank gradients; only live parameters travel (32.9 MB)."""
+@pytest.mark.parametrize("mode,inject", [("f32", False), ("bf16", True)], ids=["f32", "bf16_order_mismatch"])
+def test_data_parallel_two_ranks_real_policy(mode, inject):
+    """the data-parallel path on the REAL policy — two ranks (processes) on this box's GPU, gloo moving
+    the buckets between CUDA tensors, GradAllReducer's hook / overlap path incl. the cross-stream event waits: the exchanged
+    gradients equal the mean of the two ranks' single-rank gradients; only live parameters travel (32.9 MB).  Second case: the
+    bf16 mode (the headline), with rank 1's discovery ORDER reversed on purpose — both ranks must end up with rank 0's bucket
+    layout (DDP verifies parameter order across ranks at construction, common_trainer.py:60-66) and the same averages."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, mode, inject)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in procs)
@@ -517,7 +524,7 @@ def test_data_parallel_two_ranks_real_policy():
         p.join(timeout=120)
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "dp2_real_policy.json"), "w") as f:
+    with open(os.path.join(out_dir, f"dp2_real_policy_{mode}.json"), "w") as f:
         import json
         json.dump([dict(rank=r, status=s, info=i if isinstance(i, dict) else str(i)) for r, s, i in res], f, indent=1)
     for r, status, info in res:
@@ -525,6 +532,8 @@ def test_data_parallel_two_ranks_real_policy():
         assert info["worst"] <= 2e-3, info
         assert info["differs_from_own"] > 1e-6, "the two ranks' gradients must actually differ"
         assert 32.0e6 < info["live_bytes"] < 33.5e6, info
+        assert info["stats"]["updates"] == 3 and info["stats"]["buckets"] == info["buckets"]
+    assert res[0][2]["layout_crc"] == res[1][2]["layout_crc"], "the ranks built different bucket layouts"
 
 
 # ----------------------------------------------------------------------------- frozen encoders

@@ -18,6 +18,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _aux_losses_off():
+    """The registry is process-global (as in the reference): a test that fails between activate() and deactivate() must not
+    leave it on for the rollout tests that follow."""
+    from wsmgmap.common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    AuxLosses.clear()
+    yield
+    AuxLosses.deactivate()
+    AuxLosses.clear()
+
+
 def _oracle_grads(state, obs, prev, masks, weights, N, dtype=torch.float32):
     """The oracle's update step on the host in `dtype`: forward + DAgger loss + backward; -> (pred, loss, {state_dict key: grad})."""
     P = {k: (v.detach().cpu().clone().to(dtype) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in state.items()}

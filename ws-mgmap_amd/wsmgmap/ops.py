@@ -1200,7 +1200,7 @@ class _DaggerLoss(torch.autograd.Function):
         dloss = dloss.contiguous().float()
         dpred = torch.empty_like(pred)
         _abi.call("wsmg_dagger_loss_bwd", _p(pred), _p(waypoint), waypoint.shape[-1], _p(weights), _p(den), _p(dloss), T, N, A, _p(dpred), _stream())
-        return dpred, None, None, (dloss if ctx.has_aux else None)
+        return dpred, None, None, (dloss.reshape(1) if ctx.has_aux else None)
 
 
 def dagger_loss(pred, aux_loss, waypoint, weights):
