@@ -506,6 +506,34 @@ int wsmg_dagger_loss_fwd(const float* pred, const float* waypoint, int ld_waypoi
 int wsmg_dagger_loss_bwd(const float* pred, const float* waypoint, int ld_waypoint, const float* weights, const float* den,
                          const float* dloss, int T, int N, int A, float* dpred, wsmg_stream_t stream);
 
+/* ---- the semantic classifier's tail in one pass per direction (csrc/wsmg_cls_tail.hip) -----------------------------------
+ * Reference: `map_classfier[4:7]` = BatchNorm2d(32) + ReLU + Conv2d(32, 27, 1) (mg_map_policy.py:78-86), the prediction monitor's
+ * `F.cross_entropy(pred_sem_map, F.interpolate(gt_semantic_map, size=(48, 48)).long(), reduction='none').mean([1, 2])`
+ * (policy.py:61-66) and the `AvgPool2d(2)` in front of map_classified_linear (mg_map_policy.py:93-96, 195).
+ *   y2 [B][H][W][32] bf16: the 3 x 3 convolution's output (H even, W % 16 == 0); mean / invstd: its batch statistics
+ *   (wsmg_bn_stats_finalize); w6 [classes][32], b6 [classes] float32 (classes <= 32); gt [B][Hg][Wg] float32 class ids or NULL
+ *   (then ce_rows is NULL: no loss).
+ *   forward  -> sem [B][H][W][32] bf16 logits (channels >= classes zero), pooled [B][H/2][W/2][32] bf16, ce_rows [B].
+ *   backward <- g_rows [B] (gradient of ce_rows; NULL: none), dpooled (NULL: none)
+ *            -> dbn: the gradient of the BatchNorm's output, ReLU mask applied (feed it to wsmg_bn_bwd_apply_bf16 with the
+ *               dgamma / dbeta returned here), dgamma [32], dbeta [32], dw6 [classes][32], db6 [classes];
+ *               workspace: wsmg_cls_tail_workspace_floats(B) floats.  Every sum is taken in a fixed order. */
+long long wsmg_cls_tail_workspace_floats(int B);
+int wsmg_cls_tail_fwd_bf16(const void* y2, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                           const float* w6, const float* b6, int classes, const float* gt, int Hg, int Wg, int B, int H, int W,
+                           void* sem, void* pooled, float* ce_rows, wsmg_stream_t stream);
+int wsmg_cls_tail_bwd_bf16(const void* y2, const float* gamma, const float* beta, const float* mean, const float* invstd,
+                           const float* w6, const float* b6, int classes, const float* gt, int Hg, int Wg, const float* g_rows,
+                           const void* dpooled, int B, int H, int W, void* dbn, float* workspace, long long workspace_floats,
+                           float* dgamma, float* dbeta, float* dw6, float* db6, wsmg_stream_t stream);
+/* BatchNorm2d (train mode) in halves (torch.nn.BatchNorm2d behind map_encoder.py:10-12 / mg_map_policy.py:80-84): statistics from
+ * the slabs a convolution's epilogue filled (wsmg_conv2d_fwd_bf16_stats) -> save_mean, save_invstd, running statistics (slabs
+ * returned zeroed); and the backward's apply pass alone, for a dy already masked by the ReLU and caller-supplied sums. */
+int wsmg_bn_stats_finalize(double* stats, int nslab, int C, int64_t rows, float momentum, float eps, float* running_mean,
+                           float* running_var, float* save_mean, float* save_invstd, wsmg_stream_t stream);
+int wsmg_bn_bwd_apply_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* invstd,
+                           const float* dgamma, const float* dbeta, int64_t rows, int C, void* dx, wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

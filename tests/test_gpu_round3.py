@@ -501,3 +501,103 @@ def test_update_heads_aux_reduce_and_dagger_loss_match_the_reference_lines(shape
         assert torch.isfinite(a_).all(), name
         assert float((a_ - b_).abs().max()) <= 2e-6 * max(float(b_.abs().max()), 1e-3), (name, float((a_ - b_).abs().max()))
     assert float(g1[6][~mask].abs().sum()) == 0.0       # nothing flows into the masked rows
+
+
+# ----------------------------------------------------------------------------- the fused classifier tail
+@pytest.mark.parametrize("geom", [(6, 48, 48, 100, 27), (2, 96, 96, 196, 27), (3, 4, 16, 7, 5), (1, 48, 48, 48, 32)],
+                         ids=["bench_geometry", "e196", "one_patch_row", "identity_resize_32_classes"])
+@pytest.mark.parametrize("with_loss", [True, False], ids=["ce", "no_ce"])
+def test_cls_tail_matches_the_reference_lines_in_float64(geom, with_loss):
+    """csrc/wsmg_cls_tail.hip against the reference's lines evaluated in float64 on the same bf16-valued inputs: BatchNorm2d with
+    batch statistics + ReLU + Conv2d 1 x 1 (mg_map_policy.py:78-86), F.cross_entropy against `F.interpolate(gt, size)`'s nearest
+    resize (policy.py:61-66; the kernel reproduces torch's float32 source-index arithmetic — labels are compared exactly through
+    the loss), AvgPool2d(2) (mg_map_policy.py:93-96).  Forward within bf16 rounding of the logits (1e-2 relative), loss rows
+    within 2e-3; gradients (incoming activation, BatchNorm affine, 1 x 1 weight and bias) within 2 % of max|grad|; running
+    statistics updated as nn.BatchNorm2d does; two launches give identical bits."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from wsmgmap import ops
+    B, H, W, Hg, classes = geom
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 1000 + H + classes)
+    y2 = (torch.randn(B, H, W, 32, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    bn = nn.BatchNorm2d(32).cuda().train()
+    conv = nn.Conv2d(32, classes, 1).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(32, device="cuda", generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(32, device="cuda", generator=g) * 0.3)
+        conv.weight.copy_(conv.weight.to(torch.bfloat16).float())       # bf16-representable weights: the product itself is then exact
+    gt = torch.randint(0, classes, (B, Hg, Hg), device="cuda", generator=g).float() if with_loss else None
+    dpooled = (torch.randn(B, H // 2, W // 2, 32, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
+    g_rows = torch.rand(B, device="cuda", generator=g) + 0.5
+
+    def stats_of(t):
+        st = torch.zeros(ops.BN_SLABS, 2, 32, device="cuda", dtype=torch.float64)
+        f = t.double().reshape(-1, 32)
+        st[3, 0], st[3, 1] = f.sum(0), (f * f).sum(0)
+        return st
+
+    def fused():
+        for m in (bn, conv):
+            m.zero_grad(set_to_none=True)
+        bn.running_mean.zero_(); bn.running_var.fill_(1.0)
+        x = y2.clone().requires_grad_(True)
+        st = stats_of(y2)
+        sem, pooled, ce = ops.cls_tail(x, st, bn, conv, gt)
+        assert float(st.abs().max()) == 0.0, "the statistics slabs must come back zeroed"
+        loss = (pooled.float() * dpooled.float()).sum() + ((ce * g_rows).sum() if with_loss else 0.0)
+        loss.backward()
+        return ([sem.float(), pooled.float(), ce if with_loss else torch.zeros(1, device="cuda"), bn.running_mean.clone(), bn.running_var.clone()],
+                [x.grad.float(), bn.weight.grad, bn.bias.grad, conv.weight.grad, conv.bias.grad])
+
+    v1, g1 = fused()
+    v2, g2 = fused()
+    for a_, b_ in zip(v1 + g1, v2 + g2):
+        assert torch.equal(a_, b_), "the fused classifier tail is not repeatable"
+    # the reference lines, float64, NCHW
+    x = y2.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    bnd, convd = nn.BatchNorm2d(32).cuda().double().train(), nn.Conv2d(32, classes, 1).cuda().double()
+    with torch.no_grad():
+        bnd.weight.copy_(bn.weight); bnd.bias.copy_(bn.bias); convd.weight.copy_(conv.weight); convd.bias.copy_(conv.bias)
+    logits = convd(torch.relu(bnd(x)))
+    pooled_ref = F.avg_pool2d(logits, 2)
+    loss = (pooled_ref * dpooled.double().permute(0, 3, 1, 2)).sum()
+    ce_ref = torch.zeros(1, device="cuda", dtype=torch.float64)
+    if with_loss:
+        target = F.interpolate(gt.unsqueeze(1), size=(H, W)).squeeze(1).long()
+        ce_ref = F.cross_entropy(logits, target, reduction="none").mean([1, 2])
+        loss = loss + (ce_ref * g_rows.double()).sum()
+    loss.backward()
+    sem, pooled, ce, rm, rv = v1
+    sc = float(logits.abs().max())
+    assert float((sem[..., :classes].double() - logits.detach().permute(0, 2, 3, 1)).abs().max()) <= 1.2e-2 * sc
+    assert float(sem[..., classes:].abs().max()) == 0.0 if classes < 32 else True
+    assert float((pooled[..., :classes].double() - pooled_ref.detach().permute(0, 2, 3, 1)).abs().max()) <= 1.2e-2 * sc
+    if with_loss:
+        assert float((ce.double() - ce_ref.detach()).abs().max()) <= 2e-3 * float(ce_ref.abs().max()), (ce, ce_ref)
+    assert float((rm.double() - bnd.running_mean).abs().max()) <= 1e-5 and float((rv.double() - bnd.running_var).abs().max()) <= 1e-4
+    dx, dgm, dbt, dw, db = g1
+    for name, a_, b_ in (("dx", dx.double(), x.grad.permute(0, 2, 3, 1)), ("dgamma", dgm.double(), bnd.weight.grad), ("dbeta", dbt.double(), bnd.bias.grad),
+                         ("dW", dw.double(), convd.weight.grad), ("db", db.double(), convd.bias.grad)):
+        e = float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-12)
+        assert e <= 2e-2, (name, e)
+
+
+def test_cls_tail_in_the_policy_matches_the_unfused_route(monkeypatch):
+    """The bf16 update with the fused classifier tail against the same update with WSMG_FUSED_CLS_TAIL=0 (BatchNorm apply, 1 x 1
+    convolution, cross-entropy, average pool and their six backward passes as separate launches): logits within 1e-3, loss within
+    0.1 %, the whole gradient's cosine >= 0.9999 and the classifier's own tensors within 2 % of max|grad|; T=4 x N=8."""
+    import test_gpu_policy as tp
+    state = r2._default_state()
+    p1, l1, g1 = tp._bench_like_update("bf16", 4, 8, state)
+    monkeypatch.setenv("WSMG_FUSED_CLS_TAIL", "0")
+    p0, l0, g0 = tp._bench_like_update("bf16", 4, 8, state)
+    assert float((p1 - p0).abs().max()) <= 1e-3 and abs(l1 - l0) <= 1e-3 * abs(l0), (float((p1 - p0).abs().max()), l1, l0)
+    assert set(g1) == set(g0)
+    a = torch.cat([g1[n].flatten() for n in g0]).double()
+    b = torch.cat([g0[n].flatten() for n in g0]).double()
+    cos = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+    assert cos >= 0.9999, cos
+    for n in g0:
+        if "map_classfier" in n and n not in NULL_GRAD:
+            e = float((g1[n] - g0[n]).abs().max()) / max(float(g0[n].abs().max()), 1e-12)
+            assert e <= 2e-2, (n, e)

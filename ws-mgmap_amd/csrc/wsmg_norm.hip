@@ -481,6 +481,27 @@ extern "C" int wsmg_bn_act_fwd_bf16_pre(const void* x, const void* residual, con
   WSMG_RETURN_LAUNCH();
 }
 
+// The two halves of wsmg_bn_act_fwd_bf16_pre / wsmg_bn_act_bwd_bf16 on their own, for callers that fuse the other half into a
+// kernel of theirs (csrc/wsmg_cls_tail.hip): (1) batch statistics from the slabs a convolution's epilogue filled -> mean, 1 / sqrt(
+// var + eps), running statistics; the slabs are handed back zeroed.  (2) dx = gamma invstd (dy - dbeta / n - xhat dgamma / n) for a
+// dy that is ALREADY masked by the ReLU and whose two per-channel sums (dbeta = sum dy, dgamma = sum dy xhat) the caller supplies.
+extern "C" int wsmg_bn_stats_finalize(double* stats, int nslab, int C, int64_t rows, float momentum, float eps, float* running_mean,
+                                      float* running_var, float* save_mean, float* save_invstd, wsmg_stream_t stream) {
+  if (!chan_ok(C) || rows <= 0 || !stats || nslab <= 0 || !save_mean || !save_invstd) return WSMG_EINVAL;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, wsmg_s(stream), stats, nslab, C, rows, momentum, eps, running_mean,
+                     running_var, save_mean, save_invstd, 1);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bn_bwd_apply_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* invstd,
+                                      const float* dgamma, const float* dbeta, int64_t rows, int C, void* dx, wsmg_stream_t stream) {
+  if (!chan_ok(C) || (C & 7) || rows <= 0 || !dy || !x || !gamma || !mean || !invstd || !dgamma || !dbeta || !dx) return WSMG_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, wsmg_s(stream), (const bf16_t*)dy, (const bf16_t*)x,
+                     (const bf16_t*)nullptr, gamma, (const float*)nullptr, mean, invstd, dgamma, dbeta, 0, 1.0f / (float)rows, rows, C,
+                     (bf16_t*)dx, (bf16_t*)nullptr, (int64_t)C);
+  WSMG_RETURN_LAUNCH();
+}
+
 extern "C" int64_t wsmg_channel_reduce_workspace_bytes(int64_t rows, int C) {
   if (!chan_ok(C)) return 0;
   return (int64_t)red_blocks(rows, C) * 2 * C * (int64_t)sizeof(double);

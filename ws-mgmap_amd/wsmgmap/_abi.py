@@ -99,6 +99,11 @@ _SIG["wsmg_aux_reduce_fwd"] = [c_p, c_p, c_i, c_p, c_i, c_p, c_p]
 _SIG["wsmg_aux_reduce_bwd"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p]
 _SIG["wsmg_dagger_loss_fwd"] = [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_dagger_loss_bwd"] = [c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]
+_SIG["wsmg_cls_tail_workspace_floats"] = [c_i]
+_SIG["wsmg_cls_tail_fwd_bf16"] = [c_p] * 7 + [c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
+_SIG["wsmg_cls_tail_bwd_bf16"] = [c_p] * 7 + [c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p]
+_SIG["wsmg_bn_stats_finalize"] = [c_p, c_i, c_i, c_l, c_f, c_f, c_p, c_p, c_p, c_p, c_p]
+_SIG["wsmg_bn_bwd_apply_bf16"] = [c_p] * 7 + [c_l, c_i, c_p, c_p]
 _SIG["wsmg_bn_act_bwd_ld"] = [c_p, c_l] + _SIG["wsmg_bn_act_bwd"][1:]
 _SIG["wsmg_bn_act_bwd_ld_bf16"] = list(_SIG["wsmg_bn_act_bwd_ld"])
 _SIG["wsmg_upsample2x_bwd_ld"] = [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p]
@@ -128,7 +133,7 @@ _SIG["wsmg_path_kl_fwd"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_
 _SIG["wsmg_path_kl_bwd"] = [c_p, c_p, c_p, c_i, c_i, c_p, c_p]
 _SIG["wsmg_adam_step_multi"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_double, ctypes.c_double, c_p]
 _SIG["wsmg_adam_step_multi_dev"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
-_RESTYPE = {"wsmg_attn_fp8_workspace_bytes": c_l, "wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
+_RESTYPE = {"wsmg_cls_tail_workspace_floats": c_l, "wsmg_attn_fp8_workspace_bytes": c_l, "wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
 
 _lib = None
 

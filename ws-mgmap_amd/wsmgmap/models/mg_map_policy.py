@@ -89,6 +89,9 @@ class MGMapNet(nn.Module):
         self._side_stream = None
         self.skip_pred_map_nchw = False   # set by BasePolicy around its own forward: it consumes sem_logits_nhwc
         self.sem_logits_nhwc = None
+        self.sem_ce_rows = None           # the prediction monitor's per-sample loss when the fused classifier tail computed it
+        self._gt_semantic_map = None      # set by BasePolicy.forward for that loss (observations['gt_semantic_map'])
+        self._cls_tail_allowed = False    # likewise: the fused tail's logits carry no gradient
         # storage type of the map-stack activations: float32 (parity mode, f32 MFMA) or bfloat16
         # (BASELINE configs[1]; bf16 MFMA, float32 accumulation, float32 master weights)
         # (not a reference field; both spellings are accepted: `COMPUTE_DTYPE` as yacs nodes are usually written and
@@ -230,20 +233,29 @@ class MGMapNet(nn.Module):
         st4 = ops.bn_stats_slabs(id(c[4]), 32, dec.device) if fused else None
         y = ops.conv2d(y, c[3].weight, None, 1, 1, stats=st4)
         bump(c[4], train)
-        y = ops.bn_act(y, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var, train, True, None, c[4].momentum, c[4].eps, st4)
+        self.sem_ce_rows = None
+        # (only under BasePolicy.forward, which takes the loss from `sem_ce_rows` and never differentiates the logits themselves:
+        #  `skip_pred_map_nchw` is its mark; a caller that builds its own loss on pred_sem_map gets the unfused, differentiable route)
+        if (st4 is not None and self.skip_pred_map_nchw and getattr(self, "_cls_tail_allowed", False) and SEM_PAD == 32 and ops.cls_tail_ok(y, SEM_CLASSES) and c[6].bias is not None):
+            # BatchNorm + ReLU + the 1 x 1 convolution + the prediction monitor's cross-entropy + the 2 x 2 average pool in ONE pass
+            # per direction over the 48 x 48 x 32 activation (csrc/wsmg_cls_tail.hip) instead of four forward / six backward passes
+            sem, pooled, self.sem_ce_rows = ops.cls_tail(y, st4, c[4], c[6], getattr(self, "_gt_semantic_map", None))
+        else:
+            y = ops.bn_act(y, c[4].weight, c[4].bias, c[4].running_mean, c[4].running_var, train, True, None, c[4].momentum, c[4].eps, st4)
+            pad_o = SEM_PAD - SEM_CLASSES
+            w6 = torch.nn.functional.pad(c[6].weight, (0, 0, 0, 0, 0, 0, 0, pad_o))   # [32,32,1,1]
+            b6 = torch.nn.functional.pad(c[6].bias, (0, pad_o))
+            sem = ops.conv2d(y, w6, b6, 1, 0)                                        # [B,2S,2S,32], channels 27.. are 0
+            pooled = ops.avgpool2(sem)
         if fused:
             ops.bn_stats_done(id(c[1]), 32, dec.device)
             ops.bn_stats_done(id(c[4]), 32, dec.device)
-        pad_o = SEM_PAD - SEM_CLASSES
-        w6 = torch.nn.functional.pad(c[6].weight, (0, 0, 0, 0, 0, 0, 0, pad_o))   # [32,32,1,1]
-        b6 = torch.nn.functional.pad(c[6].bias, (0, pad_o))
-        sem = ops.conv2d(y, w6, b6, 1, 0)                                        # [B,2S,2S,32], channels 27.. are 0
         # the loss reads the NHWC logits directly (policy.aux_prediction); the reference-layout [B,27,2S,2S] tensor is
         # only materialised for callers that ask for it
         self.sem_logits_nhwc = sem
         pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
         # (27 -> 32 input channels: ops.conv2d zero-pads the weight to the activation's channel count)
-        cls_proj = ops.conv2d(ops.avgpool2(sem), self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True)
+        cls_proj = ops.conv2d(pooled, self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True)
         emb = ops.conv2d_cat([enc_proj, cls_proj], self.map_cated_linear[0].weight, self.map_cated_linear[0].bias, 1, 1, relu=True,
                              relu_sink=self._token_sink)
         b, s1, s2, ch = emb.shape

@@ -72,12 +72,15 @@ class BasePolicy(nn.Module):
         if not AuxLosses.is_active():
             return
         if cfg.PREDICTION_MONITOR.use:
-            side = self.net.sem_logits_nhwc.shape[1] if pred_map is None else pred_map.shape[-1]
-            target = F.interpolate(observations["gt_semantic_map"].unsqueeze(1), size=(side, side)).squeeze(1).long()
-            if pred_map is None:   # fused path: per-pixel CE straight from the NHWC logits of the conv engine
-                loss = ops.cross_entropy_nhwc(self.net.sem_logits_nhwc, target, SEM_CLASSES).mean([1, 2])
+            if pred_map is None and getattr(self.net, "sem_ce_rows", None) is not None:
+                loss = self.net.sem_ce_rows      # computed by the fused classifier tail (ops.cls_tail), nearest resize included
             else:
-                loss = F.cross_entropy(pred_map, target, reduction="none").mean([1, 2])
+                side = self.net.sem_logits_nhwc.shape[1] if pred_map is None else pred_map.shape[-1]
+                target = F.interpolate(observations["gt_semantic_map"].unsqueeze(1), size=(side, side)).squeeze(1).long()
+                if pred_map is None:   # per-pixel CE straight from the NHWC logits of the conv engine
+                    loss = ops.cross_entropy_nhwc(self.net.sem_logits_nhwc, target, SEM_CLASSES).mean([1, 2])
+                else:
+                    loss = F.cross_entropy(pred_map, target, reduction="none").mean([1, 2])
             AuxLosses.register_loss("prediction_monitor", loss, cfg.PREDICTION_MONITOR.alpha)
         if cfg.CONTRASTIVE_MONITOR.use:
             size = self.net.map_encoder.output_shape[-1]
@@ -98,10 +101,16 @@ class BasePolicy(nn.Module):
     # -- teacher forcing / DAgger update ---------------------------------------------
     def forward(self, observations, rnn_hidden_states, prev_actions, masks, weights):
         self.net.skip_pred_map_nchw = os.environ.get("WSMG_FUSED_CE", "1") != "0"   # the only consumer of pred_sem_map is the loss below
+        gt = observations.get("gt_semantic_map") if (AuxLosses.is_active() and self.model_config.PREDICTION_MONITOR.use) else None
+        self.net._gt_semantic_map = gt if (gt is not None and gt.is_cuda and gt.dtype == torch.float32 and gt.dim() == 3) else None
+        # the fused classifier tail returns logits that carry no gradient: it may only run when the loss on them is its own
+        self.net._cls_tail_allowed = gt is None or self.net._gt_semantic_map is not None
         try:
             features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
         finally:
             self.net.skip_pred_map_nchw = False
+            self.net._gt_semantic_map = None
+            self.net._cls_tail_allowed = False
         # = self.action_distribution(features).mean (policy.py:96-97) without building the Normal: its log-std / exp / expand
         # kernels produce nothing the update path reads (logstd gets no gradient in the reference either)
         fused = (features.is_cuda and features.dtype == torch.float32 and features.shape[1] % 4 == 0

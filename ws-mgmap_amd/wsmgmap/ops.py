@@ -1092,6 +1092,78 @@ def path_kl(dis, att, size, tau):
     return _PathKL.apply(dis.contiguous(), att.contiguous(), int(size), float(tau))
 
 
+# ----------------------------------------------------------------------------- the semantic classifier's tail, fused
+class _ClsTail(torch.autograd.Function):
+    """BatchNorm2d(32, batch statistics) + ReLU + Conv2d(32, classes, 1) + { per-sample cross-entropy against the nearest-resized
+    ground truth, AvgPool2d(2), the logits } in one pass per direction over the 32-channel activation (csrc/wsmg_cls_tail.hip):
+    mg_map_policy.py:78-86,93-96,195 and policy.py:61-66 of the reference.  bf16 training mode only."""
+
+    @staticmethod
+    def forward(ctx, y2, stats, gamma, beta, running_mean, running_var, momentum, eps, w6, b6, gt):
+        _req(y2, stats, gamma, beta, running_mean, running_var, w6, b6, gt)
+        _f32(gamma, beta, running_mean, running_var, w6, b6, gt)
+        B, H, W, C = y2.shape
+        classes = w6.shape[0]
+        if y2.dtype != torch.bfloat16 or C != 32 or w6.numel() != classes * 32 or b6.numel() != classes or stats.dtype != torch.float64:
+            raise _abi.WsmgError("cls_tail: bf16 [B,H,W,32] activation, [classes,32,1,1] weight, float64 statistics slabs")
+        if gt is not None and (gt.dim() != 3 or gt.shape[0] != B):
+            raise _abi.WsmgError("cls_tail: ground truth [B, Hg, Wg] float32")
+        dev = y2.device
+        mean, invstd = torch.empty(32, device=dev), torch.empty(32, device=dev)
+        _abi.call("wsmg_bn_stats_finalize", _p(stats), stats.shape[0], 32, B * H * W, float(momentum), float(eps), _p(running_mean),
+                  _p(running_var), _p(mean), _p(invstd), _stream())
+        torch.autograd.graph.increment_version([running_mean, running_var])
+        sem = torch.empty(B, H, W, 32, device=dev, dtype=torch.bfloat16)
+        pooled = torch.empty(B, H // 2, W // 2, 32, device=dev, dtype=torch.bfloat16)
+        ce = torch.empty(B, device=dev, dtype=torch.float32) if gt is not None else None
+        Hg, Wg = (gt.shape[1], gt.shape[2]) if gt is not None else (0, 0)
+        _abi.call("wsmg_cls_tail_fwd_bf16", _p(y2), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(w6), _p(b6), classes, _p(gt), Hg, Wg,
+                  B, H, W, _p(sem), _p(pooled), _p(ce), _stream())
+        ctx.save_for_backward(y2, gamma, beta, mean, invstd, w6, b6, gt)
+        ctx.mark_non_differentiable(sem)
+        ctx.set_materialize_grads(False)
+        return sem, pooled, ce
+
+    @staticmethod
+    def backward(ctx, _dsem, dpooled, dce):
+        y2, gamma, beta, mean, invstd, w6, b6, gt = ctx.saved_tensors
+        B, H, W, _ = y2.shape
+        classes = w6.shape[0]
+        dev = y2.device
+        dpooled = None if dpooled is None else dpooled.contiguous()
+        dce = None if dce is None else dce.contiguous().float()
+        if dpooled is not None and dpooled.dtype != torch.bfloat16:
+            raise _abi.WsmgError("cls_tail: the pooled map's gradient must be bf16")
+        Hg, Wg = (gt.shape[1], gt.shape[2]) if gt is not None else (0, 0)
+        dbn = torch.empty_like(y2)
+        nws = int(_abi.lib().wsmg_cls_tail_workspace_floats(B))
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        dgamma, dbeta = torch.empty(32, device=dev), torch.empty(32, device=dev)
+        dw6, db6 = torch.empty_like(w6), torch.empty_like(b6)
+        _abi.call("wsmg_cls_tail_bwd_bf16", _p(y2), _p(gamma), _p(beta), _p(mean), _p(invstd), _p(w6), _p(b6), classes,
+                  _p(gt if dce is not None else None), Hg, Wg, _p(dce), _p(dpooled), B, H, W, _p(dbn), _p(ws), nws, _p(dgamma), _p(dbeta),
+                  _p(dw6), _p(db6), _stream())
+        # BatchNorm's apply pass, in place (element i of dx depends on element i of dy and x only)
+        _abi.call("wsmg_bn_bwd_apply_bf16", _p(dbn), _p(y2), _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), B * H * W, 32, _p(dbn),
+                  _stream())
+        return dbn, None, dgamma, dbeta, None, None, None, None, dw6, db6, None
+
+
+def cls_tail_ok(y2, classes):
+    """Can `cls_tail` take this activation?  bf16 [B, H, W, 32] with H even and W a multiple of 16, at most 32 classes."""
+    return (y2.is_cuda and y2.dtype == torch.bfloat16 and y2.dim() == 4 and y2.shape[3] == 32 and y2.shape[1] % 2 == 0
+            and y2.shape[2] % 16 == 0 and classes <= 32 and _os.environ.get("WSMG_FUSED_CLS_TAIL", "1") != "0")
+
+
+def cls_tail(y2, stats, bn, conv1x1, gt=None):
+    """-> (logits [B,H,W,32] bf16 — not differentiable, for inspection / pred_sem_map —, pooled [B,H/2,W/2,32] bf16, ce_rows [B] or
+    None): train-mode `bn` (nn.BatchNorm2d(32), statistics in `stats` from the producing convolution's epilogue) + ReLU + `conv1x1`
+    (nn.Conv2d(32, classes, 1)) + the prediction monitor's per-sample cross-entropy against gt [B,Hg,Wg] + AvgPool2d(2)."""
+    w, b = conv1x1.weight, conv1x1.bias
+    return _ClsTail.apply(y2.contiguous(), stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                          w.contiguous(), b, None if gt is None else gt.contiguous())
+
+
 # ----------------------------------------------------------------------------- update-path heads, auxiliary reduction, trainer loss
 class _UpdateHeads(torch.autograd.Function):
     """(pred [B,A], prog [B,1], progress-loss rows [B]) of the update path in one launch per direction (csrc/wsmg_heads.hip):
