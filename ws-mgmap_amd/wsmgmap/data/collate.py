@@ -42,6 +42,43 @@ def collate_fn(batch):
     return obs, prev.view(-1, 2), masks.view(-1, 1), corr, wts
 
 
+def plan_batch(batch):
+    """The staging layout of one batch — all episodes of all sensors back to back, 16-byte aligned — without touching the data:
+    -> (plan, meta).  plan = [(name, per-episode arrays cut to T steps, pad value)]; meta is small and picklable: it describes
+    the packed bytes to whoever issues the device side (`DeviceCollator.launch`), possibly another process."""
+    N = len(batch)
+    lengths = [int(len(b[1])) for b in batch]
+    T = min(max(lengths), LIMITED_LEN_BY_GPU)
+    # episodes longer than T are cut before they travel
+    plan = [(k, [np.ascontiguousarray(np.asarray(b[0][k])[:T]) for b in batch], 1.0) for k in batch[0][0]]
+    plan.append(("__prev", [np.ascontiguousarray(np.asarray(b[1], dtype=np.float32)[:T]) for b in batch], 0.0))
+    plan.append(("__corr", [np.ascontiguousarray(np.asarray(b[2], dtype=np.float32)[:T]) for b in batch], 0.0))
+    plan.append(("__wts", [np.ascontiguousarray(np.asarray(b[3], dtype=np.float32)[:T]) for b in batch], 0.0))
+    offs, total, sensors = [], 0, []
+    for name, arrs, pad in plan:
+        if arrs[0].dtype not in _DT:
+            raise _abi.WsmgError(f"unsupported on-disk dtype {arrs[0].dtype} in the trajectory cache")
+        for a in arrs:
+            total = (total + 15) & ~15
+            offs.append(total)
+            total += a.nbytes
+        sensors.append((name, tuple(arrs[0].shape[1:]), _DT[arrs[0].dtype], float(pad)))
+    meta = dict(N=N, T=T, lengths=[min(n, T) for n in lengths], offsets=offs, total=total + 16, sensors=sensors)
+    return plan, meta
+
+
+def pack_batch(plan, meta, host_u8):
+    """Copy the planned arrays into `host_u8` (a uint8 numpy view of at least meta['total'] bytes: pinned staging, or a slot of the
+    shared-memory ring of the process feeder)."""
+    if host_u8.size < meta["total"]:
+        raise _abi.WsmgError(f"staging buffer of {host_u8.size} bytes for a batch of {meta['total']}")
+    it = iter(meta["offsets"])
+    for _, arrs, _ in plan:
+        for a in arrs:
+            o = next(it)
+            host_u8[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+
+
 class DeviceCollator:
     """collate + `.float().to(device)` of the reference, assembled on the GPU.  One pinned staging buffer per call
     holds all episodes of all sensors back to back; it goes to the device in ONE asynchronous copy on `stream`, then
@@ -57,48 +94,35 @@ class DeviceCollator:
         return self._pinned
 
     def __call__(self, batch, stream=None):
+        plan, meta = plan_batch(batch)
+        host = self._staging(meta["total"])
+        pack_batch(plan, meta, host.numpy())
+        return self.launch(meta, host, stream)
+
+    def launch(self, meta, host, stream=None):
+        """The device side of one packed batch: `host` (a uint8 CPU tensor holding the bytes `pack_batch` wrote — pinned for an
+        asynchronous copy) -> the tensors the trainer hands to `_update_agent`.  The caller may reuse `host` once `stream` has
+        passed this point."""
         stream = stream or torch.cuda.current_stream(self.device)
-        N = len(batch)
-        lengths = [int(len(b[1])) for b in batch]
-        T = min(max(lengths), LIMITED_LEN_BY_GPU)
-        # plan: (name, per-episode arrays, pad value); episodes longer than T are cut before they travel
-        plan = [(k, [np.ascontiguousarray(np.asarray(b[0][k])[:T]) for b in batch], 1.0) for k in batch[0][0]]
-        plan.append(("__prev", [np.ascontiguousarray(np.asarray(b[1], dtype=np.float32)[:T]) for b in batch], 0.0))
-        plan.append(("__corr", [np.ascontiguousarray(np.asarray(b[2], dtype=np.float32)[:T]) for b in batch], 0.0))
-        plan.append(("__wts", [np.ascontiguousarray(np.asarray(b[3], dtype=np.float32)[:T]) for b in batch], 0.0))
-        offs, total = [], 0
-        for _, arrs, _ in plan:
-            if arrs[0].dtype not in _DT:
-                raise _abi.WsmgError(f"unsupported on-disk dtype {arrs[0].dtype} in the trajectory cache")
-            for a in arrs:
-                total = (total + 15) & ~15
-                offs.append(total)
-                total += a.nbytes
-        host = self._staging(total + 16)
-        hview = host.numpy()
-        it = iter(offs)
-        for _, arrs, _ in plan:
-            for a in arrs:
-                o = next(it)
-                hview[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+        N, T, total, offs = meta["N"], meta["T"], meta["total"], meta["offsets"]
         with torch.cuda.stream(stream):
-            dev = torch.empty(total + 16, dtype=torch.uint8, device=self.device)
-            dev.copy_(host[: total + 16], non_blocking=True)
+            dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+            dev.copy_(host[:total], non_blocking=True)
             base = dev.data_ptr()
-            lens_dev = torch.tensor([min(n, T) for n in lengths], dtype=torch.int32, device=self.device)
+            lens_dev = torch.tensor(meta["lengths"], dtype=torch.int32, device=self.device)
             ptrs_dev = torch.tensor([base + o for o in offs], dtype=torch.int64, device=self.device)
-            out, it, row = {}, iter(range(len(offs))), 0
-            for name, arrs, pad in plan:
-                elems = int(np.prod(arrs[0].shape[1:], dtype=np.int64))
-                dst = torch.empty((T, N) + tuple(arrs[0].shape[1:]), dtype=torch.float32, device=self.device)
+            out, row = {}, 0
+            for name, shape, code, pad in meta["sensors"]:
+                elems = int(np.prod(shape, dtype=np.int64))
+                dst = torch.empty((T, N) + tuple(shape), dtype=torch.float32, device=self.device)
                 _abi.call("wsmg_collate_pad", ctypes.c_void_p(ptrs_dev.data_ptr() + 8 * row), ctypes.c_void_p(lens_dev.data_ptr()),
-                          N, T, max(elems, 1), _DT[arrs[0].dtype], float(pad), ctypes.c_void_p(dst.data_ptr()),
+                          N, T, max(elems, 1), code, float(pad), ctypes.c_void_p(dst.data_ptr()),
                           ctypes.c_void_p(stream.cuda_stream))
                 row += N
                 out[name] = dst
             dev.record_stream(stream)
+            masks = torch.ones(T, N, dtype=torch.float32, device=self.device)
+            masks[0] = 0
         prev, corr, wts = out.pop("__prev"), out.pop("__corr"), out.pop("__wts")
         obs = {k: v.view(-1, *v.shape[2:]) for k, v in out.items()}
-        masks = torch.ones(T, N, dtype=torch.float32, device=self.device)
-        masks[0] = 0
         return obs, prev.view(-1, 2), masks.view(-1, 1), corr, wts

@@ -36,7 +36,11 @@ class TrajectoryDataset(torch.utils.data.IterableDataset):
         self.inflec_weights = torch.tensor([1.0, inflection_weight_coef if use_iw else 1.0])
         self._preload, self.load_ordering, self.loaded_indices = [], [], []
 
+    _worker_override = None     # (num_workers, worker_id) when the decode workers are not DataLoader's (data.feeder's ring)
+
     def _shard(self):
+        if self._worker_override is not None:
+            return shard_range(self.length, self.rank, self.world_size, *self._worker_override)
         info = torch.utils.data.get_worker_info()
         return shard_range(self.length, self.rank, self.world_size, 0 if info is None else info.num_workers,
                            0 if info is None else info.id)
