@@ -528,6 +528,7 @@ def test_cls_tail_matches_the_reference_lines_in_float64(geom, with_loss):
         conv.weight.copy_(conv.weight.to(torch.bfloat16).float())       # bf16-representable weights: the product itself is then exact
     gt = torch.randint(0, classes, (B, Hg, Hg), device="cuda", generator=g).float() if with_loss else None
     dpooled = (torch.randn(B, H // 2, W // 2, 32, device="cuda", generator=g) * 0.01).to(torch.bfloat16)
+    dpooled[..., classes:] = 0       # (the consumer's zero-padded weight sends no gradient into the padded classes)
     g_rows = torch.rand(B, device="cuda", generator=g) + 0.5
 
     def stats_of(t):
@@ -560,7 +561,7 @@ def test_cls_tail_matches_the_reference_lines_in_float64(geom, with_loss):
         bnd.weight.copy_(bn.weight); bnd.bias.copy_(bn.bias); convd.weight.copy_(conv.weight); convd.bias.copy_(conv.bias)
     logits = convd(torch.relu(bnd(x)))
     pooled_ref = F.avg_pool2d(logits, 2)
-    loss = (pooled_ref * dpooled.double().permute(0, 3, 1, 2)).sum()
+    loss = (pooled_ref * dpooled.double().permute(0, 3, 1, 2)[:, :classes]).sum()
     ce_ref = torch.zeros(1, device="cuda", dtype=torch.float64)
     if with_loss:
         target = F.interpolate(gt.unsqueeze(1), size=(H, W)).squeeze(1).long()

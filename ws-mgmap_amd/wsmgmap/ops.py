@@ -246,11 +246,13 @@ def reset_pass_state():
     torch.zeros launch and, with WSMG_WGRAD_STREAM=1, optimizer.step could race the side-stream weight gradients."""
     TokenGradSink.check_none_pending()
     _prelaid.clear()
+    _pass_seen.clear()
+    _pass_shared.clear()
     if any(z["armed"] for z in _zero_pool.values()):
         _zero_pool_retire()
     if _side_join_armed:
         for main_id, side_id in list(_side_join_armed):
-            for side in _wgrad_side.values():
+            for side in list(_wgrad_side.values()) + list(_reduce_side.values()):
                 if side.cuda_stream == side_id:
                     torch.cuda.current_stream().wait_stream(side)
         _side_join_armed.clear()
@@ -293,22 +295,55 @@ def _weight_grad_oihw(dw_ohwi, I):
 # weight-gradient kernels' workgroups STORE their partial tiles into slabs of a workspace and one more launch adds the slabs in
 # a fixed order while it re-lays dW out as OIHW — no float atomics, no zero-fill of dW, bit-identical gradients from run to
 # run (the reference sets cudnn.deterministic, run.py:107-108).  WSMG_WGRAD_ATOMICS=1 restores the atomic form (A/B).
-_wgrad_ws = {}        # stream -> float32 workspace (launches of one stream use it one after the other)
+_wgrad_ws = {}        # (device, stream, layer geometry or None) -> float32 workspace
+_reduce_side = {}     # device -> the stream the slab reductions run on (beside the backward pass's next convolution kernels)
 
 
-def _wgrad_workspace(device, floats):
-    key = (device.index, _raw_stream())
+def _wgrad_workspace(device, floats, layer=None):
+    """layer=None: one workspace per stream, shared by the layers (launches of one stream use it one after the other);
+    layer=key: that layer's own workspace (its reduction runs on another stream while the next layer's kernel fills its own)."""
+    key = (device.index, _raw_stream(), layer)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < floats:
         if ws is not None:
             ws.record_stream(torch.cuda.current_stream())      # launches that still read the old one are queued on this stream
-        ws = torch.empty(max(int(floats), 1 << 24), device=device, dtype=torch.float32)
+        ws = torch.empty(max(int(floats), 1 << 24) if layer is None else int(floats), device=device, dtype=torch.float32)
         _wgrad_ws[key] = ws
     return ws
 
 
-def _weight_grad(sfx, x, dy, dims, fl, Cin_w):
-    """OIHW float32 weight gradient [Cout, Cin_w, KH, KW] of the convolution `dims` from x [B,H,W,Cin] and dy [B,OH,OW,Cout]."""
+def _reduce_stream(device, param):
+    """The side stream for the slab reductions, or None.  The reduction of a layer is pure HBM traffic (its slabs: 25-75 MB) with
+    nothing but the optimizer waiting for it: on a second stream it runs beside the backward pass's next convolution kernels,
+    which are bound by the matrix pipe and the L2 -> LDS path.  Conditions: inside a backward pass (the join is an
+    end-of-backward callback), one process (the gradient all-reduce hooks read p.grad on the main stream as soon as it is
+    accumulated), and a parameter whose gradient is SET, not added to, by this pass — autograd's accumulation into an existing
+    .grad would run on the main stream before the reduction has finished.  WSMG_WGRAD_REDUCE_STREAM=0: same stream (A/B)."""
+    if param is None or param.grad is not None or _os.environ.get("WSMG_WGRAD_REDUCE_STREAM", "1") == "0":
+        return None
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return None
+    if id(param) in _pass_shared:
+        return None
+    s = _reduce_side.get(device.index)
+    if s is None:
+        s = _reduce_side[device.index] = torch.cuda.Stream(device)
+    return s
+
+
+_pass_seen, _pass_shared = set(), set()    # parameters used by one / by several convolutions of the running pass
+
+
+def _note_param_use(w):
+    k = id(w)
+    if k in _pass_seen:
+        _pass_shared.add(k)
+    _pass_seen.add(k)
+
+
+def _weight_grad(sfx, x, dy, dims, fl, Cin_w, param=None):
+    """OIHW float32 weight gradient [Cout, Cin_w, KH, KW] of the convolution `dims` from x [B,H,W,Cin] and dy [B,OH,OW,Cout].
+    param: the parameter this gradient is for, when the caller knows it (see _reduce_stream)."""
     B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
     if _os.environ.get("WSMG_WGRAD_ATOMICS", "0") == "1":
         dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
@@ -317,10 +352,24 @@ def _weight_grad(sfx, x, dy, dims, fl, Cin_w):
     nsplit, floats = ctypes.c_int(0), ctypes.c_longlong(0)
     _abi.call("wsmg_conv2d_bwd_weight" + sfx + "_plan", *dims, ctypes.cast(ctypes.byref(nsplit), ctypes.c_void_p),
               ctypes.cast(ctypes.byref(floats), ctypes.c_void_p))
-    ws = _wgrad_workspace(x.device, floats.value)
+    side = _reduce_stream(x.device, param)
+    if side is not None:
+        main = torch.cuda.current_stream()
+        try:
+            _join_side_at_end(main, side, strict=True)     # raises outside a backward pass
+        except RuntimeError:
+            side = None
+    ws = _wgrad_workspace(x.device, floats.value, None if side is None else (tuple(dims), sfx))
     _launch("wsmg_conv2d_bwd_weight" + sfx + "_slabs", fl, _p(x), _p(dy), _p(ws), nsplit.value, floats.value, *dims, _stream())
-    out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
-    _abi.call("wsmg_weight_grad_reduce_oihw", _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream())
+    if side is None:
+        out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_weight_grad_reduce_oihw", _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream())
+        return out
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
+        _abi.call("wsmg_weight_grad_reduce_oihw", _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream())
+    out.record_stream(main)        # consumed on the main stream behind the end-of-backward join
     return out
 
 
@@ -343,18 +392,27 @@ def _wgrad_side_stream(flops=0.0):
     return _wgrad_side[dev]
 
 
-def _join_side_at_end(main, side):
+def _join_side_at_end(main, side, strict=False):
+    """main waits for side once, when the running backward pass ends.  strict: outside a backward pass raise (the caller
+    then does not use the side stream at all) instead of joining now."""
     key = (main.cuda_stream, side.cuda_stream)
     if key in _side_join_armed:
         return
 
     def join():
+        # (final callbacks run on the stream that called backward(), AFTER the engine has joined the streams of the backward
+        #  nodes into it: if `main` is one of those — the decoder's side branch — waiting on `main` alone would come too late)
         _side_join_armed.discard(key)
         main.wait_stream(side)
+        cur = torch.cuda.current_stream(main.device)
+        if cur.cuda_stream != main.cuda_stream:
+            cur.wait_stream(side)
     try:
         torch.autograd.Variable._execution_engine.queue_callback(join)
         _side_join_armed.add(key)
     except RuntimeError:      # not inside a backward pass: join now
+        if strict:
+            raise
         main.wait_stream(side)
 
 
@@ -420,6 +478,8 @@ class _Conv2d(torch.autograd.Function):
                 _abi.call("wsmg_relu_fwd", _p(y), _p(y), y.numel(), _stream())
         ctx.save_for_backward(x, w_ihwo, y if relu else None)
         ctx.cfg = dims + (bias is not None, sfx, Cin_w)
+        ctx.w_param = w_oihw if w_oihw.is_leaf else None     # (a leaf: its .grad is where the weight gradient goes)
+        _note_param_use(w_oihw)
         ctx.bias_grad_zero = bool(bias_grad_zero)
         ctx.relu_sink = relu_sink if relu else None
         if ctx.relu_sink is not None:
@@ -454,7 +514,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             side = _wgrad_side_stream(fl)
             if side is None:
-                dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
+                dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w, ctx.w_param)
             else:
                 # the weight gradient is a leaf of the backward graph: it runs on a side stream beside the backward-data
                 # chain and fills the tails of its launches (1.8-3.6 waves of workgroups each); the main stream joins the
