@@ -534,6 +534,16 @@ int wsmg_bn_stats_finalize(double* stats, int nslab, int C, int64_t rows, float 
 int wsmg_bn_bwd_apply_bf16(const void* dy, const void* x, const float* gamma, const float* mean, const float* invstd,
                            const float* dgamma, const float* dbeta, int64_t rows, int C, void* dx, wsmg_stream_t stream);
 
+/* BASELINE configs[4] on the matrix cores: `_attn` (mg_map_policy.py:173-178, call site :229-232) of B rows over U shared
+ * instruction sets, everything stored as OCP e4m3 bytes + one float scale per tensor (device scalars): S = Q K^T on
+ * v_mfma_f32_32x32x16_fp8_fp8, float32 softmax with the reference's `- 1e8 * mask` (tokens >= lengths[u]), O = P V on the bf16
+ * matrix pipe (P as a bf16 hi/lo pair, V converted exactly).  q_codes [B][256], k_codes / v_codes [U][L][256] (L <= 224),
+ * row_ids [B]: the row indices grouped by set, set_start [U+1]: offsets of the groups in row_ids; out [B][256], attn [B][L]. */
+int wsmg_attn_fp8_mfma_fwd(const uint8_t* q_codes, const float* q_scale, const uint8_t* k_codes, const float* k_scale,
+                           const uint8_t* v_codes, const float* v_scale, const int* lengths, const int* row_ids,
+                           const int* set_start, float scale, int B, int U, int L, int C, float* out, float* attn,
+                           wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

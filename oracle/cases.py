@@ -107,6 +107,26 @@ def attn_inputs(B=6, C=256, L=160, tag="g5"):
     return q, k, v, mask
 
 
+def attn_fp8_inputs(B=64, U=8, C=256, L=160, tag="g5f"):
+    """BASELINE configs[4] (cross-attention with fp8 storage, instruction length 160, batch 64) on inputs that ARE e4m3 numbers:
+    queries q [B, C], and per unique instruction u (row b uses set b % U, as the update path's T x N rows do) keys k [U, L, C] and
+    values v [U, L, C], every value on the OCP e4m3 grid times a power-of-two scale — quantising them to e4m3 with that scale is
+    lossless, so the reference's float32 `_attn` on these inputs (golden g5f) is what an fp8 kernel must reproduce, up to
+    float32 summation order.  lengths [U]: valid tokens per set (the rest masked).
+    -> dict(q, k, v float32; q_scale, k_scale, v_scale; lengths; inverse [B])"""
+    from .attn_fp8_ref import dequantize_e4m3, quantize_e4m3
+    sq, sk, sv = 2.0 ** -6, 2.0 ** -7, 2.0 ** -8
+
+    def grid(name, shape, amp, scale):
+        raw = df.uniform(f"{tag}.{name}", shape, amp)
+        return dequantize_e4m3(quantize_e4m3(raw, scale), scale).astype(np.float32)
+    q = grid("q", (B, C), 8.0, sq)
+    k = grid("k", (U, L, C), 4.0, sk)
+    v = grid("v", (U, L, C), 2.0, sv)
+    lengths = np.asarray([160, 1, 37, 80, 159, 64, 120, 100][:U], np.int64)
+    return dict(q=q, k=k, v=v, q_scale=sq, k_scale=sk, v_scale=sv, lengths=lengths, inverse=np.arange(B, dtype=np.int64) % U)
+
+
 def summarize(a, n_sample=2048):
     """Small machine-comparable digest of a float array: sums + strided sample."""
     a = np.asarray(a)

@@ -124,6 +124,30 @@ def test_g5_attention():
     np.testing.assert_allclose(o2.numpy(), g["out_nomask"], atol=1e-6, rtol=1e-5)
 
 
+def test_g5f_attention_on_e4m3_representable_inputs():
+    """g5f: the reference's `_attn` at BASELINE configs[4]'s size (B = 64, L = 160) on inputs that are exactly OCP e4m3 numbers
+    (oracle/cases.py::attn_fp8_inputs).  The oracle's float32 attention reproduces it; the inputs survive the e4m3 round trip
+    bit for bit (which is what makes this golden a pin for the fp8-storage kernels); and the fp8 oracle's float64 formula on the
+    codes agrees with it to float32 accuracy."""
+    from oracle import attn_fp8_ref as ar
+    g = golden("g5f_attn_fp8.npz")
+    c = cases.attn_fp8_inputs()
+    for name in ("q", "k", "v"):
+        sc = c[name + "_scale"]
+        assert np.array_equal(ar.dequantize_e4m3(ar.quantize_e4m3(c[name], sc), sc).astype(np.float32), c[name]), name
+    inv = c["inverse"]
+    k = np.ascontiguousarray(c["k"][inv].transpose(0, 2, 1))
+    v = np.ascontiguousarray(c["v"][inv].transpose(0, 2, 1))
+    mask = np.arange(k.shape[2])[None, :] >= c["lengths"][inv][:, None]
+    o, a = policy_ref.attn(T(c["q"]), T(k), T(v), T(mask))
+    np.testing.assert_allclose(o.numpy(), g["out"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(a.numpy(), g["attn"], atol=1e-7, rtol=1e-5)
+    # float64 evaluation of the same formula (what the fp8 kernels are held against between goldens)
+    lg = (np.einsum("bc,blc->bl", c["q"].astype(np.float64), c["k"][inv].astype(np.float64)) - 1e8 * mask) / 16
+    p = np.exp(lg - lg.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
+    assert np.abs(p - g["attn"]).max() < 5e-6 and np.abs(np.einsum("bl,blc->bc", p, c["v"][inv].astype(np.float64)) - g["out"]).max() < 5e-6
+
+
 def test_fp8_oracle_matches_f32_formula_on_representable_inputs():
     """oracle/attn_fp8_ref.py: on inputs that e4m3 represents exactly, the fp8 restatement equals the plain formula
     of g5 (mg_map_policy.py:173-178) and the codes round-trip; quantisation saturates at +-448."""

@@ -109,8 +109,14 @@ if __name__ == "__main__":      # (the decode workers are spawned: they import t
     host_side_and_collate()
 if __name__ == "__main__" and os.environ.get("WSMG_FEEDER_E2E", "1") != "0":
     print("end to end (in-memory record store -> decode processes -> pinned shared-memory ring -> H2D + device collate):")
+    st_ = os.statvfs("/dev/shm")
+    print(f"  /dev/shm free: {st_.f_bavail * st_.f_frsize / 2**30:.1f} GiB; one slot = one batch = {raw / 2**20:.0f} MiB, 2 slots per worker")
     for w in [int(x) for x in os.environ.get("WSMG_FEEDER_WORKERS", "1,8,32").split(",")]:
-        r, n, pinned = feeder_rate(w)
+        try:
+            r, n, pinned = feeder_rate(w)
+        except RuntimeError as e:
+            print(f"  ring, {w:2d} decode processes: not run — {str(e).splitlines()[-1][:300]}")
+            continue
         print(f"  ring, {w:2d} decode processes: {r:8.0f} steps/s  ({n} batches; ring pinned: {pinned}; {r / max(w, 1):.0f} steps/s per worker)")
     r, n, _ = feeder_rate(8, transport="dataloader")
     print(f"  torch DataLoader transport, 8 workers (batches pickled through a pipe): {r:8.0f} steps/s")

@@ -277,6 +277,21 @@ def g5():
     print("g5 out", o.detach().numpy().ravel()[:4])
 
 
+def g5f():
+    """BASELINE configs[4]: the reference's `_attn` (mg_map_policy.py:173-178) at B = 64, L = 160 on inputs that are exactly
+    representable in OCP e4m3 (oracle/cases.py::attn_fp8_inputs) — the pin for the fp8-storage attention kernels."""
+    pol = build_policy()
+    c = cases.attn_fp8_inputs()
+    inv = c["inverse"]
+    k = np.ascontiguousarray(c["k"][inv].transpose(0, 2, 1))      # [B, C, L], as the reference's Conv1d output
+    v = np.ascontiguousarray(c["v"][inv].transpose(0, 2, 1))
+    L = k.shape[2]
+    mask = np.arange(L)[None, :] >= c["lengths"][inv][:, None]
+    o, a = pol.net._attn(T(c["q"]), T(k), T(v), T(mask))
+    np.savez_compressed(os.path.join(OUT, "g5f_attn_fp8.npz"), out=o.detach().numpy(), attn=a.detach().numpy())
+    print("g5f out", o.detach().numpy().ravel()[:4], "attn row sums", a.detach().numpy().sum(1)[:3])
+
+
 # ============================================================================= G9: depth branch from raw depth
 def g9():
     """VlnResnetDepthEncoder.forward (resnet_encoders.py:72-102) from RAW depth: the reference's own plumbing (avg-pool
@@ -366,6 +381,6 @@ def g8():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["shapes", "g1", "g2", "g3", "g4", "g5", "g8", "g9"]
+    which = sys.argv[1:] or ["shapes", "g1", "g2", "g3", "g4", "g5", "g5f", "g8", "g9"]
     for w in which:
         globals()[w]()

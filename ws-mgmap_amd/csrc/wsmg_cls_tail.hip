@@ -187,6 +187,7 @@ __global__ __launch_bounds__(512) void cls_tail_fwd_kernel(TailArgs a) {
   for (int p = wave; p < npatch; p += WAVES) {
     const Patch q = patch_of(a, b, p, r);
     if (p + WAVES < npatch) load_raw(a, patch_of(a, b, p + WAVES, r).pix, h, nraw);
+    const int tlab = a.gt ? label_of(a, b, q, r) : -1;      // (a 4-byte gather: issued before the arithmetic that hides it)
     bf16x8 fb[2];
     act_frags(raw, cst, h, fb);
     f32x16 acc;
@@ -207,11 +208,10 @@ __global__ __launch_bounds__(512) void cls_tail_fwd_kernel(TailArgs a) {
       for (int g = 0; g < 16; ++g) if (row_of(g, h) < a.classes) mx = fmaxf(mx, v[g]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float s = 0.f, vt = 0.f;
-      const int t = label_of(a, b, q, r);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         if (row_of(g, h) < a.classes) s += expf(v[g] - mx);
-        if (row_of(g, h) == t) vt = v[g];
+        if (row_of(g, h) == tlab) vt = v[g];
       }
       s += __shfl_xor(s, 32, 64);
       vt += __shfl_xor(vt, 32, 64);
@@ -300,6 +300,20 @@ __global__ __launch_bounds__(512) void cls_tail_bwd_kernel(TailArgs a) {
   for (int p = wave; p < npatch; p += WAVES) {
     const Patch q = patch_of(a, b, p, r);
     if (p + WAVES < npatch) load_raw(a, patch_of(a, b, p + WAVES, r).pix, h, nraw);
+    // the loads this patch needs later — the pooled map's gradient, y2 once more in the accumulator layout (same cache lines as
+    // `raw`), the label — are issued first: with one workgroup per CU nothing else hides their latency
+    u32x2 dpw[4], y2w[4];
+    {
+      const int64_t pp = ((int64_t)b * (a.H >> 1) + (q.y0 >> 1)) * (a.W >> 1) + ((q.x0 + (r & 15)) >> 1);
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.dpooled) + pp * (CH * 2) + 8 * h;
+      const unsigned char* ysrc = reinterpret_cast<const unsigned char*>(a.y2) + q.pix * (CH * 2) + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dpw[j] = a.dpooled ? *reinterpret_cast<const u32x2*>(src + 16 * j) : u32x2{0u, 0u};
+        y2w[j] = *reinterpret_cast<const u32x2*>(ysrc + 16 * j);
+      }
+    }
+    const int tlab = a.g_rows ? label_of(a, b, q, r) : -1;
     bf16x8 fb[2];
     act_frags(raw, cst, h, fb);
     f32x16 acc;
@@ -328,17 +342,14 @@ __global__ __launch_bounds__(512) void cls_tail_bwd_kernel(TailArgs a) {
       for (int g = 0; g < 16; ++g) { v[g] = row_of(g, h) < a.classes ? expf(v[g] - mx) : 0.f; s += v[g]; }
       s += __shfl_xor(s, 32, 64);
       const float inv = 1.f / s;
-      const int t = label_of(a, b, q, r);
 #pragma unroll
       for (int g = 0; g < 16; ++g)
-        if (row_of(g, h) < a.classes) dl[g] = coef * (v[g] * inv - (row_of(g, h) == t ? 1.f : 0.f));
+        if (row_of(g, h) < a.classes) dl[g] = coef * (v[g] * inv - (row_of(g, h) == tlab ? 1.f : 0.f));
     }
     if (a.dpooled) {
-      const int64_t pp = ((int64_t)b * (a.H >> 1) + (q.y0 >> 1)) * (a.W >> 1) + ((q.x0 + (r & 15)) >> 1);
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.dpooled) + pp * (CH * 2) + 8 * h;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const u32x2 w = *reinterpret_cast<const u32x2*>(src + 16 * j);
+        const u32x2 w = dpw[j];
         const float d0 = __uint_as_float(w[0] << 16), d1 = __uint_as_float(w[0] & 0xffff0000u);
         const float d2 = __uint_as_float(w[1] << 16), d3 = __uint_as_float(w[1] & 0xffff0000u);
         if (row_of(4 * j, h) < a.classes) dl[4 * j] += 0.25f * d0;
@@ -364,10 +375,9 @@ __global__ __launch_bounds__(512) void cls_tail_bwd_kernel(TailArgs a) {
     // ReLU mask + BatchNorm's two sums, in the accumulator layout: channels row_of(g, h) of pixel r — re-read y2 in that layout
     float dbn[16];
     {
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(a.y2) + q.pix * (CH * 2) + 8 * h;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const u32x2 w = *reinterpret_cast<const u32x2*>(src + 16 * j);
+        const u32x2 w = y2w[j];
         const float yv[4] = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
                              __uint_as_float(w[1] & 0xffff0000u)};
         const f32x4 sc = *reinterpret_cast<const f32x4*>(&cst[0][8 * j + 4 * h]), sh = *reinterpret_cast<const f32x4*>(&cst[1][8 * j + 4 * h]);

@@ -131,6 +131,16 @@ class DeviceFeeder:
     def _iter_ring(self):
         W = self.num_workers
         nbytes = self.slot_bytes or self._probe_slot_bytes()
+        need = nbytes * W * self.slots_per_worker
+        try:     # the ring lives in /dev/shm (torch's shared-memory tensors): refuse up front what would die with a bus error later
+            import os
+            st = os.statvfs("/dev/shm")
+            if need > st.f_bavail * st.f_frsize:
+                raise RuntimeError(f"the feeder's shared-memory ring needs {need >> 20} MiB ({W} workers x {self.slots_per_worker} slots x "
+                                   f"{nbytes >> 20} MiB) but /dev/shm has {(st.f_bavail * st.f_frsize) >> 20} MiB free: fewer workers or "
+                                   "slots_per_worker, or a larger /dev/shm")
+        except OSError:
+            pass
         ctx = mp.get_context("spawn")
         slots = [torch.empty(nbytes, dtype=torch.uint8).share_memory_() for _ in range(W * self.slots_per_worker)]
         rt = torch.cuda.cudart()
@@ -160,10 +170,17 @@ class DeviceFeeder:
                 k += 1
                 if not live[w]:
                     continue
-                try:
-                    item = ready_qs[w].get(timeout=600)
-                except _queue.Empty:
-                    raise RuntimeError(f"feeder worker {w} produced nothing for 10 minutes")
+                item, waited = None, 0.0
+                while item is None:
+                    try:
+                        item = ready_qs[w].get(timeout=2.0)
+                    except _queue.Empty:
+                        waited += 2.0
+                        if not procs[w].is_alive() and ready_qs[w].empty():
+                            raise RuntimeError(f"feeder worker {w} died (exit code {procs[w].exitcode}) — a bus error (-7) means the "
+                                               f"shared-memory ring ({len(slots)} slots of {nbytes >> 20} MiB) does not fit in /dev/shm")
+                        if waited >= 900.0:
+                            raise RuntimeError(f"feeder worker {w} produced nothing for 15 minutes")
                 if item == _STOP:
                     live[w] = False
                     continue

@@ -318,8 +318,12 @@ def _reduce_stream(device, param):
     which are bound by the matrix pipe and the L2 -> LDS path.  Conditions: inside a backward pass (the join is an
     end-of-backward callback), one process (the gradient all-reduce hooks read p.grad on the main stream as soon as it is
     accumulated), and a parameter whose gradient is SET, not added to, by this pass — autograd's accumulation into an existing
-    .grad would run on the main stream before the reduction has finished.  WSMG_WGRAD_REDUCE_STREAM=0: same stream (A/B)."""
-    if param is None or param.grad is not None or _os.environ.get("WSMG_WGRAD_REDUCE_STREAM", "1") == "0":
+    .grad would run on the main stream before the reduction has finished.
+    OPT-IN (WSMG_WGRAD_REDUCE_STREAM=1): measured on MI355X in two interleaved pairs of 40-update runs it LOSES — 11.53 / 11.62 ms per
+    update against 11.41 / 11.46 ms with the reductions on the backward pass's own stream: the 1 GB of slab reads per update take
+    bandwidth and CU slots from the convolution kernels they run beside (which are bound by the L2 -> LDS path, not idle), and the
+    20 cross-stream event pairs cost more than the 0.18 ms of reduction time they hide."""
+    if param is None or param.grad is not None or _os.environ.get("WSMG_WGRAD_REDUCE_STREAM", "0") != "1":
         return None
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         return None
@@ -1619,6 +1623,44 @@ class _AttnFp8(torch.autograd.Function):
 def attention_fp8(q, w_k, b_k, x, lengths, scale=1.0 / 16):
     """(context [B,C], weights [B,L]) of the state -> instruction attention with e4m3 token storage; differentiable in q, W_k, x."""
     return _AttnFp8.apply(q, w_k, b_k, x.contiguous(), lengths, scale)
+
+
+@torch.no_grad()
+def attention_fp8_shared(q, k_sets, v_sets, lengths, inverse, scale=1.0 / 16, scales=None):
+    """BASELINE configs[4] on the matrix cores (csrc/wsmg_attn_fp8_mfma.hip): `_attn` (mg_map_policy.py:173-178) of B rows over U
+    shared instruction sets with e4m3 storage — S = Q K^T on v_mfma_f32_32x32x16_fp8_fp8, float32 softmax, O = P V on the bf16
+    matrix pipe.  q [B,256] float32; k_sets, v_sets [U,L,256] float32 (token-major keys and values of each unique instruction);
+    lengths [U] int (valid tokens; the rest are masked) or None; inverse [B] int64 (row b uses set inverse[b]).
+    scales: (q_scale, k_scale, v_scale) Python floats for the quantisation; None: amax / 448 per tensor, computed on the device.
+    Forward only (rollout / evaluation); -> (context [B,256], weights [B,L])."""
+    _req(q, k_sets, v_sets, lengths, inverse)
+    _f32(q, k_sets, v_sets)
+    B, C = q.shape
+    U, L, _ = k_sets.shape
+    if C != 256 or k_sets.shape != v_sets.shape or k_sets.shape[2] != C or inverse.numel() != B or L > 224:
+        raise _abi.WsmgError("attention_fp8_shared: q [B,256], k / v sets [U,L<=224,256], inverse [B]")
+    dev = q.device
+
+    def quant(x, s):
+        if s is None:
+            sc = (x.abs().amax() / 448.0).clamp_min(1e-30).reshape(1).float()
+            codes = torch.empty(x.shape, device=dev, dtype=torch.uint8)
+            _abi.call("wsmg_quantize_e4m3_dev", _p(x), x.numel(), _p(sc), _p(codes), _stream())
+            return codes, sc
+        return quantize_e4m3(x, s), torch.full((1,), float(s), device=dev, dtype=torch.float32)
+    s3 = scales or (None, None, None)
+    qc, qs = quant(q.contiguous(), s3[0])
+    kc, ks = quant(k_sets.contiguous(), s3[1])
+    vc, vs = quant(v_sets.contiguous(), s3[2])
+    order = torch.argsort(inverse, stable=True).to(torch.int32)                 # rows grouped by set
+    start = torch.zeros(U + 1, device=dev, dtype=torch.int32)
+    start[1:] = torch.cumsum(torch.bincount(inverse, minlength=U), 0).to(torch.int32)
+    lens = None if lengths is None else lengths.to(torch.int32).contiguous()
+    out = torch.empty(B, C, device=dev, dtype=torch.float32)
+    attn = torch.empty(B, L, device=dev, dtype=torch.float32)
+    _abi.call("wsmg_attn_fp8_mfma_fwd", _p(qc), _p(qs), _p(kc), _p(ks), _p(vc), _p(vs), _p(lens), _p(order), _p(start), float(scale),
+              B, U, L, C, _p(out), _p(attn), _stream())
+    return out, attn
 
 
 def _rnn_workspace(nbytes, device):
