@@ -118,25 +118,39 @@ struct DaggerLoss {
   int T, N, A, ld_wp;
 };
 
-// one workgroup; thread = episode n, walking its T steps in order
+// One workgroup.  Phase 1, all threads: the weighted squared error and the weight of every row (t, n) of a chunk into LDS; phase 2,
+// thread n: its episode's rows of the chunk added in step order (the order of the sums never depends on the thread count).
+constexpr int DL_CHUNK = 2048;   // rows per chunk
 __global__ __launch_bounds__(256) void dagger_loss_fwd_kernel(DaggerLoss a) {
   __shared__ float red[4];
-  float tot = 0.f;
-  for (int n = threadIdx.x; n < a.N; n += 256) {
-    float num = 0.f, den = 0.f;
-    for (int t = 0; t < a.T; ++t) {
-      const size_t r = (size_t)t * a.N + n;
-      const float w = a.weights[r];
+  __shared__ float term[DL_CHUNK], wrow[DL_CHUNK];
+  const int rows = a.T * a.N;
+  // chunks hold whole steps: tpc steps of N rows (N <= DL_CHUNK is checked by the host)
+  const int tpc = DL_CHUNK / a.N;
+  float num = 0.f, den = 0.f;        // thread n < N: its episode
+  for (int t0 = 0; t0 < a.T; t0 += tpc) {
+    const int nt = a.T - t0 < tpc ? a.T - t0 : tpc;
+    for (int i = threadIdx.x; i < nt * a.N; i += 256) {
+      const size_t r = (size_t)t0 * a.N + i;
       float al = 0.f;
       for (int j = 0; j < a.A; ++j) {
         const float d = tanhf(a.pred[r * a.A + j]) - a.waypoint[r * a.ld_wp + j];
         al += d * d;
       }
-      num += w * al;
-      den += w;
+      const float w = a.weights[r];
+      term[i] = w * al;
+      wrow[i] = w;
     }
-    a.den[n] = den;
-    tot += num / den;
+    __syncthreads();
+    for (int n = threadIdx.x; n < a.N; n += 256)      // (N <= 256: one episode per thread)
+      for (int t = 0; t < nt; ++t) { num += term[t * a.N + n]; den += wrow[t * a.N + n]; }
+    __syncthreads();
+  }
+  (void)rows;
+  float tot = 0.f;
+  if (threadIdx.x < a.N) {
+    a.den[threadIdx.x] = den;
+    tot = num / den;
   }
   tot = block_sum(tot, red);
   if (threadIdx.x == 0) {
@@ -194,7 +208,8 @@ __global__ __launch_bounds__(256) void update_heads_bwd_kernel(HeadsBwd a) {
       if (o < a.A) wv[o] = a.wm[(size_t)o * a.K + col];
     wv[MAXA] = a.wp[col];
   }
-  for (int b = g; b < a.B; b += 8) {
+#pragma unroll 4
+  for (int b = g; b < a.B; b += 8) {        // (independent rows: several in flight)
     float go[MAXA + 1];
 #pragma unroll
     for (int o = 0; o < MAXA; ++o) go[o] = (o < a.A && a.dpred) ? a.dpred[(size_t)b * a.A + o] : 0.f;
@@ -302,7 +317,7 @@ extern "C" int wsmg_update_heads_bwd(const float* x, const float* wm, const floa
 
 extern "C" int wsmg_dagger_loss_fwd(const float* pred, const float* waypoint, int ld_waypoint, const float* weights, const float* aux,
                                     int T, int N, int A, float* out2, float* den, wsmg_stream_t stream) {
-  if (!pred || !waypoint || !weights || !out2 || !den || T <= 0 || N <= 0 || A <= 0 || ld_waypoint < A) return WSMG_EINVAL;
+  if (!pred || !waypoint || !weights || !out2 || !den || T <= 0 || N <= 0 || N > 256 || A <= 0 || ld_waypoint < A) return WSMG_EINVAL;
   DaggerLoss a{pred, waypoint, weights, aux, out2, den, T, N, A, ld_waypoint};
   hipLaunchKernelGGL(dagger_loss_fwd_kernel, dim3(1), dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();

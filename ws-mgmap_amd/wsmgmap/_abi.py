@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwsmgmap.so")
+if os.environ.get("WSMG_LIB"):       # experiments only: another build of the same library (e.g. other compiler flags for one file)
+    LIB_PATH = os.environ["WSMG_LIB"]
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
