@@ -22,6 +22,7 @@
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 constexpr int AC = 256;          // channels
 constexpr int LMAX = 224;        // tokens per set at most (a multiple of 32; the reference pads instructions to 200)
 
@@ -52,6 +53,7 @@ __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float
 
 __global__ __launch_bounds__(256) void attn_fp8_mfma_fwd_kernel(F8mArgs a) {
   __shared__ __attribute__((aligned(16))) float S[32][LMAX + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t V8[2][32][AC + 16];      // two chunks of 32 tokens x 256 value bytes (+16: rows 4 banks apart)
   __shared__ int rows[32];
   const int u = blockIdx.x, tile = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,14 +77,22 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fwd_kernel(F8mArgs a) {
   for (int tt = wave; tt * 32 < LP; tt += 4) {
     const int tok = tt * 32 + r;
     const uint8_t* kp = a.k + ((size_t)u * a.L + (tok < a.L ? tok : 0)) * AC + 8 * h;
+    // Four independent accumulators over 64 channels each, added in float32 afterwards: the matrix pipe aligns the 16 products of
+    // an instruction to its accumulator and TRUNCATES what falls below (measured: one 256-deep chain sat 3e-5 from the reference
+    // on logits of magnitude 700, the error all of one sign); four short chains and three rounded adds cut that four-fold.
+    f32x16 acc4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc4[c][g] = 0.f;
+    long kb[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) kb[ks] = tok < a.L ? *reinterpret_cast<const long*>(kp + 16 * ks) : 0l;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc4[ks >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(qa[ks], kb[ks], acc4[ks >> 2], 0, 0, 0);
     f32x16 acc;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const long kb = tok < a.L ? *reinterpret_cast<const long*>(kp + 16 * ks) : 0l;
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(qa[ks], kb, acc, 0, 0, 0);
-    }
+    for (int g = 0; g < 16; ++g) acc[g] = (acc4[0][g] + acc4[1][g]) + (acc4[2][g] + acc4[3][g]);
     // D: lane (r = token column, h), register g -> query row (g & 3) + 8 (g >> 2) + 4 h
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -123,33 +133,52 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fwd_kernel(F8mArgs a) {
   __syncthreads();
 
   // ---- O = P V on the bf16 matrix pipe, P as a (hi, lo) bf16 pair.  Wave w owns channels 64 w .. 64 w + 63 (two 32-wide tiles).
+  // The values arrive in chunks of 32 tokens (8 KB of bytes): one 16-byte global load per thread and chunk, double-buffered in LDS;
+  // a B fragment is 8 tokens of ONE channel — 8 byte reads down a column of the chunk (the first version read those bytes from
+  // global memory: 160 dependent-latency byte loads per lane, 20 of the kernel's 27 us at B = 64).
   f32x16 o[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int g = 0; g < 16; ++g) o[t][g] = 0.f;
-  for (int ks = 0; ks * 16 < LP; ++ks) {
-    bf16x8 phi, plo;
+  const int nchunk = LP / 32;
+  auto stage = [&](int c, int buf) {      // tokens 32 c .. 32 c + 31 of set u -> V8[buf]; thread = (token tid / 8, 32-byte piece... 16 B each, 2 passes)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const float p = S[r][16 * ks + 8 * h + s];
-      const unsigned short hi = f2bf(p);
-      phi[s] = (short)hi;
-      plo[s] = (short)f2bf(p - bf2f(hi));
+    for (int half = 0; half < 2; ++half) {
+      const int idx = tid + 256 * half;            // 512 pieces of 16 bytes
+      const int tk = idx >> 4, piece = idx & 15;
+      const int l = 32 * c + tk;
+      u32x4v val = {0u, 0u, 0u, 0u};
+      if (l < a.L) val = *reinterpret_cast<const u32x4v*>(a.v + ((size_t)u * a.L + l) * AC + 16 * piece);
+      *reinterpret_cast<u32x4v*>(&V8[buf][tk][16 * piece]) = val;
     }
+  };
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) stage(c + 1, (c + 1) & 1);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int ch = 64 * wave + 32 * t + r;
-      bf16x8 vb;
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ks = 2 * c + kk;
+      bf16x8 phi, plo;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const int l = 16 * ks + 8 * h + s;
-        const float f = l < a.L ? e4m3_to_f32(a.v[((size_t)u * a.L + l) * AC + ch]) : 0.f;
-        vb[s] = (short)f2bf(f);          // exact: e4m3 has 4 significant bits
+        const float p = S[r][16 * ks + 8 * h + s];
+        const unsigned short hi = f2bf(p);
+        phi[s] = (short)hi;
+        plo[s] = (short)f2bf(p - bf2f(hi));
       }
-      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phi, vb, o[t], 0, 0, 0);
-      o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plo, vb, o[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ch = 64 * wave + 32 * t + r;
+        bf16x8 vb;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vb[s] = (short)f2bf(e4m3_to_f32(V8[c & 1][16 * kk + 8 * h + s][ch]));   // exact: e4m3 has 4 significant bits
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phi, vb, o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plo, vb, o[t], 0, 0, 0);
+      }
     }
+    __syncthreads();
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)

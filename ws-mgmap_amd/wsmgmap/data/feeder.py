@@ -75,6 +75,13 @@ class DeviceFeeder:
         self.slot_bytes, self.slots_per_worker, self.seed = slot_bytes, max(2, int(slots_per_worker)), int(seed)
         self.pinned_ring = None       # True / False once a ring exists: could the shared slots be registered as pinned memory
 
+    def _trace(self, msg):
+        import os
+        if os.environ.get("WSMG_FEEDER_TRACE") == "1":
+            import sys
+            import time
+            print("[feeder %.1f] %s" % (time.time() % 10000, msg), file=sys.stderr, flush=True)
+
     # -- device side --------------------------------------------------------------------------------------------------
     def _hand_over(self, out, ev):
         cur = torch.cuda.current_stream(self.device)
@@ -144,11 +151,14 @@ class DeviceFeeder:
         ctx = mp.get_context("spawn")
         slots = [torch.empty(nbytes, dtype=torch.uint8).share_memory_() for _ in range(W * self.slots_per_worker)]
         rt = torch.cuda.cudart()
-        self.pinned_ring = True
+        import os
+        self.pinned_ring = os.environ.get("WSMG_FEEDER_PIN", "1") != "0"
         for t in slots:       # pinned: the H2D copy is asynchronous and reads the worker's bytes in place
+            if not self.pinned_ring:
+                break
             if int(rt.cudaHostRegister(t.data_ptr(), t.numel(), 0)) != 0:
                 self.pinned_ring = False
-                break
+        self._trace("ring ready: %d slots of %d MiB, pinned=%s" % (len(slots), nbytes >> 20, self.pinned_ring))
         free_qs = [ctx.Queue() for _ in range(W)]
         ready_qs = [ctx.Queue() for _ in range(W)]
         procs = []
@@ -159,6 +169,7 @@ class DeviceFeeder:
                             daemon=True)
             p.start()
             procs.append(p)
+        self._trace("%d workers started" % W)
         side = torch.cuda.Stream(self.device)
         coll = DeviceCollator(self.device)
         pending = collections.deque()          # (out, event, worker, slot)
@@ -187,6 +198,7 @@ class DeviceFeeder:
                 if item[0] == "__error__":
                     raise RuntimeError("feeder worker failed:\n" + item[1])
                 sid, meta = item
+                self._trace("batch from worker %d in slot %d" % (w, sid))
                 out = coll.launch(meta, slots[sid], stream=side)
                 ev = torch.cuda.Event()
                 ev.record(side)
