@@ -462,19 +462,22 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
 
 // workspace layout: [0, 256) barrier words (zeroed per call) | [256, ...) exchange image (128-B aligned
 // when the workspace is; rows of one workgroup never share a cache line with another workgroup's)
-// CU ownership.  These persistent kernels must not share a CU with workgroups of other kernels: with a
-// bf16 implicit-GEMM conv (MFMA) workgroup co-resident on the same SIMDs, gru_bwd_kernel returned wrong
-// partial sums in isolated lanes (low half of v_pk_fma_f32 pairs; memory contents and the shuffle
-// reduction were verified identical) on every run, and never when it owned the CU.  The cause below the
-// ISA level is not established; the measured facts are in DESIGN.md ("RNN kernels: CU ownership").
-// Requesting (almost) the CU's whole 160 KiB LDS makes co-residency with any LDS-using workgroup, and
-// of two of these workgroups, impossible.  WSMG_RNN_EXCL=0 disables, any other value is KiB (debug).
+// CU ownership (round 2) and what replaced it (round 3).  With a bf16 implicit-GEMM conv (MFMA) workgroup co-resident on the
+// same SIMDs, gru_bwd_kernel returned wrong partial sums in isolated lanes — always the low half of a v_pk_fma_f32 pair; memory
+// contents and the shuffle reduction were verified identical — on every run, and never when it owned the CU.  Round 2 shipped
+// the workaround: requesting (almost) the CU's whole 160 KiB LDS makes co-residency with any LDS-using workgroup impossible.
+// Round 3 removed the trigger instead: this file is compiled WITHOUT packed-float32 instructions (csrc/Makefile:
+// -target-feature -packed-fp32-ops; the compiler had SLP-packed 425 of them) — tools/stress_rnn.py under the bf16 conv load,
+// no CU claim: 177 mismatching tensors in 60 repeats with them, 0 in 200 without, same step times (2.03 vs 2.06 ms per
+// GRU + LSTM forward + backward).  Whether the packed forms hit a hardware hazard beside MFMA-heavy waves or a missing
+// dependency stall in their scheduling cannot be told from the ISA; the measured facts are in DESIGN.md ("RNN kernels: CU
+// ownership").  The claim stays available: WSMG_RNN_EXCL=1 requests 159 KiB, any other value > 1 is KiB (debug); default 0.
 constexpr unsigned EXCL_LDS_BYTES = 159 * 1024;
 static unsigned rnn_excl_total() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("WSMG_RNN_EXCL");
-    v = e ? atoi(e) : 1;
+    v = e ? atoi(e) : 0;
   }
   return v == 0 ? 0u : (v == 1 ? EXCL_LDS_BYTES : (unsigned)v * 1024u);
 }

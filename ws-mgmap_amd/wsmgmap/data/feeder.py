@@ -137,6 +137,10 @@ class DeviceFeeder:
 
     def _iter_ring(self):
         W = self.num_workers
+        # a worker's slot comes back when its batch leaves the prefetch queue: with `prefetch` batches queued (taken from the workers
+        # in turn) a worker needs ceil(prefetch / W) slots there, one being handed over and one to fill meanwhile — fewer deadlocks
+        # the ring (the worker waits for a slot, the consumer for the worker's next batch)
+        self.slots_per_worker = max(self.slots_per_worker, -(-self.prefetch // W) + 2)
         nbytes = self.slot_bytes or self._probe_slot_bytes()
         need = nbytes * W * self.slots_per_worker
         try:     # the ring lives in /dev/shm (torch's shared-memory tensors): refuse up front what would die with a bus error later
