@@ -544,6 +544,10 @@ int wsmg_attn_fp8_mfma_fwd(const uint8_t* q_codes, const float* q_scale, const u
                            const int* set_start, float scale, int B, int U, int L, int C, float* out, float* attn,
                            wsmg_stream_t stream);
 
+/* out[r] = mean of x[r][0..n) for R rows of n <= 160 float32 values (contiguous): `nn.AdaptiveAvgPool1d(1)` + `Flatten` in front of
+ * rgb_linear (mg_map_policy.py:90-96) over the 7 x 7 positions of the RGB feature. */
+int wsmg_mean_rows(const float* x, int64_t R, int n, float* out, wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

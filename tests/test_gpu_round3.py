@@ -660,3 +660,16 @@ def test_attention_fp8_mfma_vs_float64_formula_on_quantised_operands(shape):
     out2, attn2 = ops.attention_fp8_shared(*(torch.from_numpy(t).cuda() for t in (q, k, v)), torch.from_numpy(lengths).cuda(),
                                            torch.from_numpy(inverse).cuda(), 1.0 / 16)
     assert float((out2 - out).abs().max()) <= 1e-2 * float(out.abs().max()) and float((attn2 - attn).abs().max()) <= 1e-2
+
+
+@pytest.mark.parametrize("shape", [(512, 512, 49), (7, 1), (300, 160), (3, 5, 33)], ids=["rgb_feature", "n1", "n160", "ragged"])
+def test_mean_last_matches_torch(shape):
+    """ops.mean_last (wsmg_mean_rows): AdaptiveAvgPool1d(1) + Flatten in front of rgb_linear (mg_map_policy.py:90-96) — against
+    torch's float64 mean within 1e-6 of max|x|."""
+    from wsmgmap import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(sum(shape))
+    x = torch.randn(*shape, device="cuda", generator=g)
+    got = ops.mean_last(x)
+    want = x.double().mean(-1)
+    assert got.shape == want.shape
+    assert float((got.double() - want).abs().max()) <= 1e-6 * max(1.0, float(x.abs().max()))

@@ -425,6 +425,26 @@ __global__ __launch_bounds__(256) void weight_grad_reduce_oihw_kernel(const floa
     if (i + j < I) out[((o * I + i + j) * KH + kh) * KW + kw] = acc[j];
 }
 
+// ---- mean over a short innermost axis: out[r] = mean(x[r][0..n)), x [R][n] float32 contiguous (rgb_linear's AdaptiveAvgPool1d(1)
+// over the 7 x 7 positions of the cached RGB feature, mg_map_policy.py:90-96: R = B * 512 rows of n = 49).  A thread per row would
+// read 196-byte rows 196 bytes apart; here a workgroup loads its 256 rows as one contiguous, coalesced run into LDS and every
+// thread adds its row from there (row pitch n floats: conflict-free for odd n).
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, int64_t R, int n, float* __restrict__ out) {
+  extern __shared__ float rows_lds[];
+  const int64_t r0 = (int64_t)blockIdx.x * 256;
+  const int nr = R - r0 < 256 ? (int)(R - r0) : 256;
+  const float* src = x + r0 * n;
+  const int total = nr * n;
+  for (int i = threadIdx.x; i < total; i += 256) rows_lds[i] = src[i];
+  __syncthreads();
+  if ((int)threadIdx.x < nr) {
+    float s = 0.f;
+    const float* p = rows_lds + threadIdx.x * n;
+    for (int j = 0; j < n; ++j) s += p[j];
+    out[r0 + threadIdx.x] = s / (float)n;
+  }
+}
+
 // ---- channel concatenation of two NHWC tensors (the UNet skip connections, map_encoder.py:104,110, and
 // mg_map_policy.py:99): out[p] = a[p] ++ b[p], one 16-byte chunk per thread, the pixel index computed once per chunk
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -734,6 +754,11 @@ extern "C" int wsmg_weight_relayout_multi(const WsmgRelayoutDesc* descs, int n, 
     if (bf16) hipLaunchKernelGGL(weight_relayout_multi_kernel<bf16_t>, dim3(48, (unsigned)m), dim3(256), 0, wsmg_s(s), b);
     else hipLaunchKernelGGL(weight_relayout_multi_kernel<float>, dim3(48, (unsigned)m), dim3(256), 0, wsmg_s(s), b);
   }
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_mean_rows(const float* x, int64_t R, int n, float* out, wsmg_stream_t s) {
+  if (!x || !out || R <= 0 || n <= 0 || n > 160) return WSMG_EINVAL;       // 256 rows x n floats of LDS
+  hipLaunchKernelGGL(mean_rows_kernel, dim3((unsigned)wsmg_cdiv(R, 256)), dim3(256), (size_t)256 * n * sizeof(float), wsmg_s(s), x, R, n, out);
   WSMG_RETURN_LAUNCH();
 }
 extern "C" int wsmg_weight_grad_reduce_oihw(const float* ws, int nsplit, int O, int I, int KH, int KW, int I_pad, float* dw_oihw,

@@ -107,6 +107,7 @@ _SIG["wsmg_cls_tail_bwd_bf16"] = [c_p] * 7 + [c_i, c_p, c_i, c_i, c_p, c_p, c_i,
 _SIG["wsmg_bn_stats_finalize"] = [c_p, c_i, c_i, c_l, c_f, c_f, c_p, c_p, c_p, c_p, c_p]
 _SIG["wsmg_bn_bwd_apply_bf16"] = [c_p] * 7 + [c_l, c_i, c_p, c_p]
 _SIG["wsmg_attn_fp8_mfma_fwd"] = [c_p] * 9 + [c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p]
+_SIG["wsmg_mean_rows"] = [c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_bn_act_bwd_ld"] = [c_p, c_l] + _SIG["wsmg_bn_act_bwd"][1:]
 _SIG["wsmg_bn_act_bwd_ld_bf16"] = list(_SIG["wsmg_bn_act_bwd_ld"])
 _SIG["wsmg_upsample2x_bwd_ld"] = [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p]

@@ -324,7 +324,13 @@ class MGMapNet(nn.Module):
                 state_in.append(ops.linear_rows(rgb_embedding.float().reshape(b, c, -1), self.rgb_linear[2].weight, self.rgb_linear[2].bias,
                                                 "relu", pool=int(np.prod(rgb_embedding.shape[2:]))))
             else:
-                state_in.append(self.rgb_linear(torch.flatten(rgb_embedding.float(), 2)))
+                feat = torch.flatten(rgb_embedding.float(), 2)
+                if feat.is_cuda and not feat.requires_grad and feat.is_contiguous() and feat.shape[-1] <= 160:
+                    # AdaptiveAvgPool1d(1) + Flatten as one coalesced pass (torch's reduction over a 49-long innermost axis reads
+                    # the 51 MB feature at 1 TB/s: 50 us); the Linear + ReLU stay the module's
+                    state_in.append(self.rgb_linear[3](self.rgb_linear[2](ops.mean_last(feat))))
+                else:
+                    state_in.append(self.rgb_linear(feat))
         if "depth" in self._inputs:
             if rows:   # Flatten + Linear + ReLU
                 state_in.append(lin(self.depth_linear[1], torch.flatten(depth_embedding.float(), 1), "relu"))

@@ -1522,6 +1522,16 @@ class _TokenMean(torch.autograd.Function):
         return (g * (1.0 / ctx.shape[1])).to(ctx.dtype).unsqueeze(1).expand(ctx.shape), None
 
 
+def mean_last(x):
+    """x [..., n] float32 (n <= 160) -> mean over the last axis, one launch (no gradient: the caller's input is a cached feature)."""
+    _req(x)
+    _f32(x)
+    n = x.shape[-1]
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    _abi.call("wsmg_mean_rows", _p(x), x.numel() // n, n, _p(out), _stream())
+    return out
+
+
 def token_mean(x, sink=None):
     return _TokenMean.apply(x, sink)
 
