@@ -65,6 +65,16 @@ int wsmg_bev_rotate(const float* in, const float* heading, float sign, int B, in
 int wsmg_map_fuse(const float* ego_rot, float* global_map, const float* gps, const float* masks, int B,
                   int C, int E, int G, float resolution, wsmg_stream_t stream);
 
+/* Round 3: scatter-max and the first rotation in one launch, and the fuse that consumes its output.  `wsmg_bev_scatter_rotate`
+ * = wsmg_bev_scatter_max followed by wsmg_bev_rotate (rgb_mapping.py:81-84,206-232 then 239-250, called at
+ * rgb_mapping.py:34-35) except that the rotated map stays in NCHW planes [B][C][E][E]: the plane of a channel is complete in LDS when
+ * the scatter ends and is sampled there.  `wsmg_map_fuse_planes` = wsmg_map_fuse for that layout (same values bit for bit; the
+ * global map stays [num_proc][G][G][C]).  C % 4 == 0, C <= 64, E*E*4 <= 160 KiB. */
+int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx, const float* heading, float sign, int B, int Cf, int Hf,
+                            int Wf, int C, int E, float* out_planes, wsmg_stream_t stream);
+int wsmg_map_fuse_planes(const float* ego_rot_planes, float* global_map, const float* gps, const float* masks, int B, int C,
+                         int E, int G, float resolution, wsmg_stream_t stream);
+
 /* Retrieval half (rgb_mapping.py:57-70): translate the global map back, crop the centre E x E,
  * rotate by +compass.  scratch [B][E][E][C] (intermediate crop) and out [B][E][E][C] are NHWC; the host
  * exposes `out` as a channels-last view of the reference's [B][C][E][E] tensor. */

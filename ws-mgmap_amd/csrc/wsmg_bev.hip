@@ -151,6 +151,78 @@ __device__ __forceinline__ Taps rot_taps(int x, int y, int E, Rot r) {
   return make_taps(unnorm(gx, E), unnorm(gy, E));
 }
 
+// scatter-max and the first rotation in ONE launch (round 3): the E x E plane of a channel is complete in LDS when the scatter
+// ends, so the rotation samples it there (4 LDS reads per output pixel) and only the ROTATED plane goes to memory — NCHW, whole
+// rows, coalesced — instead of plane out, plane in through 4-byte gathers, NHWC out.  map_fuse_planes_kernel consumes the planes.
+// Same arithmetic per output pixel as rotate_nchw_to_nhwc_kernel (tap order nw, ne, sw, se).
+__global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* __restrict__ feat, const int32_t* __restrict__ lin,
+                                                                  const float* __restrict__ heading, float sign, int Cf, int HW,
+                                                                  int C, int E, int CG, float* __restrict__ out) {
+  extern __shared__ unsigned tile[];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CG;
+  const int tid = threadIdx.x;
+  const int E2 = E * E;
+  for (int i = tid; i < CG * E2; i += 1024) tile[i] = 0u;
+  __syncthreads();
+  const int32_t* lb = lin + (size_t)b * HW;
+  for (int g = 0; g < CG; ++g) {
+    int c = c0 + g;
+    if (c >= C) break;
+    int ws = (int)(((int64_t)c * Cf) / C);
+    int we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
+    const float* fb = feat + ((size_t)b * Cf + ws) * HW;
+    unsigned* tg = tile + (size_t)g * E2;
+    constexpr int U = 8;
+    const int nwin = we - ws;
+    for (int s0 = tid; s0 < HW; s0 += 1024 * U) {
+      int cell[U];
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + 1024 * u;
+        cell[u] = s < HW ? lb[s] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = cell[u] >= 0 ? fb[s0 + 1024 * u] : 0.f;
+      for (int w = 1; w < nwin; ++w) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (cell[u] >= 0) v[u] = fmaxf(v[u], fb[(size_t)w * HW + s0 + 1024 * u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (cell[u] >= 0) atomicMax(&tg[cell[u]], f2key(v[u]));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < CG * E2; i += 1024) {   // keys -> the values bev_scatter_kernel writes, in place
+    const unsigned k = tile[i];
+    tile[i] = __float_as_uint(k ? key2f(k) + 0.0f : 0.0f);
+  }
+  __syncthreads();
+  const float t = sign * heading[b];
+  const Rot r{cosf(t), sinf(t)};
+  for (int g = 0; g < CG; ++g) {
+    const int c = c0 + g;
+    if (c >= C) break;
+    const float* pb = reinterpret_cast<const float*>(tile + (size_t)g * E2);
+    float* ob = out + ((size_t)b * C + c) * E2;
+    for (int p = tid; p < E2; p += 1024) {
+      const int y = p / E, x = p - y * E;
+      Taps tp = rot_taps(x, y, E, r);
+      bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
+      bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
+      float v = 0.f;
+      if (y0ok && x0ok) v += pb[tp.y0 * E + tp.x0] * tp.w00;
+      if (y0ok && x1ok) v += pb[tp.y0 * E + tp.x0 + 1] * tp.w01;
+      if (y1ok && x0ok) v += pb[(tp.y0 + 1) * E + tp.x0] * tp.w10;
+      if (y1ok && x1ok) v += pb[(tp.y0 + 1) * E + tp.x0 + 1] * tp.w11;
+      ob[p] = v;
+    }
+  }
+}
+
 // first rotation: NCHW planes in (scatter output), NHWC out through an LDS transpose
 __global__ __launch_bounds__(256) void rotate_nchw_to_nhwc_kernel(const float* __restrict__ in,
                                                                   const float* __restrict__ heading, float sign,
@@ -291,6 +363,78 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(const float* __restrict__
   }
 }
 
+// map_fuse_kernel for an ego map that arrives as ROTATED NCHW PLANES (bev_scatter_rotate_kernel).  A workgroup owns FR x FC window
+// pixels and all channels: the (FR + 2) x (FC + 4) patch of every plane its taps can touch is loaded once (whole row pieces,
+// coalesced) into LDS, [channel][row][column] with an odd channel pitch; the work items are (pixel, 4 channels) with the channel
+// quad fastest, as in map_fuse_kernel, so the global map is read and written in 16-byte pieces of consecutive addresses.
+// Same arithmetic per element (taps in k order).  A tap outside the patch (the translation is by whole cells, so this is the
+// float rounding of the grid coordinate at worst) is read from memory instead.
+constexpr int FR = 4, FC = 64, FPR = FR + 2, FPC = FC + 4;
+__global__ __launch_bounds__(256) void map_fuse_planes_kernel(const float* __restrict__ ego, float* __restrict__ gm,
+                                                              const float* __restrict__ gps, MapArgs a, int tiles_x) {
+  extern __shared__ float patch[];
+  const int b = blockIdx.y;
+  const int ty_ = blockIdx.x / tiles_x, tx_ = blockIdx.x - ty_ * tiles_x;
+  const int WN = a.E + 4;
+  Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
+  const float tx = -(ps.gy - a.halfG) / a.halfG;
+  const float ty = -(ps.gx - a.halfG) / a.halfG;
+  const int wy0 = a.lo + (int)(ps.gx - a.halfG) - 2;
+  const int wx0 = a.lo + (int)(ps.gy - a.halfG) - 2;
+  const int C4 = a.C >> 2;
+  const int E2 = a.E * a.E;
+  const int pitch = FPR * FPC + 1;
+  const int hi = a.lo + a.E;
+  // patch origin (in ego coordinates): the north-west tap of the tile's first pixel, one cell of slack to the west and north
+  const int Y0 = wy0 + ty_ * FR, X0 = wx0 + tx_ * FC;
+  Taps t0 = make_taps(unnorm(base_coord(X0, a.G) + tx, a.G), unnorm(base_coord(Y0, a.G) + ty, a.G));   // (linear in X0, Y0 < 0 too)
+  const int py0 = t0.y0 - a.lo - 1, px0 = t0.x0 - a.lo - 1;
+  const float* eb = ego + (size_t)b * a.C * E2;
+  for (int i = threadIdx.x; i < a.C * FPR * FPC; i += 256) {
+    const int c = i / (FPR * FPC), rc = i - c * (FPR * FPC);
+    const int rr = rc / FPC, cc = rc - rr * FPC;
+    const int ey = py0 + rr, ex = px0 + cc;
+    patch[c * pitch + rc] = (ey >= 0 && ey < a.E && ex >= 0 && ex < a.E) ? eb[(size_t)c * E2 + ey * a.E + ex] : 0.f;
+  }
+  __syncthreads();
+  f32x4* gb = reinterpret_cast<f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
+  for (int i = threadIdx.x; i < FR * FC * C4; i += 256) {
+    const int c = i % C4, p = i / C4;
+    const int wy = ty_ * FR + p / FC, wx = tx_ * FC + (p % FC);
+    if (wy >= WN || wx >= WN) continue;
+    const int Y = wy0 + wy, X = wx0 + wx;
+    if (Y < 0 || Y >= a.G || X < 0 || X >= a.G) continue;
+    float gx = base_coord(X, a.G) + tx;
+    float gy = base_coord(Y, a.G) + ty;
+    Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+      float w = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
+      if (yy >= a.lo && yy < hi && xx >= a.lo && xx < hi && yy < a.G && xx < a.G) {
+        const int ey = yy - a.lo, ex = xx - a.lo;
+        const int rr = ey - py0, cc = ex - px0;
+        f32x4 q;
+        if (rr >= 0 && rr < FPR && cc >= 0 && cc < FPC) {
+          const float* pp = patch + (4 * c) * pitch + rr * FPC + cc;
+          q = f32x4{pp[0], pp[pitch], pp[2 * pitch], pp[3 * pitch]};
+        } else {
+          const float* pg = eb + (size_t)(4 * c) * E2 + ey * a.E + ex;
+          q = f32x4{pg[0], pg[E2], pg[2 * (size_t)E2], pg[3 * (size_t)E2]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += q[j] * w;
+      }
+    }
+    size_t o = ((size_t)Y * a.G + X) * C4 + c;
+    f32x4 g = gb[o];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = v[j] > g[j] ? v[j] : g[j];
+    gb[o] = g;
+  }
+}
+
 // translate the global map back to the agent and crop the centre E x E (NHWC scratch)
 __global__ __launch_bounds__(256) void map_crop_kernel(const float* __restrict__ gm, const float* __restrict__ gps,
                                                        MapArgs a, float* __restrict__ crop) {
@@ -402,6 +546,46 @@ extern "C" int wsmg_map_fuse(const float* ego_rot, float* global_map, const floa
   hipLaunchKernelGGL(map_reset_kernel, dim3(sgrid(n4, 1024), B), dim3(256), 0, wsmg_s(stream), global_map, masks, n4);
   int64_t n = (int64_t)(E + 4) * (E + 4) * (C / 4);
   hipLaunchKernelGGL(map_fuse_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), ego_rot, global_map, gps, a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx, const float* heading, float sign, int B, int Cf,
+                                       int Hf, int Wf, int C, int E, float* out_planes, wsmg_stream_t stream) {
+  if (B <= 0 || Cf <= 0 || C <= 0 || C > Cf || E <= 1 || B > 65535) return WSMG_EINVAL;
+  const int E2 = E * E;
+  const size_t plane = (size_t)E2 * sizeof(unsigned);
+  if (plane > 160 * 1024) return WSMG_EINVAL;
+  int CG = (2 * plane <= 80 * 1024 && (int64_t)B * C >= 1024) ? 2 : 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bev_scatter_rotate_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)wsmg_cdiv(C, CG), (unsigned)B);
+  hipLaunchKernelGGL(bev_scatter_rotate_kernel, grid, dim3(1024), plane * CG, wsmg_s(stream), feat, lin_idx, heading, sign, Cf,
+                     Hf * Wf, C, E, CG, out_planes);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_map_fuse_planes(const float* ego_rot_planes, float* global_map, const float* gps, const float* masks, int B,
+                                    int C, int E, int G, float resolution, wsmg_stream_t stream) {
+  if (B <= 0 || C <= 0 || C % 4 || C > 64 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
+  MapArgs a = map_args(B, C, E, G, resolution);
+  int64_t n4 = (int64_t)G * G * C / 4;
+  hipLaunchKernelGGL(map_reset_kernel, dim3(sgrid(n4, 1024), B), dim3(256), 0, wsmg_s(stream), global_map, masks, n4);
+  const int tiles_x = wsmg_cdiv(E + 4, FC), tiles_y = wsmg_cdiv(E + 4, FR);
+  const size_t lds = (size_t)C * (FPR * FPC + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(map_fuse_planes_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (FPR * FPC + 1) * (int)sizeof(float));
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(map_fuse_planes_kernel, dim3((unsigned)(tiles_x * tiles_y), (unsigned)B), dim3(256), lds, wsmg_s(stream),
+                     ego_rot_planes, global_map, gps, a, tiles_x);
   WSMG_RETURN_LAUNCH();
 }
 

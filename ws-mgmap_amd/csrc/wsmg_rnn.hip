@@ -289,6 +289,138 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
   }
 }
 
+// ---- 8-wave form of the forward kernel (round 3).  One wave per SIMD issues a vector instruction every 4 cycles, two every 2:
+// the 768 FMAs per lane of the 4-wave form are the longest phase of its step (1.8 us of 5.5).  Here waves w and w + 4 share the
+// 4 units of wave w and split K: wave half q owns k = 64 j + 4 kl + e for j = 4 q .. 4 q + 3 (48 weights per lane instead of 96,
+// 384 FMAs); the upper half's sums cross to the lower half through LDS behind one more workgroup barrier, the lower half does the
+// gate math as before.  All 512 threads poll: 8 {value, tag} words each instead of 16.  Same arithmetic per output up to the
+// order of the two K halves' addition.
+__device__ __forceinline__ bool poll_row8(const unsigned long long* src, unsigned want, unsigned* sync, float (&out)[8], unsigned limit) {
+  unsigned n = 0;
+  for (;;) {
+    unsigned long long v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ok = ok && ((unsigned)(v[i] >> 32) == want);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = __uint_as_float((unsigned)v[i]);
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    if (++n >= limit || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+      __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void gru_fwd8_kernel(GruFwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float hs[2][NB][H];   // h_{t-1}, double-buffered by step parity
+  __shared__ float part[WAVES][64][2];                          // the upper K half's two sums per lane
+  const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+  const int wave = wave8 & 3, q = wave8 >> 2;                   // unit group of the wave, K half
+  const int grp = lane >> 4, kl = lane & 15;
+  const int my_unit = blockIdx.x * UNITS_WG + wave * UNITS_WAVE + grp;
+  float w[3][16];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(a.whh + (size_t)(g * H + my_unit) * H + 64 * (4 * q + j) + 4 * kl);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[g][4 * j + e] = v[e];
+    }
+  const int my_b = kl >> 1;
+  const bool worker = (q == 0) && ((kl & 1) == 0) && (my_b < a.N);
+  const float br = a.bhh[my_unit], bz = a.bhh[H + my_unit], bn = a.bhh[2 * H + my_unit];
+  // staging role: half `sh` of the 16 units of producer workgroup sw for batch sb
+  const int sw = tid >> 4, sb = (tid >> 1) & 7, sh = tid & 1;
+  const int xw = (blockIdx.x * NB + my_b) * UNITS_WG + wave * UNITS_WAVE + grp;
+  for (int t = 0; t < a.T; ++t) {
+    float (*hcur)[H] = hs[t & 1];
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    const size_t orow = (size_t)t * a.N + my_b;
+    if (worker) {
+      const float* g = a.gi + orow * 3 * H;
+      gr = g[my_unit]; gz = g[H + my_unit]; gn = g[2 * H + my_unit];
+    }
+    {
+      float row[8];
+      bool good = true;
+      if (sb >= a.N) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) row[i] = 0.f;
+      } else if (t == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)sb * H + sw * UNITS_WG + 8 * sh + 4 * i);
+          row[4 * i] = v[0]; row[4 * i + 1] = v[1]; row[4 * i + 2] = v[2]; row[4 * i + 3] = v[3];
+        }
+      } else {
+        const unsigned long long* src = a.xh + ((size_t)(t - 1) * NWG + sw) * NB * UNITS_WG + sb * UNITS_WG + 8 * sh;
+        good = poll_row8(src, a.tagbase | (unsigned)t, a.sync, row, a.spin);
+      }
+      const float sm = sb < a.N ? a.masks[t * a.N + sb] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x4 v = {row[4 * i] * sm, row[4 * i + 1] * sm, row[4 * i + 2] * sm, row[4 * i + 3] * sm};
+        *reinterpret_cast<f32x4*>(&hcur[sb][sw * UNITS_WG + 8 * sh + 4 * i]) = v;
+      }
+      if (__syncthreads_or(good ? 0 : 1)) {   // timeout or error elsewhere: every thread leaves
+        rnn_fail(a.status, 1u);
+        rnn_poison(a.y, (size_t)a.T * a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
+        return;
+      }
+    }
+    float acc[32];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      if (b < a.N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(&hcur[b][64 * (4 * q + j) + 4 * kl]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0 = fmaf(w[0][4 * j + e], hv[e], s0);
+            s1 = fmaf(w[1][4 * j + e], hv[e], s1);
+            s2 = fmaf(w[2][4 * j + e], hv[e], s2);
+          }
+        }
+      }
+      acc[4 * b] = s0; acc[4 * b + 1] = s1; acc[4 * b + 2] = s2; acc[4 * b + 3] = 0.f;
+    }
+    halve_row<32, 8>(acc, lane);
+    halve_row<16, 4>(acc, lane);
+    halve_row<8, 2>(acc, lane);
+    halve_row<4, 1>(acc, lane);
+    if (q == 1) { part[wave][lane][0] = acc[0]; part[wave][lane][1] = acc[1]; }
+    __syncthreads();
+    if (q == 0) { acc[0] += part[wave][lane][0]; acc[1] += part[wave][lane][1]; }
+    const float nsum = row_xor<1>(acc[0]);   // odd lane's acc[0] = n gate of the same batch
+    if (worker) {
+      const float ghr = acc[0] + br, ghz = acc[1] + bz, ghn = nsum + bn;
+      const float r = sigmoidf_(gr + ghr);
+      const float z = sigmoidf_(gz + ghz);
+      const float nn = tanhf(gn + r * ghn);
+      const float hprev = hcur[my_b][my_unit];   // already masked
+      const float h = (1.0f - z) * nn + z * hprev;
+      if (t + 1 < a.T)
+        __hip_atomic_store(a.xh + (size_t)t * NWG * NB * UNITS_WG + xw,
+                           ((unsigned long long)(a.tagbase | (unsigned)(t + 1)) << 32) | __float_as_uint(h),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.y[orow * H + my_unit] = h;
+      a.sr[orow * H + my_unit] = r;
+      a.sz[orow * H + my_unit] = z;
+      a.sn[orow * H + my_unit] = nn;
+      a.sghn[orow * H + my_unit] = ghn;
+    }
+  }
+}
+
 struct GruBwdArgs {
   const float* dy;     // [T][N][H]   gradient w.r.t. every h_t
   const float* dhT;    // [N][H] gradient w.r.t. the final hidden state, or null
@@ -458,6 +590,150 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
   }
 }
 
+// ---- 8-wave form of the backward kernel (round 3; see gru_fwd8_kernel).  Thread pair (tid, tid + 256) owns the same two columns
+// k = 2 c, 2 c + 1 (c = tid & 255) and splits the 48 gate ROWS: half q multiplies rows 24 q .. 24 q + 23 (24 weight pairs per lane
+// instead of 48, 384 FMAs, 48 LDS reads: the workgroup's LDS read volume is unchanged, which a split by columns would double).
+// The halves swap the partial sums the other one finishes through LDS — half 0 finishes batch slots 0-3, half 1 slots 4-7 — and
+// each publishes its 8 words; all 512 threads poll 8 words each.
+__global__ __launch_bounds__(512) void gru_bwd8_kernel(GruBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[NWG][NB][UNITS_WG];   // the 32 producers' partial sums for my units
+  __shared__ __attribute__((aligned(16))) float dgs[3 * UNITS_WG][NB];     // my gate gradients of this step: rows r, z, n
+  __shared__ __attribute__((aligned(16))) float swp[2][256][8];            // swp[q][c]: what half q hands to the other half
+  const int tid = threadIdx.x;
+  const int c = tid & 255, q = tid >> 8;
+  f32x2 w[24];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const int rw = 24 * q + i, g = rw / UNITS_WG, u = rw - g * UNITS_WG;
+    w[i] = *reinterpret_cast<const f32x2*>(a.whh + (size_t)(g * H + blockIdx.x * UNITS_WG + u) * H + 2 * c);
+  }
+  // element-wise role (threads 0..127): unit wu of this workgroup, batch slot wb
+  const int wu = tid & 15, wb = tid >> 4;
+  const bool worker = tid < 128 && wb < a.N;
+  const int my_unit = blockIdx.x * UNITS_WG + wu;
+  // polling role: half ph of the 16 units of producer pq for batch slot pb
+  const int pq = tid >> 4, pb = (tid >> 1) & 7, ph = tid & 1;
+  // publishing role: columns 2 c, 2 c + 1 belong to consumer workgroup c / 8, its units (2 c) % 16 and + 1; batch slots 4 q .. 4 q + 3
+  const size_t pub = ((size_t)(c >> 3) * NWG + blockIdx.x) * NB * UNITS_WG + ((2 * c) & 15);
+
+  float direct = 0.f, mk_next = 0.f;
+  for (int t = a.T - 1; t >= -1; --t) {
+    float dyv = 0.f, r = 0.f, z = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, mk = 0.f;
+    size_t row = 0;
+    if (worker && t >= 0) {
+      row = (size_t)t * a.N + wb;
+      const size_t o = row * H + my_unit;
+      mk = a.masks[t * a.N + wb];
+      const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
+      hprev = hsrc[(size_t)wb * H + my_unit] * mk;
+      dyv = a.dy[o];
+      r = a.sr[o]; z = a.sz[o]; nn = a.sn[o]; ghn = a.sghn[o];
+    }
+    float carry = 0.f;
+    if (t == a.T - 1) {
+      if (worker && a.dhT) carry = a.dhT[(size_t)wb * H + my_unit];
+    } else {
+      bool good = true;
+      if (pb < a.N) {
+        float rowv[8];
+        const unsigned long long* src = a.xp + (size_t)((t + 1) % BWD_RING) * XP_SLOT + (size_t)blockIdx.x * XP_CONSUMER +
+                                        ((size_t)pq * NB + pb) * UNITS_WG + 8 * ph;
+        good = poll_row8(src, a.tagbase | (unsigned)(t + 2), a.sync, rowv, a.spin);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x4 v = {rowv[4 * i], rowv[4 * i + 1], rowv[4 * i + 2], rowv[4 * i + 3]};
+          *reinterpret_cast<f32x4*>(&part[pq][pb][8 * ph + 4 * i]) = v;
+        }
+      }
+      if (__syncthreads_or(good ? 0 : 1)) {   // timeout or error elsewhere: every thread leaves
+        rnn_fail(a.status, 2u);
+        for (int g = 0; g < 3; ++g) {
+          rnn_poison(a.dgi, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
+          rnn_poison(a.dgh, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
+        }
+        rnn_poison(a.dh0, (size_t)a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
+        return;
+      }
+      if (worker) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int p2 = 0; p2 < NWG; p2 += 2) { s0 += part[p2][wb][wu]; s1 += part[p2 + 1][wb][wu]; }
+        carry = (direct + (s0 + s1)) * mk_next;
+      }
+    }
+    if (t < 0) {
+      if (worker) a.dh0[(size_t)wb * H + my_unit] = carry;
+      break;
+    }
+    if (tid < 128) {
+      float dr_pre = 0.f, dz_pre = 0.f, dnr = 0.f;
+      if (worker) {
+        const float dh = dyv + carry;
+        const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
+        dz_pre = dh * (hprev - nn) * z * (1.0f - z);
+        dr_pre = dn_pre * ghn * r * (1.0f - r);
+        dnr = dn_pre * r;
+        float* gi = a.dgi + row * 3 * H;
+        float* gh = a.dgh + row * 3 * H;
+        gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
+        gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dnr;
+        direct = dh * z;
+        mk_next = mk;
+      }
+      dgs[wu][wb] = dr_pre; dgs[UNITS_WG + wu][wb] = dz_pre; dgs[2 * UNITS_WG + wu][wb] = dnr;   // zeros for unused batch slots
+    }
+    __syncthreads();   // dgs complete; also: every read of part[] / swp[] of the previous step is done
+    float acc0[NB], acc1[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
+    const unsigned dgs_addr = (unsigned)(size_t)&dgs[0][0] + (unsigned)(24 * q * NB * 4);     // this half's 24 rows
+#pragma unroll
+    for (int c8 = 0; c8 < 24; c8 += 8) {
+      f32x4 d[16];
+      asm volatile("" :: "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]), "v"(acc0[6]), "v"(acc0[7]),
+                         "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]), "v"(acc1[3]), "v"(acc1[4]), "v"(acc1[5]), "v"(acc1[6]), "v"(acc1[7]));
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[i]) : "v"(dgs_addr), "n"((c8 * NB + 4 * i) * 4) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
+                     "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rw = c8 + i;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc0[b] = fmaf(w[rw][0], d[2 * i][b], acc0[b]);             acc1[b] = fmaf(w[rw][1], d[2 * i][b], acc1[b]);
+          acc0[4 + b] = fmaf(w[rw][0], d[2 * i + 1][b], acc0[4 + b]); acc1[4 + b] = fmaf(w[rw][1], d[2 * i + 1][b], acc1[4 + b]);
+        }
+      }
+    }
+    // hand the other half the four batch slots it finishes: half 0 keeps slots 0-3, half 1 keeps 4-7
+    {
+      const int give = 4 * (1 - q);
+      f32x4 g0 = {acc0[give], acc0[give + 1], acc0[give + 2], acc0[give + 3]};
+      f32x4 g1 = {acc1[give], acc1[give + 1], acc1[give + 2], acc1[give + 3]};
+      *reinterpret_cast<f32x4*>(&swp[q][c][0]) = g0;
+      *reinterpret_cast<f32x4*>(&swp[q][c][4]) = g1;
+    }
+    __syncthreads();
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(&swp[1 - q][c][0]), o1 = *reinterpret_cast<const f32x4*>(&swp[1 - q][c][4]);
+    unsigned long long* dst = a.xp + (size_t)(t % BWD_RING) * XP_SLOT + pub;
+    const unsigned long long tag = (unsigned long long)(a.tagbase | (unsigned)(t + 1)) << 32;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int b = 4 * q + bb;
+      if (b < a.N) {
+        // (the two halves' sums are added lower half first: the value does not depend on which thread adds)
+        const float v0 = q == 0 ? acc0[b] + o0[bb] : o0[bb] + acc0[b];
+        const float v1 = q == 0 ? acc1[b] + o1[bb] : o1[bb] + acc1[b];
+        __hip_atomic_store(dst + b * UNITS_WG, tag | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + b * UNITS_WG + 1, tag | __float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // workspace layout: [0, 256) barrier words (zeroed per call) | [256, ...) exchange image (128-B aligned
@@ -546,6 +822,13 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
   unsigned dyn = 0;
+  static int waves = -1;       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B)
+  if (waves < 0) { const char* ev = getenv("WSMG_GRU_WAVES"); waves = ev ? atoi(ev) : 8; }
+  if (waves == 8) {
+    if ((e = excl_lds(gru_fwd8_kernel, &dyn)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gru_fwd8_kernel, dim3(NWG), dim3(512), dyn, s, a);
+    WSMG_RETURN_LAUNCH();
+  }
   if ((e = excl_lds(gru_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
   WSMG_RETURN_LAUNCH();
@@ -565,6 +848,13 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
   unsigned dyn = 0;
+  static int waves = -1;       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B)
+  if (waves < 0) { const char* ev = getenv("WSMG_GRU_WAVES"); waves = ev ? atoi(ev) : 8; }
+  if (waves == 8) {
+    if ((e = excl_lds(gru_bwd8_kernel, &dyn)) != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gru_bwd8_kernel, dim3(NWG), dim3(512), dyn, s, a);
+    WSMG_RETURN_LAUNCH();
+  }
   if ((e = excl_lds(gru_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
   WSMG_RETURN_LAUNCH();

@@ -40,6 +40,8 @@ _SIG = {
     "wsmg_bev_rotate": [c_p, c_p, c_f, c_i, c_i, c_i, c_p, c_p],
     "wsmg_map_fuse": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "wsmg_map_retrieve": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
+    "wsmg_bev_scatter_rotate": [c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
+    "wsmg_map_fuse_planes": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "wsmg_conv2d_fwd": [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_p],
     "wsmg_conv2d_bwd_data": [c_p, c_p, c_p] + [c_i] * 11 + [c_p],
     "wsmg_conv2d_bwd_weight": [c_p, c_p, c_p] + [c_i] * 11 + [c_p],

@@ -10,6 +10,8 @@ the gfx950 kernels paste/translate/fuse directly inside the (E+4)^2 window the v
 All arithmetic runs in libwsmgmap.so (wsmg_bev_index / _scatter_max / _rotate / wsmg_map_fuse /
 _retrieve); nothing here has a CPU fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -55,11 +57,16 @@ class Mapping(nn.Module):
             raise ops._abi.WsmgError("full_global_map must be a contiguous [num_proc,G,G,C] tensor")
         local_scale = float(self.global_map_size * self.resolution) / float(self.global_map_size)
         lin = ops.bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
-        planes = ops.bev_scatter_max(features.float().contiguous(), lin, C, E)
         compass = observations["compass"].reshape(bs).float().contiguous()
         gps = observations["gps"].reshape(bs, 2).float().contiguous()
-        rotated = ops.bev_rotate(planes, compass, -1.0)
-        ops.map_fuse(rotated, gm, gps, masks.reshape(bs).float().contiguous(), self.resolution)
+        if ops.bev_planes_ok(C, E) and os.environ.get("WSMG_BEV_FUSED", "1") != "0":
+            # scatter-max + rotation in one launch (the channel plane is rotated out of LDS); the fuse reads the rotated planes
+            rotated = ops.bev_scatter_rotate(features.float().contiguous(), lin, compass, -1.0, C, E)
+            ops.map_fuse(rotated, gm, gps, masks.reshape(bs).float().contiguous(), self.resolution, planes=True)
+        else:
+            planes = ops.bev_scatter_max(features.float().contiguous(), lin, C, E)
+            rotated = ops.bev_rotate(planes, compass, -1.0)
+            ops.map_fuse(rotated, gm, gps, masks.reshape(bs).float().contiguous(), self.resolution)
         ego_nhwc = ops.map_retrieve(gm, gps, compass, E, self.resolution)
         return ego_nhwc.permute(0, 3, 1, 2), gm
 

@@ -1818,6 +1818,22 @@ def bev_rotate(planes, heading, sign):
 
 
 @torch.no_grad()
+def bev_scatter_rotate(feat, lin, heading, sign, C, E):
+    """bev_scatter_max + bev_rotate in one launch; the rotated map stays in NCHW planes [B,C,E,E] (for map_fuse(..., planes=True))."""
+    _req(feat, lin, heading)
+    _f32(feat, heading)
+    B, Cf, Hf, Wf = feat.shape
+    out = torch.empty(B, C, E, E, device=feat.device, dtype=torch.float32)
+    _abi.call("wsmg_bev_scatter_rotate", _p(feat), _p(lin), _p(heading), float(sign), B, Cf, Hf, Wf, C, E, _p(out), _stream())
+    return out
+
+
+def bev_planes_ok(C, E):
+    """Shapes the one-launch scatter + rotation and the plane-consuming fuse take."""
+    return C % 4 == 0 and C <= 64 and E > 1 and E * E * 4 <= 160 * 1024
+
+
+@torch.no_grad()
 def _check_global_map(global_map, B, C, *f32s):
     """The kernels index global_map[b] for b < B: the reference slices `full_global_map[:bs]` (rgb_mapping.py:43) and
     fails with a shape error when the batch has more rows than num_proc — here that would be an out-of-bounds access."""
@@ -1831,14 +1847,19 @@ def _check_global_map(global_map, B, C, *f32s):
         raise _abi.WsmgError(f"full_global_map has {global_map.shape[3]} channels, the ego map {C}")
 
 
-def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12):
+def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12, planes=False):
+    """planes: ego_rot is [B,C,E,E] (bev_scatter_rotate's output) instead of NHWC [B,E,E,C]; same result bit for bit."""
     _req(ego_rot, global_map, gps, masks)
-    B, E, _, C = ego_rot.shape
+    if planes:
+        B, C, E, _ = ego_rot.shape
+    else:
+        B, E, _, C = ego_rot.shape
     _check_global_map(global_map, B, C, ego_rot, gps, masks)
     if gps.shape[0] != B or masks.numel() != B:
         raise _abi.WsmgError("map_fuse: gps [B,2] and masks [B] must match the ego maps' batch")
     G = global_map.shape[1]
-    _abi.call("wsmg_map_fuse", _p(ego_rot), _p(global_map), _p(gps), _p(masks), B, C, E, G, float(resolution), _stream())
+    _abi.call("wsmg_map_fuse_planes" if planes else "wsmg_map_fuse", _p(ego_rot), _p(global_map), _p(gps), _p(masks), B, C, E, G,
+              float(resolution), _stream())
 
 
 @torch.no_grad()
