@@ -80,6 +80,10 @@ int wsmg_map_fuse_planes(const float* ego_rot_planes, float* global_map, const f
  * exposes `out` as a channels-last view of the reference's [B][C][E][E] tensor. */
 int wsmg_map_retrieve(const float* global_map, const float* gps, const float* compass, int B, int C, int E,
                       int G, float resolution, float* scratch, float* out, wsmg_stream_t stream);
+/* The same in ONE launch (round 3): every output element computes the four cropped values its rotation taps need in registers
+ * instead of the crop going through `scratch`; bit-identical to wsmg_map_retrieve. */
+int wsmg_map_retrieve_fused(const float* global_map, const float* gps, const float* compass, int B, int C, int E, int G,
+                            float resolution, float* out, wsmg_stream_t stream);
 
 /* ============================ operator 2: map conv / UNet decoder engine ============================ */
 /* cuDNN conv2d forward / backward at map_encoder.py:19-29,94-112, mg_map_policy.py:78-100,127,130.
@@ -553,6 +557,16 @@ int wsmg_attn_fp8_mfma_fwd(const uint8_t* q_codes, const float* q_scale, const u
                            const uint8_t* v_codes, const float* v_scale, const int* lengths, const int* row_ids,
                            const int* set_start, float scale, int B, int U, int L, int C, float* out, float* attn,
                            wsmg_stream_t stream);
+
+/* The operands of wsmg_attn_fp8_mfma_fwd from float32 tensors in two launches (round 3): per-tensor scales (x_scale > 0: the
+ * caller's; otherwise max(amax|x| * float32(1/448), 1e-30) — bit-equal to torch's `(x.abs().amax() / 448.0).clamp_min(1e-30)` — a NaN
+ * input giving a NaN scale), the e4m3 codes of q [B][C], k_sets and v_sets
+ * [U][L][C] (as wsmg_quantize_e4m3_dev rounds them), and the rows grouped by set: row_ids [B], set_start [U+1] from inverse [B]
+ * (0 <= inverse[b] < U; the order of the rows inside a set is arbitrary — every row's result is its own).  scales [3] = q, k, v.
+ * amax_ws: 3 words, ZERO on entry (left holding the maxima).  U <= 1024, C % 4 == 0. */
+int wsmg_attn_fp8_prep(const float* q, const float* k_sets, const float* v_sets, const int64_t* inverse, int B, int U, int L, int C,
+                       float q_scale, float k_scale, float v_scale, uint8_t* q_codes, uint8_t* k_codes, uint8_t* v_codes,
+                       float* scales, int* row_ids, int* set_start, unsigned* amax_ws, wsmg_stream_t stream);
 
 /* out[r] = mean of x[r][0..n) for R rows of n <= 160 float32 values (contiguous): `nn.AdaptiveAvgPool1d(1)` + `Flatten` in front of
  * rgb_linear (mg_map_policy.py:90-96) over the 7 x 7 positions of the RGB feature. */

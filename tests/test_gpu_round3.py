@@ -666,6 +666,48 @@ def test_attention_fp8_mfma_vs_float64_formula_on_quantised_operands(shape):
     assert float((out2 - out).abs().max()) <= 1e-2 * float(out.abs().max()) and float((attn2 - attn).abs().max()) <= 1e-2
 
 
+@pytest.mark.parametrize("shape", [(64, 8, 160), (4096, 64, 160), (37, 5, 200), (1, 1, 1)], ids=["cfg5", "b4096", "ragged", "one"])
+def test_attention_fp8_prep_scales_codes_and_grouping(shape):
+    """wsmg_attn_fp8_prep (the operands of the matrix-core attention in two launches) against the stock ops it replaces: scales
+    bit-equal to `(x.abs().amax() / 448).clamp_min(1e-30)` in float32, codes bit-equal to wsmg_quantize_e4m3_dev's with those
+    scales (which test_gpu_kernels.py pins to the oracle's encoder), `set_start` = the exclusive prefix of bincount(inverse),
+    `row_ids` a permutation whose group u holds exactly the rows of set u; caller-supplied scales pass through unchanged."""
+    from wsmgmap import ops, _abi
+    B, U, L = shape
+    C = 256
+    g = torch.Generator(device="cuda"); g.manual_seed(B + U + L)
+    q = torch.randn(B, C, device="cuda", generator=g) * 3
+    k = torch.randn(U, L, C, device="cuda", generator=g) * 0.7
+    v = torch.randn(U, L, C, device="cuda", generator=g)
+    inverse = torch.randint(0, U, (B,), device="cuda", generator=g)
+    for fixed in ((0.0, 0.0, 0.0), (0.0, 0.0125, 0.0)):
+        qc = torch.empty(B, C, device="cuda", dtype=torch.uint8); kc = torch.empty(U, L, C, device="cuda", dtype=torch.uint8)
+        vc = torch.empty_like(kc); sc = torch.empty(3, device="cuda"); order = torch.empty(B, device="cuda", dtype=torch.int32)
+        start = torch.empty(U + 1, device="cuda", dtype=torch.int32); ws = torch.zeros(4, device="cuda", dtype=torch.int32)
+        P = ops._p
+        _abi.call("wsmg_attn_fp8_prep", P(q), P(k), P(v), P(inverse), B, U, L, C, *fixed, P(qc), P(kc), P(vc), P(sc), P(order), P(start), P(ws),
+                  ops._stream())
+        for i, (x, codes) in enumerate(((q, qc), (k, kc), (v, vc))):
+            want_s = (x.abs().amax() / 448.0).clamp_min(1e-30).reshape(1).float() if fixed[i] == 0.0 else torch.full((1,), fixed[i], device="cuda")
+            assert torch.equal(sc[i:i + 1], want_s), (i, float(sc[i]), float(want_s))
+            want_c = torch.empty_like(codes)
+            _abi.call("wsmg_quantize_e4m3_dev", P(x), x.numel(), P(want_s), P(want_c), ops._stream())
+            assert torch.equal(codes, want_c), f"tensor {i}: {int((codes != want_c).sum())} codes differ"
+        cnt = torch.bincount(inverse, minlength=U)
+        want_start = torch.zeros(U + 1, device="cuda", dtype=torch.int64); want_start[1:] = torch.cumsum(cnt, 0)
+        assert torch.equal(start.long(), want_start)
+        o = order.long()
+        assert torch.equal(torch.sort(o).values, torch.arange(B, device="cuda"))
+        group_of_slot = torch.repeat_interleave(torch.arange(U, device="cuda"), cnt)
+        assert torch.equal(inverse[o], group_of_slot)
+    # a NaN in an operand reaches its scale (torch's amax propagates it), not a silent saturation
+    q2 = q.clone(); q2[0, 3] = float("nan")
+    ws = torch.zeros(4, device="cuda", dtype=torch.int32)
+    _abi.call("wsmg_attn_fp8_prep", P(q2), P(k), P(v), P(inverse), B, U, L, C, 0.0, 0.0, 0.0, P(qc), P(kc), P(vc), P(sc), P(order), P(start), P(ws),
+              ops._stream())
+    assert bool(torch.isnan(sc[0])) and not bool(torch.isnan(sc[1:]).any())
+
+
 @pytest.mark.parametrize("shape", [(512, 512, 49), (7, 1), (300, 160), (3, 5, 33)], ids=["rgb_feature", "n1", "n160", "ragged"])
 def test_mean_last_matches_torch(shape):
     """ops.mean_last (wsmg_mean_rows): AdaptiveAvgPool1d(1) + Flatten in front of rgb_linear (mg_map_policy.py:90-96) — against
@@ -677,3 +719,66 @@ def test_mean_last_matches_torch(shape):
     want = x.double().mean(-1)
     assert got.shape == want.shape
     assert float((got.double() - want).abs().max()) <= 1e-6 * max(1.0, float(x.abs().max()))
+
+
+# ----------------------------------------------------------------------------- BEV: scatter + rotation in one launch
+@pytest.mark.parametrize("B,E,C,G", [(3, 100, 64, 240), (2, 200, 40, 480), (2, 33, 8, 64)], ids=["e100_c64", "e200_c40", "e33_c8"])
+def test_bev_scatter_rotate_and_plane_fuse_equal_the_separate_launches(B, E, C, G):
+    """wsmg_bev_scatter_rotate + wsmg_map_fuse_planes + wsmg_map_retrieve_fused (round 3: what Mapping.project_feat_to_map runs)
+    against the launches they replace (wsmg_bev_scatter_max, wsmg_bev_rotate, wsmg_map_fuse, wsmg_map_retrieve;
+    rgb_mapping.py:34-70,81-84,206-250), which the oracle tests pin: the rotated map, the global map and the retrieved map bit for bit, over several steps so the max-fuse meets a non-empty map,
+    with agents near the border of the global map (window partly outside), a mid-sequence episode reset and every heading sign."""
+    from wsmgmap import ops
+    Hf = 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    gm_a = torch.zeros(B, G, G, C, device="cuda")
+    gm_b = torch.zeros(B, G, G, C, device="cuda")
+    half = G * 0.12 / 2
+    for step in range(4):
+        depth = torch.rand(B, 256, 256, device="cuda", generator=g) + 0.05
+        depth[:, :8] = 0
+        feat = torch.relu(torch.randn(B, 64, Hf, Hf, device="cuda", generator=g))
+        lin = ops.bev_index(depth, Hf, Hf, E)
+        compass = (torch.rand(B, device="cuda", generator=g) * 6.28 - 3.14) * (1.0 if step != 2 else 0.0)
+        gps = (torch.rand(B, 2, device="cuda", generator=g) * 2 - 1) * half * (1.0 if step % 2 else 0.35)   # odd steps reach the border
+        masks = torch.ones(B, device="cuda")
+        if step == 2:
+            masks[0] = 0
+        planes = ops.bev_scatter_max(feat, lin, C, E)
+        rot = ops.bev_rotate(planes, compass, -1.0)
+        rotp = ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E)
+        assert torch.equal(rotp.permute(0, 2, 3, 1), rot), f"step {step}: rotated map differs"
+        ops.map_fuse(rot, gm_a, gps, masks, 0.12)
+        ops.map_fuse(rotp, gm_b, gps, masks, 0.12, planes=True)
+        assert torch.equal(gm_a, gm_b), f"step {step}: global map differs in {int((gm_a != gm_b).sum())} elements"
+        one = ops.map_retrieve(gm_a, gps, compass, E, 0.12, fused=True)       # crop + rotation in one launch
+        two = ops.map_retrieve(gm_a, gps, compass, E, 0.12, fused=False)
+        assert torch.equal(one, two), f"step {step}: retrieved map differs in {int((one != two).sum())} elements"
+    assert float(gm_a.abs().max()) > 0
+
+
+def test_map_sequence_vs_oracle_through_the_mapping_module():
+    """The G2 sequence (rotate / paste / translate / max-fuse / retrieve over 4 steps with an episode reset) through
+    `Mapping.project_feat_to_map` itself — the one-launch scatter + rotation and the plane-consuming fuse — against the oracle and
+    the golden patch, at the tolerance of test_map_sequence_vs_oracle (2e-4 absolute: bilinear weights from float32 grid maths)."""
+    from oracle import bev_ref, cases
+    from util import T, golden
+    from test_gpu_kernels import dev, close
+    from wsmgmap import ops
+    from wsmgmap.common.rgb_mapping import Mapping
+    g = golden("g2_mapseq.npz")
+    m = cases.MAP_SEQ
+    ref = bev_ref.MapperRef(m["B"])
+    mp = Mapping.__new__(Mapping)
+    torch.nn.Module.__init__(mp)
+    mp.egocentric_map_size, mp.global_map_depth, mp.global_map_size, mp.resolution = m["E"], m["C"], m["G"], 0.12
+    gm = torch.zeros(m["B"], m["G"], m["G"], m["C"], device="cuda")
+    assert ops.bev_planes_ok(m["C"], m["E"])
+    for s in range(m["steps"]):
+        c = cases.mapseq_inputs(s)
+        ego_ref = ref.step(T(c["feat"]), T(c["depth"]), T(c["gps"]), T(c["compass"]), T(c["masks"]))
+        obs = {"depth": dev(c["depth"]), "gps": dev(c["gps"]), "compass": dev(c["compass"])}
+        ego, gm = mp.project_feat_to_map(dev(c["feat"]), gm, obs, dev(c["masks"]))
+        close(f"s{s}.global", gm, ref.full_global_map, 0, 2e-4)
+        close(f"s{s}.ego", ego, ego_ref, 0, 2e-4)
+        np.testing.assert_allclose(ego[:, ::16, 40:56, 44:60].cpu().numpy(), g[f"s{s}.ego_patch"], atol=2e-4, rtol=0)

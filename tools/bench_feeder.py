@@ -111,7 +111,9 @@ if __name__ == "__main__" and os.environ.get("WSMG_FEEDER_E2E", "1") != "0":
     print("end to end (in-memory record store -> decode processes -> pinned shared-memory ring -> H2D + device collate):")
     st_ = os.statvfs("/dev/shm")
     print(f"  /dev/shm free: {st_.f_bavail * st_.f_frsize / 2**30:.1f} GiB; one slot = one batch = {raw / 2**20:.0f} MiB, 2 slots per worker")
-    for w in [int(x) for x in os.environ.get("WSMG_FEEDER_WORKERS", "1,8,32").split(",")]:
+    from wsmgmap.data.feeder import _host_memory_available
+    print(f"  host memory this process may use: {(_host_memory_available() or 0) / 2**30:.0f} GiB; CPUs: {len(os.sched_getaffinity(0))}")
+    for w in [min(int(x), 32) for x in os.environ.get("WSMG_FEEDER_WORKERS", "1,8,32").split(",")]:   # (a 96-worker ring is 212 GB pinned)
         try:
             r, n, pinned = feeder_rate(w)
         except RuntimeError as e:

@@ -190,7 +190,128 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fwd_kernel(F8mArgs a) {
     }
 }
 
+// ---- operands of one call in two launches (round 3; the host side took ~25 stock launches for them: three abs / amax /
+// divide / clamp chains, three quantisations, argsort + bincount + cumsum — 185 of the op's 200 us at B = 64).
+// prep 1: |x| maxima of the three tensors (non-negative floats order like their bit patterns: atomicMax on the words).
+struct PrepArgs {
+  const float* x[3];
+  int64_t n4[3];          // float4 pieces of q, k, v
+  unsigned* amax;         // [3], zero on entry
+  float fixed[3];         // > 0: the caller's scale for that tensor (its maximum is not taken)
+  uint8_t* codes[3];
+  float* scales;          // [3] out
+  const int64_t* inverse; // [B]
+  int* order;             // [B] out: rows grouped by set (order inside a set is arbitrary: every row's result is its own)
+  int* start;             // [U + 1] out
+  int B, U;
+};
+__global__ __launch_bounds__(256) void attn_fp8_amax_kernel(PrepArgs a) {
+  const int64_t tot = a.n4[0] + a.n4[1] + a.n4[2];
+  float m[3] = {0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int t = i < a.n4[0] ? 0 : i < a.n4[0] + a.n4[1] ? 1 : 2;
+    if (a.fixed[t] > 0.f) continue;
+    const int64_t k = i - (t == 0 ? 0 : t == 1 ? a.n4[0] : a.n4[0] + a.n4[1]);
+    const f32x4 v = reinterpret_cast<const f32x4*>(a.x[t])[k];
+    const float mm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    // a NaN anywhere must reach the scale, as torch's amax propagates it (fmaxf drops NaNs: test the elements)
+    const bool bad = v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3];
+    m[t] = (bad || m[t] != m[t]) ? __builtin_nanf("") : fmaxf(m[t], mm);
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float v = m[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float w = __shfl_xor(v, o, 64);
+      v = (v != v || w != w) ? __builtin_nanf("") : fmaxf(v, w);
+    }
+    m[t] = v;
+  }
+  // one atomic per workgroup and tensor (one per wave was 5 120 same-address atomics at U = 64, L = 160: 200 us of serialisation)
+  __shared__ float wm[4][3];
+  if ((threadIdx.x & 63) == 0) { wm[threadIdx.x >> 6][0] = m[0]; wm[threadIdx.x >> 6][1] = m[1]; wm[threadIdx.x >> 6][2] = m[2]; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float v = wm[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float o = wm[w][threadIdx.x];
+      v = (v != v || o != o) ? __builtin_nanf("") : fmaxf(v, o);
+    }
+    if (v > 0.f || v != v) atomicMax(a.amax + threadIdx.x, v != v ? 0x7fc00000u : __float_as_uint(v));
+  }
+}
+// prep 2: the three quantisations (scale = max(amax * float32(1 / 448), 1e-30) — the value `(x.abs().amax() / 448.0).clamp_min(1e-30)`
+// has in torch, which multiplies by the reciprocal of a scalar divisor — or the caller's; codes as wsmg_quantize_e4m3_dev makes them) and,
+// in one extra workgroup, the grouping of the rows by instruction set.
+__global__ __launch_bounds__(256) void attn_fp8_quant_group_kernel(PrepArgs a, int qblocks) {
+  __shared__ int cnt[1025];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x == qblocks) {     // grouping: histogram, exclusive prefix, placement
+    for (int u = tid; u <= a.U; u += 256) cnt[u] = 0;
+    __syncthreads();
+    auto set_of = [&](int b) {        // (an index outside [0, U) is a caller error; clamped so that it cannot leave the arrays)
+      const int64_t u = a.inverse[b];
+      return (int)(u < 0 ? 0 : u >= a.U ? a.U - 1 : u);
+    };
+    for (int b = tid; b < a.B; b += 256) atomicAdd(&cnt[set_of(b) + 1], 1);
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int u = 0; u <= a.U; ++u) { run += cnt[u]; cnt[u] = run; a.start[u] = run; }   // cnt[u] = first slot of set u
+    }
+    __syncthreads();
+    for (int b = tid; b < a.B; b += 256) a.order[atomicAdd(&cnt[set_of(b)], 1)] = b;
+    if (tid < 3) {
+      const float am = __uint_as_float(a.amax[tid]);
+      a.scales[tid] = a.fixed[tid] > 0.f ? a.fixed[tid] : (am != am ? am : fmaxf(am * (1.0f / 448.0f), 1e-30f));
+    }
+    return;
+  }
+  const int64_t tot = a.n4[0] + a.n4[1] + a.n4[2];
+  const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+  if (i >= tot) return;
+  const int t = i < a.n4[0] ? 0 : i < a.n4[0] + a.n4[1] ? 1 : 2;
+  const int64_t k = i - (t == 0 ? 0 : t == 1 ? a.n4[0] : a.n4[0] + a.n4[1]);
+  const float am = __uint_as_float(a.amax[t]);
+  const float sc = a.fixed[t] > 0.f ? a.fixed[t] : (am != am ? am : fmaxf(am * (1.0f / 448.0f), 1e-30f));
+  const float inv_scale = (float)(1.0 / (double)sc);
+  f32x4 v = reinterpret_cast<const f32x4*>(a.x[t])[k];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j] * inv_scale, -448.f), 448.f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+  reinterpret_cast<unsigned*>(a.codes[t])[k] = (unsigned)w;
+}
+
 }  // namespace
+
+extern "C" int wsmg_attn_fp8_prep(const float* q, const float* k_sets, const float* v_sets, const int64_t* inverse, int B, int U, int L,
+                                  int C, float q_scale, float k_scale, float v_scale, uint8_t* q_codes, uint8_t* k_codes,
+                                  uint8_t* v_codes, float* scales, int* row_ids, int* set_start, unsigned* amax_ws,
+                                  wsmg_stream_t stream) {
+  if (!q || !k_sets || !v_sets || !inverse || !q_codes || !k_codes || !v_codes || !scales || !row_ids || !set_start || !amax_ws)
+    return WSMG_EINVAL;
+  if (B <= 0 || U <= 0 || U > 1024 || L <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
+  PrepArgs a;
+  a.x[0] = q; a.x[1] = k_sets; a.x[2] = v_sets;
+  a.n4[0] = (int64_t)B * C / 4; a.n4[1] = a.n4[2] = (int64_t)U * L * C / 4;
+  a.amax = amax_ws;
+  a.fixed[0] = q_scale; a.fixed[1] = k_scale; a.fixed[2] = v_scale;
+  a.codes[0] = q_codes; a.codes[1] = k_codes; a.codes[2] = v_codes;
+  a.scales = scales; a.inverse = inverse; a.order = row_ids; a.start = set_start; a.B = B; a.U = U;
+  const int64_t tot = a.n4[0] + a.n4[1] + a.n4[2];
+  if (!(q_scale > 0.f && k_scale > 0.f && v_scale > 0.f)) {
+    int64_t g = wsmg_cdiv(tot, 256 * 4);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(attn_fp8_amax_kernel, dim3((unsigned)g), dim3(256), 0, wsmg_s(stream), a);
+  }
+  const int64_t qb = wsmg_cdiv(tot, 256);
+  if (qb >= (1ll << 31) - 1) return WSMG_EINVAL;
+  hipLaunchKernelGGL(attn_fp8_quant_group_kernel, dim3((unsigned)qb + 1), dim3(256), 0, wsmg_s(stream), a, (int)qb);
+  WSMG_RETURN_LAUNCH();
+}
 
 extern "C" int wsmg_attn_fp8_mfma_fwd(const uint8_t* q_codes, const float* q_scale, const uint8_t* k_codes, const float* k_scale,
                                       const uint8_t* v_codes, const float* v_scale, const int* lengths, const int* row_ids,

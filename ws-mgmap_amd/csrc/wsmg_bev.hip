@@ -143,6 +143,14 @@ __device__ __forceinline__ Taps make_taps(float ix, float iy) {
 
 struct Rot { float c, s; };
 
+// Block order of the gather kernels: hardware block b runs on XCD b % 8; logical block = a contiguous eighth of the grid per XCD,
+// so that output rows that share source rows (the +1 taps) meet in one L2 instead of fetching them into several.
+__device__ __forceinline__ int bev_block() {
+  const int nb = gridDim.x, bid = blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, x = bid & 7;
+  return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
 // rotation of an E x E map: gx = bx*c + by*s ; gy = -bx*s + by*c
 __device__ __forceinline__ Taps rot_taps(int x, int y, int E, Rot r) {
   float bx = base_coord(x, E), by = base_coord(y, E);
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void rotate_nhwc_kernel(const float* __restric
   Rot r{cosf(t), sinf(t)};
   const f32x4* ib = reinterpret_cast<const f32x4*>(in + (size_t)b * E2 * C);
   f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * E2 * C);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)E2 * C4;
+  for (int64_t i = (int64_t)bev_block() * blockDim.x + threadIdx.x; i < (int64_t)E2 * C4;
        i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(i % C4);
     int p = (int)(i / C4);
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(const float* __restrict__
   const f32x4* eb = reinterpret_cast<const f32x4*>(ego + (size_t)b * a.E * a.E * a.C);
   f32x4* gb = reinterpret_cast<f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
   const int hi = a.lo + a.E;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)WN * WN * C4;
+  for (int64_t i = (int64_t)bev_block() * blockDim.x + threadIdx.x; i < (int64_t)WN * WN * C4;
        i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(i % C4);
     int p = (int)(i / C4);
@@ -363,18 +371,21 @@ __global__ __launch_bounds__(256) void map_fuse_kernel(const float* __restrict__
   }
 }
 
-// map_fuse_kernel for an ego map that arrives as ROTATED NCHW PLANES (bev_scatter_rotate_kernel).  A workgroup owns FR x FC window
-// pixels and all channels: the (FR + 2) x (FC + 4) patch of every plane its taps can touch is loaded once (whole row pieces,
-// coalesced) into LDS, [channel][row][column] with an odd channel pitch; the work items are (pixel, 4 channels) with the channel
-// quad fastest, as in map_fuse_kernel, so the global map is read and written in 16-byte pieces of consecutive addresses.
-// Same arithmetic per element (taps in k order).  A tap outside the patch (the translation is by whole cells, so this is the
-// float rounding of the grid coordinate at worst) is read from memory instead.
-constexpr int FR = 4, FC = 64, FPR = FR + 2, FPC = FC + 4;
+// map_fuse_kernel for an ego map that arrives as ROTATED NCHW PLANES (bev_scatter_rotate_kernel).  A workgroup owns FP
+// consecutive window pixels of one window row and all channels, in two phases:
+//   1. work item = (channel, pixel) with the PIXEL fastest: the four taps are 4-byte loads that run along a plane row (coalesced,
+//      independent — several items in flight per thread), the translated value goes to LDS as t[pixel][channel];
+//   2. work item = (pixel, 4 channels) with the channel quad fastest, as in map_fuse_kernel: the value comes back from LDS as one
+//      16-byte read and the global map is read-modify-written in 16-byte pieces of consecutive addresses.
+// Same arithmetic per element (taps in k order).  (First form of this kernel: the (FR + 2) x (FC + 4) patch of every plane in LDS,
+// then gathers out of it — 65 KB per workgroup, two workgroups per CU, load and compute phases that could not overlap: 334 us at
+// cfg4 against 144 us of map_fuse_kernel.)
+constexpr int FP = 64;
 __global__ __launch_bounds__(256) void map_fuse_planes_kernel(const float* __restrict__ ego, float* __restrict__ gm,
                                                               const float* __restrict__ gps, MapArgs a, int tiles_x) {
-  extern __shared__ float patch[];
+  extern __shared__ float tl[];           // [FP][C + 1]... pitch C + 4 keeps the 16-byte reads aligned
   const int b = blockIdx.y;
-  const int ty_ = blockIdx.x / tiles_x, tx_ = blockIdx.x - ty_ * tiles_x;
+  const int wy = blockIdx.x / tiles_x, tx_ = blockIdx.x - wy * tiles_x;
   const int WN = a.E + 4;
   Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
   const float tx = -(ps.gy - a.halfG) / a.halfG;
@@ -383,55 +394,79 @@ __global__ __launch_bounds__(256) void map_fuse_planes_kernel(const float* __res
   const int wx0 = a.lo + (int)(ps.gy - a.halfG) - 2;
   const int C4 = a.C >> 2;
   const int E2 = a.E * a.E;
-  const int pitch = FPR * FPC + 1;
+  const int pitch = a.C + 4;
   const int hi = a.lo + a.E;
-  // patch origin (in ego coordinates): the north-west tap of the tile's first pixel, one cell of slack to the west and north
-  const int Y0 = wy0 + ty_ * FR, X0 = wx0 + tx_ * FC;
-  Taps t0 = make_taps(unnorm(base_coord(X0, a.G) + tx, a.G), unnorm(base_coord(Y0, a.G) + ty, a.G));   // (linear in X0, Y0 < 0 too)
-  const int py0 = t0.y0 - a.lo - 1, px0 = t0.x0 - a.lo - 1;
+  const int Y = wy0 + wy;
+  if (Y < 0 || Y >= a.G) return;          // (whole workgroup: the row is outside the global map)
   const float* eb = ego + (size_t)b * a.C * E2;
-  for (int i = threadIdx.x; i < a.C * FPR * FPC; i += 256) {
-    const int c = i / (FPR * FPC), rc = i - c * (FPR * FPC);
-    const int rr = rc / FPC, cc = rc - rr * FPC;
-    const int ey = py0 + rr, ex = px0 + cc;
-    patch[c * pitch + rc] = (ey >= 0 && ey < a.E && ex >= 0 && ex < a.E) ? eb[(size_t)c * E2 + ey * a.E + ex] : 0.f;
-  }
-  __syncthreads();
-  f32x4* gb = reinterpret_cast<f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
-  for (int i = threadIdx.x; i < FR * FC * C4; i += 256) {
-    const int c = i % C4, p = i / C4;
-    const int wy = ty_ * FR + p / FC, wx = tx_ * FC + (p % FC);
-    if (wy >= WN || wx >= WN) continue;
-    const int Y = wy0 + wy, X = wx0 + wx;
-    if (Y < 0 || Y >= a.G || X < 0 || X >= a.G) continue;
-    float gx = base_coord(X, a.G) + tx;
+  // ---- phase 1
+  {
+    const int p = threadIdx.x & (FP - 1), cq = threadIdx.x >> 6;     // pixel of the tile, channel phase (256 / FP = 4)
+    const int wx = tx_ * FP + p, X = wx0 + wx;
+    const bool pok = wx < WN && X >= 0 && X < a.G;
+    float gx = base_coord(pok ? X : 0, a.G) + tx;
     float gy = base_coord(Y, a.G) + ty;
     Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int off[4];
+    float w[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
-      float w = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
-      if (yy >= a.lo && yy < hi && xx >= a.lo && xx < hi && yy < a.G && xx < a.G) {
-        const int ey = yy - a.lo, ex = xx - a.lo;
-        const int rr = ey - py0, cc = ex - px0;
-        f32x4 q;
-        if (rr >= 0 && rr < FPR && cc >= 0 && cc < FPC) {
-          const float* pp = patch + (4 * c) * pitch + rr * FPC + cc;
-          q = f32x4{pp[0], pp[pitch], pp[2 * pitch], pp[3 * pitch]};
-        } else {
-          const float* pg = eb + (size_t)(4 * c) * E2 + ey * a.E + ex;
-          q = f32x4{pg[0], pg[E2], pg[2 * (size_t)E2], pg[3 * (size_t)E2]};
-        }
+      const int yy = tp.y0 + (k >> 1), xx = tp.x0 + (k & 1);
+      w[k] = k == 0 ? tp.w00 : k == 1 ? tp.w01 : k == 2 ? tp.w10 : tp.w11;
+      // zero padding of grid_sample, then the zero border of the agent view around the paste
+      const bool ok = pok && yy >= a.lo && yy < hi && xx >= a.lo && xx < hi && yy < a.G && xx < a.G;
+      off[k] = ok ? (yy - a.lo) * a.E + (xx - a.lo) : -1;
+    }
+    constexpr int U = 4;
+    for (int c0 = cq; c0 < a.C; c0 += 4 * U) {
+      float q[U][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += q[j] * w;
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + 4 * u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[u][k] = (c < a.C && off[k] >= 0) ? eb[(size_t)c * E2 + off[k]] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = c0 + 4 * u;
+        if (c >= a.C) break;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (off[k] >= 0) v += q[u][k] * w[k];
+        tl[p * pitch + c] = v;
       }
     }
-    size_t o = ((size_t)Y * a.G + X) * C4 + c;
-    f32x4 g = gb[o];
+  }
+  __syncthreads();
+  // ---- phase 2
+  f32x4* gb = reinterpret_cast<f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
+  constexpr int V = 4;
+  const int nitems = FP * C4;
+  for (int i0 = threadIdx.x; i0 < nitems; i0 += 256 * V) {
+    bool ok[V];
+    size_t o[V];
+    f32x4 g[V];
+    int li[V];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = v[j] > g[j] ? v[j] : g[j];
-    gb[o] = g;
+    for (int u = 0; u < V; ++u) {
+      const int i = i0 + 256 * u;
+      const int c = i % C4, p = i / C4;
+      const int wx = tx_ * FP + p, X = wx0 + wx;
+      ok[u] = i < nitems && wx < WN && X >= 0 && X < a.G;
+      o[u] = ((size_t)Y * a.G + X) * C4 + c;
+      li[u] = p * pitch + 4 * c;
+      if (ok[u]) g[u] = gb[o[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < V; ++u) {
+      if (!ok[u]) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tl + li[u]);
+      f32x4 gg = g[u];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gg[j] = v[j] > gg[j] ? v[j] : gg[j];
+      gb[o[u]] = gg;
+    }
   }
 }
 
@@ -445,7 +480,7 @@ __global__ __launch_bounds__(256) void map_crop_kernel(const float* __restrict__
   const int C4 = a.C >> 2;
   const f32x4* gb = reinterpret_cast<const f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
   f32x4* cb = reinterpret_cast<f32x4*>(crop + (size_t)b * a.E * a.E * a.C);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)a.E * a.E * C4;
+  for (int64_t i = (int64_t)bev_block() * blockDim.x + threadIdx.x; i < (int64_t)a.E * a.E * C4;
        i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(i % C4);
     int p = (int)(i / C4);
@@ -465,6 +500,65 @@ __global__ __launch_bounds__(256) void map_crop_kernel(const float* __restrict__
       }
     }
     cb[i] = v;
+  }
+}
+
+// map_crop_kernel + rotate_nhwc_kernel in one pass (round 3): a rotation tap needs the cropped map at an integer pixel, which is
+// itself four taps of the global map — the item (output pixel, 4 channels) computes its four crop values in registers (16 loads of
+// 16 bytes, all independent, neighbours' loads hitting the same lines in L1 / L2) instead of the crop going to memory (205 MB out,
+// 205 MB back at cfg4) between two launches.  Same arithmetic per value as the two kernels: crop = sum over k of q_k w_k, output =
+// sum over the rotation taps (nw, ne, sw, se) of crop w.
+__global__ __launch_bounds__(256) void map_retrieve_fused_kernel(const float* __restrict__ gm, const float* __restrict__ gps,
+                                                                 const float* __restrict__ heading, MapArgs a,
+                                                                 float* __restrict__ out) {
+  const int b = blockIdx.y;
+  Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
+  const float tx = (ps.gy - a.halfG) / a.halfG;
+  const float ty = (ps.gx - a.halfG) / a.halfG;
+  const int C4 = a.C >> 2, E = a.E;
+  const float t = heading[b];
+  const Rot r{cosf(t), sinf(t)};
+  const f32x4* gb = reinterpret_cast<const f32x4*>(gm + (size_t)b * a.G * a.G * a.C);
+  f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * E * E * a.C);
+  for (int64_t i = (int64_t)bev_block() * blockDim.x + threadIdx.x; i < (int64_t)E * E * C4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const int p = (int)(i / C4);
+    const int y = p / E, x = p - y * E;
+    const Taps rt = rot_taps(x, y, E, r);
+    f32x4 q[4][4];
+    float w[4][4];
+    bool rok[4], cok[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // rotation tap k = crop pixel (cy, cx)
+      const int cy = rt.y0 + (k >> 1), cx = rt.x0 + (k & 1);
+      rok[k] = cy >= 0 && cy < E && cx >= 0 && cx < E;
+      float gx = base_coord(a.lo + (rok[k] ? cx : 0), a.G) + tx;
+      float gy = base_coord(a.lo + (rok[k] ? cy : 0), a.G) + ty;
+      const Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int yy = tp.y0 + (m >> 1), xx = tp.x0 + (m & 1);
+        w[k][m] = m == 0 ? tp.w00 : m == 1 ? tp.w01 : m == 2 ? tp.w10 : tp.w11;
+        cok[k][m] = rok[k] && yy >= 0 && yy < a.G && xx >= 0 && xx < a.G;
+        if (cok[k][m]) q[k][m] = gb[((size_t)yy * a.G + xx) * C4 + c];
+      }
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!rok[k]) continue;
+      f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        if (cok[k][m]) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cv[j] += q[k][m][j] * w[k][m];
+        }
+      const float wr = k == 0 ? rt.w00 : k == 1 ? rt.w01 : k == 2 ? rt.w10 : rt.w11;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += cv[j] * wr;
+    }
+    ob[i] = v;
   }
 }
 
@@ -575,17 +669,19 @@ extern "C" int wsmg_map_fuse_planes(const float* ego_rot_planes, float* global_m
   MapArgs a = map_args(B, C, E, G, resolution);
   int64_t n4 = (int64_t)G * G * C / 4;
   hipLaunchKernelGGL(map_reset_kernel, dim3(sgrid(n4, 1024), B), dim3(256), 0, wsmg_s(stream), global_map, masks, n4);
-  const int tiles_x = wsmg_cdiv(E + 4, FC), tiles_y = wsmg_cdiv(E + 4, FR);
-  const size_t lds = (size_t)C * (FPR * FPC + 1) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(map_fuse_planes_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (FPR * FPC + 1) * (int)sizeof(float));
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const int tiles_x = wsmg_cdiv(E + 4, FP), tiles_y = E + 4;
+  const size_t lds = (size_t)FP * (C + 4) * sizeof(float);
   hipLaunchKernelGGL(map_fuse_planes_kernel, dim3((unsigned)(tiles_x * tiles_y), (unsigned)B), dim3(256), lds, wsmg_s(stream),
                      ego_rot_planes, global_map, gps, a, tiles_x);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_map_retrieve_fused(const float* global_map, const float* gps, const float* compass, int B, int C, int E, int G,
+                                       float resolution, float* out, wsmg_stream_t stream) {
+  if (B <= 0 || C <= 0 || C % 4 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
+  MapArgs a = map_args(B, C, E, G, resolution);
+  int64_t n = (int64_t)E * E * (C / 4);
+  hipLaunchKernelGGL(map_retrieve_fused_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), global_map, gps, compass, a, out);
   WSMG_RETURN_LAUNCH();
 }
 

@@ -30,6 +30,32 @@ def _identity(batch):
     return batch
 
 
+def _host_memory_available():
+    """Bytes of host memory this process may still take: min(MemAvailable, cgroup limit - usage); None when unknown."""
+    vals = []
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    vals.append(int(line.split()[1]) * 1024)
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            with open(lim) as f:
+                v = f.read().strip()
+            if v == "max":
+                continue
+            with open(cur) as f:
+                used = int(f.read().strip())
+            if int(v) < (1 << 60):
+                vals.append(max(0, int(v) - used))
+        except (OSError, ValueError):
+            pass
+    return min(vals) if vals else None
+
+
 def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, seed):
     """Decode worker: its shard of the dataset, whole batches, packed into the shared slots it is handed."""
     import random
@@ -152,6 +178,14 @@ class DeviceFeeder:
                                    "slots_per_worker, or a larger /dev/shm")
         except OSError:
             pass
+        # ... and what would take the machine with it: the ring is page-locked host memory, and every worker is a process with its
+        # own decode buffers on top — refuse a ring above 40 % of what this process may still use (the smaller of MemAvailable and
+        # the control group's limit; a 96-worker ring of 700 MiB batches is 212 GB)
+        avail = _host_memory_available()
+        if avail is not None and need > 0.4 * avail:
+            raise RuntimeError(f"the feeder's shared-memory ring needs {need >> 20} MiB ({W} workers x {self.slots_per_worker} slots x "
+                               f"{nbytes >> 20} MiB), more than 40 % of the {avail >> 20} MiB of host memory this process may use: "
+                               "fewer workers or slots_per_worker")
         ctx = mp.get_context("spawn")
         slots = [torch.empty(nbytes, dtype=torch.uint8).share_memory_() for _ in range(W * self.slots_per_worker)]
         rt = torch.cuda.cudart()

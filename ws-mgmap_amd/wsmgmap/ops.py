@@ -1650,21 +1650,21 @@ def attention_fp8_shared(q, k_sets, v_sets, lengths, inverse, scale=1.0 / 16, sc
     if C != 256 or k_sets.shape != v_sets.shape or k_sets.shape[2] != C or inverse.numel() != B or L > 224:
         raise _abi.WsmgError("attention_fp8_shared: q [B,256], k / v sets [U,L<=224,256], inverse [B]")
     dev = q.device
-
-    def quant(x, s):
-        if s is None:
-            sc = (x.abs().amax() / 448.0).clamp_min(1e-30).reshape(1).float()
-            codes = torch.empty(x.shape, device=dev, dtype=torch.uint8)
-            _abi.call("wsmg_quantize_e4m3_dev", _p(x), x.numel(), _p(sc), _p(codes), _stream())
-            return codes, sc
-        return quantize_e4m3(x, s), torch.full((1,), float(s), device=dev, dtype=torch.float32)
-    s3 = scales or (None, None, None)
-    qc, qs = quant(q.contiguous(), s3[0])
-    kc, ks = quant(k_sets.contiguous(), s3[1])
-    vc, vs = quant(v_sets.contiguous(), s3[2])
-    order = torch.argsort(inverse, stable=True).to(torch.int32)                 # rows grouped by set
-    start = torch.zeros(U + 1, device=dev, dtype=torch.int32)
-    start[1:] = torch.cumsum(torch.bincount(inverse, minlength=U), 0).to(torch.int32)
+    if inverse.dtype != torch.int64:
+        inverse = inverse.long()
+    q, k_sets, v_sets, inverse = q.contiguous(), k_sets.contiguous(), v_sets.contiguous(), inverse.contiguous()
+    s3 = [float(x) if x is not None else 0.0 for x in (scales or (None, None, None))]
+    # scales, codes and the row grouping in two launches (wsmg_attn_fp8_prep) instead of ~25 stock ones
+    qc = torch.empty(B, C, device=dev, dtype=torch.uint8)
+    kc = torch.empty(U, L, C, device=dev, dtype=torch.uint8)
+    vc = torch.empty(U, L, C, device=dev, dtype=torch.uint8)
+    sc = torch.empty(3, device=dev, dtype=torch.float32)
+    order = torch.empty(B, device=dev, dtype=torch.int32)
+    start = torch.empty(U + 1, device=dev, dtype=torch.int32)
+    ws = torch.zeros(4, device=dev, dtype=torch.int32)
+    _abi.call("wsmg_attn_fp8_prep", _p(q), _p(k_sets), _p(v_sets), _p(inverse), B, U, L, C, s3[0], s3[1], s3[2], _p(qc), _p(kc), _p(vc),
+              _p(sc), _p(order), _p(start), _p(ws), _stream())
+    qs, ks, vs = sc[0:1], sc[1:2], sc[2:3]
     lens = None if lengths is None else lengths.to(torch.int32).contiguous()
     out = torch.empty(B, C, device=dev, dtype=torch.float32)
     attn = torch.empty(B, L, device=dev, dtype=torch.float32)
@@ -1863,14 +1863,23 @@ def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12, planes=False):
 
 
 @torch.no_grad()
-def map_retrieve(global_map, gps, compass, E, resolution=0.12):
+def map_retrieve(global_map, gps, compass, E, resolution=0.12, fused=None):
+    """fused: crop + rotation in one launch, bit-identical to the two.  Default: for small batches only (B E^2 C / 4 <= 500 000
+    work items: 11 vs 16 us at B = 1; at B = 8 the 16 gathers per item already cost more than the crop's round trip through memory —
+    35 vs 26 us, 311 vs 219 us at cfg4); WSMG_BEV_RETRIEVE_FUSED=0 / 1 forces either."""
     _req(global_map, gps, compass)
     B = gps.shape[0]
     _check_global_map(global_map, B, global_map.shape[3] if global_map.dim() == 4 else -1, gps, compass)
     if compass.numel() != B:
         raise _abi.WsmgError("map_retrieve: compass [B] must match gps [B,2]")
     G, C = global_map.shape[1], global_map.shape[3]
-    scratch = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
     out = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
+    if fused is None:
+        ev = _os.environ.get("WSMG_BEV_RETRIEVE_FUSED")
+        fused = (B * E * E * (C // 4) <= 500_000) if ev is None else ev != "0"
+    if fused:
+        _abi.call("wsmg_map_retrieve_fused", _p(global_map), _p(gps), _p(compass), B, C, E, G, float(resolution), _p(out), _stream())
+        return out
+    scratch = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
     _abi.call("wsmg_map_retrieve", _p(global_map), _p(gps), _p(compass), B, C, E, G, float(resolution), _p(scratch), _p(out), _stream())
     return out
