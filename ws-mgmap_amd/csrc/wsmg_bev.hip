@@ -61,30 +61,26 @@ __device__ __forceinline__ float key2f(unsigned k) {
   return __uint_as_float(u);
 }
 
-// one workgroup = (sample, CG consecutive map channels); the CG E*E planes live in LDS
-__global__ __launch_bounds__(1024) void bev_scatter_kernel(const float* __restrict__ feat,
-                                                           const int32_t* __restrict__ lin, int Cf, int HW, int C,
-                                                           int E2, int CG, float* __restrict__ out) {
-  extern __shared__ unsigned tile[];
-  const int b = blockIdx.y;
-  const int c0 = blockIdx.x * CG;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < CG * E2; i += 1024) tile[i] = 0u;  // 0 = empty (below every float key)
-  __syncthreads();
-  const int32_t* lb = lin + (size_t)b * HW;
-  for (int g = 0; g < CG; ++g) {
-    int c = c0 + g;
-    if (c >= C) break;
-    // adaptive_max_pool1d window of output channel c over the Cf feature channels
-    int ws = (int)(((int64_t)c * Cf) / C);
-    int we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
-    const float* fb = feat + ((size_t)b * Cf + ws) * HW;
-    unsigned* tg = tile + (size_t)g * E2;
-    // Eight sources per thread and trip, every load of a trip issued before the first is used: with one dependent index ->
-    // feature -> atomic chain per trip the 16 waves of the workgroup (its 160 KB plane leaves room for one workgroup per CU at
-    // E = 200) kept 4 KB of loads in flight per CU and the kernel ran at the memory LATENCY, 14 GB/s per CU.
-    constexpr int U = 8;
-    const int nwin = we - ws;
+// Scatter-max of one (sample, map channel) into its LDS plane `tg` (keys; 0 = empty), by the 1024 threads of a workgroup.
+// adaptive_max_pool1d window of output channel c over the Cf feature channels: [ws, we).
+// Memory-level parallelism is the whole game here: the plane leaves room for ONE workgroup per CU at E = 200 (16 waves), and a
+// trip is index -> feature -> atomic.  Round 2 went from one source per thread and trip (14 GB/s per CU: pure latency) to eight
+// with their loads issued together (16 GB/s per CU x 256); round 3 also issues the (up to four) window channels of all eight
+// sources together instead of one channel per dependent loop trip, and fetches the NEXT trip's indices before this trip's
+// features are used, so that an index round trip is never exposed.
+// WU: window channels fetched together (the launcher picks the widest window of the geometry, up to 4; at Cf == C it is 1, and
+// the 40 VGPRs of that form keep two workgroups per CU at E = 100, which the 78 of WU = 4 do not).
+template <int WU>
+__device__ __forceinline__ void scatter_plane(const float* __restrict__ feat, const int32_t* __restrict__ lb, int b, int c, int Cf,
+                                              int HW, int C, unsigned* tg, int tid) {
+  const int ws = (int)(((int64_t)c * Cf) / C);
+  const int we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
+  const float* fb = feat + ((size_t)b * Cf + ws) * HW;
+  constexpr int U = 8;
+  const int nwin = we - ws;
+  if constexpr (WU == 1) {
+    // Cf == C (the rollout geometry, one feature channel per map channel): the round-2 loop, which at B = 8 already runs at
+    // 6.6 TB/s — the pipelined form below measured 30.6 instead of 23.8 us there (56 instead of 34 VGPRs)
     for (int s0 = tid; s0 < HW; s0 += 1024 * U) {
       int cell[U];
       float v[U];
@@ -104,6 +100,63 @@ __global__ __launch_bounds__(1024) void bev_scatter_kernel(const float* __restri
       for (int u = 0; u < U; ++u)
         if (cell[u] >= 0) atomicMax(&tg[cell[u]], f2key(v[u]));
     }
+    return;
+  }
+  int nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int s = tid + 1024 * u;
+    nxt[u] = s < HW ? lb[s] : -1;
+  }
+  for (int s0 = tid; s0 < HW; s0 += 1024 * U) {
+    int cell[U];
+    float f[U][WU];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cell[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int w = 0; w < WU; ++w) f[u][w] = (cell[u] >= 0 && w < nwin) ? fb[(size_t)w * HW + s0 + 1024 * u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + 1024 * (U + u);
+      nxt[u] = s < HW ? lb[s] : -1;
+    }
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = f[u][0];
+#pragma unroll
+      for (int w = 1; w < WU; ++w)
+        if (w < nwin) v[u] = fmaxf(v[u], f[u][w]);
+    }
+    for (int w = WU; w < nwin; ++w) {       // wider windows (Cf > 4 C): the rest one channel per trip
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (cell[u] >= 0) v[u] = fmaxf(v[u], fb[(size_t)w * HW + s0 + 1024 * u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (cell[u] >= 0) atomicMax(&tg[cell[u]], f2key(v[u]));
+  }
+}
+
+// one workgroup = (sample, CG consecutive map channels); the CG E*E planes live in LDS
+template <int WU>
+__global__ __launch_bounds__(1024) void bev_scatter_kernel(const float* __restrict__ feat,
+                                                           const int32_t* __restrict__ lin, int Cf, int HW, int C,
+                                                           int E2, int CG, float* __restrict__ out) {
+  extern __shared__ unsigned tile[];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CG;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < CG * E2; i += 1024) tile[i] = 0u;  // 0 = empty (below every float key)
+  __syncthreads();
+  const int32_t* lb = lin + (size_t)b * HW;
+  for (int g = 0; g < CG; ++g) {
+    int c = c0 + g;
+    if (c >= C) break;
+    scatter_plane<WU>(feat, lb, b, c, Cf, HW, C, tile + (size_t)g * E2, tid);
   }
   __syncthreads();
   for (int i = tid; i < CG * E2; i += 1024) {
@@ -163,6 +216,7 @@ __device__ __forceinline__ Taps rot_taps(int x, int y, int E, Rot r) {
 // ends, so the rotation samples it there (4 LDS reads per output pixel) and only the ROTATED plane goes to memory — NCHW, whole
 // rows, coalesced — instead of plane out, plane in through 4-byte gathers, NHWC out.  map_fuse_planes_kernel consumes the planes.
 // Same arithmetic per output pixel as rotate_nchw_to_nhwc_kernel (tap order nw, ne, sw, se).
+template <int WU>
 __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* __restrict__ feat, const int32_t* __restrict__ lin,
                                                                   const float* __restrict__ heading, float sign, int Cf, int HW,
                                                                   int C, int E, int CG, float* __restrict__ out) {
@@ -177,31 +231,7 @@ __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* _
   for (int g = 0; g < CG; ++g) {
     int c = c0 + g;
     if (c >= C) break;
-    int ws = (int)(((int64_t)c * Cf) / C);
-    int we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
-    const float* fb = feat + ((size_t)b * Cf + ws) * HW;
-    unsigned* tg = tile + (size_t)g * E2;
-    constexpr int U = 8;
-    const int nwin = we - ws;
-    for (int s0 = tid; s0 < HW; s0 += 1024 * U) {
-      int cell[U];
-      float v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int s = s0 + 1024 * u;
-        cell[u] = s < HW ? lb[s] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = cell[u] >= 0 ? fb[s0 + 1024 * u] : 0.f;
-      for (int w = 1; w < nwin; ++w) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (cell[u] >= 0) v[u] = fmaxf(v[u], fb[(size_t)w * HW + s0 + 1024 * u]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (cell[u] >= 0) atomicMax(&tg[cell[u]], f2key(v[u]));
-    }
+    scatter_plane<WU>(feat, lb, b, c, Cf, HW, C, tile + (size_t)g * E2, tid);
   }
   __syncthreads();
   for (int i = tid; i < CG * E2; i += 1024) {   // keys -> the values bev_scatter_kernel writes, in place
@@ -574,6 +604,16 @@ MapArgs map_args(int B, int C, int E, int G, float resolution) {
   return a;
 }
 
+// widest adaptive_max_pool1d window of Cf -> C channels, capped at 4 (scatter_plane's WU)
+int scatter_window(int Cf, int C) {
+  int m = 1;
+  for (int c = 0; c < C; ++c) {
+    const int ws = (int)(((int64_t)c * Cf) / C), we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
+    if (we - ws > m) m = we - ws;
+  }
+  return m > 4 ? 4 : m;
+}
+
 int sgrid(int64_t n, int cap = 4096) {
   int64_t g = wsmg_cdiv(n, 256);
   if (g > cap) g = cap;
@@ -610,16 +650,21 @@ extern "C" int wsmg_bev_scatter_max(const float* feat, const int32_t* lin_idx, i
   // two planes per workgroup when that still leaves >= 2 workgroups per CU's LDS and enough workgroups
   int CG = (2 * plane <= 80 * 1024 && (int64_t)B * C >= 1024) ? 2 : 1;
   size_t lds = plane * CG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bev_scatter_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
   dim3 grid((unsigned)wsmg_cdiv(C, CG), (unsigned)B);
-  hipLaunchKernelGGL(bev_scatter_kernel, grid, dim3(1024), lds, wsmg_s(stream), feat, lin_idx, Cf, Hf * Wf, C, E2, CG,
-                     out);
+  const int wu = scatter_window(Cf, C);
+#define WSMG_SCATTER(WU_)                                                                                                          \
+  {                                                                                                                                \
+    static bool attr_set = false;                                                                                                  \
+    if (!attr_set) {                                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bev_scatter_kernel<WU_>),                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
+      if (e != hipSuccess) return (int)e;                                                                                          \
+      attr_set = true;                                                                                                             \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(bev_scatter_kernel<WU_>, grid, dim3(1024), lds, wsmg_s(stream), feat, lin_idx, Cf, Hf * Wf, C, E2, CG, out); \
+  }
+  if (wu == 1) WSMG_SCATTER(1) else if (wu == 2) WSMG_SCATTER(2) else if (wu == 3) WSMG_SCATTER(3) else WSMG_SCATTER(4)
+#undef WSMG_SCATTER
   WSMG_RETURN_LAUNCH();
 }
 
@@ -650,16 +695,22 @@ extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx
   const size_t plane = (size_t)E2 * sizeof(unsigned);
   if (plane > 160 * 1024) return WSMG_EINVAL;
   int CG = (2 * plane <= 80 * 1024 && (int64_t)B * C >= 1024) ? 2 : 1;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bev_scatter_rotate_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
   dim3 grid((unsigned)wsmg_cdiv(C, CG), (unsigned)B);
-  hipLaunchKernelGGL(bev_scatter_rotate_kernel, grid, dim3(1024), plane * CG, wsmg_s(stream), feat, lin_idx, heading, sign, Cf,
-                     Hf * Wf, C, E, CG, out_planes);
+  const int wu = scatter_window(Cf, C);
+#define WSMG_SCATTER(WU_)                                                                                                          \
+  {                                                                                                                                \
+    static bool attr_set = false;                                                                                                  \
+    if (!attr_set) {                                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bev_scatter_rotate_kernel<WU_>),                             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                  \
+      if (e != hipSuccess) return (int)e;                                                                                          \
+      attr_set = true;                                                                                                             \
+    }                                                                                                                              \
+    hipLaunchKernelGGL(bev_scatter_rotate_kernel<WU_>, grid, dim3(1024), plane * CG, wsmg_s(stream), feat, lin_idx, heading, sign, \
+                       Cf, Hf * Wf, C, E, CG, out_planes);                                                                         \
+  }
+  if (wu == 1) WSMG_SCATTER(1) else if (wu == 2) WSMG_SCATTER(2) else if (wu == 3) WSMG_SCATTER(3) else WSMG_SCATTER(4)
+#undef WSMG_SCATTER
   WSMG_RETURN_LAUNCH();
 }
 
