@@ -396,3 +396,30 @@ def test_fold_cache_folds_eval_batchnorm_and_refreshes_in_place():
     lin = nn.Conv2d(8, 4, 1)                                         # no BatchNorm: the bias is a copy, not the parameter
     wl, bl = cache.get(None, None, None, 8, 0, owner=lin)
     assert bl.data_ptr() != lin.bias.data_ptr() and torch.equal(bl, lin.bias.detach())
+
+
+def test_rnn_kernels_are_built_without_packed_fp32_math():
+    """DESIGN §4 "RNN kernels: wrong values beside a co-resident conv wave": the persistent GRU / LSTM kernels returned wrong values
+    with `v_pk_fma_f32` in their dependent FMA chains whenever an MFMA-heavy wave shared the SIMD (177 mismatching tensors in 60
+    loaded repeats; 0 in 300 without them).  The build turns packed fp32 math off for wsmg_rnn.hip (csrc/Makefile: EXTRA_wsmg_rnn):
+    compile that file for gfx950 exactly as the Makefile does and look at the ISA."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    csrc = os.path.join(ROOT, "ws-mgmap_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    m = re.search(r"^EXTRA_wsmg_rnn\s*:=\s*(.+)$", mk, re.M)
+    assert m, "csrc/Makefile no longer sets EXTRA_wsmg_rnn"
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "rnn.s")
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), *m.group(1).split(),
+                        "--cuda-device-only", "-S", os.path.join(csrc, "wsmg_rnn.hip"), "-o", out],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        isa = open(out).read()
+    packed = re.findall(r"\bv_pk_(?:fma|mul|add)_f32", isa)
+    assert not packed, f"{len(packed)} packed fp32 instructions in the RNN kernels"
+    assert len(re.findall(r"\bv_fmac?_f32", isa)) > 1000      # the scalar FMAs are there instead
