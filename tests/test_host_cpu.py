@@ -423,3 +423,16 @@ def test_rnn_kernels_are_built_without_packed_fp32_math():
     packed = re.findall(r"\bv_pk_(?:fma|mul|add)_f32", isa)
     assert not packed, f"{len(packed)} packed fp32 instructions in the RNN kernels"
     assert len(re.findall(r"\bv_fmac?_f32", isa)) > 1000      # the scalar FMAs are there instead
+
+
+def test_feeder_ring_refuses_what_the_host_cannot_hold():
+    """A 96-worker ring of 700 MiB batches (212 GB page-locked + 96 processes) took a GPU box down in round 3: the ring is refused up
+    front when it exceeds 40 % of min(MemAvailable, control-group limit - usage) — before any process or shared tensor exists."""
+    from wsmgmap.data import feeder
+    avail = feeder._host_memory_available()
+    assert avail is None or (isinstance(avail, int) and avail > 0)
+    if avail is None:
+        pytest.skip("host memory not readable here")
+    fd = feeder.DeviceFeeder(dataset=[], batch_size=2, device="cpu", num_workers=4, slot_bytes=avail // 4, slots_per_worker=2)
+    with pytest.raises(RuntimeError, match="host memory|/dev/shm"):
+        next(iter(fd))
