@@ -261,3 +261,6 @@ class DeviceFeeder:
             if self.pinned_ring:
                 for t in slots:
                     rt.cudaHostUnregister(t.data_ptr())
+            for q in free_qs + ready_qs:      # the queues' feeder threads and semaphores go with the ring, not with the interpreter
+                q.close()
+                q.cancel_join_thread()
