@@ -440,7 +440,7 @@ def test_stock_ddp_wrap_matches_goldens():
 
 
 # ----------------------------------------------------------------------------- two data-parallel ranks, the real policy
-def _dp_worker(rank, world, port, q, mode="f32", inject=False):
+def _dp_worker(rank, world, port, q, mode="f32", inject=False, backend="gloo"):
     for p in (ROOT, os.path.join(ROOT, "ws-mgmap_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -450,7 +450,10 @@ def _dp_worker(rank, world, port, q, mode="f32", inject=False):
     try:
         torch.cuda.set_device(0)           # both ranks share the box's one GPU (functional test; gloo moves the buckets)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         Tn, N = 4, 2
         AuxLosses.activate()
 
@@ -476,7 +479,7 @@ def _dp_worker(rank, world, port, q, mode="f32", inject=False):
         want = {n: v / world for n, v in want.items()}
         del plain
         pol = _train_mode(_policy(num_proc=2, compute_dtype=mode))
-        red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20)
+        red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20, single_rank_exchange=True)
         red.broadcast_parameters(pol)
         worst = 0.0
         for it in range(3):                 # 0: discovery pass; 1, 2: hook / overlap path with side-stream event waits
@@ -534,6 +537,26 @@ def test_data_parallel_two_ranks_real_policy(mode, inject):
         assert 32.0e6 < info["live_bytes"] < 33.5e6, info
         assert info["stats"]["updates"] == 3 and info["stats"]["buckets"] == info["buckets"]
     assert res[0][2]["layout_crc"] == res[1][2]["layout_crc"], "the ranks built different bucket layouts"
+
+
+def test_data_parallel_one_rank_over_rccl():
+    """The same exchange with backend "nccl" (= RCCL), the backend `bench.py --gpus N` and the reference's DDP use
+    (common_trainer.py:35-38): a one-rank communicator is all a 1-GPU box can host, but it runs the real thing end to end — the
+    layout agreement's MIN / MAX all-reduces on device tensors, the flat buckets all-reduced by RCCL kernels on the reducer's own
+    stream while backward still runs, the event joins, the device-side error flag — and the averaged gradients must equal the
+    plain single-rank gradients (world = 1: the mean of one)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_worker, args=(0, 1, _free_port(), q, "bf16", False, "nccl"))
+    p.start()
+    rank, status, info = q.get(timeout=600)
+    p.join(timeout=120)
+    assert status == "ok", info
+    assert info["worst"] <= 2e-3, info
+    assert 32.0e6 < info["live_bytes"] < 33.5e6, info
+    assert info["stats"]["updates"] == 3 and info["stats"]["buckets"] == info["buckets"]
+    assert info["differs_from_own"] == 0.0          # one rank: the expected mean IS the rank's own gradient
 
 
 # ----------------------------------------------------------------------------- frozen encoders (SURVEY 8f-3)

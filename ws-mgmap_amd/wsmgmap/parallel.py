@@ -46,7 +46,9 @@ class GradExchangeError(RuntimeError):
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=8 << 20, group=None):
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, single_rank_exchange=False):
+        """single_rank_exchange: run the whole exchange even in a one-rank group (by default one rank does nothing at all) — the
+        way to put the real backend (RCCL) through this code on a box with one GPU (tests/test_gpu_round2.py)."""
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:
@@ -58,6 +60,7 @@ class GradAllReducer:
         self.bucket_bytes = bucket_bytes
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._off = self.world == 1 and not (single_rank_exchange and dist.is_initialized())
         self._order = []          # discovery pass: params in gradient-ready order
         self._buckets = None      # list of dicts: params, flat buffer, pending count
         self._where = {}          # id(param) -> (bucket index, offset)
@@ -76,7 +79,7 @@ class GradAllReducer:
     # -- setup ---------------------------------------------------------------------
     def broadcast_parameters(self, module, src=0):
         """rank-`src` parameters and buffers to every rank (DDP constructor behaviour)."""
-        if self.world == 1:
+        if self._off:
             return
         for t in list(module.parameters()) + [b for b in module.buffers() if b.is_floating_point() or b.dtype == torch.int64]:
             dist.broadcast(t.data, src=src, group=self.group)
@@ -87,7 +90,7 @@ class GradAllReducer:
         `broadcast_buffers=True` keeps identical by re-broadcasting before every forward (common_trainer.py:61-66
         default).  Statistics here stay per rank during training; call this before evaluating or checkpointing from a
         rank other than `src` (the reference checkpoints rank 0's, common_trainer.py:99)."""
-        if self.world == 1:
+        if self._off:
             return
         for b in module.buffers():
             if b.is_floating_point() or b.dtype == torch.int64:
@@ -199,7 +202,7 @@ class GradAllReducer:
             self._next += 1
 
     def _on_grad(self, p):
-        if self.world == 1:
+        if self._off:
             return
         if self._buckets is None:
             self._order.append(p)
@@ -262,7 +265,7 @@ class GradAllReducer:
         and leaves the averaged gradients in `p.grad` — zeros on every rank if any rank flagged an error in this update.
         check_now=True: read the ranks' error flag of THIS update before returning (one host synchronisation per update) and
         raise GradExchangeError here; default: the flag is read at the start of the next finish()."""
-        if self.world == 1:
+        if self._off:
             return
         self._raise_if_flagged()
         t_host = time.perf_counter()
