@@ -180,7 +180,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # the reference's torch.optim.Adam (common_trainer.py:67-69) as one multi-tensor HIP launch per 48 tensors; WSMG_STOCK_ADAM=1: stock
     from wsmgmap.optim import Adam as WsmgAdam
     opt = (torch.optim.Adam if os.environ.get("WSMG_STOCK_ADAM") == "1" else WsmgAdam)(policy.parameters(), lr=2.5e-4)
-    reducer = GradAllReducer(policy.parameters()) if world > 1 else None
+    reducer = GradAllReducer(policy.parameters(), single_rank_exchange=True) if args.dp else None
     if reducer:
         reducer.broadcast_parameters(policy)
     measure.dp_info = None
@@ -207,7 +207,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # measured before it is trusted: 3 updates with and 3 without it (after one untimed update each), max over ranks; more than
     # 1.3x slower with the stream -> fall back to one stream for the run and say so in the line.
     measure.side_stream = None
-    if world > 1 and os.environ.get("WSMG_DECODER_STREAMS") is None:
+    if args.dp and os.environ.get("WSMG_DECODER_STREAMS") is None:
         def timed(k):
             update()
             torch.cuda.synchronize()
@@ -254,7 +254,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         tied = [r for r in warm_prof.values() if r["ms_total"] >= 0.85 * top]
         tied.sort(key=lambda r: (r["entry"] != "wsmg_conv2d_bwd_weight_bf16", -r["ms_total"]))
         dom_entry = tied[0]["entry"]
-    if world > 1:
+    if args.dp:
         dist.barrier()
     torch.cuda.synchronize()
     if reducer:
@@ -288,7 +288,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
                                  note="HIP-event time of consecutive 50-update windows inside the same timed region")
     if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
         print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
-    if world > 1:
+    if args.dp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -308,7 +308,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     for name, r in warm_prof.items():     # the other families: per-launch figures from the warm-up updates, labelled so
         if name not in prof:
             prof[name] = dict(r, per_steps=1, phase="last warm-up update")
-    if world > 1:
+    if args.dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -350,6 +350,12 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
 
 
 def main():
+    # The contract is ONE JSON line on rank 0's stdout.  Libraries write there too — RCCL prints a five-line version banner through
+    # C stdio when a communicator is created, and being block-buffered on a pipe it lands AFTER Python's own line, at exit — so
+    # file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved original descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=30)
@@ -386,7 +392,7 @@ def main():
             env = dict(os.environ)
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env.setdefault("OMP_NUM_THREADS", "8")
-            raise SystemExit(subprocess.run(cmd, env=env).returncode)
+            raise SystemExit(subprocess.run(cmd, env=env, stdout=real_stdout).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -402,8 +408,14 @@ def main():
     local = local % max(1, torch.cuda.device_count()) if share else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # WSMG_BENCH_DP_ONE_RANK=1: the data-parallel code path (process group, gradient exchange, its statistics, the side-stream check)
+    # with ONE rank — a functional run of what `--gpus N` does, over the real backend, on a box with one GPU
+    args.dp = world > 1 or os.environ.get("WSMG_BENCH_DP_ONE_RANK") == "1"
+    if args.dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("WSMG_BENCH_BACKEND", "nccl")  # "gloo": functional test of the DP path on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -503,8 +515,8 @@ def main():
             out["gpu_over_cpu"] = round(steps_per_s / out["cpu_baseline"]["value"], 1)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if args.dp:
         dist.destroy_process_group()
 
 
