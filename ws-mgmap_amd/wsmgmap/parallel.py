@@ -146,23 +146,25 @@ class GradAllReducer:
             self._buckets.append(cur)
         out = []
         for bi, ps in enumerate(self._buckets):
-            n = sum(p.numel() for p in ps)
-            flat = torch.empty(n, dtype=ps[0].dtype, device=ps[0].device)
-            off = 0
+            # every gradient starts on a 16-byte boundary of the bucket (the averaged gradient IS the bucket view, and the
+            # multi-tensor Adam kernel takes its 16-byte path only when all four of a tensor's pointers allow it); the few
+            # padding elements are zero and travel with the all-reduce
+            al = max(1, 16 // ps[0].element_size())
+            offs, off = [], 0
             for p in ps:
-                self._where[id(p)] = (bi, off)
-                off += p.numel()
-            views, o2 = [], 0
-            for p in ps:
-                views.append(flat[o2:o2 + p.numel()].view_as(p))
-                o2 += p.numel()
+                offs.append(off)
+                off += -(-p.numel() // al) * al
+            flat = torch.zeros(off, dtype=ps[0].dtype, device=ps[0].device)
+            for p, o in zip(ps, offs):
+                self._where[id(p)] = (bi, o)
+            views = [flat[o:o + p.numel()].view_as(p) for p, o in zip(ps, offs)]
             out.append(dict(params=ps, flat=flat, views=views, pending=len(ps), total=len(ps), launched=False))
         self._buckets = out
         self._next = 0
 
     @property
     def live_bytes(self):
-        return sum(b["flat"].numel() * b["flat"].element_size() for b in (self._buckets or []))
+        return sum(p.numel() * p.element_size() for b in (self._buckets or []) for p in b["params"])     # (without the alignment padding)
 
     @property
     def num_buckets(self):
