@@ -381,14 +381,28 @@ _wgrad_side = {}
 _side_join_armed = set()
 
 
-def _wgrad_side_stream(flops=0.0):
-    """Side stream of the weight-gradient launches (WSMG_WGRAD_STREAM=1: all of them; =2: only the layers below 60 GFLOP,
-    which cannot fill the chip on their own; not with a process group: the gradient all-reduce hooks read p.grad on the main
-    stream as soon as it is accumulated)."""
+def _wgrad_side_stream(flops=0.0, param=None):
+    """The side stream a layer's weight-gradient launches (kernel + ordered reduce) run on, or None for the backward pass's own.
+    A weight gradient is a leaf of the backward graph — nothing but the optimizer waits for it — so beside the backward-data
+    chain it fills what that chain leaves idle: the tails of its launches and the stretches of small kernels.  Measured (round 3,
+    interleaved 40-update runs, three rounds on one box): layers below 30 / 60 / 100 GFLOP on the side stream 11.44 / 11.46 / 11.42 ms
+    per update against 11.61 without, 11.50 / 11.46 / 11.54 against 11.53 / 11.54 / 11.65 in a second call; from 150 GFLOP up it LOSES
+    (11.82, 11.74 with every layer: two chip-filling kernels side by side only share the chip).  OPT-IN all the same
+    (WSMG_WGRAD_STREAM=2: layers below WSMG_WGRAD_STREAM_GF = 100 GFLOP; =1: every layer; default 0): the gain is 0.1 ms, the
+    family's own launches get 13 % LONGER under the overlap (0.30 -> 0.26 of the bf16 peak by the bench's per-launch clock, which
+    is the figure the roofline object reports), and a HIP-graph capture of the update with this stream in it crashed in
+    capture_end (record_stream on tensors of the capture's pool) — under capture it is always off.  Conditions, as for the reduce stream above: one process (with a process group the gradient all-reduce hooks read
+    p.grad on the main stream as soon as it is accumulated), and a leaf parameter whose .grad this pass SETS — autograd's add into
+    an existing .grad, or into the gradient of a weight that several convolutions share, would run on the main stream before the
+    side stream has finished.  The main stream waits for the side stream once, when the backward pass ends."""
     mode = _os.environ.get("WSMG_WGRAD_STREAM", "0")
-    if mode not in ("1", "2") or (mode == "2" and flops >= 60e9):
+    if mode not in ("1", "2") or (mode == "2" and flops >= float(_os.environ.get("WSMG_WGRAD_STREAM_GF", "100")) * 1e9):
         return None
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    if param is None or param.grad is not None or id(param) in _pass_shared:
+        return None
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         return None
     dev = torch.cuda.current_device()
     if dev not in _wgrad_side:
@@ -516,7 +530,12 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            side = _wgrad_side_stream(fl)
+            side = _wgrad_side_stream(fl, ctx.w_param)
+            if side is not None:
+                try:
+                    _join_side_at_end(torch.cuda.current_stream(), side, strict=True)   # raises outside a backward pass
+                except RuntimeError:
+                    side = None
             if side is None:
                 dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w, ctx.w_param)
             else:
@@ -529,7 +548,7 @@ class _Conv2d(torch.autograd.Function):
                 dy.record_stream(side)
                 with torch.cuda.stream(side):
                     dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
-                _join_side_at_end(main, side)
+                dw.record_stream(main)         # consumed on the main stream (the optimizer) behind the end-of-backward join
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
