@@ -782,3 +782,28 @@ def test_map_sequence_vs_oracle_through_the_mapping_module():
         close(f"s{s}.global", gm, ref.full_global_map, 0, 2e-4)
         close(f"s{s}.ego", ego, ego_ref, 0, 2e-4)
         np.testing.assert_allclose(ego[:, ::16, 40:56, 44:60].cpu().numpy(), g[f"s{s}.ego_patch"], atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("C,E", [(32, 100), (8, 100), (13, 64), (40, 200), (64, 100)], ids=["c32_win2", "c8_win8", "c13_win5_6", "c40_win2_3", "c64_win1"])
+def test_bev_scatter_window_widths_vs_oracle(C, E):
+    """The scatter loop fetches the channels of an adaptive-max-pool window together, `WU` at a time (1 - 4, chosen from the widest
+    window of the geometry; wider windows finish one channel per trip): every width against the oracle's channel pool + scatter-max
+    (rgb_mapping.py:81-84,206-232), bit for bit; the fused scatter + rotation launch (same loop, then a rotation out of LDS) is held
+    to the separate scatter and rotation launches on the same inputs."""
+    from oracle import bev_ref, cases
+    from oracle import detfill as df
+    from util import T
+    from wsmgmap import ops
+    c = cases.bev_inputs("e200_c40_f256")
+    B = c["B"]
+    feat64 = df.uniform(f"r3.scatterw.{C}.{E}", (B, 64, 256, 256), 4.0)
+    pooled = bev_ref.channel_maxpool(T(feat64), C).numpy()
+    proj_ref, *_ = bev_ref.project_to_ground(pooled, c["depth"], E)
+    depth = torch.from_numpy(c["depth"][..., 0]).cuda()
+    lin = ops.bev_index(depth, 256, 256, E)
+    feat = torch.from_numpy(feat64).cuda()
+    proj = ops.bev_scatter_max(feat, lin, C, E)
+    assert np.array_equal(proj.cpu().numpy().view(np.uint32), proj_ref.view(np.uint32)), "scatter-max differs from the oracle"
+    heading = torch.tensor(([0.3, -1.1, 2.0, 0.0] * B)[:B], device="cuda")
+    rotp = ops.bev_scatter_rotate(feat, lin, heading, -1.0, C, E)      # (any C: only the plane-consuming fuse needs C % 4 == 0)
+    assert torch.equal(rotp.permute(0, 2, 3, 1), ops.bev_rotate(proj, heading, -1.0))
