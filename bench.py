@@ -101,13 +101,34 @@ def host_cpu_info():
     return model, (len(phys) or logical or os.cpu_count() or 1), (logical or os.cpu_count() or 1)
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the control group of this process may use (cgroup v2 cpu.max, v1 cfs quota), or None if unlimited."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(state, T_full, N, budget_s=90.0):
     """The oracle's update step (fwd + loss + bwd + Adam, PyTorch CPU fp32) on the host cores (one thread per
     physical core, >= 1 warm-up + >= 2 timed updates, CPU model and core count in the report).
     Sample: the same workload at the largest T in {T_full, 32, 16, ...} whose TWO timed updates are expected to fit `budget_s`."""
     from oracle import policy_ref
     model, phys, logical = host_cpu_info()
-    torch.set_num_threads(max(1, phys))
+    # one thread per physical core — of those the process may actually use: under a control-group CPU quota (the GPU boxes of this
+    # pool: 16 CPUs on a 128-core host) more threads than that only take turns being throttled
+    quota = cgroup_cpu_quota()
+    nthreads = max(1, phys if quota is None else min(phys, int(quota + 0.999)))
+    if os.environ.get("WSMG_CPU_THREADS"):
+        nthreads = int(os.environ["WSMG_CPU_THREADS"])
+    torch.set_num_threads(nthreads)
     cores = torch.get_num_threads()
 
     def make_P():
@@ -155,10 +176,11 @@ def cpu_baseline(state, T_full, N, budget_s=90.0):
     dt = sum(dts) / len(dts)
     scaled = "" if T == T_full else f" — T={T} instead of {T_full}: policy steps/s assumed linear in T"
     return dict(value=T * N / dt, unit="policy steps/s", cores=cores, kind="port", cpu_model=model, physical_cores=phys,
-                logical_cpus=logical, timed_updates=len(dts), seconds_per_update=[round(d, 2) for d in dts],
+                logical_cpus=logical, cgroup_cpu_quota=quota, timed_updates=len(dts), seconds_per_update=[round(d, 2) for d in dts],
                 sample=f"{len(dts)} updates of T={T} x N={N} ({T * N} policy steps each; {', '.join('%.1f s' % d for d in dts)}; mean) "
                        f"of the oracle (PyTorch-CPU fp32 port of the reference update: fwd+loss+bwd+Adam) after a warm-up, "
-                       f"{cores} threads = physical cores of {model}{scaled}")
+                       f"{cores} threads on {model} ({phys} physical cores"
+                       + (f", control-group quota {quota:g} CPUs" if quota is not None else "") + f"){scaled}")
 
 
 def measure(args, dtype, steps, warmup, rank, world, local, dev):

@@ -14,6 +14,16 @@ warnings.filterwarnings("ignore", message="Default grid_sample and affine_grid")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle runs on the host.  Under a control-group CPU quota (the GPU boxes: 16 CPUs of a 256-thread host) torch's default
+    # of one thread per logical CPU only makes the threads take turns being throttled: the full-size backward oracle took 128 s
+    # that way.  One thread per CPU the process may actually use.
+    try:
+        import torch
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            torch.set_num_threads(max(1, min(torch.get_num_threads(), int(float(q) / float(per) + 0.999))))
+    except (OSError, ValueError, ImportError):
+        pass
 
 
 def _has_gpu():
