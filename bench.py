@@ -282,12 +282,15 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     if reducer:
         reducer.stats(reset=True)
     ops.profile_begin(only=[dom_entry] if dom_entry else None)
-    WIN = 50                     # --steps >= 200: an event every 50 updates, for the `sustained` sub-object (no synchronisation)
+    # an event every WIN updates (no synchronisation): `sustained` for --steps >= 200 (50-update windows), and `windows` for every
+    # run (a quarter of the run each), so that a transient stall inside the timed region — one run in ~40 on this pool came out at
+    # 14-19 ms per update for no reason the process could see — shows in the line as what it is
+    WIN = 50 if steps >= 200 else max(1, (steps + 3) // 4)
     marks = []
     t0 = time.perf_counter()
     host = 0.0
     for i in range(steps):
-        if steps >= 200 and i % WIN == 0:
+        if i % WIN == 0:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
@@ -299,10 +302,13 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         ev.record()
         marks.append(ev)
     torch.cuda.synchronize()
-    measure.sustained = None
-    if len(marks) >= 3:
+    measure.sustained = measure.windows = None
+    if len(marks) >= 2:
         spans = [(min(WIN, steps - j * WIN), marks[j].elapsed_time(marks[j + 1])) for j in range(len(marks) - 1)]
         per = [ms / n for n, ms in spans if n > 0]
+        measure.windows = dict(window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
+                               note="HIP-event time of consecutive windows of the timed region (rank 0's stream)")
+    if len(marks) >= 3 and steps >= 200:
         tail = per[len(per) // 2:]
         measure.sustained = dict(updates=steps, window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
                                  ms_per_update_first_window=round(per[0], 3),
@@ -449,6 +455,7 @@ def main():
     dp_info = measure.dp_info
     graphed = getattr(measure, "graphed", None)
     sustained = getattr(measure, "sustained", None)
+    windows = getattr(measure, "windows", None)
     parity = None
     if args.dtype == "bf16" and not args.no_f32:
         k32 = max(2, args.steps // 2)
@@ -529,6 +536,7 @@ def main():
             "f32_parity_mode": parity,
             "graphed_update": graphed,
             "sustained": sustained,
+            "windows": windows,
             "roofline": roofline,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
         }
