@@ -286,6 +286,8 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # run (a quarter of the run each), so that a transient stall inside the timed region — one run in ~40 on this pool came out at
     # 14-19 ms per update for no reason the process could see — shows in the line as what it is
     WIN = 50 if steps >= 200 else max(1, (steps + 3) // 4)
+    if os.environ.get("WSMG_BENCH_WINDOW"):        # diagnostic: another window length (1 = an event per update)
+        WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
     marks = []
     t0 = time.perf_counter()
     host = 0.0
