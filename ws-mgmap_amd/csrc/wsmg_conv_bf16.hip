@@ -589,7 +589,17 @@ int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 25
 // ones but need >= 4 rounds of workgroups over the 256 CUs to keep the last round's idle CUs cheap (N = 128 layers: 256).
 int win3_choice(int64_t M, int Kc, int N) {
   const int t = win3_tile();
-  if (t == 0 || M < 256 * 256 || Kc < 64 || Kc % 32 || N % 128) return 0;
+  if (t == 0 || M < 256 * 256 || Kc < 64 || Kc % 32 || N % 64) return 0;
+  if (N % 128) {                     // 64-channel tiles (round 3; WSMG_CONV_WIN3_N64=0: the implicit-GEMM kernel, 512 / 256: the tile)
+    static int n64 = -1;
+    if (n64 < 0) { const char* e = getenv("WSMG_CONV_WIN3_N64"); n64 = e ? atoi(e) : 1; }
+    if (t != 1) return t;           // (forced by wsmg_conv_debug_win3_tile / WSMG_CONV_WIN3)
+    // measured alone at B = 512, 24 x 24 (tools/bench_conv.py): orig0 (256 -> 64) forward 0.118 -> 0.103 ms, orig2 (192 -> 64)
+    // forward 0.091 -> 0.083 and backward-data (64 -> 192) 0.106 -> 0.090; orig1 (64 -> 64: 18 k-steps, one 64-channel tile)
+    // 0.037 -> 0.043: that one stays on the implicit-GEMM kernel
+    if (n64 == 0 || M < 2 * 256 * 256 || (Kc < 128 && N < 192)) return 0;
+    return n64 == 1 ? 512 : n64;
+  }
   if (t != 1) return t;
   if (M < 2 * 256 * 256) return 0;   // 12 x 12 maps at B = 512 (73 728 pixels, 128 -> 128): 0.035 vs 0.033 ms
   return ((M + 511) / 512) * (N / 128) >= 1024 ? 512 : 256;

@@ -62,8 +62,7 @@ struct Win3Args {
   int nslab;
 };
 
-constexpr int DK = 32, ROWB = 64, NT = 128, NST = 4;
-constexpr int BSTAGE = NT * ROWB;            // 8 KB of weights per k-step
+constexpr int DK = 32, ROWB = 64, NST = 4;
 constexpr int OPITCH = 64 * 2 + 16;          // epilogue staging: 64 columns of bf16 + 16
 
 __device__ __forceinline__ int xcd_swizzle3(int bid, int nb) {
@@ -80,10 +79,15 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* l
 // DMA instructions a wave issues in the k-step at tap `tap`: a window piece of the next chunk (taps 0 .. npw - 1) and the weights of 3 steps on
 constexpr int n_issue(int tap, int npw) { return ((tap % 9 + 9) % 9) < npw ? 2 : 1; }
 
-// MT: pixels per workgroup (512 or 256); NPW: window pieces (16 entries each) per wave — window capacity 128 NPW entries
-template <int MT, int NPW>
+// MT: pixels per workgroup (512 or 256); NPW: window pieces (16 entries each) per wave — window capacity 128 NPW entries;
+// NT: output channels per workgroup — 128 (8 waves as 4 along the pixels x 2 along the channels) or, round 3, 64 for the
+// 64-channel layers (8 x 1: every wave takes MT / 8 pixels x all 64 channels; waves 4-7 have no weight rows to fetch and issue
+// their weight DMA as a zero-fill into a dummy KB, so that every wave's `vmcnt` counts the same instructions)
+template <int MT, int NPW, int NT>
 __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
-  constexpr int TT = MT / 128;                 // 32-row accumulator tiles per wave along the pixels
+  constexpr int WN = NT / 64, WM = 8 / WN;     // waves along the channels / along the pixels
+  constexpr int TT = MT / (32 * WM);           // 32-row accumulator tiles per wave along the pixels
+  constexpr int BSTAGE = NT * ROWB;            // 8 KB (4 KB) of weights per k-step
   constexpr int WCAP = 128 * NPW;              // window entries
   constexpr int WINB = WCAP * ROWB;
   constexpr int OFF_B = 2 * WINB;
@@ -130,12 +134,13 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   };
   auto dma_weights = [&](int chunk, int tap) {       // k-step (chunk, tap) -> stage (9 chunk + tap) % NST
     const int step = 9 * chunk + tap;
-    unsigned char* const dst = smem + OFF_B + (step % NST) * BSTAGE + wave * 1024;
-    dma16(rs_wt, dst, chunk < nchunks ? boff + (tap * a.Kc + chunk * DK) * 2 : (int)0x80000000);
+    const bool mine = 16 * wave < NT;                // (NT = 64: the tile has 64 weight rows, pieces 0-3)
+    unsigned char* const dst = mine ? smem + OFF_B + (step % NST) * BSTAGE + wave * 1024 : smem + OFF_DUMMY;
+    dma16(rs_wt, dst, (mine && chunk < nchunks) ? boff + (tap * a.Kc + chunk * DK) * 2 : (int)0x80000000);
   };
 
-  // ---- MFMA roles: wave tile (MT / 4) x 64 at (wm, wn)
-  const int wm = (wave & 3) * (MT / 4), wn = (wave >> 2) * 64;
+  // ---- MFMA roles: wave tile (MT / WM) x 64 at (wm, wn)
+  const int wm = (wave % WM) * (MT / WM), wn = (wave / WM) * 64;
   const int r = lane & 31, h = lane >> 5;
   int ecen[TT];    // window entry of this lane's row of accumulator tile t, centre tap
 #pragma unroll
@@ -227,10 +232,11 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs past the last k-step must not land in the staging below
   __syncthreads();
 
-  // ---- epilogue: two passes of 64 columns (column tile u of every wave) through LDS, then 16-byte stores
+  // ---- epilogue: two passes (column tile u of every wave: 32 WN staged columns) through LDS, then 16-byte stores
+  constexpr int PCS = 4 * WN;                               // 16-byte pieces per staged row
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int scol = (wave >> 2) * 32 + r;                  // column in the staged half
+    const int scol = (wave / WM) * 32 + r;                  // column in the staged half
     const float bv = a.bias ? a.bias[n0 + wn + 32 * u + r] : 0.f;
     float sv = 0.f, qv = 0.f;
 #pragma unroll
@@ -259,9 +265,9 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < MT * 8 / 512; ++j) {
+    for (int j = 0; j < MT * PCS / 512; ++j) {
       const int c = tid + 512 * j;
-      const int row = c >> 3, ch = c & 7;                   // 16-byte piece ch of the staged row: staged columns 8 ch .. 8 ch + 7
+      const int row = c / PCS, ch = c % PCS;                // 16-byte piece ch of the staged row: staged columns 8 ch .. 8 ch + 7
       const int n = n0 + (ch >> 2) * 64 + 32 * u + (ch & 3) * 8;
       if (m0 + row >= Mtot) continue;
       *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)(m0 + row) * a.N + n) * 2) =
@@ -271,19 +277,19 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   }
 }
 
-template <int MT, int NPW>
+template <int MT, int NPW, int NT>
 int launch_win3(Win3Args& a, hipStream_t s) {
-  constexpr int LDS = 2 * 128 * NPW * ROWB + NST * BSTAGE + 1024;
+  constexpr int LDS = 2 * 128 * NPW * ROWB + NST * NT * ROWB + 1024;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_kernel<MT, NPW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_kernel<MT, NPW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   const int64_t M = (int64_t)a.B * a.H * a.W;
   a.mtiles = (int)wsmg_cdiv(M, MT);
   a.ntiles = a.N / NT;
-  hipLaunchKernelGGL((conv_win3_kernel<MT, NPW>), dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((conv_win3_kernel<MT, NPW, NT>), dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -298,16 +304,22 @@ int window_bound(int mt, int H, int W) {
 
 }  // namespace
 
-// 3 x 3 / stride 1 / pad 1, bf16 in / bf16 out, N % 128 == 0, Kc % 32 == 0; WSMG_EINVAL otherwise (the caller then uses the
+// 3 x 3 / stride 1 / pad 1, bf16 in / bf16 out, N % 64 == 0 (128-channel tiles when N % 128 == 0), Kc % 32 == 0; WSMG_EINVAL otherwise (the caller then uses the
 // implicit-GEMM kernel).  bwd = 0: forward (src = x, wt = OHWI); 1: backward-data (src = dy, wt = IHWO).
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
                         int B, int H, int W, int Kc, int N, int mt, hipStream_t s) {
-  if (N <= 0 || N % NT || Kc % DK || B <= 0) return WSMG_EINVAL;
+  if (N <= 0 || N % 64 || Kc % DK || B <= 0) return WSMG_EINVAL;
   if ((int64_t)B * (H + 2) * (W + 2) * 1 > (1 << 30) || (int64_t)B * H * W * (Kc > N ? Kc : N) * 2 >= (1ll << 31)) return WSMG_EINVAL;
   Win3Args a{(const bf16_t*)src, (const bf16_t*)wt, bias, (bf16_t*)dst, B, H, W, Kc, N, 0, 0, relu, bwd,
              (unsigned)((size_t)B * H * W * Kc * 2), (unsigned)((size_t)N * 9 * Kc * 2), stats, nslab};
-  if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6>(a, s);
-  if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4>(a, s);
+  if (N % 128 == 0) {
+    if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 128>(a, s);
+    if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 128>(a, s);
+    return WSMG_EINVAL;
+  }
+  // 64-channel tiles (N = 64, 192, ...)
+  if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 64>(a, s);
+  if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 64>(a, s);
   return WSMG_EINVAL;
 }
 
