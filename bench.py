@@ -202,7 +202,8 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # the reference's torch.optim.Adam (common_trainer.py:67-69) as one multi-tensor HIP launch per 48 tensors; WSMG_STOCK_ADAM=1: stock
     from wsmgmap.optim import Adam as WsmgAdam
     opt = (torch.optim.Adam if os.environ.get("WSMG_STOCK_ADAM") == "1" else WsmgAdam)(policy.parameters(), lr=2.5e-4)
-    reducer = GradAllReducer(policy.parameters(), single_rank_exchange=True) if args.dp else None
+    reducer = GradAllReducer(policy.parameters(), bucket_bytes=int(float(os.environ.get("WSMG_DP_BUCKET_MB", "8")) * (1 << 20)),
+                             single_rank_exchange=True) if args.dp else None
     if reducer:
         reducer.broadcast_parameters(policy)
     measure.dp_info = None
