@@ -562,7 +562,7 @@ def test_data_parallel_one_rank_over_rccl():
 # ----------------------------------------------------------------------------- frozen encoders
 def test_act_from_raw_depth_vs_oracle():
     """No `depth_features` in the observations: the DD-PPO GroupNorm ResNet50 runs (resnet_encoders.py:79-82).  float32 mode
-    (stock convolutions + F.group_norm) against the oracle: action within 1e-4; the backbone output within 1e-4."""
+    (stock convolutions + F.group_norm) against the oracle: action within 1e-4; the backbone output within 3e-4."""
     from wsmgmap.common.aux_losses import AuxLosses
     AuxLosses.deactivate()
     pol = _policy(num_proc=2).eval()
@@ -580,7 +580,9 @@ def test_act_from_raw_depth_vs_oracle():
         feat_ref = policy_ref.ddppo_resnet50(ref.P, oc["depth"])
     hk.remove()
     assert tuple(seen["feat"].shape) == (2, 128, 4, 4)
-    assert float((seen["feat"].cpu() - feat_ref).abs().max()) <= 1e-4
+    # (53 float32 conv + GroupNorm layers, MIOpen's algorithm choice on one side and the host's thread split on the other: the
+    #  largest element difference was seen between 6e-5 and 1.02e-4 over repeated runs of the suite; values reach 1.2)
+    assert float((seen["feat"].cpu() - feat_ref).abs().max()) <= 3e-4
     assert float((action.cpu() - ar).abs().max()) <= 1e-4
     assert float((value.cpu() - vr).abs().max()) <= 2e-4
 
