@@ -652,8 +652,8 @@ def test_depth_backbone_engine_path_opt_in():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mt", [512, 256])
 @pytest.mark.parametrize("shape", [(128, 24, 256, 256), (115, 24, 64, 128), (29, 48, 32, 128), (131, (18, 31), 96, 128),
-                                   (128, 24, 256, 64), (115, 24, 64, 192), (131, (18, 31), 64, 64)],
-                         ids=["cated", "ragged", "48x48", "18x31", "n64_orig0", "n192_k64", "n64_k64_18x31"])
+                                   (128, 24, 256, 64), (115, 24, 64, 192), (131, (18, 31), 64, 64), (29, 48, 32, 32), (64, 33, 96, 32)],
+                         ids=["cated", "ragged", "48x48", "18x31", "n64_orig0", "n192_k64", "n64_k64_18x31", "n32_k32_48x48", "n32_k96"])
 def test_conv_window_kernel_3x3_fwd_bwd_stats(mt, shape):
     """wsmg_conv_win3.hip (zero-padded LDS pixel window, fwd + backward-data, bias / ReLU / BatchNorm sums) against a float64
     convolution of the same bf16 operands, through the public entry points at sizes that reach it (B*H*W >= 65536):

@@ -589,7 +589,18 @@ int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 25
 // ones but need >= 4 rounds of workgroups over the 256 CUs to keep the last round's idle CUs cheap (N = 128 layers: 256).
 int win3_choice(int64_t M, int Kc, int N) {
   const int t = win3_tile();
-  if (t == 0 || M < 256 * 256 || Kc < 64 || Kc % 32 || N % 64) return 0;
+  if (t == 0 || M < 256 * 256 || Kc % 32 || N % 32) return 0;
+  if (N % 64) {                      // 32-channel tiles (round 3; WSMG_CONV_WIN3_N32=0: implicit-GEMM kernel, 512 / 256: the tile).
+    // The classifier's 32 -> 32 layer at 48 x 48 (B = 512), alone: forward 0.071 -> 0.063 (512-pixel tiles) -> 0.055 ms (256),
+    // backward-data 0.075 -> 0.063 -> 0.056: the implicit-GEMM kernel pads the 32 channels to a 64-wide tile and re-fetches the
+    // pixels per tap; nine k-steps are too few to hide the window's load, so this is 390 TFLOP/s, not 800
+    static int n32 = -1;
+    if (n32 < 0) { const char* e = getenv("WSMG_CONV_WIN3_N32"); n32 = e ? atoi(e) : 256; }
+    if (t != 1) return t;
+    if (n32 == 0 || M < 2 * 256 * 256) return 0;
+    return n32;
+  }
+  if (Kc < 64) return 0;
   if (N % 128) {                     // 64-channel tiles (round 3; WSMG_CONV_WIN3_N64=0: the implicit-GEMM kernel, 512 / 256: the tile)
     static int n64 = -1;
     if (n64 < 0) { const char* e = getenv("WSMG_CONV_WIN3_N64"); n64 = e ? atoi(e) : 1; }

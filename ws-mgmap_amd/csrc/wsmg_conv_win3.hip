@@ -85,7 +85,8 @@ constexpr int n_issue(int tap, int npw) { return ((tap % 9 + 9) % 9) < npw ? 2 :
 // their weight DMA as a zero-fill into a dummy KB, so that every wave's `vmcnt` counts the same instructions)
 template <int MT, int NPW, int NT>
 __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
-  constexpr int WN = NT / 64, WM = 8 / WN;     // waves along the channels / along the pixels
+  constexpr int WN = NT >= 128 ? 2 : 1, WM = 8 / WN;   // waves along the channels / along the pixels
+  constexpr int NU = NT >= 64 ? 2 : 1;         // 32-column accumulator tiles per wave (NT = 32: one)
   constexpr int TT = MT / (32 * WM);           // 32-row accumulator tiles per wave along the pixels
   constexpr int BSTAGE = NT * ROWB;            // 8 KB (4 KB) of weights per k-step
   constexpr int WCAP = 128 * NPW;              // window entries
@@ -148,19 +149,19 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
     const int m = m0 + wm + 32 * t + r;
     ecen[t] = padded(m < Mtot ? m : Mtot - 1) - q0;
   }
-  int bpos[2][2];  // byte offset of this lane's weight fragment (column tile u, 16-deep slice ks) in a stage
+  int bpos[NU][2];  // byte offset of this lane's weight fragment (column tile u, 16-deep slice ks) in a stage
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int n = wn + 32 * u + r;
       bpos[u][ks] = n * ROWB + (((2 * ks + h) ^ ((n >> 2) & 3)) << 4);
     }
-  f32x16 acc[TT][2];
+  f32x16 acc[TT][NU];
 #pragma unroll
   for (int t = 0; t < TT; ++t)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
@@ -174,21 +175,21 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   const int sgn = a.bwd ? -1 : 1;
   // Fragments of a k-step's first 16-deep slice are read one step EARLY (during the previous step's MFMAs), so the MFMAs
   // that follow a barrier never wait on LDS: the wait at the top of step s therefore covers the weights of step s + 1.
-  bf16x8 af0[TT], bf0[2];
-  auto read_slice = [&](bf16x8 (&af)[TT], bf16x8 (&bfr)[2], const unsigned char* win, const unsigned char* bst, int shift, int ks) {
+  bf16x8 af0[TT], bf0[NU];
+  auto read_slice = [&](bf16x8 (&af)[TT], bf16x8 (&bfr)[NU], const unsigned char* win, const unsigned char* bst, int shift, int ks) {
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
       const int e = ecen[t] + shift;
       af[t] = *reinterpret_cast<const bf16x8*>(win + e * ROWB + (((2 * ks + h) ^ ((e >> 2) & 3)) << 4));
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) bfr[u] = *reinterpret_cast<const bf16x8*>(bst + bpos[u][ks]);
+    for (int u = 0; u < NU; ++u) bfr[u] = *reinterpret_cast<const bf16x8*>(bst + bpos[u][ks]);
   };
-  auto mfma_slice = [&](const bf16x8 (&af)[TT], const bf16x8 (&bfr)[2]) {
+  auto mfma_slice = [&](const bf16x8 (&af)[TT], const bf16x8 (&bfr)[NU]) {
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfr[u], acc[t][u], 0, 0, 0);
+      for (int u = 0; u < NU; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bfr[u], acc[t][u], 0, 0, 0);
   };
   auto tap_shift = [&](int tap) {
     int shift = sgn * ((tap / 3 - 1) * PW + (tap % 3 - 1));
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
     // measured slower: the wave-uniform branch splits the step into blocks the scheduler cannot interleave across)
     if constexpr (tap < NPW) dma_window_piece(tap, chunk + 1);
     dma_weights(chunk + (tap + 3) / 9, (tap + 3) % 9);
-    bf16x8 af1[TT], bf1[2];
+    bf16x8 af1[TT], bf1[NU];
     read_slice(af1, bf1, win, smem + OFF_B + (step % NST) * BSTAGE, tap_shift(tap), 1);
     mfma_slice(af0, bf0);
     read_slice(af0, bf0, nwinp, smem + OFF_B + ((step + 1) % NST) * BSTAGE, tap_shift(ntap), 0);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   // ---- epilogue: two passes (column tile u of every wave: 32 WN staged columns) through LDS, then 16-byte stores
   constexpr int PCS = 4 * WN;                               // 16-byte pieces per staged row
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int scol = (wave / WM) * 32 + r;                  // column in the staged half
     const float bv = a.bias ? a.bias[n0 + wn + 32 * u + r] : 0.f;
     float sv = 0.f, qv = 0.f;
@@ -308,7 +309,7 @@ int window_bound(int mt, int H, int W) {
 // implicit-GEMM kernel).  bwd = 0: forward (src = x, wt = OHWI); 1: backward-data (src = dy, wt = IHWO).
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
                         int B, int H, int W, int Kc, int N, int mt, hipStream_t s) {
-  if (N <= 0 || N % 64 || Kc % DK || B <= 0) return WSMG_EINVAL;
+  if (N <= 0 || N % 32 || Kc % DK || B <= 0) return WSMG_EINVAL;
   if ((int64_t)B * (H + 2) * (W + 2) * 1 > (1 << 30) || (int64_t)B * H * W * (Kc > N ? Kc : N) * 2 >= (1ll << 31)) return WSMG_EINVAL;
   Win3Args a{(const bf16_t*)src, (const bf16_t*)wt, bias, (bf16_t*)dst, B, H, W, Kc, N, 0, 0, relu, bwd,
              (unsigned)((size_t)B * H * W * Kc * 2), (unsigned)((size_t)N * 9 * Kc * 2), stats, nslab};
@@ -317,9 +318,14 @@ int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* b
     if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 128>(a, s);
     return WSMG_EINVAL;
   }
-  // 64-channel tiles (N = 64, 192, ...)
-  if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 64>(a, s);
-  if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 64>(a, s);
+  if (N % 64 == 0) {   // 64-channel tiles (N = 64, 192, ...)
+    if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 64>(a, s);
+    if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 64>(a, s);
+    return WSMG_EINVAL;
+  }
+  // 32-channel tiles (N = 32, 96, ...)
+  if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 32>(a, s);
+  if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 32>(a, s);
   return WSMG_EINVAL;
 }
 
