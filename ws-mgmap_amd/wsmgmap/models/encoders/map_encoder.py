@@ -273,6 +273,13 @@ class MapDecoder(nn.Module):
                 main.wait_stream(side)
                 x_original.record_stream(main)
             return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2)
+        if x.dtype == torch.bfloat16 and os.environ.get("WSMG_UPCAT_TRAIN", "1") != "0":
+            # upsample + torch.cat(dim=1) of the reference in one launch, under autograd too (ops._Up2Cat)
+            up = cr(ops.upsample2x_cat(cr(layer1, self.layer1_1x1), cr(layer0, self.layer0_1x1)), self.conv_up0)
+            if side is not None:
+                main.wait_stream(side)
+                x_original.record_stream(main)
+            return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2)
         up = ops.upsample2x(cr(layer1, self.layer1_1x1))
         up = cr([up, cr(layer0, self.layer0_1x1)], self.conv_up0)        # torch.cat(dim=1) of the reference, folded into the conv
         up = ops.upsample2x(up)

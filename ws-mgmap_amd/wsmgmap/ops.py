@@ -1487,21 +1487,44 @@ class _CatChannels(torch.autograd.Function):
         return dy[..., :ctx.ca], dy[..., ctx.ca:]
 
 
-@torch.no_grad()
+class _Up2Cat(torch.autograd.Function):
+    """cat([upsample2x(a), b], channels) in one launch, with autograd: the gradients are the upsampling's backward of dy's first
+    channel slice (read in place: wsmg_upsample2x_bwd_ld) and dy's second slice as a view, as `_Up2` + `_CatChannels` return them."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        B, H, W, Ca = a.shape
+        Cb = b.shape[-1]
+        y = torch.empty(B, 2 * H, 2 * W, Ca + Cb, device=a.device, dtype=torch.bfloat16)
+        _abi.call("wsmg_upsample2x_cat_bf16", _p(a), _p(b), _p(y), B, H, W, Ca, Cb, _stream())
+        ctx.shape = (B, H, W, Ca)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Ca = ctx.shape
+        da = None
+        if ctx.needs_input_grad[0]:
+            part, ld = _rows_of(dy[..., :Ca], Ca)
+            da = torch.empty(B, H, W, Ca, device=dy.device, dtype=dy.dtype)
+            if ld != Ca:
+                _abi.call("wsmg_upsample2x_bwd_ld_bf16", _p(part), ld, _p(da), B, H, W, Ca, _stream())
+            else:
+                _abi.call("wsmg_upsample2x_bwd_bf16", _p(part), _p(da), B, H, W, Ca, _stream())
+        return da, (dy[..., Ca:] if ctx.needs_input_grad[1] else None)
+
+
 def upsample2x_cat(a, b):
-    """cat([upsample2x(a), b], channels) of bf16 NHWC activations in one launch (wsmg_upsample2x_cat_bf16; inference only: the
-    upsampled tensor is never materialised).  Other types / channel counts: the two separate operators."""
+    """cat([upsample2x(a), b], channels) of bf16 NHWC activations in one launch (wsmg_upsample2x_cat_bf16: the upsampled tensor
+    is never materialised), forward and — round 3 — under autograd.  Other types / channel counts: the two separate operators."""
     if (a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.shape[-1] % 8 or b.shape[-1] % 8
             or _os.environ.get("WSMG_UPCAT", "1") == "0"):
         return cat_channels(upsample2x(a), b)
     _req(a, b)
     B, H, W, Ca = a.shape
-    Cb = b.shape[-1]
     if b.shape[:3] != (B, 2 * H, 2 * W):
         raise _abi.WsmgError(f"upsample2x_cat: {tuple(b.shape)} is not twice the size of {tuple(a.shape)}")
-    y = torch.empty(B, 2 * H, 2 * W, Ca + Cb, device=a.device, dtype=torch.bfloat16)
-    _abi.call("wsmg_upsample2x_cat_bf16", _p(a), _p(b), _p(y), B, H, W, Ca, Cb, _stream())
-    return y
+    return _Up2Cat.apply(a.contiguous(), b.contiguous())
 
 
 def cat_channels(a, b):
