@@ -129,6 +129,11 @@ int wsmg_bn_act_bwd(const float* dy, const float* x, const float* y, const float
                     float* dx, float* dresidual, float* dgamma, float* dbeta, double* workspace,
                     int64_t workspace_bytes, wsmg_stream_t stream);
 
+/* y = a + b + c of three bf16 tensors in one pass (float32 sums, one rounding): the accumulated gradient of an activation with
+ * three consumers (the encoded map of mg_map_policy.py:78-100: token projection, decoder stem, decoder full-resolution branch).
+ * n % 8 == 0, 16-byte aligned pointers. */
+int wsmg_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, wsmg_stream_t stream);
+
 /* bias-less activation helpers of the decoder (NHWC):
  *   relu:        F.relu after the bias-carrying convs of mg_map_policy.py:89-100
  *   maxpool:     MaxPool2d(3,2,1)            torchvision resnet18 child 3 (map_encoder.py:80)

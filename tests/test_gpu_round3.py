@@ -807,3 +807,26 @@ def test_bev_scatter_window_widths_vs_oracle(C, E):
     heading = torch.tensor(([0.3, -1.1, 2.0, 0.0] * B)[:B], device="cuda")
     rotp = ops.bev_scatter_rotate(feat, lin, heading, -1.0, C, E)      # (any C: only the plane-consuming fuse needs C % 4 == 0)
     assert torch.equal(rotp.permute(0, 2, 3, 1), ops.bev_rotate(proj, heading, -1.0))
+
+
+def test_fanout3_sums_three_gradients_in_one_pass():
+    """ops.fanout3 (the encoded map's three consumers, mg_map_policy.py:78-100 / map_encoder.py:94-112): three aliases forward, and
+    backward the float32 sum of the three bf16 gradients rounded once (wsmg_add3_bf16) — within one bf16 rounding of the float64
+    sum, at least as close as autograd's two successive bf16 adds; missing gradients and other dtypes take the stock adds."""
+    from wsmgmap import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.randn(7, 24, 24, 256, device="cuda", generator=g).bfloat16().requires_grad_(True)
+    a, b, c = ops.fanout3(x)
+    assert a.data_ptr() == x.data_ptr() and b.data_ptr() == x.data_ptr() and c.data_ptr() == x.data_ptr()
+    gs = [torch.randn(x.shape, device="cuda", generator=g).bfloat16() for _ in range(3)]
+    torch.autograd.backward([a, b, c], gs)
+    want = gs[0].double() + gs[1].double() + gs[2].double()
+    err = (x.grad.double() - want).abs()
+    assert float((err - 2.0 ** -8 * want.abs()).max()) <= 1e-6
+    two_adds = ((gs[0] + gs[1]) + gs[2]).double()
+    assert float(err.mean()) <= float((two_adds - want).abs().mean())
+    # two consumers only / float32: the stock path
+    y = torch.randn(5, 8, device="cuda", generator=g, requires_grad=True)
+    p, q, r = ops.fanout3(y)
+    (p.sum() + 2 * q.sum()).backward()
+    assert torch.equal(y.grad, torch.full_like(y, 3.0))

@@ -510,6 +510,23 @@ __device__ __forceinline__ unsigned mask2(unsigned g, unsigned y) {   // g where
   const float lo = __uint_as_float(y << 16), hi = __uint_as_float(y & 0xffff0000u);
   return (lo > 0.f ? (g & 0xffffu) : 0u) | (hi > 0.f ? (g & 0xffff0000u) : 0u);
 }
+// a + b + c of three bf16 tensors in one pass, float32 sums, one rounding (round 3: the gradient of a tensor with three
+// consumers — the encoded map feeds the token projection, the decoder's stem and its full-resolution branch — instead of two
+// add launches of six passes over 151 MB each way)
+__device__ __forceinline__ unsigned add3_2(unsigned a, unsigned b, unsigned c) {
+  const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16) + __uint_as_float(c << 16);
+  const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u) + __uint_as_float(c & 0xffff0000u);
+  const bf16_t l = (bf16_t)lo, h = (bf16_t)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+}
+__global__ void add3_bf16_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b, const u32x4_t* __restrict__ c,
+                                 u32x4_t* __restrict__ y, int64_t n8) {
+  GRID_STRIDE(i, n8) {
+    const u32x4_t u = a[i], v = b[i], w = c[i];
+    u32x4_t o = {add3_2(u[0], v[0], w[0]), add3_2(u[1], v[1], w[1]), add3_2(u[2], v[2], w[2]), add3_2(u[3], v[3], w[3])};
+    y[i] = o;
+  }
+}
 __global__ void relu_fwd8_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ y, int64_t n8) {
   GRID_STRIDE(i, n8) {
     const u32x4_t v = x[i];
@@ -669,6 +686,12 @@ extern "C" int wsmg_upsample2x_cat_bf16(const void* a, const void* b, void* y, i
   if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) return WSMG_EINVAL;
   hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3(sgrid((int64_t)B * 4 * H * W * (Ca + Cb) / 8)), dim3(256), 0, wsmg_s(s), CB16(a),
                      (const u32x4_t*)b, (u32x4_t*)y, B, H, W, Ca / 8, Cb / 8);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_add3_bf16(const void* a, const void* b, const void* c, void* y, int64_t n, wsmg_stream_t s) {
+  if (!a || !b || !c || !y || n <= 0 || (n & 7) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)y) & 15)) return WSMG_EINVAL;
+  hipLaunchKernelGGL(add3_bf16_kernel, dim3(sgrid(n / 8)), dim3(256), 0, wsmg_s(s), (const u32x4_t*)a, (const u32x4_t*)b, (const u32x4_t*)c,
+                     (u32x4_t*)y, n / 8);
   WSMG_RETURN_LAUNCH();
 }
 extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<float>(x, y, n, s); }

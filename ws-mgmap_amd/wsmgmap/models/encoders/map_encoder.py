@@ -232,6 +232,8 @@ class MapDecoder(nn.Module):
 
     def forward(self, x, fold=None):
         import torch
+        # x: the encoded map, or (alias for the full-resolution branch, alias for the stem) of it — ops.fanout3 in MGMapNet._map_stack
+        x_full, x = x if isinstance(x, (tuple, list)) else (x, x)
         train = self.training
         if fold is not None:
             cr = lambda t, seq: conv_infer(t, fold, seq[0], seq[1])  # noqa: E731
@@ -257,11 +259,11 @@ class MapDecoder(nn.Module):
                 self._side = torch.cuda.Stream()
             side, main = self._side, torch.cuda.current_stream()
             side.wait_stream(main)
-            x.record_stream(side)   # x is saved for the side-stream backward of these layers: no reuse of its memory before that ran
+            x_full.record_stream(side)   # saved for the side-stream backward of these layers: no reuse of its memory before that ran
             with torch.cuda.stream(side):
-                x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
+                x_original = cr(cr(x_full, self.conv_original_size0), self.conv_original_size1)
         else:
-            x_original = cr(cr(x, self.conv_original_size0), self.conv_original_size1)
+            x_original = cr(cr(x_full, self.conv_original_size0), self.conv_original_size1)
         stem = self.base_model
         layer0 = cr(x, (stem.conv1, stem.bn1))
         layer1 = ops.maxpool3x3s2(layer0)

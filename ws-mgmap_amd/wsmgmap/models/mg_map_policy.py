@@ -221,8 +221,10 @@ class MGMapNet(nn.Module):
             self._encoder_done = torch.cuda.Event()
             self._encoder_done.record(torch.cuda.current_stream())
         conv = lambda t, seq, pad: ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad, relu=True)  # noqa: E731
-        enc_proj = conv(enc, self.map_encoded_linear, 1)
-        dec = self.map_decoder(enc)
+        # the encoded map has three consumers: their gradients meet in one launch (ops.fanout3) instead of two autograd adds
+        e_tok, e_full, e_stem = ops.fanout3(enc) if (train and enc.dtype == torch.bfloat16) else (enc, enc, enc)
+        enc_proj = conv(e_tok, self.map_encoded_linear, 1)
+        dec = self.map_decoder((e_full, e_stem))
         c = self.map_classfier
         from .encoders.map_encoder import bump
         fused = train and dec.dtype == torch.bfloat16

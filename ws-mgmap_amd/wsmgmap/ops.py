@@ -1487,6 +1487,39 @@ class _CatChannels(torch.autograd.Function):
         return dy[..., :ctx.ca], dy[..., ctx.ca:]
 
 
+class _Fanout3(torch.autograd.Function):
+    """Three aliases of one activation for its three consumers; backward adds the three gradients in ONE pass (wsmg_add3_bf16,
+    float32 sums, one rounding) where autograd's own accumulation is two add launches over the tensor."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        gs = [g for g in (g0, g1, g2) if g is not None]
+        if (len(gs) == 3 and all(g.is_cuda and g.dtype == torch.bfloat16 and g.shape == gs[0].shape for g in gs)
+                and gs[0].numel() % 8 == 0):
+            gs = [g.contiguous() for g in gs]
+            if all(g.data_ptr() % 16 == 0 for g in gs):
+                out = torch.empty_like(gs[0])
+                _abi.call("wsmg_add3_bf16", _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(out), out.numel(), _stream())
+                return out
+        if not gs:
+            return None
+        out = gs[0]
+        for g in gs[1:]:
+            out = out + g
+        return out
+
+
+def fanout3(x):
+    """(x, x, x) for an activation with three consumers, whose gradients then meet in one launch (see _Fanout3)."""
+    if not (x.requires_grad and torch.is_grad_enabled()) or _os.environ.get("WSMG_FANOUT3", "1") == "0":
+        return x, x, x
+    return _Fanout3.apply(x)
+
+
 class _Up2Cat(torch.autograd.Function):
     """cat([upsample2x(a), b], channels) in one launch, with autograd: the gradients are the upsampling's backward of dy's first
     channel slice (read in place: wsmg_upsample2x_bwd_ld) and dy's second slice as a view, as `_Up2` + `_CatChannels` return them."""
