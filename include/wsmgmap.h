@@ -291,6 +291,11 @@ int wsmg_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int H, int W, int 
                                wsmg_stream_t stream);
 int wsmg_maxpool3x3s2_bwd_bf16(const void* dy, const void* x, void* dx, int B, int H, int W, int C, int OH,
                                int OW, wsmg_stream_t stream);
+/* The same pool keeping the winning tap of every output element (idx: one byte per element, 3 ky + kx, packed four channels to a
+ * word, [B][OH][OW][C/4]) and the backward that reads the taps instead of recomputing up to four windows' arg-max per input element. */
+int wsmg_maxpool3x3s2_fwd_idx_bf16(const void* x, void* y, uint32_t* idx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t stream);
+int wsmg_maxpool3x3s2_bwd_idx_bf16(const void* dy, const uint32_t* idx, void* dx, int B, int H, int W, int C, int OH, int OW,
+                                   wsmg_stream_t stream);
 int wsmg_upsample2x_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t stream);
 int wsmg_upsample2x_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, wsmg_stream_t stream);
 int wsmg_avgpool2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, wsmg_stream_t stream);

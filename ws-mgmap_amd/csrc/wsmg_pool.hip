@@ -116,6 +116,59 @@ __global__ void maxpool_bwd_kernel(const T* dy, const T* x, T* dx, int B, int H,
   }
 }
 
+// ---- the same pool with the winning tap of every output element kept (round 3): one byte per element, tap = 3 ky + kx in the
+// scan order whose first maximum wins.  The backward above recomputes the arg-max of up to four windows per input element —
+// 36 loads and their compares for one store: 50 us for the decoder's 12 x 12 map at B = 512, a 9 MB tensor, on the critical
+// chain of small launches; with the taps it is four index words and four gradient loads.
+template <class T>
+__global__ void maxpool_fwd_idx_kernel(const T* x, T* y, unsigned* idx, int B, int H, int W, int C, int OH, int OW) {
+  const int C4 = C / 4;
+  int64_t n = (int64_t)B * OH * OW * C4;
+  GRID_STRIDE(i, n) {
+    PIX_DECODE(i, C4, OW, OH, c, ox, oy, b)
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int arg[4] = {-1, -1, -1, -1};
+    for (int ky = 0; ky < 3; ++ky) {
+      int iy = oy * 2 - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        int ix = ox * 2 - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        f32x4 v = ld4(x + (((size_t)b * H + iy) * W + ix) * C + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > best[j] || v[j] != v[j] || arg[j] < 0) { best[j] = v[j]; arg[j] = 3 * ky + kx; }
+      }
+    }
+    st4(y + i * 4, best);
+    idx[i] = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+  }
+}
+template <class T>
+__global__ void maxpool_bwd_idx_kernel(const T* dy, const unsigned* idx, T* dx, int B, int H, int W, int C, int OH, int OW) {
+  const int C4 = C / 4;
+  int64_t n = (int64_t)B * H * W * C4;
+  GRID_STRIDE(i, n) {
+    PIX_DECODE(i, C4, W, H, c, ix, iy, b)
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int oy0 = iy / 2, oy1 = (iy + 1) / 2, ox0 = ix / 2, ox1 = (ix + 1) / 2;   // windows [2o - 1, 2o + 1] containing (iy, ix)
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      if (oy >= OH) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        if (ox >= OW) continue;
+        const unsigned tap = (unsigned)(3 * (iy - (2 * oy - 1)) + (ix - (2 * ox - 1)));
+        const size_t o = (((size_t)b * OH + oy) * OW + ox) * C4 + c / 4;
+        const unsigned w = idx[o];
+        const f32x4 d = ld4(dy + o * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (((w >> (8 * j)) & 0xffu) == tap) g[j] += d[j];
+      }
+    }
+    st4(dx + i * 4, g);
+  }
+}
+
 // ---- bilinear x2, align_corners=True (ATen upsample_bilinear2d: src = dst * (in-1)/(out-1))
 __device__ inline void up_src(int o, int in, float scale, int& i0, int& i1, float& l0, float& l1) {
   float s = scale * (float)o;
@@ -712,6 +765,18 @@ extern "C" int wsmg_relu_bwd_rows_bf16(const void* dy, int64_t ld_dy, const void
 }
 extern "C" int wsmg_maxpool3x3s2_fwd(const float* x, float* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<float>(x, y, B, H, W, C, OH, OW, s); }
 extern "C" int wsmg_maxpool3x3s2_fwd_bf16(const void* x, void* y, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_fwd_t<bf16_t>(CB16(x), B16(y), B, H, W, C, OH, OW, s); }
+extern "C" int wsmg_maxpool3x3s2_fwd_idx_bf16(const void* x, void* y, uint32_t* idx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) {
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0 || (C & 3) || !idx) return WSMG_EINVAL;
+  hipLaunchKernelGGL(maxpool_fwd_idx_kernel<bf16_t>, dim3(sgrid((int64_t)B * OH * OW * C / 4)), dim3(256), 0, wsmg_s(s), CB16(x), B16(y), idx,
+                     B, H, W, C, OH, OW);
+  WSMG_RETURN_LAUNCH();
+}
+extern "C" int wsmg_maxpool3x3s2_bwd_idx_bf16(const void* dy, const uint32_t* idx, void* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) {
+  if (OH != (H + 2 - 3) / 2 + 1 || OW != (W + 2 - 3) / 2 + 1 || B <= 0 || C <= 0 || (C & 3) || !idx) return WSMG_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel<bf16_t>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(s), CB16(dy), idx, B16(dx),
+                     B, H, W, C, OH, OW);
+  WSMG_RETURN_LAUNCH();
+}
 extern "C" int wsmg_maxpool3x3s2_bwd(const float* dy, const float* x, float* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_bwd_t<float>(dy, x, dx, B, H, W, C, OH, OW, s); }
 extern "C" int wsmg_maxpool3x3s2_bwd_bf16(const void* dy, const void* x, void* dx, int B, int H, int W, int C, int OH, int OW, wsmg_stream_t s) { return maxpool_bwd_t<bf16_t>(CB16(dy), CB16(x), B16(dx), B, H, W, C, OH, OW, s); }
 extern "C" int wsmg_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, wsmg_stream_t s) { return upsample_fwd_t<float>(x, y, B, H, W, C, s); }

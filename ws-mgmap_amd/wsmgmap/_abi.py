@@ -110,6 +110,8 @@ _SIG["wsmg_cls_tail_bwd_bf16"] = [c_p] * 7 + [c_i, c_p, c_i, c_i, c_p, c_p, c_i,
 _SIG["wsmg_bn_stats_finalize"] = [c_p, c_i, c_i, c_l, c_f, c_f, c_p, c_p, c_p, c_p, c_p]
 _SIG["wsmg_bn_bwd_apply_bf16"] = [c_p] * 7 + [c_l, c_i, c_p, c_p]
 _SIG["wsmg_attn_fp8_mfma_fwd"] = [c_p] * 9 + [c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p]
+_SIG["wsmg_maxpool3x3s2_fwd_idx_bf16"] = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]
+_SIG["wsmg_maxpool3x3s2_bwd_idx_bf16"] = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]
 _SIG["wsmg_add3_bf16"] = [c_p, c_p, c_p, c_p, c_l, c_p]
 _SIG["wsmg_attn_fp8_prep"] = [c_p] * 4 + [c_i, c_i, c_i, c_i, c_f, c_f, c_f] + [c_p] * 8
 _SIG["wsmg_mean_rows"] = [c_p, c_l, c_i, c_p, c_p]

@@ -963,17 +963,31 @@ class _MaxPool(torch.autograd.Function):
         B, H, W, C = x.shape
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
+        ctx.dims = (B, H, W, C, OH, OW)
+        if x.dtype == torch.bfloat16 and x.requires_grad and _os.environ.get("WSMG_MAXPOOL_IDX", "1") != "0":
+            # training: keep every output element's winning tap (one byte) — the backward then reads four taps per input element
+            # instead of recomputing four windows' arg-max from x
+            idx = torch.empty(B, OH, OW, C // 4, device=x.device, dtype=torch.int32)
+            _abi.call("wsmg_maxpool3x3s2_fwd_idx_bf16", _p(x), _p(y), _p(idx), B, H, W, C, OH, OW, _stream())
+            ctx.save_for_backward(idx)
+            ctx.by_idx = True
+            return y
         _abi.call("wsmg_maxpool3x3s2_fwd" + _sfx(x), _p(x), _p(y), B, H, W, C, OH, OW, _stream())
         ctx.save_for_backward(x)
+        ctx.by_idx = False
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        B, H, W, C = x.shape
+        B, H, W, C, OH, OW = ctx.dims
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        _abi.call("wsmg_maxpool3x3s2_bwd" + _sfx(x), _p(dy), _p(x), _p(dx), B, H, W, C, dy.shape[1], dy.shape[2], _stream())
+        dx = torch.empty(B, H, W, C, device=dy.device, dtype=dy.dtype)
+        if ctx.by_idx:
+            (idx,) = ctx.saved_tensors
+            _abi.call("wsmg_maxpool3x3s2_bwd_idx_bf16", _p(dy), _p(idx), _p(dx), B, H, W, C, OH, OW, _stream())
+            return dx
+        (x,) = ctx.saved_tensors
+        _abi.call("wsmg_maxpool3x3s2_bwd" + _sfx(x), _p(dy), _p(x), _p(dx), B, H, W, C, OH, OW, _stream())
         return dx
 
 
