@@ -329,6 +329,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         reducer.check()
         st = reducer.stats()
         measure.dp_info = dict(ranks_in_process_group=dist.get_world_size(), backend=dist.get_backend(),
+                               gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
                                live_gradient_bytes=reducer.live_bytes, buckets=reducer.num_buckets,
                                devices_visible=torch.cuda.device_count(),
                                exposed_allreduce_ms=st["exposed_allreduce_ms"], exposed_allreduce_max_ms=st["exposed_allreduce_max_ms"],
@@ -387,6 +388,15 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    # Data-parallel runs: RCCL brings its own streams, and HIP multiplexes a process's streams onto 4 hardware queues by default —
+    # the update's three compute streams then share queues with the collective library's.  Measured with a ONE-rank communicator
+    # (nothing but the process group existing): 11.78 ms per update against 11.45 without it, and 11.45 again with 8 queues; the
+    # whole exchange 12.07 -> 11.65 ms.  Must be in the environment before the HIP runtime starts (nothing has touched it yet).
+    # Not when ranks SHARE a GPU (the functional mode of a 1-GPU box): two processes with 8 queues each oversubscribe the GPU's
+    # queues outright — 609 ms per update instead of 44.
+    if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WSMG_BENCH_DP_ONE_RANK") == "1")
+            and os.environ.get("WSMG_BENCH_SHARE_GPU") != "1"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=30)
