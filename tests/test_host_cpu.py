@@ -436,3 +436,85 @@ def test_feeder_ring_refuses_what_the_host_cannot_hold():
     fd = feeder.DeviceFeeder(dataset=[], batch_size=2, device="cpu", num_workers=4, slot_bytes=avail // 4, slots_per_worker=2)
     with pytest.raises(RuntimeError, match="host memory|/dev/shm"):
         next(iter(fd))
+
+
+class _BlobStore:
+    def __init__(self, blobs):
+        self.blobs = blobs
+
+    def __call__(self, i):
+        return self.blobs[i]
+
+
+def _tiny_dataset(batch_size):
+    from oracle import data_cases as dc
+    from wsmgmap.data import TrajectoryDataset, pack_record
+    store = _BlobStore([pack_record(*dc.episode(1000 + i, n)) for i, n in enumerate(dc.DATASET_LENGTHS)])
+    return TrajectoryDataset(store, len(store.blobs), batch_size=batch_size, rank=0, world_size=1)
+
+
+def test_feeder_probe_bounds_the_slot_and_leaves_the_random_state_alone():
+    """the slot size comes from a probe batch — 1.5 x its packed bytes, never above batch_size x 200 steps of the
+    probe's per-step bytes — and the probe's block shuffle / tie-breaks must not advance the parent's `random` state."""
+    import random
+    from wsmgmap.data import feeder
+    from wsmgmap.data.collate import plan_batch
+    fd = feeder.DeviceFeeder(_tiny_dataset(4), 4, device="cpu", num_workers=2)
+    random.seed(77)
+    before = random.getstate()
+    nbytes = fd._probe_slot_bytes()
+    assert random.getstate() == before
+    from oracle import data_cases as dc
+    # prev [2] f32 + oracle [2] f32 + weights [] f32 = 20 bytes on top of the sensors
+    per_step = sum(int(np.prod(shape)) * np.dtype(dt).itemsize for dt, shape in dc.SENSORS.values()) + 20
+    assert nbytes <= (per_step * 200 + 16 * (len(dc.SENSORS) + 3)) * 4 + 4096
+    ds = _tiny_dataset(4)
+    ds._worker_override = (2, 0)
+    random.seed(77)
+    it = iter(ds)
+    _, meta = plan_batch([next(it) for _ in range(4)])
+    assert nbytes == int(meta["total"] * 1.5) + 4096
+
+
+def test_feeder_worker_sends_an_oversize_batch_outside_the_ring_and_waits_for_the_ack():
+    """a batch larger than a ring slot used to raise inside the worker and abort the epoch.  Now it travels as its own
+    shared block; the worker goes on only after the consumer's "ack", and slot ids that come back meanwhile are kept."""
+    import queue
+    import threading
+    from wsmgmap.data import feeder
+    from wsmgmap.data.collate import plan_batch
+    ds = _tiny_dataset(2)
+    ds._worker_override = (1, 0)
+    import random
+    random.seed(5)
+    sizes = []
+    items = [x for x in ds]              # ONE __iter__ call, as in the worker
+    for i in range(0, len(items) - 1, 2):
+        sizes.append(plan_batch(items[i:i + 2])[1]["total"])
+    cap = sorted(sizes)[len(sizes) // 2]                     # about half of the batches do not fit
+    slots = [torch.empty(cap, dtype=torch.uint8) for _ in range(2)]
+    free_q, ready_q = queue.Queue(), queue.Queue()
+    free_q.put(0)
+    free_q.put(1)
+    nthreads = torch.get_num_threads()       # the worker is a process in production and pins ITS torch to one thread
+    th = threading.Thread(target=feeder._ring_worker, args=(_tiny_dataset(2), 2, 0, 1, slots, free_q, ready_q, 5), daemon=True)
+    th.start()
+    got, big = [], 0
+    while True:
+        item = ready_q.get(timeout=60)
+        if item == feeder._STOP:
+            break
+        assert item[0] != "__error__", item
+        if item[0] == "__big__":
+            _, meta, blk = item
+            assert meta["total"] > cap and blk.numel() >= meta["total"]
+            big += 1
+            free_q.put("ack")
+        else:
+            sid, meta = item
+            assert meta["total"] <= cap
+            free_q.put(sid)
+        got.append(meta["total"])
+    th.join(timeout=10)
+    torch.set_num_threads(nthreads)
+    assert not th.is_alive() and big >= 1 and len(got) == len(sizes) and sorted(got) == sorted(sizes)

@@ -23,6 +23,13 @@
 
 #include "wsmg_common.h"
 
+// This file must be compiled WITHOUT packed-float32 instructions (Makefile: EXTRA_wsmg_rnn): with them the gradient
+// kernels returned wrong partial sums beside co-resident MFMA waves.  The define travels with the compiler flag.
+#ifndef WSMG_RNN_NO_PK_FP32
+#error "wsmg_rnn.hip: compile with -Xclang -target-feature -Xclang -packed-fp32-ops -DWSMG_RNN_NO_PK_FP32 (see csrc/Makefile)"
+#endif
+__attribute__((visibility("hidden"))) int wsmgi_rnn_no_pk_fp32() { return 1; }
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -168,6 +168,13 @@ def lib():
                 raise WsmgError(f"{LIB_PATH} does not export {name}") from e
             fn.argtypes = args
             fn.restype = _RESTYPE.get(name, c_i)
+        info = L.wsmg_build_info() or b""
+        if b"rnn-nopk" not in info:
+            # the GRU / LSTM gradient kernels are only correct when wsmg_rnn.hip was compiled without packed-fp32 instructions
+            # (csrc/Makefile: EXTRA_wsmg_rnn; 177 wrong tensors in 60 loaded repeats otherwise): a stale object or another build
+            # of the library (WSMG_LIB) must not bring that back silently
+            raise WsmgError(f"{LIB_PATH} ({info.decode(errors='replace')}) was not built with the RNN kernels' compiler flags "
+                            "(no 'rnn-nopk' in wsmg_build_info()): rebuild with `make -C ws-mgmap_amd/csrc`")
         _lib = L
     return _lib
 

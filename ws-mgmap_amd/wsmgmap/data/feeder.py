@@ -57,7 +57,9 @@ def _host_memory_available():
 
 
 def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, seed):
-    """Decode worker: its shard of the dataset, whole batches, packed into the shared slots it is handed."""
+    """Decode worker: its shard of the dataset, whole batches, packed into the shared slots it is handed.  A batch larger than a
+    slot (the slots are sized from a probe batch; episodes vary in length) does NOT fail the epoch: it travels once as its own
+    shared-memory block ("__big__") and the worker waits for the consumer's acknowledgement before it goes on."""
     import random
 
     import numpy as np
@@ -67,6 +69,18 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
         np.random.seed((seed + wid) % (1 << 32))
         dataset._worker_override = (nworkers, wid)
         it = iter(dataset)
+        spare = []                     # slot ids that came back while this worker was waiting for an acknowledgement
+
+        def take(want_ack):
+            while True:
+                if not want_ack and spare:
+                    return spare.pop()
+                tok = free_q.get()
+                if tok is None or (tok == "ack") == want_ack:
+                    return tok
+                if tok != "ack":
+                    spare.append(tok)
+
         while True:
             batch = []
             try:
@@ -77,7 +91,14 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
             if len(batch) < batch_size:          # drop_last=True, as the reference's loader (dagger_trainer.py:585-594)
                 break
             plan, meta = plan_batch(batch)
-            sid = free_q.get()
+            if meta["total"] > slots[0].numel():
+                big = torch.empty(meta["total"], dtype=torch.uint8).share_memory_()
+                pack_batch(plan, meta, big.numpy())
+                ready_q.put(("__big__", meta, big))
+                if take(True) is None:
+                    return
+                continue
+            sid = take(False)
             if sid is None:
                 return
             pack_batch(plan, meta, slots[sid].numpy())
@@ -90,15 +111,22 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
 
 class DeviceFeeder:
     def __init__(self, dataset, batch_size, device="cuda", num_workers=0, prefetch=2, workers="ring", slot_bytes=None,
-                 slots_per_worker=2, seed=0):
-        """slot_bytes: capacity of one ring slot (default: sized from the first batch this process plans itself — it decodes
-        one batch of the first shard for that — with 25 % headroom)."""
+                 slots_per_worker=2, seed=None):
+        """slot_bytes: capacity of one ring slot (default: sized from one batch this process plans itself — it decodes one batch
+        of the first shard for that — with 50 % headroom, capped at the true upper bound batch_size x 200 steps; a larger batch
+        travels outside the ring, counted in `oversize_batches`).
+        seed: None (default) draws a fresh base seed from torch's generator for every epoch (= every `iter()`), which is what
+        DataLoader does for its workers (dagger_trainer.py:116-119,585-594: the shuffle order changes each epoch); an integer is
+        a reproducibility override: epoch e seeds worker w with seed + e * num_workers + w."""
         self.dataset, self.batch_size, self.device = dataset, batch_size, torch.device(device)
         self.num_workers, self.prefetch = int(num_workers), max(1, prefetch)
         self.workers = workers if self.num_workers > 0 else "none"
         if self.workers not in ("none", "ring", "dataloader"):
             raise ValueError("workers: 'ring' or 'dataloader'")
-        self.slot_bytes, self.slots_per_worker, self.seed = slot_bytes, max(2, int(slots_per_worker)), int(seed)
+        self.slot_bytes, self.slots_per_worker = slot_bytes, max(2, int(slots_per_worker))
+        self.seed = None if seed is None else int(seed)
+        self.epoch = 0                # iterators created so far (ring transport)
+        self.oversize_batches = 0     # batches that did not fit a ring slot and travelled as their own shared-memory block
         self.pinned_ring = None       # True / False once a ring exists: could the shared slots be registered as pinned memory
 
     def _trace(self, msg):
@@ -144,22 +172,32 @@ class DeviceFeeder:
 
     # -- shared-memory ring ---------------------------------------------------------------------------------------------
     def _probe_slot_bytes(self):
+        """Slot capacity from one probe batch: 1.5 x its packed size, at most the true upper bound (every episode of a batch at
+        the collate's 200-step cap: per-step bytes from the probe's sensor shapes and dtypes x batch_size x 200).  The probe decodes
+        in this process; the global `random` state it advances (block shuffle, tie-breaks) is put back."""
         import copy
-        ds = copy.copy(self.dataset)
-        ds._worker_override = (self.num_workers, 0)
-        it, batch = iter(ds), []
+        import random
+
+        import numpy as np
+        state = random.getstate()
         try:
-            while len(batch) < self.batch_size:
-                batch.append(next(it))
-        except StopIteration:
-            pass
+            ds = copy.copy(self.dataset)
+            ds._worker_override = (self.num_workers, 0)
+            it, batch = iter(ds), []
+            try:
+                while len(batch) < self.batch_size:
+                    batch.append(next(it))
+            except StopIteration:
+                pass
+        finally:
+            random.setstate(state)
         if not batch:
             return 1 << 20
-        _, meta = plan_batch(batch)
-        # episodes of other batches may be longer (up to the collate's 200-step cap): scale to the cap
+        plan, meta = plan_batch(batch)
         from .collate import LIMITED_LEN_BY_GPU
-        scale = LIMITED_LEN_BY_GPU / max(1, meta["T"])
-        return int(meta["total"] * min(scale, 4.0) * 1.25) + 4096
+        per_step = sum(int(np.prod(a[0].shape[1:], dtype=np.int64)) * a[0].dtype.itemsize for _, a, _ in plan)
+        bound = (per_step * LIMITED_LEN_BY_GPU + 16 * len(plan)) * self.batch_size + 4096
+        return min(bound, int(meta["total"] * 1.5) + 4096)
 
     def _iter_ring(self):
         W = self.num_workers
@@ -186,6 +224,13 @@ class DeviceFeeder:
             raise RuntimeError(f"the feeder's shared-memory ring needs {need >> 20} MiB ({W} workers x {self.slots_per_worker} slots x "
                                f"{nbytes >> 20} MiB), more than 40 % of the {avail >> 20} MiB of host memory this process may use: "
                                "fewer workers or slots_per_worker")
+        # DataLoader draws a fresh base seed per iterator from torch's default generator (worker w gets base_seed + w): the block
+        # shuffle and the tie-breaks of equal-length episodes differ from epoch to epoch.  An explicit seed stays reproducible.
+        if self.seed is None:
+            base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        else:
+            base_seed = self.seed + self.epoch * W
+        self.epoch += 1
         ctx = mp.get_context("spawn")
         slots = [torch.empty(nbytes, dtype=torch.uint8).share_memory_() for _ in range(W * self.slots_per_worker)]
         rt = torch.cuda.cudart()
@@ -203,7 +248,7 @@ class DeviceFeeder:
         for w in range(W):
             for k in range(self.slots_per_worker):
                 free_qs[w].put(w * self.slots_per_worker + k)
-            p = ctx.Process(target=_ring_worker, args=(self.dataset, self.batch_size, w, W, slots, free_qs[w], ready_qs[w], self.seed),
+            p = ctx.Process(target=_ring_worker, args=(self.dataset, self.batch_size, w, W, slots, free_qs[w], ready_qs[w], base_seed),
                             daemon=True)
             p.start()
             procs.append(p)
@@ -235,21 +280,35 @@ class DeviceFeeder:
                     continue
                 if item[0] == "__error__":
                     raise RuntimeError("feeder worker failed:\n" + item[1])
-                sid, meta = item
-                self._trace("batch from worker %d in slot %d" % (w, sid))
-                out = coll.launch(meta, slots[sid], stream=side)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                pending.append((out, ev, w, sid))
+                if item[0] == "__big__":               # a batch larger than a slot: its own (unpinned) shared block, copied now
+                    _, meta, big = item
+                    self.oversize_batches += 1
+                    self._trace("oversize batch from worker %d: %d MiB (slot %d MiB)" % (w, meta["total"] >> 20, nbytes >> 20))
+                    out = coll.launch(meta, big, stream=side)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    ev.synchronize()                   # the pageable copy has left `big`
+                    del big
+                    free_qs[w].put("ack")
+                    pending.append((out, ev, w, None))
+                else:
+                    sid, meta = item
+                    self._trace("batch from worker %d in slot %d" % (w, sid))
+                    out = coll.launch(meta, slots[sid], stream=side)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    pending.append((out, ev, w, sid))
                 if len(pending) > self.prefetch:
                     out, ev, w0, s0 = pending.popleft()
                     ev.synchronize()                  # the copy out of the slot has finished: the worker may refill it
-                    free_qs[w0].put(s0)
+                    if s0 is not None:
+                        free_qs[w0].put(s0)
                     yield self._hand_over(out, ev)
             while pending:
                 out, ev, w0, s0 = pending.popleft()
                 ev.synchronize()
-                free_qs[w0].put(s0)
+                if s0 is not None:
+                    free_qs[w0].put(s0)
                 yield self._hand_over(out, ev)
         finally:
             for q in free_qs:
