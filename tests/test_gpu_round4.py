@@ -66,3 +66,148 @@ def test_feeder_ring_reshuffles_every_epoch_and_survives_oversize_batches():
     c, vc = epoch(small)
     _, va = epoch(DeviceFeeder(mk(), 2, "cuda", num_workers=2, prefetch=2, seed=9))
     assert small.oversize_batches > 0 and c == a and vc == va
+
+
+# ----------------------------------------------------------------------------- the pipelined recurrent core
+def _one_update(pol, obs, prev, masks, weights, N, chunks):
+    """forward + DAgger loss + backward with the recurrent core staged (chunks = 0) or pipelined; -> (pred, loss, att, h, grads)."""
+    import bench
+    from wsmgmap.common.aux_losses import AuxLosses
+    pol.net.recurrent_chunks = chunks
+    for p in pol.parameters():
+        p.grad = None
+    AuxLosses.activate()
+    AuxLosses.clear()
+    h = torch.zeros(2, N, 512, device="cuda")
+    o = dict(obs)
+    pred, aux = pol(o, h, prev, masks, weights)
+    loss = bench.dagger_loss(pred, aux, o["waypoint"], weights)
+    loss.backward()
+    torch.cuda.synchronize()
+    AuxLosses.deactivate()
+    grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in pol.named_parameters()}
+    return pred.detach().clone(), float(loss), pol.net.att_map_t_m.detach().clone(), h.clone(), grads
+
+
+@pytest.mark.parametrize("mode,T,N", [("bf16", 64, 8), ("f32", 16, 8), ("bf16", 12, 3)])
+def test_pipelined_recurrent_core_matches_the_staged_route(mode, T, N):
+    """mg_map_policy.py:220-249 of the reference — GRU 1 -> text attention -> map attention -> second_state_compress -> GRU 2 — as one
+    autograd node pipelined over 4 time chunks on three streams (wsmgmap/recurrent.py) against the stage-after-stage route of
+    rounds 1-3, on the bench workload (T = 64 x N = 8, bf16) and two smaller shapes: action logits, loss, the map attention row, the
+    carried hidden states and EVERY parameter gradient.  The kernels and the float32 GEMMs are the same row for row; the only
+    freedom is the GEMM library's kernel choice for 128-row chunks vs 512 rows (float32 rounding): 2e-5 of the largest element."""
+    import bench
+    import test_gpu_round2 as r2
+    from wsmgmap import ops
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype=mode, state=r2._default_state()))
+    obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 77)
+    masks = masks.clone()
+    masks.view(T, N)[T // 2 + 1, N - 1] = 0          # an episode restart inside a chunk
+    a = _one_update(pol, obs, prev, masks, weights, N, 0)
+    b = _one_update(pol, obs, prev, masks, weights, N, 4)
+    c = _one_update(pol, obs, prev, masks, weights, N, 4)
+    ops.check_rnn_status()
+
+    def close(x, y, name, tol=2e-5):
+        assert x.shape == y.shape, name
+        d = float((x.double() - y.double()).abs().max())
+        assert d <= tol * max(1e-6, float(y.double().abs().max())), (name, d, float(y.abs().max()))
+    close(b[0], a[0], "pred")
+    assert abs(a[1] - b[1]) <= 2e-6 * max(1.0, abs(a[1]))
+    close(b[2], a[2], "att_map_t_m")
+    close(b[3], a[3], "rnn_hidden_states")
+    assert set(k for k, g in a[4].items() if g is not None) == set(k for k, g in b[4].items() if g is not None)
+    for k, g in a[4].items():
+        if g is not None:
+            close(b[4][k], g, k, tol=5e-5 if mode == "f32" else 2e-3)   # (bf16 map stack: its own gradients round through bf16)
+    # the pipelined route is repeatable bit for bit (streams and chunk order change no arithmetic)
+    assert torch.equal(b[0], c[0]) and b[1] == c[1]
+    for k, g in b[4].items():
+        if g is not None:
+            assert torch.equal(g, c[4][k]), k
+
+
+def test_recurrent_block_alone_vs_float64_autograd():
+    """The block as an operator: against the same formulas in float64 torch autograd (GRU as explicit steps), values and all gradients,
+    with chunk counts 1, 2 and 4 agreeing with each other."""
+    from wsmgmap import recurrent
+    from wsmgmap.config import default_model_config
+    from wsmgmap.models.mg_map_policy import MGMapNet
+    torch.manual_seed(3)
+    T, N, I, U, L = 8, 4, 36, 3, 11
+    B = T * N
+    net = MGMapNet(None, default_model_config(num_proc=1)).cuda()
+    state_in = torch.randn(B, 640, device="cuda") * 0.5
+    tokens = torch.randn(B, I, 256, device="cuda") * 0.5
+    tk, tv = torch.randn(U, L, 256, device="cuda"), torch.randn(U, L, 256, device="cuda")
+    tmask = torch.zeros(U, L, dtype=torch.uint8, device="cuda")
+    tmask[1, 7:] = 1
+    inverse = torch.randint(0, U, (B,), device="cuda")
+    masks = torch.ones(T, N, device="cuda")
+    masks[0] = 0
+    masks[5, 2] = 0
+    h01, h02 = torch.randn(N, 512, device="cuda") * 0.3, torch.randn(N, 512, device="cuda") * 0.3
+    gy, ga = torch.randn(B, 512, device="cuda"), torch.randn(B, I, device="cuda") * 0.1
+    names = ["state_encoder.rnn.weight_ih_l0", "state_encoder.rnn.bias_ih_l0", "state_encoder.rnn.weight_hh_l0", "state_encoder.rnn.bias_hh_l0",
+             "state_text_q_layer.weight", "state_text_q_layer.bias", "text_map_q_layer.weight", "text_map_q_layer.bias", "text_map_k_layer.weight",
+             "second_state_compress.0.weight", "second_state_compress.0.bias", "second_state_encoder.rnn.weight_ih_l0",
+             "second_state_encoder.rnn.bias_ih_l0", "second_state_encoder.rnn.weight_hh_l0", "second_state_encoder.rnn.bias_hh_l0"]
+    P = dict(net.named_parameters())
+
+    def run(chunks):
+        for n in names:
+            P[n].grad = None
+        ins = [t.clone().requires_grad_(True) for t in (state_in, tokens, tk, tv, h01, h02)]
+        x, att, h1n, h2n = recurrent.recurrent_block(ins[0], ins[1], (ins[2], ins[3], tmask, inverse), masks.view(B, 1), ins[4], ins[5],
+                                                     net, N, chunks=chunks)
+        ((x * gy).sum() + (att * ga).sum()).backward()
+        torch.cuda.synchronize()
+        return [x.detach(), att.detach(), h1n, h2n] + [t.grad for t in ins] + [P[n].grad.clone() for n in names]
+
+    def gru64(x, rnn, h, m):
+        wi, bi, wh, bh = [t.detach().double() for t in (rnn.weight_ih_l0, rnn.bias_ih_l0, rnn.weight_hh_l0, rnn.bias_hh_l0)]
+        ws = [t.requires_grad_(True) for t in (wi, bi, wh, bh)]
+        ys = []
+        for t in range(T):
+            h = h * m[t].unsqueeze(-1)
+            gi, gh = x[t] @ ws[0].t() + ws[1], h @ ws[2].t() + ws[3]
+            ir, iz, inn = gi.chunk(3, 1)
+            hr, hz, hn = gh.chunk(3, 1)
+            r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+            n = torch.tanh(inn + r * hn)
+            h = (1 - z) * n + z * h
+            ys.append(h)
+        return torch.stack(ys), ws
+
+    ins64 = [t.double().clone().requires_grad_(True) for t in (state_in, tokens, tk, tv, h01, h02)]
+    d = lambda n: P[n].detach().double().requires_grad_(True)    # noqa: E731
+    wq1, bq1, wq2, bq2, wk, wc, bc = (d(n) for n in names[4:11])
+    m64 = masks.double()
+    y1, ws1 = gru64(ins64[0].view(T, N, -1), net.state_encoder.rnn, ins64[4], m64)
+    state = y1.reshape(B, 512)
+    sc = net._scale_f
+
+    def attn(q, k, v, mask):
+        logits = torch.einsum("bc,bic->bi", q, k)
+        if mask is not None:
+            logits = logits - mask.double() * 1e8
+        a = torch.softmax(logits * sc, dim=1)
+        return torch.einsum("bi,bic->bc", a, v), a
+    te, _ = attn(state @ wq1.t() + bq1, ins64[2][inverse], ins64[3][inverse], tmask[inverse])
+    q2 = te @ wq2.t() + bq2
+    keys = torch.einsum("oc,bic->bio", wk.reshape(256, 256), ins64[1])       # the k = 1 Conv1d key projection (bias cancels)
+    me, att64 = attn(q2, keys, ins64[1], None)
+    xc = torch.relu(torch.cat([state, te, me], 1) @ wc.t() + bc)
+    y2, ws2 = gru64(xc.view(T, N, -1), net.second_state_encoder.rnn, ins64[5], m64)
+    ((y2.reshape(B, 512) * gy.double()).sum() + (att64 * ga.double()).sum()).backward()
+    ref = [y2.reshape(B, 512).detach(), att64.detach(), y1[-1:].detach(), y2[-1:].detach()] + [t.grad for t in ins64] + \
+          [ws1[0].grad, ws1[1].grad, ws1[2].grad, ws1[3].grad, wq1.grad, bq1.grad, wq2.grad, bq2.grad, wk.grad, wc.grad, bc.grad,
+           ws2[0].grad, ws2[1].grad, ws2[2].grad, ws2[3].grad]
+    outs = {c: run(c) for c in (1, 2, 4)}
+    for c, got in outs.items():
+        assert len(got) == len(ref)
+        for i, (g, r) in enumerate(zip(got, ref)):
+            err = float((g.double() - r).abs().max())
+            assert err <= 3e-5 * max(1e-3, float(r.abs().max())), (c, i, err, float(r.abs().max()))
+    for i, (g1, g4) in enumerate(zip(outs[1], outs[4])):
+        assert float((g1 - g4).abs().max()) <= 1e-5 * max(1e-3, float(g1.abs().max())), i

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, recurrent
 from ..common.rgb_mapping import RGBMapping
 from .encoders.instruction_encoder import InstructionEncoder
 from .encoders.map_encoder import MapDecoder, MapEncoder
@@ -87,6 +87,8 @@ class MGMapNet(nn.Module):
         self._output_size = hid
         self.att_map_t_m = None
         self._side_stream = None
+        # time chunks of the pipelined recurrent core of the update path (wsmgmap/recurrent.py); 0 = the staged route
+        self.recurrent_chunks = 4
         self.skip_pred_map_nchw = False   # set by BasePolicy around its own forward: it consumes sem_logits_nhwc
         self.sem_logits_nhwc = None
         self.sem_ce_rows = None           # the prediction monitor's per-sample loss when the fused classifier tail computed it
@@ -345,6 +347,23 @@ class MGMapNet(nn.Module):
 
         n1 = self.state_encoder.num_recurrent_layers
         ops.mark("state_in", state_in)
+        n_env = rnn_hidden_states.size(1)
+        if (self.recurrent_chunks > 0 and torch.is_grad_enabled() and not rows and "map" in self._inputs and n1 == 1
+                and rnn_hidden_states.size(0) == 2 and recurrent.usable(state_in, map_tokens, n_env, text)):
+            # GRU 1 -> text attention -> map attention -> compress -> GRU 2 as one autograd node, pipelined over time chunks on three
+            # streams, parameter gradients off the chain (wsmgmap/recurrent.py); same kernels, same arithmetic row for row
+            text_ready = torch.cuda.Event()
+            text_ready.record(side)
+            main = torch.cuda.current_stream()
+            for t in text:
+                t.record_stream(main)
+            x, self.att_map_t_m, h1n, h2n = recurrent.recurrent_block(
+                state_in, map_tokens, text, masks, rnn_hidden_states[0], rnn_hidden_states[1], self, n_env,
+                chunks=self.recurrent_chunks, sink=sink, text_ready=text_ready)
+            rnn_hidden_states[0:n1] = h1n
+            rnn_hidden_states[n1:] = h2n
+            ops.mark("gru2", x)
+            return x, rnn_hidden_states, pred_sem_map
         state, rnn_hidden_states[0:n1] = self.state_encoder(state_in, rnn_hidden_states[0:n1], masks)
         ops.mark("gru1", state)
 

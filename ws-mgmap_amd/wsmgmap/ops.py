@@ -252,7 +252,7 @@ def reset_pass_state():
         _zero_pool_retire()
     if _side_join_armed:
         for main_id, side_id in list(_side_join_armed):
-            for side in list(_wgrad_side.values()) + list(_reduce_side.values()):
+            for side in list(_wgrad_side.values()) + list(_reduce_side.values()) + _leaf_streams:
                 if side.cuda_stream == side_id:
                     torch.cuda.current_stream().wait_stream(side)
         _side_join_armed.clear()
@@ -379,6 +379,7 @@ def _weight_grad(sfx, x, dy, dims, fl, Cin_w, param=None):
 
 _wgrad_side = {}
 _side_join_armed = set()
+_leaf_streams = []     # other streams that join the main stream at the end of a backward pass (wsmgmap.recurrent's leaf stream)
 
 
 def _wgrad_side_stream(flops=0.0, param=None):

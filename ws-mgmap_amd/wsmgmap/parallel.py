@@ -226,6 +226,9 @@ class GradAllReducer:
         if p.is_cuda:
             st = torch.cuda.current_stream()
             b.setdefault("streams", {})[st.cuda_stream] = st     # see _launch
+            leaf = getattr(p, "_wsmg_grad_stream", None)         # wsmgmap.recurrent computes parameter gradients on a leaf stream
+            if leaf is not None:
+                b["streams"][leaf.cuda_stream] = leaf
         if b["pending"] == 0:
             self._launch_ready()
 

@@ -1,0 +1,321 @@
+"""The recurrent core of the update path as ONE autograd node, software-pipelined over time chunks.
+
+Reference: MGMapNet.forward, vlnce_baselines/models/mg_map_policy.py:220-249 —
+
+    state           = state_encoder(state_in, h[0], masks)                       # GRU 1, T serial steps
+    text_embedding  = _attn(state_text_q_layer(state), text_k, text_v, text_mask) # per row
+    map_embedding   = _attn(text_map_q_layer(text_embedding), map_k, map_v)       # per row
+    x               = second_state_compress(cat(state, text_embedding, map_embedding))
+    x               = second_state_encoder(x, h[1], masks)                        # GRU 2, T serial steps
+
+Only the two GRUs are recurrent; everything between them is per ROW.  Run stage after stage (rounds 1-3) the update's critical
+path holds 2 x T dependent GRU steps forward and 2 x T backward (4 x 64 steps of 5.6-6.0 us = 1.5 ms with 224 of the 256 CUs idle)
+plus ~60 dependent small launches around them.  Here the T steps are cut into K chunks: while GRU 1 runs chunk k+1 on one
+stream, the attention stage of chunk k runs on a second and GRU 2 of chunk k on a third (the carried hidden state is bit-exact
+across split launches: tests/test_gpu_kernels.py::test_fullsize_gru_sequence_split_cfg2), and the reverse order in backward:
+T + T/K serial steps each way instead of 2 T.  Weight and bias gradients are NOT part of the chain: the backward chain only
+produces activation gradients into full-batch buffers, and every parameter gradient is one full-batch GEMM / column sum on a
+"leaf" stream that joins the main stream when the whole backward pass ends (nothing but the optimizer waits for them).
+
+Arithmetic: the same kernels and the same float32 GEMMs as the staged route, row for row; chunking changes no reduction order
+inside a row except where the GEMM library picks another kernel for 128 rows than for 512 (float32 rounding differences, <= 1e-6
+relative; tests/test_gpu_round4.py holds the block against the staged route)."""
+import ctypes
+
+import torch
+
+from . import _abi
+from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _stream
+
+MAX_BATCH = 8          # batch slots of the persistent GRU kernels
+_streams = {}          # device index -> (attention stream, GRU-2 stream, leaf stream)
+
+
+def _side_streams(device):
+    s = _streams.get(device.index)
+    if s is None:
+        s = _streams[device.index] = tuple(torch.cuda.Stream(device) for _ in range(3))
+        from . import ops
+        ops._leaf_streams.append(s[2])      # (ops.reset_pass_state re-joins it if a backward pass died before its final callbacks)
+    return s
+
+
+def usable(state_in, tokens, n_env, text, capturing_ok=True):
+    """Can the pipelined block take this call?  Training-size sequences (more than one step) of at most 8 environments on the GPU,
+    float32 state / text tensors, map tokens [B, I, 256]."""
+    B = state_in.shape[0]
+    return (state_in.is_cuda and state_in.dtype == torch.float32 and n_env <= MAX_BATCH and B % n_env == 0 and B // n_env > 1
+            and tokens.dim() == 3 and tokens.shape[2] == 256 and all(t.dtype in (torch.float32, torch.bfloat16) for t in text[:2]))
+
+
+def chunk_plan(T, want):
+    """Time steps per chunk: `want` chunks of equal length when T divides, else the largest divisor count below it (chunks of
+    unequal length would only complicate the plan: T = 64 in the bench, DAgger batches are padded to their longest episode)."""
+    k = max(1, min(int(want), T))
+    while T % k:
+        k -= 1
+    return k, T // k
+
+
+class _RecurrentBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, state_in, tokens, text_k, text_v, text_mask, inverse, masks, h01, h02,
+                w_ih1, b_ih1, w_hh1, b_hh1, wq1, bq1, wq2, bq2, wk, bk, wc, bc, w_ih2, b_ih2, w_hh2, b_hh2):
+        N, K, scale, sink, text_ev = cfg["N"], cfg["chunks"], cfg["scale"], cfg["sink"], cfg["text_ready"]
+        B = state_in.shape[0]
+        T = B // N
+        H = w_hh1.shape[1]
+        dev = state_in.device
+        K, Tc = chunk_plan(T, K)
+        rows = Tc * N
+        main = torch.cuda.current_stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if K == 1 or capturing:
+            K, Tc, rows = 1, T, B
+            sa = sg = main
+        else:
+            sa, sg, _ = _side_streams(dev)
+        f32 = dict(device=dev, dtype=torch.float32)
+        wk2 = wk.reshape(wk.shape[0], -1)
+        I, C = tokens.shape[1], tokens.shape[2]
+        L = text_k.shape[1]
+        lib = _abi.lib()
+        # full-batch buffers (main stream's pool; every other stream is joined into main before this function returns, and they
+        # live on as saved tensors until the backward pass)
+        gi1 = torch.addmm(b_ih1, state_in, w_ih1.t())
+        y1 = torch.empty(T, N, H, **f32)
+        sv1 = [torch.empty(T, N, H, **f32) for _ in range(4)]
+        y2 = torch.empty(T, N, H, **f32)
+        sv2 = [torch.empty(T, N, H, **f32) for _ in range(4)]
+        q1 = torch.empty(B, wq1.shape[0], **f32)
+        text_emb = torch.empty(B, C, **f32)
+        attn_text = torch.empty(B, L, **f32)
+        q2 = torch.empty(B, wq2.shape[0], **f32)
+        qf = torch.empty(B, C, **f32)
+        map_emb = torch.empty(B, C, **f32)
+        att_map = torch.empty(B, I, **f32)
+        x = torch.empty(B, wc.shape[1], **f32)
+        xc = torch.empty(B, wc.shape[0], **f32)
+        gi2 = torch.empty(B, 3 * H, **f32)
+        m = masks.reshape(T, N)
+        h01 = h01.clone()          # the caller overwrites rnn_hidden_states in place (reference contract)
+        h02 = h02.clone()
+        tsfx = _sfx(text_k)
+        ksfx = _sfx(tokens)
+        nbytes = lib.wsmg_gru_workspace_bytes(Tc)
+        if sa is not main:
+            if text_ev is not None:
+                sa.wait_event(text_ev)
+            else:
+                sa.wait_stream(main)
+            sg.wait_stream(main)     # (h02, the buffers)
+        elif text_ev is not None:
+            main.wait_event(text_ev)
+
+        def gru(gi, w_hh, b_hh, h0, y, sv, k):
+            t0 = k * Tc
+            hk = h0 if k == 0 else y[t0 - 1]
+            ws = _rnn_workspace(nbytes, dev)
+            _abi.call("wsmg_gru_fwd", _p(gi[t0:]), _p(w_hh), _p(b_hh), _p(hk), _p(m[t0:]), Tc, N, H, _p(y[t0:]),
+                      *[_p(s[t0:]) for s in sv], _p(ws), _stream())
+            _rnn_launched()
+
+        gi1v, gi2v = gi1.view(T, N, 3 * H), gi2.view(T, N, 3 * H)
+        y1r = y1.view(B, H)
+        for k in range(K):
+            r0, r1 = k * rows, (k + 1) * rows
+            gru(gi1v, w_hh1, b_hh1, h01, y1, sv1, k)                                   # main
+            if sa is not main:
+                e1 = torch.cuda.Event()
+                e1.record(main)
+                sa.wait_event(e1)
+            with torch.cuda.stream(sa):
+                torch.addmm(bq1, y1r[r0:r1], wq1.t(), out=q1[r0:r1])
+                _abi.call("wsmg_attn_shared_fwd" + tsfx, _p(q1[r0:r1]), _p(text_k), _p(text_v), _p(text_mask), _p(inverse[r0:r1]),
+                          scale, rows, L, C, _p(text_emb[r0:r1]), _p(attn_text[r0:r1]), _stream())
+                torch.addmm(bq2, text_emb[r0:r1], wq2.t(), out=q2[r0:r1])
+                torch.mm(q2[r0:r1], wk2, out=qf[r0:r1])
+                _abi.call("wsmg_attn_fwd" + ksfx, _p(qf[r0:r1]), _p(tokens[r0:r1]), _p(tokens[r0:r1]), None, scale, rows, I, C,
+                          _p(map_emb[r0:r1]), _p(att_map[r0:r1]), _stream())
+                torch.cat([y1r[r0:r1], text_emb[r0:r1], map_emb[r0:r1]], dim=1, out=x[r0:r1])
+                torch.addmm(bc, x[r0:r1], wc.t(), out=xc[r0:r1])
+                torch.relu_(xc[r0:r1])
+                torch.addmm(b_ih2, xc[r0:r1], w_ih2.t(), out=gi2[r0:r1])
+            if sg is not main:
+                ea = torch.cuda.Event()
+                ea.record(sa)
+                sg.wait_event(ea)
+            with torch.cuda.stream(sg):
+                gru(gi2v, w_hh2, b_hh2, h02, y2, sv2, k)
+        if sg is not main:
+            main.wait_stream(sg)
+            main.wait_stream(sa)
+        ctx.save_for_backward(state_in, tokens, text_k, text_v, inverse, m, h01, h02, w_ih1, w_hh1, wq1, wq2, wk2, wc, w_ih2, w_hh2,
+                              gi1, y1, *sv1, y2, *sv2, q1, text_emb, attn_text, q2, qf, att_map, x, xc)
+        ctx.cfg = (N, K, Tc, scale, sink, tuple(wk.shape), text_mask is not None)
+        ctx.params = (w_ih1, b_ih1, w_hh1, b_hh1, wq1, bq1, wq2, bq2, wk, bk, wc, bc, w_ih2, b_ih2, w_hh2, b_hh2)
+        h1n, h2n = y1[-1:].clone(), y2[-1:].clone()
+        ctx.mark_non_differentiable(h1n, h2n)
+        ctx.set_materialize_grads(False)
+        return y2.view(B, H), att_map, h1n, h2n
+
+    @staticmethod
+    def backward(ctx, dy2, datt, _dh1, _dh2):
+        (state_in, tokens, text_k, text_v, inverse, m, h01, h02, w_ih1, w_hh1, wq1, wq2, wk2, wc, w_ih2, w_hh2,
+         gi1, y1, sr1, sz1, sn1, sg1, y2, sr2, sz2, sn2, sg2, q1, text_emb, attn_text, q2, qf, att_map, x, xc) = ctx.saved_tensors
+        N, K, Tc, scale, sink, wk_shape, _ = ctx.cfg
+        T = y1.shape[0]
+        H = y1.shape[2]
+        B = T * N
+        rows = Tc * N
+        dev = y1.device
+        I, C = tokens.shape[1], tokens.shape[2]
+        L = text_k.shape[1]
+        U = text_k.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        main = torch.cuda.current_stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        params = ctx.params
+        # side streams only when this pass SETS the parameter gradients (an accumulation into an existing .grad is a kernel autograd
+        # launches on the main stream: it would race the leaf stream) and nothing is being captured
+        multi = (not capturing) and all(p.grad is None for p in params if p is not None and p.is_leaf)
+        if multi:
+            sa, sg, sl = _side_streams(dev)
+            try:
+                _join_side_at_end(main, sl, strict=True)      # raises outside a backward pass (torch.autograd.grad of a test)
+            except RuntimeError:
+                multi = False
+        if not multi:
+            sa = sg = sl = main
+            K, Tc, rows = 1, T, B
+        dy2 = torch.zeros(T, N, H, **f32) if dy2 is None else dy2.contiguous().float().view(T, N, H)
+        datt = None if datt is None else datt.contiguous().float()
+        lib = _abi.lib()
+        nbytes = lib.wsmg_gru_workspace_bytes(Tc)
+        tsfx, ksfx = _sfx(text_k), _sfx(tokens)
+        # full-batch gradient buffers, allocated on the main stream and used on the others: the allocator must not hand their memory
+        # to a later main-stream allocation while a side stream still works on them
+        dgi2, dgh2 = torch.empty(T, N, 3 * H, **f32), torch.empty(T, N, 3 * H, **f32)
+        dgi1, dgh1 = torch.empty(T, N, 3 * H, **f32), torch.empty(T, N, 3 * H, **f32)
+        dxc = torch.empty(B, wc.shape[0], **f32)
+        dqf, dq2, dq1 = torch.empty(B, C, **f32), torch.empty(B, wq2.shape[0], **f32), torch.empty(B, wq1.shape[0], **f32)
+        dtext = torch.empty(B, C, **f32)
+        dl = torch.empty(B, L, **f32)
+        dstate = torch.empty(T, N, H, **f32)
+        dtokens = torch.empty_like(tokens)
+        dh01, dh02 = torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+        carry2 = [torch.empty(N, H, **f32) for _ in range(2)]
+        carry1 = [torch.empty(N, H, **f32) for _ in range(2)]
+        if multi:
+            for t in (dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dl, dstate, dtokens, dh02, dy2, *carry2) + ((datt,) if datt is not None else ()):
+                for s in (sa, sg, sl):
+                    t.record_stream(s)
+            sg.wait_stream(main)
+            sa.wait_stream(main)
+        xcr = xc
+        y1r = y1.view(B, H)
+        dstate_r = dstate.view(B, H)
+        dgi2r = dgi2.view(B, 3 * H)
+
+        def gru_bwd(dy, w_hh, h0, y, sv, dgi, dgh, dh0_out, carry, k):
+            t0 = k * Tc
+            hk = h0 if k == 0 else y[t0 - 1]
+            dhT = None if k == K - 1 else carry[(k + 1) & 1]
+            out = dh0_out if k == 0 else carry[k & 1]
+            ws = _rnn_workspace(nbytes, dev)
+            _abi.call("wsmg_gru_bwd", _p(dy[t0:]), _p(dhT), _p(w_hh), _p(hk), _p(m[t0:]), _p(y[t0:]), *[_p(s[t0:]) for s in sv],
+                      Tc, N, H, _p(dgi[t0:]), _p(dgh[t0:]), _p(out), _p(ws), _stream())
+            _rnn_launched()
+
+        for k in range(K - 1, -1, -1):
+            r0, r1 = k * rows, (k + 1) * rows
+            with torch.cuda.stream(sg):
+                gru_bwd(dy2, w_hh2, h02, y2, (sr2, sz2, sn2, sg2), dgi2, dgh2, dh02, carry2, k)
+            if multi:
+                e2 = torch.cuda.Event()
+                e2.record(sg)
+                sa.wait_event(e2)
+            with torch.cuda.stream(sa):
+                # ReLU of second_state_compress: d(pre-activation) = d(xc) where xc > 0
+                torch.ops.aten.threshold_backward.grad_input(torch.mm(dgi2r[r0:r1], w_ih2), xcr[r0:r1], 0.0, grad_input=dxc[r0:r1])
+                dstate_a = torch.mm(dxc[r0:r1], wc[:, :H])
+                dtext_a = torch.mm(dxc[r0:r1], wc[:, H:H + C])
+                dmap = torch.mm(dxc[r0:r1], wc[:, H + C:])
+                _abi.call("wsmg_attn_bwd" + ksfx, _p(qf[r0:r1]), _p(tokens[r0:r1]), _p(tokens[r0:r1]), _p(att_map[r0:r1]), _p(dmap),
+                          _p(None if datt is None else datt[r0:r1]), scale, rows, I, C, _p(dqf[r0:r1]), _p(dtokens[r0:r1]),
+                          _p(dtokens[r0:r1]), _stream())
+                torch.mm(dqf[r0:r1], wk2.t(), out=dq2[r0:r1])
+                torch.addmm(dtext_a, dq2[r0:r1], wq2, out=dtext[r0:r1])
+                _abi.call("wsmg_attn_shared_bwd" + tsfx, _p(q1[r0:r1]), _p(text_k), _p(text_v), _p(attn_text[r0:r1]), _p(dtext[r0:r1]),
+                          None, _p(inverse[r0:r1]), scale, rows, L, C, _p(dq1[r0:r1]), _p(dl[r0:r1]), _stream())
+                torch.addmm(dstate_a, dq1[r0:r1], wq1, out=dstate_r[r0:r1])
+            if multi:
+                ea = torch.cuda.Event()
+                ea.record(sa)
+                main.wait_event(ea)
+            gru_bwd(dstate, w_hh1, h01, y1, (sr1, sz1, sn1, sg1), dgi1, dgh1, dh01, carry1, k)      # main
+        d_state_in = torch.mm(dgi1.view(B, 3 * H), w_ih1) if ctx.needs_input_grad[1] else None
+        # gradients of the shared instruction sets (they feed the instruction branch's backward, on ITS stream): after the last
+        # attention chunk on the attention stream, joined into main below — by then GRU 1's last chunk has long hidden them
+        with torch.cuda.stream(sa):
+            member = torch.nn.functional.one_hot(inverse, U).to(torch.float32).t()            # [U, B]
+            dk = torch.matmul((member.unsqueeze(2) * dl.unsqueeze(0)).transpose(1, 2), q1).to(text_k.dtype)
+            dv = torch.matmul((member.unsqueeze(2) * attn_text.unsqueeze(0)).transpose(1, 2), dtext).to(text_v.dtype)
+        if multi:
+            ekv = torch.cuda.Event()
+            ekv.record(sa)
+            sl.wait_stream(main)
+            sl.wait_stream(sg)
+        # parameter gradients: full-batch GEMMs and column sums, off the chain
+        with torch.cuda.stream(sl):
+            g2 = dgi2r
+            dw_ih2, db_ih2 = g2.t() @ xc, g2.sum(0)
+            hp2 = torch.cat([h02.unsqueeze(0), y2[:-1]], dim=0) * m.unsqueeze(-1)
+            gh2 = dgh2.view(B, 3 * H)
+            dw_hh2, db_hh2 = gh2.t() @ hp2.view(B, H), gh2.sum(0)
+            dwc, dbc = dxc.t() @ x, dxc.sum(0)
+            dwk = (q2.t() @ dqf).reshape(wk_shape)
+            # (the key projection's bias adds the same number to every token's logit: it cancels in the softmax, gradient exactly 0)
+            dbk = torch.zeros(wk_shape[0], **f32) if params[9] is not None else None
+            dwq2, dbq2 = dq2.t() @ text_emb, dq2.sum(0)
+            dwq1, dbq1 = dq1.t() @ y1r, dq1.sum(0)
+            g1 = dgi1.view(B, 3 * H)
+            hp1 = torch.cat([h01.unsqueeze(0), y1[:-1]], dim=0) * m.unsqueeze(-1)
+            gh1 = dgh1.view(B, 3 * H)
+            dw_hh1, db_hh1 = gh1.t() @ hp1.view(B, H), gh1.sum(0)
+            dw_ih1, db_ih1 = g1.t() @ state_in, g1.sum(0)
+        if multi:
+            main.wait_event(ekv)
+            for p in params:
+                if p is not None:
+                    p._wsmg_grad_stream = sl       # wsmgmap.parallel.GradAllReducer packs this gradient behind that stream
+            for t in (dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2):
+                if t is not None:
+                    t.record_stream(main)              # read by the optimizer on the main stream behind the end-of-backward join
+            for t in (dk, dv):
+                t.record_stream(main)
+        # the map tokens' gradient: parked for the token mean's backward, which merges its broadcast row and the producing
+        # convolution's ReLU mask into it in one pass (ops.TokenGradSink), or returned
+        if sink is not None:
+            sink.park(dtokens)
+            dtokens = None
+        return (None, d_state_in, dtokens, dk, dv, None, None, None, dh01, dh02,
+                dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2)
+
+
+def recurrent_block(state_in, tokens, text, masks, h01, h02, net, n_env, chunks=4, sink=None, text_ready=None):
+    """-> (x [B, H] = GRU 2's outputs, att_map [B, I], h1_n [1, N, H], h2_n [1, N, H]).
+    state_in [B, in] (rows time-major, B = T * n_env); tokens [B, I, 256] map tokens (keys == values, the key projection
+    `net.text_map_k_layer` folded into the query); text = (keys [U, L, 256], values [U, L, 256], pad mask uint8 [U, L], inverse
+    int64 [B]) of the U unique instructions; masks [B, 1]; h01 / h02 [N, H]; net: the MGMapNet whose layers these are;
+    text_ready: an event after which `text` is complete (recorded on the instruction branch's stream), or None when the caller's
+    stream already waited."""
+    r1, r2 = net.state_encoder.rnn, net.second_state_encoder.rnn
+    tk, tv, tm, inv = text
+    cfg = dict(N=int(n_env), chunks=int(chunks), scale=float(net._scale_f), sink=sink, text_ready=text_ready)
+    return _RecurrentBlock.apply(
+        cfg, state_in.contiguous(), tokens.contiguous(), tk, tv, tm, inv, masks.reshape(-1).float().contiguous(), h01, h02,
+        r1.weight_ih_l0, r1.bias_ih_l0, r1.weight_hh_l0, r1.bias_hh_l0,
+        net.state_text_q_layer.weight, net.state_text_q_layer.bias, net.text_map_q_layer.weight, net.text_map_q_layer.bias,
+        net.text_map_k_layer.weight, net.text_map_k_layer.bias, net.second_state_compress[0].weight, net.second_state_compress[0].bias,
+        r2.weight_ih_l0, r2.bias_ih_l0, r2.weight_hh_l0, r2.bias_hh_l0)
