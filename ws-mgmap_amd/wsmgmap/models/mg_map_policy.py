@@ -88,7 +88,8 @@ class MGMapNet(nn.Module):
         self.att_map_t_m = None
         self._side_stream = None
         # time chunks of the pipelined recurrent core of the update path (wsmgmap/recurrent.py); 0 = the staged route
-        self.recurrent_chunks = 4
+        import os
+        self.recurrent_chunks = int(os.environ.get("WSMG_RECURRENT_CHUNKS", "4"))
         self.skip_pred_map_nchw = False   # set by BasePolicy around its own forward: it consumes sem_logits_nhwc
         self.sem_logits_nhwc = None
         self.sem_ce_rows = None           # the prediction monitor's per-sample loss when the fused classifier tail computed it
@@ -211,9 +212,24 @@ class MGMapNet(nn.Module):
         if (not train and not torch.is_grad_enabled() and ego_map.is_cuda and self.compute_dtype == torch.bfloat16
                 and os.environ.get("WSMG_ROLLOUT_FOLD", "1") != "0"):
             return self._map_stack_rollout(ego_map)
-        if ego_map.is_cuda:   # operands of all the map stack's convolutions in one launch (they are on the main stream only)
-            ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
+        laid = None
+        if ego_map.is_cuda:
+            # operands of all the map stack's convolutions in one launch — on the instruction branch's stream, beside the ego
+            # map's NCHW -> NHWC conversion (0.37 ms of pure HBM traffic) instead of in front of it (0.06 ms)
+            entry = getattr(self, "_entry_event", None)
+            if entry is not None and self.recurrent_chunks > 0:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream()
+                self._side_stream.wait_event(entry)          # the optimizer's writes to the parameters are complete there
+                with torch.cuda.stream(self._side_stream):
+                    ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
+                laid = torch.cuda.Event()
+                laid.record(self._side_stream)
+            else:
+                ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
         x = self._ego_to_nhwc(ego_map)
+        if laid is not None:
+            torch.cuda.current_stream().wait_event(laid)
         enc = self.map_encoder(x)
         # the stem's forward is a PERSISTENT kernel, one workgroup per CU: the instruction branch's persistent LSTM (16 workgroups
         # that claim their CUs) must not start beside it, or 16 of the stem's workgroups wait for the LSTM to finish and then
@@ -295,6 +311,7 @@ class MGMapNet(nn.Module):
         ops.reset_pass_state()
         entry = torch.cuda.Event()
         entry.record(torch.cuda.current_stream())
+        self._entry_event = entry
         ops.mark("entry")
         import os
         # Rollout (no autograd, RGB encoded from pixels): the instruction branch is queued FIRST and runs beside the frozen
@@ -307,6 +324,44 @@ class MGMapNet(nn.Module):
             text, side = self._encode_instruction(observations, entry)
         rgb_embedding, rgb_embedding_proj = self.rgb_encoder(observations)
         depth_embedding = self.depth_encoder(observations)
+        rows = ops.rows_route(rgb_embedding.float())   # rollout: every dense layer below is one launch (ops.linear_rows)
+        lin = lambda m, x, act=None: ops.linear_rows(x, m.weight, m.bias, act) if rows else m(x)  # noqa: E731
+
+        def dense_inputs():
+            """The rgb / depth parts of the first state encoder's input (mg_map_policy.py:209-216 of the reference)."""
+            out = []
+            if "rgb" in self._inputs:
+                if rows:   # AdaptiveAvgPool1d(1) + Flatten + Linear + ReLU
+                    b, c = rgb_embedding.shape[:2]
+                    out.append(ops.linear_rows(rgb_embedding.float().reshape(b, c, -1), self.rgb_linear[2].weight, self.rgb_linear[2].bias,
+                                               "relu", pool=int(np.prod(rgb_embedding.shape[2:]))))
+                else:
+                    feat = torch.flatten(rgb_embedding.float(), 2)
+                    if feat.is_cuda and not feat.requires_grad and feat.is_contiguous() and feat.shape[-1] <= 160:
+                        # AdaptiveAvgPool1d(1) + Flatten as one coalesced pass (torch's reduction over a 49-long innermost axis reads
+                        # the 51 MB feature at 1 TB/s: 50 us); the Linear + ReLU stay the module's
+                        out.append(self.rgb_linear[3](self.rgb_linear[2](ops.mean_last(feat))))
+                    else:
+                        out.append(self.rgb_linear(feat))
+            if "depth" in self._inputs:
+                if rows:   # Flatten + Linear + ReLU
+                    out.append(lin(self.depth_linear[1], torch.flatten(depth_embedding.float(), 1), "relu"))
+                else:
+                    out.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
+            return out
+
+        # Update path: these two depend on the cached features only, not on the map stack — they (and, under autograd, their
+        # backward: leaves of the graph) run on the instruction branch's stream beside the map stack instead of on the critical
+        # path between the map stack and the first recurrence (8 + 12 dependent launches of 5-20 us)
+        dense_early = (torch.is_grad_enabled() and not rows and not early and rgb_embedding.is_cuda and self.recurrent_chunks > 0)
+        if dense_early:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side_stream.wait_event(entry)
+            with torch.cuda.stream(self._side_stream):
+                state_in = dense_inputs()
+            dense_ready = torch.cuda.Event()
+            dense_ready.record(self._side_stream)
 
         self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
         # the map tokens feed their mean (state input) and the map attention: one merged, ReLU-masked gradient pass (TokenGradSink)
@@ -315,31 +370,18 @@ class MGMapNet(nn.Module):
         sink = self._token_sink
         map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
         self._token_sink = None
+        self._entry_event = None      # (a direct map_stack() call outside forward() lays its weights out on its own stream)
         ops.mark("map_stack", map_tokens)
         if not early:
             text, side = self._encode_instruction(observations, entry)   # queued after the map stack, runs beside it
 
-        rows = ops.rows_route(rgb_embedding.float())   # rollout: every dense layer below is one launch (ops.linear_rows)
-        lin = lambda m, x, act=None: ops.linear_rows(x, m.weight, m.bias, act) if rows else m(x)  # noqa: E731
-        state_in = []
-        if "rgb" in self._inputs:
-            if rows:   # AdaptiveAvgPool1d(1) + Flatten + Linear + ReLU
-                b, c = rgb_embedding.shape[:2]
-                state_in.append(ops.linear_rows(rgb_embedding.float().reshape(b, c, -1), self.rgb_linear[2].weight, self.rgb_linear[2].bias,
-                                                "relu", pool=int(np.prod(rgb_embedding.shape[2:]))))
-            else:
-                feat = torch.flatten(rgb_embedding.float(), 2)
-                if feat.is_cuda and not feat.requires_grad and feat.is_contiguous() and feat.shape[-1] <= 160:
-                    # AdaptiveAvgPool1d(1) + Flatten as one coalesced pass (torch's reduction over a 49-long innermost axis reads
-                    # the 51 MB feature at 1 TB/s: 50 us); the Linear + ReLU stay the module's
-                    state_in.append(self.rgb_linear[3](self.rgb_linear[2](ops.mean_last(feat))))
-                else:
-                    state_in.append(self.rgb_linear(feat))
-        if "depth" in self._inputs:
-            if rows:   # Flatten + Linear + ReLU
-                state_in.append(lin(self.depth_linear[1], torch.flatten(depth_embedding.float(), 1), "relu"))
-            else:
-                state_in.append(self.depth_linear(torch.flatten(depth_embedding.float(), 2)))
+        if dense_early:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(dense_ready)
+            for t in state_in:
+                t.record_stream(cur)
+        else:
+            state_in = dense_inputs()
         if "map" in self._inputs:
             tm = ops.token_mean(map_tokens, sink)
             state_in.append(lin(self.map_linear[2], tm, "relu") if rows else self.map_linear[3](self.map_linear[2](tm)))

@@ -25,6 +25,7 @@ import ctypes
 import torch
 
 from . import _abi
+from . import ops as _ops
 from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _stream
 
 MAX_BATCH = 8          # batch slots of the persistent GRU kernels
@@ -69,9 +70,7 @@ class _RecurrentBlock(torch.autograd.Function):
         K, Tc = chunk_plan(T, K)
         rows = Tc * N
         main = torch.cuda.current_stream()
-        capturing = torch.cuda.is_current_stream_capturing()
-        if K == 1 or capturing:
-            K, Tc, rows = 1, T, B
+        if K == 1:
             sa = sg = main
         else:
             sa, sg, _ = _side_streams(dev)
@@ -87,6 +86,8 @@ class _RecurrentBlock(torch.autograd.Function):
         sv1 = [torch.empty(T, N, H, **f32) for _ in range(4)]
         y2 = torch.empty(T, N, H, **f32)
         sv2 = [torch.empty(T, N, H, **f32) for _ in range(4)]
+        # (projection outputs start as their bias rows and are accumulated into: `addmm` with a 1-D bias takes hipBLASLt's bias-epilogue
+        #  route, whose heuristic picks ONE 256 x 128 macro-tile for a 128-row chunk — 64 us for a 33-MFLOP product)
         q1 = torch.empty(B, wq1.shape[0], **f32)
         text_emb = torch.empty(B, C, **f32)
         attn_text = torch.empty(B, L, **f32)
@@ -104,11 +105,11 @@ class _RecurrentBlock(torch.autograd.Function):
         ksfx = _sfx(tokens)
         nbytes = lib.wsmg_gru_workspace_bytes(Tc)
         if sa is not main:
+            # the buffers above come from the main stream's pool: whatever used their memory before is queued on main
+            sa.wait_stream(main)
+            sg.wait_stream(main)
             if text_ev is not None:
                 sa.wait_event(text_ev)
-            else:
-                sa.wait_stream(main)
-            sg.wait_stream(main)     # (h02, the buffers)
         elif text_ev is not None:
             main.wait_event(text_ev)
 
@@ -125,28 +126,39 @@ class _RecurrentBlock(torch.autograd.Function):
         for k in range(K):
             r0, r1 = k * rows, (k + 1) * rows
             gru(gi1v, w_hh1, b_hh1, h01, y1, sv1, k)                                   # main
+            _ops.mark("f.g1.%d" % k)
             if sa is not main:
                 e1 = torch.cuda.Event()
                 e1.record(main)
-                sa.wait_event(e1)
+                if k:
+                    sa.wait_event(e1)
             with torch.cuda.stream(sa):
-                torch.addmm(bq1, y1r[r0:r1], wq1.t(), out=q1[r0:r1])
+                if k == 0:
+                    q1.copy_(bq1.expand_as(q1))
+                    q2.copy_(bq2.expand_as(q2))
+                    xc.copy_(bc.expand_as(xc))
+                    gi2.copy_(b_ih2.expand_as(gi2))
+                    if sa is not main:
+                        sa.wait_event(e1)
+                q1[r0:r1].addmm_(y1r[r0:r1], wq1.t())
                 _abi.call("wsmg_attn_shared_fwd" + tsfx, _p(q1[r0:r1]), _p(text_k), _p(text_v), _p(text_mask), _p(inverse[r0:r1]),
                           scale, rows, L, C, _p(text_emb[r0:r1]), _p(attn_text[r0:r1]), _stream())
-                torch.addmm(bq2, text_emb[r0:r1], wq2.t(), out=q2[r0:r1])
+                q2[r0:r1].addmm_(text_emb[r0:r1], wq2.t())
                 torch.mm(q2[r0:r1], wk2, out=qf[r0:r1])
                 _abi.call("wsmg_attn_fwd" + ksfx, _p(qf[r0:r1]), _p(tokens[r0:r1]), _p(tokens[r0:r1]), None, scale, rows, I, C,
                           _p(map_emb[r0:r1]), _p(att_map[r0:r1]), _stream())
                 torch.cat([y1r[r0:r1], text_emb[r0:r1], map_emb[r0:r1]], dim=1, out=x[r0:r1])
-                torch.addmm(bc, x[r0:r1], wc.t(), out=xc[r0:r1])
+                xc[r0:r1].addmm_(x[r0:r1], wc.t())
                 torch.relu_(xc[r0:r1])
-                torch.addmm(b_ih2, xc[r0:r1], w_ih2.t(), out=gi2[r0:r1])
+                gi2[r0:r1].addmm_(xc[r0:r1], w_ih2.t())
+                _ops.mark("f.at.%d" % k)
             if sg is not main:
                 ea = torch.cuda.Event()
                 ea.record(sa)
                 sg.wait_event(ea)
             with torch.cuda.stream(sg):
                 gru(gi2v, w_hh2, b_hh2, h02, y2, sv2, k)
+                _ops.mark("f.g2.%d" % k)
         if sg is not main:
             main.wait_stream(sg)
             main.wait_stream(sa)
@@ -174,11 +186,10 @@ class _RecurrentBlock(torch.autograd.Function):
         U = text_k.shape[0]
         f32 = dict(device=dev, dtype=torch.float32)
         main = torch.cuda.current_stream()
-        capturing = torch.cuda.is_current_stream_capturing()
         params = ctx.params
         # side streams only when this pass SETS the parameter gradients (an accumulation into an existing .grad is a kernel autograd
-        # launches on the main stream: it would race the leaf stream) and nothing is being captured
-        multi = (not capturing) and all(p.grad is None for p in params if p is not None and p.is_leaf)
+        # launches on the main stream: it would race the leaf stream)
+        multi = ctx.cfg[1] > 1 and all(p.grad is None for p in params if p is not None and p.is_leaf)
         if multi:
             sa, sg, sl = _side_streams(dev)
             try:
@@ -207,9 +218,11 @@ class _RecurrentBlock(torch.autograd.Function):
         carry2 = [torch.empty(N, H, **f32) for _ in range(2)]
         carry1 = [torch.empty(N, H, **f32) for _ in range(2)]
         if multi:
-            for t in (dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dl, dstate, dtokens, dh02, dy2, *carry2) + ((datt,) if datt is not None else ()):
-                for s in (sa, sg, sl):
-                    t.record_stream(s)
+            # these are allocated from the main stream's pool and used on the others: they must not be handed to a later main-stream
+            # allocation while a side stream still works on them — a reference is held until the pass's final callbacks, which run
+            # after the leaf stream has been joined into main (cheaper than ~50 record_stream calls, and legal under graph capture)
+            keep = [dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dl, dstate, dtokens, dh02, dy2, datt, carry2, carry1]
+            torch.autograd.Variable._execution_engine.queue_callback(keep.clear)
             sg.wait_stream(main)
             sa.wait_stream(main)
         xcr = xc
@@ -231,6 +244,7 @@ class _RecurrentBlock(torch.autograd.Function):
             r0, r1 = k * rows, (k + 1) * rows
             with torch.cuda.stream(sg):
                 gru_bwd(dy2, w_hh2, h02, y2, (sr2, sz2, sn2, sg2), dgi2, dgh2, dh02, carry2, k)
+                _ops.mark("b.g2.%d" % k)
             if multi:
                 e2 = torch.cuda.Event()
                 e2.record(sg)
@@ -249,11 +263,13 @@ class _RecurrentBlock(torch.autograd.Function):
                 _abi.call("wsmg_attn_shared_bwd" + tsfx, _p(q1[r0:r1]), _p(text_k), _p(text_v), _p(attn_text[r0:r1]), _p(dtext[r0:r1]),
                           None, _p(inverse[r0:r1]), scale, rows, L, C, _p(dq1[r0:r1]), _p(dl[r0:r1]), _stream())
                 torch.addmm(dstate_a, dq1[r0:r1], wq1, out=dstate_r[r0:r1])
+                _ops.mark("b.at.%d" % k)
             if multi:
                 ea = torch.cuda.Event()
                 ea.record(sa)
                 main.wait_event(ea)
             gru_bwd(dstate, w_hh1, h01, y1, (sr1, sz1, sn1, sg1), dgi1, dgh1, dh01, carry1, k)      # main
+            _ops.mark("b.g1.%d" % k)
         d_state_in = torch.mm(dgi1.view(B, 3 * H), w_ih1) if ctx.needs_input_grad[1] else None
         # gradients of the shared instruction sets (they feed the instruction branch's backward, on ITS stream): after the last
         # attention chunk on the attention stream, joined into main below — by then GRU 1's last chunk has long hidden them
@@ -289,11 +305,6 @@ class _RecurrentBlock(torch.autograd.Function):
             for p in params:
                 if p is not None:
                     p._wsmg_grad_stream = sl       # wsmgmap.parallel.GradAllReducer packs this gradient behind that stream
-            for t in (dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2):
-                if t is not None:
-                    t.record_stream(main)              # read by the optimizer on the main stream behind the end-of-backward join
-            for t in (dk, dv):
-                t.record_stream(main)
         # the map tokens' gradient: parked for the token mean's backward, which merges its broadcast row and the producing
         # convolution's ReLU mask into it in one pass (ops.TokenGradSink), or returned
         if sink is not None:
