@@ -401,7 +401,8 @@ class MGMapNet(nn.Module):
                 t.record_stream(main)
             x, self.att_map_t_m, h1n, h2n = recurrent.recurrent_block(
                 state_in, map_tokens, text, masks, rnn_hidden_states[0], rnn_hidden_states[1], self, n_env,
-                chunks=self.recurrent_chunks, sink=sink, text_ready=text_ready)
+                chunks=self.recurrent_chunks, sink=sink, text_ready=text_ready,
+                streams=(side, getattr(self.map_decoder, "_side", None)))
             rnn_hidden_states[0:n1] = h1n
             rnn_hidden_states[n1:] = h2n
             ops.mark("gru2", x)

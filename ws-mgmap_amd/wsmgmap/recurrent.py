@@ -29,16 +29,21 @@ from . import ops as _ops
 from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _stream
 
 MAX_BATCH = 8          # batch slots of the persistent GRU kernels
-_streams = {}          # device index -> (attention stream, GRU-2 stream, leaf stream)
 
 
-def _side_streams(device):
-    s = _streams.get(device.index)
-    if s is None:
-        s = _streams[device.index] = tuple(torch.cuda.Stream(device) for _ in range(3))
-        from . import ops
-        ops._leaf_streams.append(s[2])      # (ops.reset_pass_state re-joins it if a backward pass died before its final callbacks)
-    return s
+def _roles(streams, main):
+    """(attention stream, GRU-2 stream, leaf stream) out of the caller's helper streams.  The block creates NO stream of its own: HIP
+    multiplexes a process's streams onto 4 hardware queues, and two streams that share a queue run their work in submission order
+    — with three private streams on top of the policy's (instruction branch, decoder branch) the attention stage of chunk k+1
+    queued behind GRU 2 of chunk k (measured: 200 us per chunk instead of 117).  The policy's two helper streams are idle while
+    this block runs, in both directions, so they are what it uses; the leaf work shares the attention stream (behind its last
+    chunk), which is also the stream the instruction branch's backward — the consumer of the shared sets' gradients — runs on."""
+    streams = [s for s in (streams or ()) if s is not None and s.cuda_stream != main.cuda_stream]
+    if not streams:
+        return main, main, main
+    sa = streams[0]
+    sg = streams[1] if len(streams) > 1 else streams[0]
+    return sa, sg, sa
 
 
 def usable(state_in, tokens, n_env, text, capturing_ok=True):
@@ -63,6 +68,7 @@ class _RecurrentBlock(torch.autograd.Function):
     def forward(ctx, cfg, state_in, tokens, text_k, text_v, text_mask, inverse, masks, h01, h02,
                 w_ih1, b_ih1, w_hh1, b_hh1, wq1, bq1, wq2, bq2, wk, bk, wc, bc, w_ih2, b_ih2, w_hh2, b_hh2):
         N, K, scale, sink, text_ev = cfg["N"], cfg["chunks"], cfg["scale"], cfg["sink"], cfg["text_ready"]
+        ctx.streams = cfg["streams"]
         B = state_in.shape[0]
         T = B // N
         H = w_hh1.shape[1]
@@ -70,10 +76,9 @@ class _RecurrentBlock(torch.autograd.Function):
         K, Tc = chunk_plan(T, K)
         rows = Tc * N
         main = torch.cuda.current_stream()
-        if K == 1:
-            sa = sg = main
-        else:
-            sa, sg, _ = _side_streams(dev)
+        sa, sg, _ = _roles(ctx.streams if K > 1 else None, main)
+        if sa is main:
+            K, Tc, rows = 1, T, B
         f32 = dict(device=dev, dtype=torch.float32)
         wk2 = wk.reshape(wk.shape[0], -1)
         I, C = tokens.shape[1], tokens.shape[2]
@@ -190,10 +195,13 @@ class _RecurrentBlock(torch.autograd.Function):
         # side streams only when this pass SETS the parameter gradients (an accumulation into an existing .grad is a kernel autograd
         # launches on the main stream: it would race the leaf stream)
         multi = ctx.cfg[1] > 1 and all(p.grad is None for p in params if p is not None and p.is_leaf)
+        sa, sg, sl = _roles(ctx.streams if multi else None, main)
+        multi = sa is not main
         if multi:
-            sa, sg, sl = _side_streams(dev)
             try:
                 _join_side_at_end(main, sl, strict=True)      # raises outside a backward pass (torch.autograd.grad of a test)
+                if sl not in _ops._leaf_streams:              # (ops.reset_pass_state re-joins it if a pass died before its callbacks)
+                    _ops._leaf_streams.append(sl)
             except RuntimeError:
                 multi = False
         if not multi:
@@ -314,16 +322,16 @@ class _RecurrentBlock(torch.autograd.Function):
                 dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2)
 
 
-def recurrent_block(state_in, tokens, text, masks, h01, h02, net, n_env, chunks=4, sink=None, text_ready=None):
+def recurrent_block(state_in, tokens, text, masks, h01, h02, net, n_env, chunks=4, sink=None, text_ready=None, streams=None):
     """-> (x [B, H] = GRU 2's outputs, att_map [B, I], h1_n [1, N, H], h2_n [1, N, H]).
     state_in [B, in] (rows time-major, B = T * n_env); tokens [B, I, 256] map tokens (keys == values, the key projection
     `net.text_map_k_layer` folded into the query); text = (keys [U, L, 256], values [U, L, 256], pad mask uint8 [U, L], inverse
     int64 [B]) of the U unique instructions; masks [B, 1]; h01 / h02 [N, H]; net: the MGMapNet whose layers these are;
     text_ready: an event after which `text` is complete (recorded on the instruction branch's stream), or None when the caller's
-    stream already waited."""
+    stream already waited; streams: up to two helper streams that are idle while the block runs (see _roles), None = one stream."""
     r1, r2 = net.state_encoder.rnn, net.second_state_encoder.rnn
     tk, tv, tm, inv = text
-    cfg = dict(N=int(n_env), chunks=int(chunks), scale=float(net._scale_f), sink=sink, text_ready=text_ready)
+    cfg = dict(N=int(n_env), chunks=int(chunks), scale=float(net._scale_f), sink=sink, text_ready=text_ready, streams=tuple(streams or ()))
     return _RecurrentBlock.apply(
         cfg, state_in.contiguous(), tokens.contiguous(), tk, tv, tm, inv, masks.reshape(-1).float().contiguous(), h01, h02,
         r1.weight_ih_l0, r1.bias_ih_l0, r1.weight_hh_l0, r1.bias_hh_l0,
