@@ -217,7 +217,7 @@ class MGMapNet(nn.Module):
             # operands of all the map stack's convolutions in one launch — on the instruction branch's stream, beside the ego
             # map's NCHW -> NHWC conversion (0.37 ms of pure HBM traffic) instead of in front of it (0.06 ms)
             entry = getattr(self, "_entry_event", None)
-            if entry is not None and self.recurrent_chunks > 0:
+            if entry is not None and self.recurrent_chunks > 0 and not torch.cuda.is_current_stream_capturing():
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream()
                 self._side_stream.wait_event(entry)          # the optimizer's writes to the parameters are complete there
@@ -353,7 +353,11 @@ class MGMapNet(nn.Module):
         # Update path: these two depend on the cached features only, not on the map stack — they (and, under autograd, their
         # backward: leaves of the graph) run on the instruction branch's stream beside the map stack instead of on the critical
         # path between the map stack and the first recurrence (8 + 12 dependent launches of 5-20 us)
-        dense_early = (torch.is_grad_enabled() and not rows and not early and rgb_embedding.is_cuda and self.recurrent_chunks > 0)
+        # (not under a HIP-graph capture: wsmgmap.graph captures the one-stream form of these three — this, the weight layout
+        #  and the pipelined recurrent core; the end of a capture that held the three-stream form crashed in the runtime)
+        capturing = rgb_embedding.is_cuda and torch.cuda.is_current_stream_capturing()
+        dense_early = (torch.is_grad_enabled() and not rows and not early and rgb_embedding.is_cuda and self.recurrent_chunks > 0
+                       and not capturing)
         if dense_early:
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream()
@@ -402,7 +406,7 @@ class MGMapNet(nn.Module):
             x, self.att_map_t_m, h1n, h2n = recurrent.recurrent_block(
                 state_in, map_tokens, text, masks, rnn_hidden_states[0], rnn_hidden_states[1], self, n_env,
                 chunks=self.recurrent_chunks, sink=sink, text_ready=text_ready,
-                streams=(side, getattr(self.map_decoder, "_side", None)))
+                streams=None if capturing else (side, getattr(self.map_decoder, "_side", None)))
             rnn_hidden_states[0:n1] = h1n
             rnn_hidden_states[n1:] = h2n
             ops.mark("gru2", x)
