@@ -481,7 +481,7 @@ def _dp_worker(rank, world, port, q, mode="f32", inject=False, backend="gloo"):
         pol = _train_mode(_policy(num_proc=2, compute_dtype=mode))
         red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20, single_rank_exchange=True)
         red.broadcast_parameters(pol)
-        worst = 0.0
+        worst, worst_name = 0.0, None
         for it in range(3):                 # 0: discovery pass; 1, 2: hook / overlap path with side-stream event waits
             grads_of(pol, rank)
             if it == 0 and inject and rank == 1:
@@ -495,10 +495,12 @@ def _dp_worker(rank, world, port, q, mode="f32", inject=False, backend="gloo"):
                     continue
                 scale = float(want[n].abs().max()) + 1e-12
                 # identical arithmetic on both sides except the float32 atomics' summation order in dW
-                worst = max(worst, float((got[n] - want[n]).abs().max()) / scale)
+                e_n = float((got[n] - want[n]).abs().max()) / scale
+                if e_n > worst:
+                    worst, worst_name = e_n, f"{n} (update {it})"
         red.check()
         layout = [red._index[id(p)] for b in red._buckets for p in b["params"]]
-        info = dict(live_bytes=red.live_bytes, buckets=red.num_buckets, worst=worst, mode=mode, injected_order_mismatch=bool(inject),
+        info = dict(live_bytes=red.live_bytes, buckets=red.num_buckets, worst=worst, worst_name=worst_name, mode=mode, injected_order_mismatch=bool(inject),
                     layout_crc=__import__("zlib").crc32(repr(layout).encode()), stats=red.stats(),
                     differs_from_own=max(float((want[n] - own[n]).abs().max()) for n in want))
         q.put((rank, "ok", info))

@@ -225,3 +225,135 @@ def test_recurrent_block_alone_vs_float64_autograd():
             assert err <= 3e-5 * max(1e-3, float(r.abs().max())), (c, i, err, float(r.abs().max()))
     for i, (g1, g4) in enumerate(zip(outs[1], outs[4])):
         assert float((g1 - g4).abs().max()) <= 1e-5 * max(1e-3, float(g1.abs().max())), i
+
+
+# ----------------------------------------------------------------------------- data-parallel launch path
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_soak_worker(port, q, queues, updates):
+    """One rank over RCCL on this box's GPU: `updates` teacher-forcing updates (bf16, T = 16 x N = 8, the pipelined recurrent core on
+    its three streams, decoder and instruction side streams, multi-tensor Adam) with the gradient exchange, then the same from the
+    same state without it."""
+    if queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(queues)       # before the HIP runtime starts in this process
+    else:
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+    for p in (ROOT, os.path.join(ROOT, "ws-mgmap_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        import torch.distributed as dist
+        import bench
+        import test_gpu_round2 as r2
+        from wsmgmap import ops
+        from wsmgmap.common.aux_losses import AuxLosses
+        from wsmgmap.optim import Adam
+        from wsmgmap.parallel import GradAllReducer
+        torch.cuda.set_device(0)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        T_, N = 16, 8
+        state = r2._default_state()
+        obs, prev, masks, weights = bench.synth_batch(T_, N, torch.device("cuda"), 5)
+        AuxLosses.activate()
+
+        def run(exchange):
+            pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=state))
+            assert pol.net.recurrent_chunks == 4
+            opt = Adam(pol.parameters(), lr=2.5e-4)
+            red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20, single_rank_exchange=True) if exchange else None
+            if red:
+                red.broadcast_parameters(pol)
+            losses = []
+            for _ in range(updates):
+                opt.zero_grad(set_to_none=True)
+                AuxLosses.clear()
+                o = dict(obs)
+                pred, aux = pol(o, torch.zeros(2, N, 512, device="cuda"), prev, masks, weights)
+                loss = bench.dagger_loss(pred, aux, o["waypoint"], weights)
+                loss.backward()
+                if red:
+                    red.finish()
+                opt.step()
+                losses.append(loss.detach())
+            torch.cuda.synchronize()
+            if red:
+                red.check()
+            ops.check_rnn_status()          # raises on any persistent-RNN timeout of the run
+            return [float(x) for x in losses], (red.stats() if red else None)
+        with_x, stats = run(True)
+        without, _ = run(False)
+        q.put(("ok", dict(with_exchange=with_x, without=without, stats=stats, queues=os.environ.get("GPU_MAX_HW_QUEUES"))))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("error", traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("queues", [0, 8], ids=["hwq_default4", "hwq8"])
+def test_data_parallel_soak_over_rccl_beside_the_persistent_kernels(queues):
+    """The N > 1 launch path as far as a 1-GPU box can take it (common_trainer.py:35-38,60-66 of the reference): 50 updates with the
+    whole gradient exchange going through RCCL (one-rank communicator: its kernels, its streams, the bucket hooks inside backward)
+    WHILE the pipelined recurrent core runs up to three persistent kernels on three streams and the decoder / instruction branches
+    run on theirs — with HIP's default 4 hardware queues and with GPU_MAX_HW_QUEUES=8 (what bench.py sets for --gpus N).  The
+    persistent kernels are ordinary (non-cooperative) launches that rely on their 32 workgroups being co-resident: zero timeouts,
+    and the loss sequence equal BIT FOR BIT to the same 50 updates without the exchange (world = 1: averaging changes nothing)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_dp_soak_worker, args=(_free_port(), q, queues, 50))
+    p.start()
+    status, info = q.get(timeout=900)
+    p.join(timeout=120)
+    assert status == "ok", info
+    assert info["queues"] == (str(queues) if queues else None)
+    assert len(info["with_exchange"]) == 50 and info["with_exchange"] == info["without"], \
+        [(i, a, b) for i, (a, b) in enumerate(zip(info["with_exchange"], info["without"])) if a != b][:5]
+    assert info["with_exchange"][-1] < info["with_exchange"][0]          # it trained
+    assert info["stats"]["updates"] == 50
+
+
+def test_rnn_timeout_in_a_data_parallel_run_names_the_likely_cause():
+    """a persistent-RNN timeout seen by GradAllReducer.finish() is agreed on by the ranks (gradients zeroed) and
+    raised at the next finish() as GradExchangeError WITH the likely cause in a data-parallel run — the persistent kernels'
+    workgroups not co-resident beside the collective's kernels — and the switches that fall back to one persistent kernel at a
+    time.  One-rank gloo group in this process; the timeout is forced with the spin-limit hook."""
+    import torch.distributed as dist
+    from wsmgmap import _abi, ops
+    from wsmgmap.parallel import GradAllReducer, GradExchangeError
+    torch.cuda.synchronize()
+    ops.check_rnn_status()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    L = _abi.lib()
+    try:
+        g = torch.Generator().manual_seed(3)
+        gi = torch.randn(6, 4, 1536, generator=g).cuda()
+        w = torch.nn.Parameter((torch.randn(1536, 512, generator=g) * 0.04).cuda())
+        b, h0, m = torch.zeros(1536).cuda(), torch.randn(4, 512, generator=g).cuda(), torch.ones(6, 4).cuda()
+        red = GradAllReducer([w], single_rank_exchange=True)
+        ops.masked_gru(gi, w, b, h0, m).sum().backward()
+        red.finish()                                   # discovery pass, clean
+        w.grad = None
+        L.wsmg_rnn_debug_spin_limit(1)
+        ops.masked_gru(gi, w, b, h0, m).sum().backward()
+        torch.cuda.synchronize()
+        L.wsmg_rnn_debug_spin_limit(0)
+        red.finish()                                   # sees the timeout, takes part in the exchange, zeroes the gradients
+        torch.cuda.synchronize()
+        assert float(w.grad.abs().max()) == 0.0
+        with pytest.raises(GradExchangeError) as ei:
+            red.check()
+        msg = str(ei.value)
+        assert "timed out" in msg and "co-resident" in msg and "recurrent_chunks" in msg and "WSMG_DECODER_STREAMS" in msg, msg
+    finally:
+        L.wsmg_rnn_debug_spin_limit(0)
+        torch.cuda.synchronize()
+        L.wsmg_rnn_status(1)
+        dist.destroy_process_group()

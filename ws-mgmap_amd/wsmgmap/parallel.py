@@ -75,6 +75,8 @@ class GradAllReducer:
         self._timing = []         # per update: (host seconds inside finish(), event at finish() entry, event after the last wait)
         self._stats = dict(updates=0, host_wait_ms=0.0, exposed_ms=0.0, exposed_max_ms=0.0)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        for p in self.params:
+            p._wsmg_reducer = True      # wsmgmap.recurrent: this parameter's gradient-ready hook is ours (it follows _wsmg_grad_stream)
 
     # -- setup ---------------------------------------------------------------------
     def broadcast_parameters(self, module, src=0):
@@ -287,7 +289,13 @@ class GradAllReducer:
             try:
                 _abi.check_rnn_status()
             except _abi.WsmgError as e:   # agreed on with the other ranks below: no rank may leave the collectives alone
-                self._note(str(e))
+                # in a data-parallel run the first suspect is co-residency: a persistent GRU / LSTM kernel needs all of its 32 / 16
+                # workgroups running at once and spins (bounded) for its peers — beside the collective library's kernels and up to
+                # three persistent kernels of the pipelined recurrent core, a workgroup that is not scheduled in time looks like this
+                self._note(str(e) + " [data-parallel run: most likely the persistent kernels' workgroups were not co-resident beside "
+                           "the collective's kernels — fall back to one persistent kernel at a time with policy.net.recurrent_chunks = 0 "
+                           "(WSMG_RECURRENT_CHUNKS=0) and WSMG_DECODER_STREAMS=0, and check GPU_MAX_HW_QUEUES (8 for one process per GPU, "
+                           "unset when ranks share a GPU)]")
         if self._buckets is None:  # first update: discovery pass, exchange synchronously
             self._agree_on_layout()
             self._build_buckets()

@@ -192,9 +192,17 @@ class _RecurrentBlock(torch.autograd.Function):
         f32 = dict(device=dev, dtype=torch.float32)
         main = torch.cuda.current_stream()
         params = ctx.params
-        # side streams only when this pass SETS the parameter gradients (an accumulation into an existing .grad is a kernel autograd
-        # launches on the main stream: it would race the leaf stream)
-        multi = ctx.cfg[1] > 1 and all(p.grad is None for p in params if p is not None and p.is_leaf)
+        # Side streams only when this pass SETS the gradients of leaf parameters that nothing but this block uses: the parameter
+        # gradients are produced on the leaf stream, so they must not pass through autograd's AccumulateGrad — it runs on the main
+        # stream right after this function returns and, whenever it does not simply keep the tensor (an existing .grad to add to; a
+        # tensor it decides to copy), launches a kernel there that reads a gradient the leaf stream has not written yet (seen as
+        # one wrong weight gradient in 8 runs of two ranks sharing a GPU).  In that mode this function ASSIGNS p.grad itself, runs
+        # the parameters' post-accumulate hooks (wsmgmap.parallel.GradAllReducer's bucket hooks) and returns None for them.
+        # A stock DistributedDataParallel wrap hooks the AccumulateGrad nodes instead: there the block stays on one stream.
+        own = [p for p in params if p is not None and p.requires_grad]
+        multi = ctx.cfg[1] > 1 and all(p.is_leaf and p.grad is None for p in own)
+        if multi and torch.distributed.is_available() and torch.distributed.is_initialized():
+            multi = all(getattr(p, "_wsmg_reducer", False) for p in own)
         sa, sg, sl = _roles(ctx.streams if multi else None, main)
         multi = sa is not main
         if multi:
@@ -308,18 +316,23 @@ class _RecurrentBlock(torch.autograd.Function):
             gh1 = dgh1.view(B, 3 * H)
             dw_hh1, db_hh1 = gh1.t() @ hp1.view(B, H), gh1.sum(0)
             dw_ih1, db_ih1 = g1.t() @ state_in, g1.sum(0)
+        pgrads = [dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2]
         if multi:
             main.wait_event(ekv)
-            for p in params:
-                if p is not None:
-                    p._wsmg_grad_stream = sl       # wsmgmap.parallel.GradAllReducer packs this gradient behind that stream
+            for i, p in enumerate(params):
+                if p is None or not p.requires_grad or pgrads[i] is None:
+                    continue
+                p._wsmg_grad_stream = sl           # wsmgmap.parallel.GradAllReducer packs this gradient behind that stream
+                p.grad = pgrads[i]
+                for hook in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
+                    hook(p)
+            pgrads = [None] * len(pgrads)
         # the map tokens' gradient: parked for the token mean's backward, which merges its broadcast row and the producing
         # convolution's ReLU mask into it in one pass (ops.TokenGradSink), or returned
         if sink is not None:
             sink.park(dtokens)
             dtokens = None
-        return (None, d_state_in, dtokens, dk, dv, None, None, None, dh01, dh02,
-                dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2)
+        return (None, d_state_in, dtokens, dk, dv, None, None, None, dh01, dh02, *pgrads)
 
 
 def recurrent_block(state_in, tokens, text, masks, h01, h02, net, n_env, chunks=4, sink=None, text_ready=None, streams=None):
