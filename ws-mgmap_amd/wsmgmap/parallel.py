@@ -65,6 +65,7 @@ class GradAllReducer:
         self._buckets = None      # list of dicts: params, flat buffer, pending count
         self._where = {}          # id(param) -> (bucket index, offset)
         self._works = []
+        self._seen = set()        # parameters whose gradient-ready hook ran in the running update
         self._next = 0            # buckets are issued in index order: the next one to launch
         self._local_error = None  # first local problem of the running update
         self._flag = None         # device int32 [1]: this rank's error flag, summed over the ranks
@@ -215,6 +216,11 @@ class GradAllReducer:
     def _on_grad(self, p):
         if self._off:
             return
+        # once per parameter and update: wsmgmap.recurrent assigns the gradients it produces on its leaf stream itself and calls this
+        # hook from its backward; autograd's AccumulateGrad node may call it again for the same parameter afterwards
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         if self._buckets is None:
             self._order.append(p)
             return
@@ -236,6 +242,7 @@ class GradAllReducer:
 
     def reset(self):
         self._order, self._buckets, self._where, self._works = [], None, {}, []
+        self._seen = set()
         self._next = 0
         self._local_error = None
 
@@ -307,7 +314,11 @@ class GradAllReducer:
             if self._next < len(self._buckets):
                 # (only on an error path: a bucket never became ready.  The rest go out now, in index order — the order the
                 # peers issue theirs in — with zeros for the missing gradients.)
-                self._note("a live parameter received no gradient in this update")
+                missing = [(self._index[id(q)], tuple(q.shape)) for b in self._buckets[self._next:] for q in b["params"] if q.grad is None]
+                self._note("a live parameter received no gradient in this update"
+                           + (f" (parameter index, shape: {missing[:4]}{' ...' if len(missing) > 4 else ''})" if missing else
+                              f" (every gradient exists, but bucket {self._next} still waits for {self._buckets[self._next]['pending']} "
+                              "gradient-ready hook call(s))"))
                 while self._next < len(self._buckets):
                     self._launch(self._next)
                     self._next += 1
@@ -325,6 +336,7 @@ class GradAllReducer:
             b["pending"] = b["total"]
             b["launched"] = False
         self._works = []
+        self._seen = set()
         self._next = 0
         if ev0 is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
