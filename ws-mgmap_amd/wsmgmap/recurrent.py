@@ -237,7 +237,11 @@ class _RecurrentBlock(torch.autograd.Function):
             # these are allocated from the main stream's pool and used on the others: they must not be handed to a later main-stream
             # allocation while a side stream still works on them — a reference is held until the pass's final callbacks, which run
             # after the leaf stream has been joined into main (cheaper than ~50 record_stream calls, and legal under graph capture)
-            keep = [dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dl, dstate, dtokens, dh02, dy2, datt, carry2, carry1]
+            # — and so do the tensors SAVED by the forward pass: autograd drops them the moment this function returns, long before
+            # the leaf stream's GEMMs have read x, xc, q2, text_emb, y1, y2, ... (seen as one wrong weight gradient in ~8 runs of two
+            # ranks sharing a GPU, where the leaf stream starts late)
+            keep = [dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dl, dstate, dtokens, dh02, dy2, datt, carry2, carry1,
+                    list(ctx.saved_tensors)]
             torch.autograd.Variable._execution_engine.queue_callback(keep.clear)
             sg.wait_stream(main)
             sa.wait_stream(main)
