@@ -271,6 +271,12 @@ def _dp_soak_worker(port, q, queues, updates):
             red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20, single_rank_exchange=True) if exchange else None
             if red:
                 red.broadcast_parameters(pol)
+            else:
+                # under an initialised process group the pipelined core keeps its chunked, leaf-stream backward only for parameters
+                # whose gradient-ready hook is GradAllReducer's (a stock DDP wrap hooks AccumulateGrad instead): the comparison run
+                # must take the same route — full-batch GEMMs round differently from four 128-row chunks, in the sixth digit
+                for p_ in pol.parameters():
+                    p_._wsmg_reducer = True
             losses = []
             for _ in range(updates):
                 opt.zero_grad(set_to_none=True)
