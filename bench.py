@@ -335,6 +335,10 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     if os.environ.get("WSMG_BENCH_WINDOW"):        # diagnostic: another window length (1 = an event per update)
         WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
     marks = []
+    import gc
+    if os.environ.get("WSMG_BENCH_GC") == "0":      # diagnostic: are the slow updates the host's garbage collector?
+        gc.collect()
+        gc.disable()
     t0 = time.perf_counter()
     host = 0.0
     for i in range(steps):
@@ -362,6 +366,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
                                  ms_per_update_first_window=round(per[0], 3),
                                  ms_per_update_second_half=round(sum(tail) / len(tail), 3),
                                  note="HIP-event time of consecutive 50-update windows inside the same timed region")
+    gc.enable()
     if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
         print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
     if args.dp:

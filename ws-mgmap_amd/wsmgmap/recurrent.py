@@ -36,14 +36,16 @@ def _roles(streams, main):
     multiplexes a process's streams onto 4 hardware queues, and two streams that share a queue run their work in submission order
     — with three private streams on top of the policy's (instruction branch, decoder branch) the attention stage of chunk k+1
     queued behind GRU 2 of chunk k (measured: 200 us per chunk instead of 117).  The policy's two helper streams are idle while
-    this block runs, in both directions, so they are what it uses; the leaf work shares the attention stream (behind its last
-    chunk), which is also the stream the instruction branch's backward — the consumer of the shared sets' gradients — runs on."""
+    this block runs, in both directions, so they are what it uses.  The attention stream is the instruction branch's — the stream
+    that branch's backward, the consumer of the shared sets' gradients, runs on; the leaf work goes behind GRU 2's last chunk on
+    the other one (the decoder branch's, idle until the map stack's backward reaches that branch), so that it does not delay the
+    instruction branch's persistent LSTM backward into the map stack's one-workgroup-per-CU kernels."""
     streams = [s for s in (streams or ()) if s is not None and s.cuda_stream != main.cuda_stream]
     if not streams:
         return main, main, main
     sa = streams[0]
     sg = streams[1] if len(streams) > 1 else streams[0]
-    return sa, sg, sa
+    return sa, sg, sg
 
 
 def usable(state_in, tokens, n_env, text, capturing_ok=True):
@@ -301,7 +303,7 @@ class _RecurrentBlock(torch.autograd.Function):
             ekv = torch.cuda.Event()
             ekv.record(sa)
             sl.wait_stream(main)
-            sl.wait_stream(sg)
+            sl.wait_event(ekv)        # (the attention stream's buffers; sl is the GRU-2 stream itself or the same stream)
         # parameter gradients: full-batch GEMMs and column sums, off the chain
         with torch.cuda.stream(sl):
             g2 = dgi2r
