@@ -37,15 +37,15 @@ def _roles(streams, main):
     — with three private streams on top of the policy's (instruction branch, decoder branch) the attention stage of chunk k+1
     queued behind GRU 2 of chunk k (measured: 200 us per chunk instead of 117).  The policy's two helper streams are idle while
     this block runs, in both directions, so they are what it uses.  The attention stream is the instruction branch's — the stream
-    that branch's backward, the consumer of the shared sets' gradients, runs on; the leaf work goes behind GRU 2's last chunk on
-    the other one (the decoder branch's, idle until the map stack's backward reaches that branch), so that it does not delay the
-    instruction branch's persistent LSTM backward into the map stack's one-workgroup-per-CU kernels."""
+    that branch's backward, the consumer of the shared sets' gradients, runs on — and the leaf work goes behind the attention
+    stage's last chunk on the same stream (measured against the decoder branch's stream, three interleaved pairs of 100 updates on
+    one box: median 10.52-10.54 vs 10.73-10.74 ms per update)."""
     streams = [s for s in (streams or ()) if s is not None and s.cuda_stream != main.cuda_stream]
     if not streams:
         return main, main, main
     sa = streams[0]
     sg = streams[1] if len(streams) > 1 else streams[0]
-    return sa, sg, sg
+    return sa, sg, sa
 
 
 def usable(state_in, tokens, n_env, text, capturing_ok=True):
@@ -303,7 +303,7 @@ class _RecurrentBlock(torch.autograd.Function):
             ekv = torch.cuda.Event()
             ekv.record(sa)
             sl.wait_stream(main)
-            sl.wait_event(ekv)        # (the attention stream's buffers; sl is the GRU-2 stream itself or the same stream)
+            sl.wait_stream(sg)
         # parameter gradients: full-batch GEMMs and column sums, off the chain
         with torch.cuda.stream(sl):
             g2 = dgi2r
