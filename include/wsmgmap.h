@@ -582,6 +582,14 @@ int wsmg_attn_fp8_prep(const float* q, const float* k_sets, const float* v_sets,
  * rgb_linear (mg_map_policy.py:90-96) over the 7 x 7 positions of the RGB feature. */
 int wsmg_mean_rows(const float* x, int64_t R, int n, float* out, wsmg_stream_t stream);
 
+/* Distinct rows of an instruction-token matrix in one launch (the policy encodes every distinct instruction of a teacher-forcing
+ * batch once instead of T x N times: instruction_encoder.py:68-93 / mg_map_policy.py:182 of the reference run the encoder over
+ * every row).  tokens [B][L]: float32 (is_f32 != 0: integer-valued floats, as dagger_trainer.py:614-617 hands them over) or int64;
+ * B <= 4096.  uniq [B][L] int64: rows 0 .. U-1 are the distinct rows in order of first appearance; inverse [B] int64: row b is
+ * uniq[inverse[b]]; meta [2 + B] int64: meta[0] = U, meta[1] = the longest row (non-zero tokens), meta[2 + u] = length of uniq[u]. */
+int wsmg_instruction_dedup(const void* tokens, int is_f32, int B, int L, long long* uniq, long long* inverse, long long* meta,
+                           wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

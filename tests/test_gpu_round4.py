@@ -363,3 +363,34 @@ def test_rnn_timeout_in_a_data_parallel_run_names_the_likely_cause():
         torch.cuda.synchronize()
         L.wsmg_rnn_status(1)
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- instruction dedup in one launch
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int64])
+def test_instruction_dedup_in_one_launch_matches_torch_unique(dtype):
+    """csrc/wsmg_dedup.hip against torch.unique(dim=0): the same SET of distinct rows, inverse reconstructs the input exactly,
+    rows in order of first appearance, lengths = non-zero tokens; cases: the teacher-forcing pattern (N rows repeated over T),
+    all rows distinct, all rows equal, rows that differ in the last token only, B = 1, a wide batch (B = 2400)."""
+    from wsmgmap.models.encoders.instruction_encoder import InstructionEncoder
+    g = torch.Generator().manual_seed(11)
+
+    def rows(n, L=200, length=80):
+        t = torch.zeros(n, L, dtype=torch.int64)
+        t[:, :length] = torch.randint(1, 2504, (n, length), generator=g)
+        return t
+    base = rows(8)
+    last = rows(1).repeat(6, 1)
+    last[:, 79] = torch.arange(1, 7)
+    cases = [base.repeat(64, 1), rows(300), rows(1).repeat(77, 1), last, rows(1), torch.cat([rows(40, length=37), rows(5)]).repeat(53, 1)[:2400],
+             torch.cat([rows(3, length=200), torch.zeros(2, 200, dtype=torch.int64)])]
+    for t in cases:
+        tok = t.to(dtype).cuda()
+        uniq, inverse, len_host, len_dev = InstructionEncoder._dedup_fused(tok)
+        torch.cuda.synchronize()
+        ref_u, ref_inv = torch.unique(t, dim=0, return_inverse=True)
+        assert uniq.shape[0] == ref_u.shape[0]
+        assert torch.equal(uniq.cpu()[inverse.cpu()], t)                           # exact reconstruction
+        assert set(map(tuple, uniq.cpu().tolist())) == set(map(tuple, ref_u.tolist()))
+        first = [int((inverse.cpu() == u).nonzero()[0]) for u in range(uniq.shape[0])]
+        assert first == sorted(first)                                              # order of first appearance
+        assert torch.equal(len_host, (uniq.cpu() != 0).sum(1)) and torch.equal(len_dev.cpu(), len_host)

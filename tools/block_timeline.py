@@ -53,6 +53,16 @@ for r, m in acc.items():
     base = d.get("f:state_in")
     for n, e in m:
         tot.setdefault(n, []).append(base.elapsed_time(e) * 1e3)
-print("event                 us after f:state_in (mean of %d updates)" % reps)
+print("event                 us after f:state_in (mean / max of %d updates)" % reps)
 for n, v in tot.items():
-    print("%-20s %9.1f" % (n, sum(v) / len(v)))
+    print("%-20s %9.1f %9.1f" % (n, sum(v) / len(v), max(v)))
+# intervals per update: where do slow updates lose their time?
+names = list(tot)
+def col(n): return tot[n]
+pairs = [("f:entry", "f:map_stack"), ("f:map_stack", "f:state_in"), ("f:state_in", "f:gru2"), ("f:gru2", "b:gru2"), ("b:gru2", "b:state_in"),
+         ("b:state_in", "b:map_stack"), ("b:map_stack", "f:backward_done")]
+print("\ninterval                         med      p90      max   (us, over %d updates)" % reps)
+for a, b in pairs:
+    if a in tot and b in tot:
+        d = sorted(y - x for x, y in zip(col(a), col(b)))
+        print("%-14s -> %-14s %8.1f %8.1f %8.1f" % (a, b, d[len(d) // 2], d[int(len(d) * .9)], d[-1]))

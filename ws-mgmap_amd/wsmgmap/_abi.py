@@ -136,6 +136,7 @@ _SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
 _SIG["wsmg_group_norm_nhwc_bf16"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]
 _SIG["wsmg_rnn_status"] = [c_i]
 _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
+_SIG["wsmg_instruction_dedup"] = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
 _SIG["wsmg_conv_debug_win3_tile"] = [c_i]
 _SIG["wsmg_copy_multi"] = [c_p, c_i, c_p]
 _SIG["wsmg_linear_rows"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]

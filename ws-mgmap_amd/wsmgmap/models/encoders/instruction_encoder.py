@@ -44,6 +44,8 @@ class InstructionEncoder(nn.Module):
         row, a 1-D unique over the B hashes, and an exact on-device check (a hash collision falls back
         to torch.unique(dim=0)).  Returns (unique rows [U, L], inverse [B], lengths on host, on device)."""
         B, L = tokens.shape
+        if tokens.is_cuda and 0 < B <= 4096 and tokens.is_contiguous() and tokens.dtype in (torch.int64, torch.float32):
+            return InstructionEncoder._dedup_fused(tokens)
         memo = InstructionEncoder._diag_memo if os.environ.get("WSMG_DIAG_DEDUP_MEMO") == "1" else None
         if memo is not None and memo[0] == (B, L):   # diagnostic only (static inputs): no host read-back at all
             U, host, inverse = memo[1], memo[2], memo[3]
@@ -74,6 +76,25 @@ class InstructionEncoder(nn.Module):
             InstructionEncoder._diag_memo = ((B, L), U, host, inverse)
         return uniq, inverse, host[1:], lengths
 
+    @staticmethod
+    def _dedup_fused(tokens):
+        """The same result in ONE launch and ONE small read-back (csrc/wsmg_dedup.hip): distinct rows in order of first appearance.
+        tokens: int64 or integer-valued float32 [B, L] on the GPU."""
+        import ctypes
+        from ... import _abi, ops
+        B, L = tokens.shape
+        dev = tokens.device
+        uniq = torch.empty(B, L, device=dev, dtype=torch.int64)
+        inverse = torch.empty(B, device=dev, dtype=torch.int64)
+        meta = torch.empty(2 + B, device=dev, dtype=torch.int64)
+        _abi.call("wsmg_instruction_dedup", ctypes.c_void_p(tokens.data_ptr()), int(tokens.dtype == torch.float32), B, L,
+                  ctypes.c_void_p(uniq.data_ptr()), ctypes.c_void_p(inverse.data_ptr()), ctypes.c_void_p(meta.data_ptr()),
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        host = meta.cpu()        # the one host read-back of a forward pass
+        ops.check_rnn_status()   # (everything queued before it has finished: the persistent kernels' status word is final)
+        U = int(host[0])
+        return uniq[:U], inverse, host[2:2 + U], meta[2:2 + U]
+
     _kept = None     # (tokens, dedup of them) of the last rollout-size call
 
     def dedup(self, instruction, reuse=None):
@@ -84,7 +105,7 @@ class InstructionEncoder(nn.Module):
         reuse (default: without autograd, up to 64 rows — the rollout): the last tokens and their result are kept, and equal
         tokens (one compare + one host read-back, instead of the ~30 launches of hash / unique / gather and theirs) return the
         kept result: a rollout's instructions change at episode boundaries only.  WSMG_DEDUP_REUSE=0 turns it off."""
-        tokens = instruction.long()
+        tokens = instruction if (instruction.is_cuda and instruction.dtype == torch.float32 and instruction.is_contiguous()) else instruction.long()
         if reuse is None:
             reuse = not torch.is_grad_enabled()
         if not (reuse and tokens.is_cuda and tokens.shape[0] <= 64 and os.environ.get("WSMG_DEDUP_REUSE", "1") != "0"):
@@ -133,8 +154,7 @@ class InstructionEncoder(nn.Module):
         sequence (MIOpen / CPU), kept for comparison in tests.  dedup: the result of `dedup()` for these tokens, if the caller
         already has it (no host read-back here then).  lstm_after: an event the persistent LSTM launch waits for (the dedup, the
         embedding and the input projection do not)."""
-        tokens = instruction.long()
-        uniq, inverse, len_host, len_dev = self.dedup(tokens) if dedup is None else dedup
+        uniq, inverse, len_host, len_dev = self.dedup(instruction) if dedup is None else dedup
         if stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
             embedded = self.embedding_layer(uniq)
             packed = nn.utils.rnn.pack_padded_sequence(embedded, len_host, batch_first=True, enforce_sorted=False)

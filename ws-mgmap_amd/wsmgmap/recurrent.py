@@ -31,6 +31,11 @@ from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _st
 MAX_BATCH = 8          # batch slots of the persistent GRU kernels
 
 
+def _prow(t, row):
+    """Pointer to row `row` of a contiguous tensor (a view object per kernel argument costs more host time than the launch)."""
+    return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
+
+
 def _roles(streams, main):
     """(attention stream, GRU-2 stream, leaf stream) out of the caller's helper streams.  The block creates NO stream of its own: HIP
     multiplexes a process's streams onto 4 hardware queues, and two streams that share a queue run their work in submission order
@@ -130,40 +135,47 @@ class _RecurrentBlock(torch.autograd.Function):
 
         gi1v, gi2v = gi1.view(T, N, 3 * H), gi2.view(T, N, 3 * H)
         y1r = y1.view(B, H)
+        multi = sa is not main
+        # Enqueue order: stream by stream (all of GRU 1's chunks, then all attention chunks, then all of GRU 2's) — the dependencies are
+        # events, so the GPU sees the same pipeline as with a chunk-by-chunk order, and the host changes its current stream twice
+        # instead of eight times (the host has < 1.5 ms of lead over the GPU in this part of an update)
+        ev1, eva = [], []
         for k in range(K):
-            r0, r1 = k * rows, (k + 1) * rows
             gru(gi1v, w_hh1, b_hh1, h01, y1, sv1, k)                                   # main
             _ops.mark("f.g1.%d" % k)
-            if sa is not main:
+            if multi:
                 e1 = torch.cuda.Event()
                 e1.record(main)
-                if k:
-                    sa.wait_event(e1)
-            with torch.cuda.stream(sa):
-                if k == 0:
-                    q1.copy_(bq1.expand_as(q1))
-                    q2.copy_(bq2.expand_as(q2))
-                    xc.copy_(bc.expand_as(xc))
-                    gi2.copy_(b_ih2.expand_as(gi2))
-                    if sa is not main:
-                        sa.wait_event(e1)
+                ev1.append(e1)
+        with torch.cuda.stream(sa):
+            q1.copy_(bq1.expand_as(q1))
+            q2.copy_(bq2.expand_as(q2))
+            xc.copy_(bc.expand_as(xc))
+            gi2.copy_(b_ih2.expand_as(gi2))
+            for k in range(K):
+                r0, r1 = k * rows, (k + 1) * rows
+                if multi:
+                    sa.wait_event(ev1[k])
                 q1[r0:r1].addmm_(y1r[r0:r1], wq1.t())
-                _abi.call("wsmg_attn_shared_fwd" + tsfx, _p(q1[r0:r1]), _p(text_k), _p(text_v), _p(text_mask), _p(inverse[r0:r1]),
-                          scale, rows, L, C, _p(text_emb[r0:r1]), _p(attn_text[r0:r1]), _stream())
+                _abi.call("wsmg_attn_shared_fwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _p(text_mask), _prow(inverse, r0),
+                          scale, rows, L, C, _prow(text_emb, r0), _prow(attn_text, r0), _stream())
                 q2[r0:r1].addmm_(text_emb[r0:r1], wq2.t())
                 torch.mm(q2[r0:r1], wk2, out=qf[r0:r1])
-                _abi.call("wsmg_attn_fwd" + ksfx, _p(qf[r0:r1]), _p(tokens[r0:r1]), _p(tokens[r0:r1]), None, scale, rows, I, C,
-                          _p(map_emb[r0:r1]), _p(att_map[r0:r1]), _stream())
+                _abi.call("wsmg_attn_fwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), None, scale, rows, I, C,
+                          _prow(map_emb, r0), _prow(att_map, r0), _stream())
                 torch.cat([y1r[r0:r1], text_emb[r0:r1], map_emb[r0:r1]], dim=1, out=x[r0:r1])
                 xc[r0:r1].addmm_(x[r0:r1], wc.t())
                 torch.relu_(xc[r0:r1])
                 gi2[r0:r1].addmm_(xc[r0:r1], w_ih2.t())
                 _ops.mark("f.at.%d" % k)
-            if sg is not main:
-                ea = torch.cuda.Event()
-                ea.record(sa)
-                sg.wait_event(ea)
-            with torch.cuda.stream(sg):
+                if multi:
+                    ea = torch.cuda.Event()
+                    ea.record(sa)
+                    eva.append(ea)
+        with torch.cuda.stream(sg):
+            for k in range(K):
+                if multi:
+                    sg.wait_event(eva[k])
                 gru(gi2v, w_hh2, b_hh2, h02, y2, sv2, k)
                 _ops.mark("f.g2.%d" % k)
         if sg is not main:
@@ -262,34 +274,44 @@ class _RecurrentBlock(torch.autograd.Function):
                       Tc, N, H, _p(dgi[t0:]), _p(dgh[t0:]), _p(out), _p(ws), _stream())
             _rnn_launched()
 
-        for k in range(K - 1, -1, -1):
-            r0, r1 = k * rows, (k + 1) * rows
-            with torch.cuda.stream(sg):
+        # stream by stream, as in forward: GRU 2's chunks (last chunk first), the attention stage's, GRU 1's
+        ev2, eva = {}, {}
+        with torch.cuda.stream(sg):
+            for k in range(K - 1, -1, -1):
                 gru_bwd(dy2, w_hh2, h02, y2, (sr2, sz2, sn2, sg2), dgi2, dgh2, dh02, carry2, k)
                 _ops.mark("b.g2.%d" % k)
-            if multi:
-                e2 = torch.cuda.Event()
-                e2.record(sg)
-                sa.wait_event(e2)
-            with torch.cuda.stream(sa):
+                if multi:
+                    ev2[k] = torch.cuda.Event()
+                    ev2[k].record(sg)
+        with torch.cuda.stream(sa):
+            wc_s, wc_t, wc_m = wc[:, :H], wc[:, H:H + C], wc[:, H + C:]
+            wk2t = wk2.t()
+            for k in range(K - 1, -1, -1):
+                r0, r1 = k * rows, (k + 1) * rows
+                if multi:
+                    sa.wait_event(ev2[k])
                 # ReLU of second_state_compress: d(pre-activation) = d(xc) where xc > 0
-                torch.ops.aten.threshold_backward.grad_input(torch.mm(dgi2r[r0:r1], w_ih2), xcr[r0:r1], 0.0, grad_input=dxc[r0:r1])
-                dstate_a = torch.mm(dxc[r0:r1], wc[:, :H])
-                dtext_a = torch.mm(dxc[r0:r1], wc[:, H:H + C])
-                dmap = torch.mm(dxc[r0:r1], wc[:, H + C:])
-                _abi.call("wsmg_attn_bwd" + ksfx, _p(qf[r0:r1]), _p(tokens[r0:r1]), _p(tokens[r0:r1]), _p(att_map[r0:r1]), _p(dmap),
-                          _p(None if datt is None else datt[r0:r1]), scale, rows, I, C, _p(dqf[r0:r1]), _p(dtokens[r0:r1]),
-                          _p(dtokens[r0:r1]), _stream())
-                torch.mm(dqf[r0:r1], wk2.t(), out=dq2[r0:r1])
-                torch.addmm(dtext_a, dq2[r0:r1], wq2, out=dtext[r0:r1])
-                _abi.call("wsmg_attn_shared_bwd" + tsfx, _p(q1[r0:r1]), _p(text_k), _p(text_v), _p(attn_text[r0:r1]), _p(dtext[r0:r1]),
-                          None, _p(inverse[r0:r1]), scale, rows, L, C, _p(dq1[r0:r1]), _p(dl[r0:r1]), _stream())
+                dxc_k = dxc[r0:r1]
+                torch.ops.aten.threshold_backward.grad_input(torch.mm(dgi2r[r0:r1], w_ih2), xcr[r0:r1], 0.0, grad_input=dxc_k)
+                dstate_a = torch.mm(dxc_k, wc_s)
+                dtext_a = torch.mm(dxc_k, wc_t)
+                dmap = torch.mm(dxc_k, wc_m)
+                _abi.call("wsmg_attn_bwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), _prow(att_map, r0), _p(dmap),
+                          None if datt is None else _prow(datt, r0), scale, rows, I, C, _prow(dqf, r0), _prow(dtokens, r0),
+                          _prow(dtokens, r0), _stream())
+                dq2_k = dq2[r0:r1]
+                torch.mm(dqf[r0:r1], wk2t, out=dq2_k)
+                torch.addmm(dtext_a, dq2_k, wq2, out=dtext[r0:r1])
+                _abi.call("wsmg_attn_shared_bwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _prow(attn_text, r0), _prow(dtext, r0),
+                          None, _prow(inverse, r0), scale, rows, L, C, _prow(dq1, r0), _prow(dl, r0), _stream())
                 torch.addmm(dstate_a, dq1[r0:r1], wq1, out=dstate_r[r0:r1])
                 _ops.mark("b.at.%d" % k)
+                if multi:
+                    eva[k] = torch.cuda.Event()
+                    eva[k].record(sa)
+        for k in range(K - 1, -1, -1):
             if multi:
-                ea = torch.cuda.Event()
-                ea.record(sa)
-                main.wait_event(ea)
+                main.wait_event(eva[k])
             gru_bwd(dstate, w_hh1, h01, y1, (sr1, sz1, sn1, sg1), dgi1, dgh1, dh01, carry1, k)      # main
             _ops.mark("b.g1.%d" % k)
         d_state_in = torch.mm(dgi1.view(B, 3 * H), w_ih1) if ctx.needs_input_grad[1] else None
