@@ -253,6 +253,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # measured before it is trusted: 3 updates with and 3 without it (after one untimed update each), max over ranks; more than
     # 1.3x slower with the stream -> fall back to one stream for the run and say so in the line.
     measure.side_stream = None
+    from wsmgmap import debug
     if args.dp and os.environ.get("WSMG_DECODER_STREAMS") is None:
         def timed(k):
             update()
@@ -266,13 +267,13 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item()) / k
         update()                                   # discovery pass of the gradient exchange, allocator warm-up
-        os.environ["WSMG_DECODER_STREAMS"] = "0"
+        debug.sw.decoder_streams = 0
         t_one = timed(3)
-        os.environ["WSMG_DECODER_STREAMS"] = "1"
+        debug.sw.decoder_streams = 1
         t_two = timed(3)
         keep = t_two <= 1.3 * t_one
         if not keep:
-            os.environ["WSMG_DECODER_STREAMS"] = "0"
+            debug.sw.decoder_streams = 0
         measure.side_stream = dict(ms_per_update_one_stream=round(t_one * 1e3, 3), ms_per_update_with_decoder_side_stream=round(t_two * 1e3, 3),
                                    decoder_side_stream_used=bool(keep),
                                    note="3 updates each, max over ranks; the side stream is dropped for the run when it is > 1.3x slower")

@@ -918,9 +918,9 @@ def test_conv2d_with_fused_relu(ops, dt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("relu,pad_last", [(False, 0), (True, 0), (True, 5)])
 def test_conv2d_over_concatenated_parts(ops, relu, pad_last):
-    """ops.conv2d_cat([a, b], w) == conv2d(torch.cat([a, b], -1), w) (map_encoder.py:104,110 / mg_map_policy.py:99):
-    the bf16 engine runs one launch per part with the second accumulating into y (flag bit 2), and backward works on
-    the parts, so forward and every gradient are held against a float64 evaluation of the concatenated convolution.
+    """ops.conv2d_cat([a, b], w) == conv2d(torch.cat([a, b], -1), w) (map_encoder.py:104,110 / mg_map_policy.py:99): one
+    vectorised concatenation launch and the convolution, the gradients of the parts coming back as channel slices; forward and
+    every gradient are held against a float64 evaluation of the concatenated convolution.
     pad_last: the last part carries 5 zero-padded channels beyond the weight's (27 -> 32 logits case)."""
     torch.manual_seed(11)
     B, Ca, Cb, Cout, H = 3, 64, 32, 64, 12
@@ -933,7 +933,7 @@ def test_conv2d_over_concatenated_parts(ops, relu, pad_last):
     gy = torch.randn(B, H, H, Cout, device="cuda").bfloat16()
     ai, bi = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
     wi, biasi = w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-    y = ops._Conv2dCat.apply(wi, biasi, 1, 1, False, relu, ai, bi)   # (ops.conv2d_cat takes this route with WSMG_CONV_CAT=1)
+    y = ops.conv2d_cat([ai, bi], wi, biasi, 1, 1, relu=relu)
     assert y.dtype == torch.bfloat16
     y.backward(gy)
     # float64 reference on the same bf16-rounded inputs.  With ReLU the gradient is taken through the mask the engine

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from wsmgmap.debug import sw as _SW     # the package's A/B switches (read once at import; tests flip attributes)
+
 from oracle import cases, policy_ref
 from util import NULL_GRAD, T, golden, make_params, state_dict_values
 
@@ -341,7 +343,7 @@ def test_update_gradients_repeatable_with_side_streams(monkeypatch):
             assert l == l0, (l, l0)
             diff = [n for n in g0 if not torch.equal(g[n], g0[n])]
             assert not diff, f"{mode}: {len(diff)} gradient tensors differ between two identical updates: {diff[:6]}"
-    monkeypatch.setenv("WSMG_WGRAD_ATOMICS", "1")
+    monkeypatch.setattr(_SW, "wgrad_atomics", True)
     runs = [_bench_like_update("bf16", 16, 8, state) for _ in range(2)]
     p0, l0, g0 = runs[0]
     a = torch.cat([g0[n].flatten() for n in g0])

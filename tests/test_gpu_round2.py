@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from wsmgmap.debug import sw as _SW     # the package's A/B switches (read once at import; tests flip attributes)
+
 from oracle import cases, detfill, policy_ref
 from util import NULL_GRAD, T, golden, make_params, state_dict_values, state_spec
 
@@ -1007,10 +1009,10 @@ def test_rollout_fold_matches_unfolded_map_stack(monkeypatch):
     ego = torch.randn(B, 64, 100, 100, device="cuda", generator=gen).relu()
     net = pol.net
     with torch.no_grad():
-        monkeypatch.setenv("WSMG_ROLLOUT_FOLD", "0")
+        monkeypatch.setattr(_SW, "rollout_fold", False)
         tok0, sem0 = net.map_stack(ego)
         assert net._fold is None
-        monkeypatch.setenv("WSMG_ROLLOUT_FOLD", "1")
+        monkeypatch.setattr(_SW, "rollout_fold", True)
         tok1, sem1 = net.map_stack(ego)
         assert net._fold is not None and len(net._fold.entries) == 20
         tokf, semf = ref.net.map_stack(ego)
@@ -1087,9 +1089,9 @@ def test_splitk_conv_matches_unsplit_and_torch(geom, mode, monkeypatch):
     def run():
         return ops.conv2d_infer_bf16(x, w, bias, stride, pad, relu=mode != "f32out", out_f32=mode == "f32out",
                                      add_to=None if res is None else res.clone())
-    monkeypatch.setenv("WSMG_CONV_SPLITK", "1")
+    monkeypatch.setattr(_SW, "conv_splitk", True)
     y1, y2 = run(), run()
-    monkeypatch.setenv("WSMG_CONV_SPLITK", "0")
+    monkeypatch.setattr(_SW, "conv_splitk", False)
     y0 = run()
     assert torch.equal(y1, y2)
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, stride, pad).permute(0, 2, 3, 1)
@@ -1180,7 +1182,7 @@ def test_act_heads_match_the_module_heads(deterministic, monkeypatch):
     with torch.no_grad():
         torch.manual_seed(5)
         va, aa, la, ha = pa.act(dict(obs), h.clone(), prev, masks, deterministic=deterministic)
-        monkeypatch.setenv("WSMG_ROWS_LINEAR", "0")
+        monkeypatch.setattr(_SW, "rows_linear", False)
         torch.manual_seed(5)
         vb, ab, lb, hb = pb.act(dict(obs), h.clone(), prev, masks, deterministic=deterministic)
     for name, x, y in (("value", va, vb), ("action", aa, ab), ("logp", la, lb), ("h", ha, hb), ("prog", pa.prog, pb.prog)):
@@ -1233,9 +1235,9 @@ def test_concatenation_gradient_halves_are_read_in_place(dtype, monkeypatch):
         y = ops.cat_channels(ops.cat_channels(a, b), ops.upsample2x(xu))
         (y.float() * wout.float()).sum().backward()
         return [t.grad.clone() for t in (xa, xb, w, bias, gamma, beta, xu)]
-    monkeypatch.setenv("WSMG_STRIDED_GRADS", "1")
+    monkeypatch.setattr(_SW, "strided_grads", True)
     g1 = grads()
-    monkeypatch.setenv("WSMG_STRIDED_GRADS", "0")
+    monkeypatch.setattr(_SW, "strided_grads", False)
     g0 = grads()
     for name, x, y in zip(("xa", "xb", "w", "bias", "gamma", "beta", "xu"), g1, g0):
         if name == "w":      # float32 atomics: the summation order differs from run to run

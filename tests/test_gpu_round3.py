@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from wsmgmap.debug import sw as _SW     # the package's A/B switches (read once at import; tests flip attributes)
+
 from oracle import policy_ref
 from util import NULL_GRAD
 
@@ -426,9 +428,9 @@ def test_weight_gradient_slabs_are_deterministic_and_match_atomics(geom, dtype, 
     torch.cuda.synchronize()
     assert outs[0].shape == (Cout, Cin_w, K, K)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the slab-reduced weight gradient is not repeatable"
-    monkeypatch.setenv("WSMG_WGRAD_ATOMICS", "1")
+    monkeypatch.setattr(_SW, "wgrad_atomics", True)
     ref_atomic = ops._weight_grad(sfx, x, dy, dims, fl, Cin_w)
-    monkeypatch.delenv("WSMG_WGRAD_ATOMICS")
+    monkeypatch.setattr(_SW, "wgrad_atomics", False)
     xs = x.double().permute(0, 3, 1, 2)[:, :Cin_w]
     dys = dy.double().permute(0, 3, 1, 2)
     want = torch.nn.grad.conv2d_weight(xs, (Cout, Cin_w, K, K), dys, stride=stride, padding=pad)
@@ -596,7 +598,7 @@ def test_cls_tail_in_the_policy_matches_the_unfused_route(monkeypatch):
     import test_gpu_policy as tp
     state = r2._default_state()
     p1, l1, g1 = tp._bench_like_update("bf16", 4, 8, state)
-    monkeypatch.setenv("WSMG_FUSED_CLS_TAIL", "0")
+    monkeypatch.setattr(_SW, "fused_cls_tail", False)
     p0, l0, g0 = tp._bench_like_update("bf16", 4, 8, state)
     assert float((p1 - p0).abs().max()) <= 1e-3 and abs(l1 - l0) <= 1e-3 * abs(l0), (float((p1 - p0).abs().max()), l1, l0)
     assert set(g1) == set(g0)

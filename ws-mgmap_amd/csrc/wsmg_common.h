@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "wsmgmap.h"
 
@@ -45,6 +46,15 @@ __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
   } while (0)
 
 static inline hipStream_t wsmg_s(wsmg_stream_t s) { return (hipStream_t)s; }
+
+// Tuning / A-B switches of the library (WSMG_* environment variables of the launchers: tile choices, kernel variants).  Every one
+// is read ONCE per process, at the first launch that asks — no launch after that touches the environment.  WSMG_TUNE is the
+// only way the library reads it.
+static inline int wsmg_tune_read(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+#define WSMG_TUNE(name, dflt) ([]() -> int { static const int v_ = wsmg_tune_read(name, dflt); return v_; }())
 
 static inline int64_t wsmg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

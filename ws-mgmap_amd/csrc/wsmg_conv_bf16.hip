@@ -372,7 +372,6 @@ struct WgradArgsB {
   int64_t npix, chunk;
   unsigned x_bytes, dy_bytes;
   int gx, gy;   // unit tiles, co tiles (1-D grid of gx*gy*gz blocks, XCD-swizzled)
-  int dbg_skip;  // timing experiments only (WSMG_WGRAD_DBG_SKIP=1): leave the epilogue out
   int64_t slab;  // > 0: floats per slab — `dw` is a workspace [gz][Cout][KH][KW][Cin] and the workgroup of pixel chunk z STORES its
                  // partial tile into slab z (plain stores: no atomics, no zero fill — every element of every slab is written once);
                  // wsmg_weight_grad_reduce_oihw adds the slabs in slab order, so dW is bit-reproducible (run.py:107-108 of the
@@ -533,7 +532,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgsB a) {
   }
   const int r = lane & 31;
   const int taps = a.KH * a.KW;
-  if (a.dbg_skip) { if (acc[0][0][0] == 123.456f) a.dw[0] = 1.f; return; }
 #pragma unroll
   for (int u = 0; u < TU; ++u) {
     const int uu = u0 + wave * TU + u;
@@ -569,18 +567,13 @@ int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int strid
 // register prefetch depth (k-steps in flight).  Measured on MI355X (tools/bench_conv.py): the igemm
 // kernels are fastest at 1 (deeper costs occupancy, which hides more latency than the prefetch does).
 int conv_prefetch(int dflt) {
-  static int v = -2;
-  if (v == -2) {
-    const char* e = getenv("WSMG_CONV_PF");
-    v = e ? atoi(e) : -1;
-    if (v < 1 || v > 3) v = -1;
-  }
-  return v > 0 ? v : dflt;
+  const int v = WSMG_TUNE("WSMG_CONV_PF", -1);
+  return (v >= 1 && v <= 3) ? v : dflt;
 }
 
 int g_win3_tile = -1;
 int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 256 = that many pixels per workgroup
-  if (g_win3_tile < 0) { const char* e = getenv("WSMG_CONV_WIN3"); g_win3_tile = e ? atoi(e) : 1; }
+  if (g_win3_tile < 0) g_win3_tile = WSMG_TUNE("WSMG_CONV_WIN3", 1);
   return g_win3_tile;
 }
 // The LDS-window kernel (wsmg_conv_win3.hip) for a 3 x 3 / stride 1 / pad 1 layer of M pixels, Kc reduction channels and N output
@@ -594,16 +587,14 @@ int win3_choice(int64_t M, int Kc, int N) {
     // The classifier's 32 -> 32 layer at 48 x 48 (B = 512), alone: forward 0.071 -> 0.063 (512-pixel tiles) -> 0.055 ms (256),
     // backward-data 0.075 -> 0.063 -> 0.056: the implicit-GEMM kernel pads the 32 channels to a 64-wide tile and re-fetches the
     // pixels per tap; nine k-steps are too few to hide the window's load, so this is 390 TFLOP/s, not 800
-    static int n32 = -1;
-    if (n32 < 0) { const char* e = getenv("WSMG_CONV_WIN3_N32"); n32 = e ? atoi(e) : 256; }
+    const int n32 = WSMG_TUNE("WSMG_CONV_WIN3_N32", 256);
     if (t != 1) return t;
     if (n32 == 0 || M < 2 * 256 * 256) return 0;
     return n32;
   }
   if (Kc < 64) return 0;
   if (N % 128) {                     // 64-channel tiles (round 3; WSMG_CONV_WIN3_N64=0: the implicit-GEMM kernel, 512 / 256: the tile)
-    static int n64 = -1;
-    if (n64 < 0) { const char* e = getenv("WSMG_CONV_WIN3_N64"); n64 = e ? atoi(e) : 1; }
+    const int n64 = WSMG_TUNE("WSMG_CONV_WIN3_N64", 1);
     if (t != 1) return t;           // (forced by wsmg_conv_debug_win3_tile / WSMG_CONV_WIN3)
     // measured alone at B = 512, 24 x 24 (tools/bench_conv.py): orig0 (256 -> 64) forward 0.118 -> 0.103 ms, orig2 (192 -> 64)
     // forward 0.091 -> 0.083 and backward-data (64 -> 192) 0.106 -> 0.090; orig1 (64 -> 64: 18 k-steps, one 64-channel tile)
@@ -651,12 +642,9 @@ int splitk_plan(int64_t M, int Kc, int N, int KH, int KW) {
   const int bk = (Kc % 64) == 0 ? 64 : 32;
   const int steps = KH * KW * (Kc / bk);
   const int tiles = (int)(wsmg_cdiv(M, BM) * wsmg_cdiv(N, 64));
-  static int target = 0, minsteps = 0, maxtiles = 0;   // experiments: WSMG_SPLITK_TARGET / _MINSTEPS / _MAXTILES
-  if (!target) {
-    const char* e = getenv("WSMG_SPLITK_TARGET"); target = e && atoi(e) > 0 ? atoi(e) : 256;
-    e = getenv("WSMG_SPLITK_MINSTEPS"); minsteps = e && atoi(e) > 0 ? atoi(e) : 4;
-    e = getenv("WSMG_SPLITK_MAXTILES"); maxtiles = e && atoi(e) > 0 ? atoi(e) : 128;
-  }
+  const int target = WSMG_TUNE("WSMG_SPLITK_TARGET", 256) > 0 ? WSMG_TUNE("WSMG_SPLITK_TARGET", 256) : 256;
+  const int minsteps = WSMG_TUNE("WSMG_SPLITK_MINSTEPS", 4) > 0 ? WSMG_TUNE("WSMG_SPLITK_MINSTEPS", 4) : 4;
+  const int maxtiles = WSMG_TUNE("WSMG_SPLITK_MAXTILES", 128) > 0 ? WSMG_TUNE("WSMG_SPLITK_MAXTILES", 128) : 128;
   if (tiles >= maxtiles || steps < 4 * minsteps || (N & 7)) return 1;
   int ks = (int)wsmg_cdiv(target, tiles);
   if (ks > steps / minsteps) ks = steps / minsteps;
@@ -762,9 +750,7 @@ extern "C" int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, con
   if (Cin == 64 && Cout == 64 && KH == 8 && KW == 8 && stride == 2 && pad == 3 && (out_f32 & 5) == 0) {
     // the map encoder's stem: direct convolution out of an LDS-resident input window (wsmg_conv_win.hip); WSMG_CONV_WIN=0
     // keeps the implicit-GEMM kernel (A/B)
-    static int use_win = -1;
-    if (use_win < 0) { const char* e = getenv("WSMG_CONV_WIN"); use_win = e ? atoi(e) : 1; }
-    if (use_win) {
+    if (WSMG_TUNE("WSMG_CONV_WIN", 1)) {
       int rc = wsmg_conv_win_fwd_bf16(x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
     }
@@ -856,15 +842,12 @@ struct WgradPlan {
 WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
   WgradPlan p{0, 0, 0, 0, 0, 0, 0};
   // the map encoder's stem: LDS-window variant (wsmg_conv_win_wgrad.hip); WSMG_WGRAD_WIN=0 keeps the generic kernel (A/B)
-  static int use_win = -1;
-  if (use_win < 0) { const char* e = getenv("WSMG_WGRAD_WIN"); use_win = e ? atoi(e) : 1; }
-  if (use_win) {
+  if (WSMG_TUNE("WSMG_WGRAD_WIN", 1)) {
     if (const int n = wsmg_conv_win_wgrad_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) { p.kind = 1; p.nsplit = n; return p; }
   }
   // 3 x 3 stride-1 layers: zero-padded LDS window (wsmg_conv_win3_wgrad.hip); WSMG_WGRAD_WIN3=0 (or the tests' tile switch = 0)
   // keeps the generic kernel (A/B)
-  static int use_w3w = -1;
-  if (use_w3w < 0) { const char* e = getenv("WSMG_WGRAD_WIN3"); use_w3w = e ? atoi(e) : 1; }
+  const int use_w3w = WSMG_TUNE("WSMG_WGRAD_WIN3", 1);
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && use_w3w && win3_tile() && (int64_t)B * H * W >= 256 * 256) {
     if (const int n = wsmg_conv_win3_wgrad_splits(B, H, W, Cin, Cout)) { p.kind = 2; p.nsplit = n; return p; }
   }
@@ -875,8 +858,8 @@ WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW
   // (the 64-channel k8 stem, 128 units of 64 input channels: 64 co x 8 units measured 0.94 vs 0.99 ms; every other
   // 64-wide layer is faster with 4 units)
   int tc = (Cout % 128 == 0 && units >= 48) ? 4 : 2, tu = (tc == 4 || (Cin == 64 && units >= 128)) ? 2 : 1;
-  if (const char* e = getenv("WSMG_WGRAD_TILE")) {   // debug: "42", "21", "22"
-    int v = atoi(e);
+  {   // tuning: WSMG_WGRAD_TILE = 42, 21 or 22
+    const int v = WSMG_TUNE("WSMG_WGRAD_TILE", 0);
     if (v == 42 || v == 21 || v == 22) { tc = v / 10; tu = v % 10; }
   }
   const int gx = (int)wsmg_cdiv(units, 4 * tu), gy = (int)wsmg_cdiv(Cout, 32 * tc);
@@ -886,7 +869,7 @@ WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW
   // layers of the update; tools sweep, WSMG_WGRAD_WANT)
   const double gflop = 2.0 * (double)npix * Cout * Cin * KH * KW * 1e-9;
   int64_t target = tc == 4 ? 1024 : (gflop < 40.0 ? 768 : 2048);
-  if (const char* e = getenv("WSMG_WGRAD_WANT")) { int v = atoi(e); if (v > 0) target = v; }
+  if (const int v = WSMG_TUNE("WSMG_WGRAD_WANT", 0); v > 0) target = v;
   int64_t want = wsmg_cdiv(target, (int64_t)gx * gy);
   int64_t maxz = wsmg_cdiv(npix, WKP * 8);
   int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);
@@ -905,8 +888,7 @@ int launch_wgrad_bf16(const void* x, const void* dy, float* dw, long long slab_f
   if (p.kind == 1) return wsmg_conv_win_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
   if (p.kind == 2) return wsmg_conv_win3_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, stream);
   WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
-               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, 0, (int64_t)slab_floats};
-  { static int sk = -1; if (sk < 0) { const char* e = getenv("WSMG_WGRAD_DBG_SKIP"); sk = e ? atoi(e) : 0; } a.dbg_skip = sk; }
+               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, (int64_t)slab_floats};
   a.units = KH * KW * (Cin / 32);
   a.npix = (int64_t)B * OH * OW;
   a.chunk = p.chunk;

@@ -272,7 +272,7 @@ void plan_w3w(W3wArgs& a) {
   a.gci = a.Cin / (32 * WCI);
   const int ntile = a.gco * a.gci;
   int gz = w3w_cus() / ntile;
-  if (const char* e = getenv("WSMG_WIN3W_SPLITS")) { int v = atoi(e); if (v > 0) gz = v; }
+  if (const int v = WSMG_TUNE("WSMG_WIN3W_SPLITS", 0); v > 0) gz = v;
   if (gz < 1) gz = 1;
   if (gz > a.B) gz = a.B;
   a.imgs = (a.B + gz - 1) / gz;
@@ -329,8 +329,7 @@ int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, lon
   // 0.216 / 0.216 with all eight loading, and 0.421 / 0.247 / 0.225 for the generic kernel); WSMG_WIN3W_LOADERS=8: all eight (A/B).
   // (A 64 x 128-channel tile <2, 4> for the 64-output-channel layers was slower than the generic kernel — 0.175 vs 0.137 ms on
   // 256->64: its 26 KB window per step feeds two output-channel tiles only — and is not built.)
-  static int nlw = -1;
-  if (nlw < 0) { const char* e = getenv("WSMG_WIN3W_LOADERS"); nlw = e ? atoi(e) : 4; }
+  const int nlw = WSMG_TUNE("WSMG_WIN3W_LOADERS", 4);
   if (Cout % 128 == 0 && Cin % 64 == 0) return nlw == 8 ? launch_w3w<4, 2, 8>(a, s) : launch_w3w<4, 2, 4>(a, s);
   return WSMG_EINVAL;
 }

@@ -369,9 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
 
 // WSMG_BN_VEC8=0: the 4-channel kernels for bf16 as well (A/B)
 bool bn_vec8() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("WSMG_BN_VEC8"); v = e ? atoi(e) : 1; }
-  return v != 0;
+  return WSMG_TUNE("WSMG_BN_VEC8", 1) != 0;
 }
 
 int stream_grid8(int64_t rows, int C) {

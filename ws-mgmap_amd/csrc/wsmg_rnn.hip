@@ -754,26 +754,7 @@ __global__ __launch_bounds__(512) void gru_bwd8_kernel(GruBwdArgs a) {
 // no CU claim: 177 mismatching tensors in 60 repeats with them, 0 in 200 without, same step times (2.03 vs 2.06 ms per
 // GRU + LSTM forward + backward).  Whether the packed forms hit a hardware hazard beside MFMA-heavy waves or a missing
 // dependency stall in their scheduling cannot be told from the ISA; the measured facts are in DESIGN.md ("RNN kernels: CU
-// ownership").  The claim stays available: WSMG_RNN_EXCL=1 requests 159 KiB, any other value > 1 is KiB (debug); default 0.
-constexpr unsigned EXCL_LDS_BYTES = 159 * 1024;
-static unsigned rnn_excl_total() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("WSMG_RNN_EXCL");
-    v = e ? atoi(e) : 0;
-  }
-  return v == 0 ? 0u : (v == 1 ? EXCL_LDS_BYTES : (unsigned)v * 1024u);
-}
-// dynamic LDS to request so that the static + dynamic LDS of `kernel` together own the CU
-template <class K>
-static hipError_t excl_lds(K kernel, unsigned* dyn) {
-  hipFuncAttributes at;
-  hipError_t e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(kernel));
-  if (e != hipSuccess) return e;
-  const unsigned total = rnn_excl_total(), st = (unsigned)at.sharedSizeBytes;
-  *dyn = total > st ? total - st : 0u;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*dyn);
-}
+// ownership").  (The claim itself, and its two attribute calls per launch, were removed in round 4.)
 // launch-unique tag bits for the flag-in-data exchange (22-bit epoch above the 10-bit step number)
 // Process-wide status word of the persistent kernels in host-mapped pinned memory: bit 0 gru_fwd, 1 gru_bwd, 2 lstm_fwd,
 // 3 lstm_bwd timed out.  The host polls it without synchronising (wsmg_rnn_status).
@@ -828,16 +809,11 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   if (e != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
-  unsigned dyn = 0;
-  static int waves = -1;       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B)
-  if (waves < 0) { const char* ev = getenv("WSMG_GRU_WAVES"); waves = ev ? atoi(ev) : 8; }
-  if (waves == 8) {
-    if ((e = excl_lds(gru_fwd8_kernel, &dyn)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gru_fwd8_kernel, dim3(NWG), dim3(512), dyn, s, a);
+  if (WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B)
+    hipLaunchKernelGGL(gru_fwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
     WSMG_RETURN_LAUNCH();
   }
-  if ((e = excl_lds(gru_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -854,16 +830,11 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   if (e != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
-  unsigned dyn = 0;
-  static int waves = -1;       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B)
-  if (waves < 0) { const char* ev = getenv("WSMG_GRU_WAVES"); waves = ev ? atoi(ev) : 8; }
-  if (waves == 8) {
-    if ((e = excl_lds(gru_bwd8_kernel, &dyn)) != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gru_bwd8_kernel, dim3(NWG), dim3(512), dyn, s, a);
+  if (WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B)
+    hipLaunchKernelGGL(gru_bwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
     WSMG_RETURN_LAUNCH();
   }
-  if ((e = excl_lds(gru_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), dyn, s, a);
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -1109,9 +1080,7 @@ extern "C" int wsmg_lstm_fwd(const float* gi, const float* w_hh, const float* b_
   if (e != hipSuccess) return (int)e;
   LstmFwdArgs a{gi, w_hh, b_hh, lengths, out, (float*)((char*)state_ws + 256), save_gates, save_c,
                 (unsigned*)state_ws, U, L, rnn_status_dev(), g_spin};
-  unsigned dyn = 0;
-  if ((e = excl_lds(lstm_fwd_kernel, &dyn)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), dyn, s, a);
+  hipLaunchKernelGGL(lstm_fwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -1124,8 +1093,6 @@ extern "C" int wsmg_lstm_bwd(const float* dout, const float* w_hh, const int32_t
   hipError_t e = hipMemsetAsync(state_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
   LstmBwdArgs a{dout, w_hh, lengths, save_gates, save_c, dgates, (unsigned*)state_ws, (float*)((char*)state_ws + 256), U, L, rnn_status_dev(), g_spin};
-  unsigned dyn = 0;
-  if ((e = excl_lds(lstm_bwd_kernel, &dyn)) != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), dyn, s, a);
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(2 * L_NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }

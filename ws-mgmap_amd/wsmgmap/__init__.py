@@ -128,8 +128,8 @@ def _prefer_rocblas():
     workgroup, 118 us for a 67-MFLOP product that rocBLAS runs in 7 us (measured on MI355X, tools/bench notes in
     DESIGN.md) — so rocBLAS is selected process-wide when the package is imported.  WSMG_KEEP_BLAS=1 leaves PyTorch's
     choice alone."""
-    import os
-    if os.environ.get("WSMG_KEEP_BLAS", "0") == "1":
+    from .debug import sw
+    if sw.keep_blas:
         return
     try:
         import warnings

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwsmgmap.so")
-if os.environ.get("WSMG_LIB"):       # experiments only: another build of the same library (e.g. other compiler flags for one file)
+if os.environ.get("WSMG_LIB"):       # experiments only: another build of the same library (read once, here)
     LIB_PATH = os.environ["WSMG_LIB"]
 
 c_p = ctypes.c_void_p
@@ -197,7 +197,8 @@ def check_rnn_status():
         names = [n for b, n in ((1, "gru_fwd"), (2, "gru_bwd"), (4, "lstm_fwd"), (8, "lstm_bwd")) if v & b]
         raise WsmgError("persistent RNN kernel(s) timed out waiting for their cooperating workgroups: " + ", ".join(names) +
                         " — their outputs were filled with NaN; results since the previous check are invalid "
-                        "(CU oversubscription? every RNN workgroup needs a whole CU, see WSMG_RNN_EXCL)")
+                        "(the persistent kernels need all their workgroups resident at once: too many concurrent persistent "
+                        "kernels for the free CUs?  net.recurrent_chunks = 0 runs one at a time)")
 
 
 def exported_names():

@@ -10,12 +10,10 @@ the gfx950 kernels paste/translate/fuse directly inside the (E+4)^2 window the v
 All arithmetic runs in libwsmgmap.so (wsmg_bev_index / _scatter_max / _rotate / wsmg_map_fuse /
 _retrieve); nothing here has a CPU fallback.
 """
-import os
-
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import debug, ops
 
 
 class Mapping(nn.Module):
@@ -59,7 +57,7 @@ class Mapping(nn.Module):
         lin = ops.bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
         compass = observations["compass"].reshape(bs).float().contiguous()
         gps = observations["gps"].reshape(bs, 2).float().contiguous()
-        if ops.bev_planes_ok(C, E) and os.environ.get("WSMG_BEV_FUSED", "1") != "0":
+        if ops.bev_planes_ok(C, E) and debug.sw.bev_fused:
             # scatter-max + rotation in one launch (the channel plane is rotated out of LDS); the fuse reads the rotated planes
             rotated = ops.bev_scatter_rotate(features.float().contiguous(), lin, compass, -1.0, C, E)
             ops.map_fuse(rotated, gm, gps, masks.reshape(bs).float().contiguous(), self.resolution, planes=True)

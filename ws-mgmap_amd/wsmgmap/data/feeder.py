@@ -130,8 +130,8 @@ class DeviceFeeder:
         self.pinned_ring = None       # True / False once a ring exists: could the shared slots be registered as pinned memory
 
     def _trace(self, msg):
-        import os
-        if os.environ.get("WSMG_FEEDER_TRACE") == "1":
+        from ..debug import sw
+        if sw.feeder_trace:
             import sys
             import time
             print("[feeder %.1f] %s" % (time.time() % 10000, msg), file=sys.stderr, flush=True)
@@ -234,8 +234,8 @@ class DeviceFeeder:
         ctx = mp.get_context("spawn")
         slots = [torch.empty(nbytes, dtype=torch.uint8).share_memory_() for _ in range(W * self.slots_per_worker)]
         rt = torch.cuda.cudart()
-        import os
-        self.pinned_ring = os.environ.get("WSMG_FEEDER_PIN", "1") != "0"
+        from ..debug import sw
+        self.pinned_ring = bool(sw.feeder_pin)
         for t in slots:       # pinned: the H2D copy is asynchronous and reads the worker's bytes in place
             if not self.pinned_ring:
                 break

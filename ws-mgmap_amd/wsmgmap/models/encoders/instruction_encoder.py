@@ -36,8 +36,6 @@ class InstructionEncoder(nn.Module):
     def output_size(self):
         return self.config.hidden_size * (2 if self.bidir else 1)
 
-    _diag_memo = None
-
     @staticmethod
     def _dedup(tokens):
         """Unique rows of a [B, L] token matrix without a row-wise sort: a 64-bit polynomial hash per
@@ -46,13 +44,6 @@ class InstructionEncoder(nn.Module):
         B, L = tokens.shape
         if tokens.is_cuda and 0 < B <= 4096 and tokens.is_contiguous() and tokens.dtype in (torch.int64, torch.float32):
             return InstructionEncoder._dedup_fused(tokens)
-        memo = InstructionEncoder._diag_memo if os.environ.get("WSMG_DIAG_DEDUP_MEMO") == "1" else None
-        if memo is not None and memo[0] == (B, L):   # diagnostic only (static inputs): no host read-back at all
-            U, host, inverse = memo[1], memo[2], memo[3]
-            rep = torch.full((U,), B, device=tokens.device, dtype=torch.int64)
-            rep.scatter_reduce_(0, inverse, torch.arange(B, device=tokens.device), reduce="amin")
-            uniq = tokens[rep]
-            return uniq, inverse, host[1:], (uniq != 0).long().sum(dim=1)
         mult = (torch.arange(1, L + 1, device=tokens.device, dtype=torch.int64) * 0x9E3779B97F4A7C15) | 1
         h = (tokens * mult).sum(dim=1)
         _, inverse = torch.unique(h, return_inverse=True)
@@ -72,8 +63,6 @@ class InstructionEncoder(nn.Module):
             uniq, inverse = torch.unique(tokens, dim=0, return_inverse=True)
             lengths = (uniq != 0).long().sum(dim=1)
             return uniq, inverse, lengths.cpu(), lengths
-        if os.environ.get("WSMG_DIAG_DEDUP_MEMO") == "1":
-            InstructionEncoder._diag_memo = ((B, L), U, host, inverse)
         return uniq, inverse, host[1:], lengths
 
     @staticmethod
@@ -103,12 +92,12 @@ class InstructionEncoder(nn.Module):
         result back through `observations["instruction_dedup"]` (U and the longest length fix the shapes the graph was captured
         for).
         reuse (default: without autograd, up to 64 rows — the rollout): the last tokens and their result are kept, and equal
-        tokens (one compare + one host read-back, instead of the ~30 launches of hash / unique / gather and theirs) return the
-        kept result: a rollout's instructions change at episode boundaries only.  WSMG_DEDUP_REUSE=0 turns it off."""
+        tokens (one compare + one host read-back) return the kept result: a rollout's instructions change at episode boundaries
+        only."""
         tokens = instruction if (instruction.is_cuda and instruction.dtype == torch.float32 and instruction.is_contiguous()) else instruction.long()
         if reuse is None:
             reuse = not torch.is_grad_enabled()
-        if not (reuse and tokens.is_cuda and tokens.shape[0] <= 64 and os.environ.get("WSMG_DEDUP_REUSE", "1") != "0"):
+        if not (reuse and tokens.is_cuda and tokens.shape[0] <= 64):
             return self._dedup(tokens)
         kept = self._kept
         if kept is not None and kept[0].shape == tokens.shape and torch.equal(kept[0], tokens):

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import debug, ops
 from .resnet18 import ResNet18
 
 
@@ -48,13 +48,9 @@ class batched_bumps:
 def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
     """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
     # (if x carries zero-padded channels, ops.conv2d pads the weight's input channels to match)
-    if isinstance(x, (list, tuple)):   # convolution over a channel concatenation, run part by part (no torch.cat)
-        if len(x) == 2 and not (x[0].dtype == torch.bfloat16 and os.environ.get("WSMG_CONV_CAT", "0") == "1"):
-            x = ops.cat_channels(x[0], x[1])
-        else:
-            y = ops.conv2d_cat(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train)
-            bump(bn, train)
-            return ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps)
+    if isinstance(x, (list, tuple)):   # convolution over a channel concatenation: one vectorised concatenation, then the conv
+        # (running it part by part over the weight's input-channel slices was measured and dropped: DESIGN.md section 7)
+        x = ops.cat_channels(x[0], x[1]) if len(x) == 2 else torch.cat(list(x), dim=-1)
     # bf16 training: the convolution's epilogue accumulates the BatchNorm sums of its output (no statistics pass over y)
     stats = None
     if train and x.dtype == torch.bfloat16 and conv.out_channels % 8 == 0:
@@ -253,8 +249,8 @@ class MapDecoder(nn.Module):
         # (12.36 vs 12.62 ms, single process, one run).
         lws = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
         shared = multi and not (0 < lws <= torch.cuda.device_count())
-        mode = os.environ.get("WSMG_DECODER_STREAMS", "1")   # "0": one stream; "2": side stream even when ranks share a GPU (experiments)
-        if x.is_cuda and mode != "0" and (not shared or mode == "2"):
+        mode = int(debug.sw.decoder_streams)     # 0: one stream; 2: side stream even when ranks share a GPU (experiments)
+        if x.is_cuda and mode != 0 and (not shared or mode == 2):
             if self._side is None:
                 self._side = torch.cuda.Stream()
             side, main = self._side, torch.cuda.current_stream()
@@ -275,7 +271,7 @@ class MapDecoder(nn.Module):
                 main.wait_stream(side)
                 x_original.record_stream(main)
             return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2)
-        if x.dtype == torch.bfloat16 and os.environ.get("WSMG_UPCAT_TRAIN", "1") != "0":
+        if x.dtype == torch.bfloat16:
             # upsample + torch.cat(dim=1) of the reference in one launch, under autograd too (ops._Up2Cat)
             up = cr(ops.upsample2x_cat(cr(layer1, self.layer1_1x1), cr(layer0, self.layer0_1x1)), self.conv_up0)
             if side is not None:

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops, recurrent
+from .. import debug, ops, recurrent
 from ..common.rgb_mapping import RGBMapping
 from .encoders.instruction_encoder import InstructionEncoder
 from .encoders.map_encoder import MapDecoder, MapEncoder
@@ -88,8 +88,7 @@ class MGMapNet(nn.Module):
         self.att_map_t_m = None
         self._side_stream = None
         # time chunks of the pipelined recurrent core of the update path (wsmgmap/recurrent.py); 0 = the staged route
-        import os
-        self.recurrent_chunks = int(os.environ.get("WSMG_RECURRENT_CHUNKS", "4"))
+        self.recurrent_chunks = int(debug.sw.recurrent_chunks)
         self.skip_pred_map_nchw = False   # set by BasePolicy around its own forward: it consumes sem_logits_nhwc
         self.sem_logits_nhwc = None
         self.sem_ce_rows = None           # the prediction monitor's per-sample loss when the fused classifier tail computed it
@@ -109,8 +108,7 @@ class MGMapNet(nn.Module):
         if self.compute_dtype == torch.bfloat16:   # the frozen RGB UNet follows: bf16 NHWC engine on the rollout path
             self.rgb_encoder.base_model.engine_dtype = torch.bfloat16
             # the depth ResNet50 stays float32 by default (ddppo_resnet.py: bf16 storage compounds over its 53 GroupNorm layers)
-            import os
-            if os.environ.get("WSMG_DEPTH_ENGINE", "0") == "1" and hasattr(self.depth_encoder.visual_encoder, "engine_dtype"):
+            if debug.sw.depth_engine and hasattr(self.depth_encoder.visual_encoder, "engine_dtype"):
                 self.depth_encoder.visual_encoder.engine_dtype = torch.bfloat16
 
         self.train()
@@ -208,9 +206,8 @@ class MGMapNet(nn.Module):
 
     def _map_stack(self, ego_map):
         train = self.training
-        import os
         if (not train and not torch.is_grad_enabled() and ego_map.is_cuda and self.compute_dtype == torch.bfloat16
-                and os.environ.get("WSMG_ROLLOUT_FOLD", "1") != "0"):
+                and debug.sw.rollout_fold):
             return self._map_stack_rollout(ego_map)
         laid = None
         if ego_map.is_cuda:
@@ -298,8 +295,7 @@ class MGMapNet(nn.Module):
         side = self._side_stream
         side.wait_event(entry)
         with torch.cuda.stream(side):
-            import os
-            after = getattr(self, "_encoder_done", None) if os.environ.get("WSMG_LSTM_AFTER_STEM", "1") != "0" else None
+            after = getattr(self, "_encoder_done", None)
             instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"],
                                                                              dedup=observations.get("instruction_dedup"), lstm_after=after)
             text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
@@ -313,12 +309,10 @@ class MGMapNet(nn.Module):
         entry.record(torch.cuda.current_stream())
         self._entry_event = entry
         ops.mark("entry")
-        import os
         # Rollout (no autograd, RGB encoded from pixels): the instruction branch is queued FIRST and runs beside the frozen
         # RGB encoder — in a captured step (graph.GraphedAct) it otherwise lands behind the map decoder's side branch and the
         # main stream idles through the whole 0.45 ms LSTM (B = 1).  Training keeps the order described in _encode_instruction.
-        early = (not torch.is_grad_enabled() and "rgb_features" not in observations and observations["instruction"].is_cuda
-                 and os.environ.get("WSMG_ROLLOUT_TEXT_FIRST", "1") != "0")
+        early = not torch.is_grad_enabled() and "rgb_features" not in observations and observations["instruction"].is_cuda
         if early:
             self._encoder_done = None
             text, side = self._encode_instruction(observations, entry)
@@ -369,8 +363,7 @@ class MGMapNet(nn.Module):
 
         self.rgb_mapping_module(rgb_embedding_proj, observations, masks)
         # the map tokens feed their mean (state input) and the map attention: one merged, ReLU-masked gradient pass (TokenGradSink)
-        self._token_sink = ops.TokenGradSink() if (torch.is_grad_enabled() and "map" in self._inputs
-                                                   and os.environ.get("WSMG_TOKEN_SINK", "1") != "0") else None
+        self._token_sink = ops.TokenGradSink() if (torch.is_grad_enabled() and "map" in self._inputs) else None
         sink = self._token_sink
         map_tokens, pred_sem_map = self.map_stack(observations["rgb_ego_map"])
         self._token_sink = None

@@ -7,15 +7,13 @@ Same constructor, `forward` / `act` / `update_map` signatures, attribute tree
 compute behind `self.net` runs in the gfx950 kernels of libwsmgmap.so.  `CMAPolicy` is an alias
 (BASELINE.json names the surface that way; the reference class is `BasePolicy`).
 """
-import os
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..common.aux_losses import AuxLosses
 from ..common.distributions import DiagGaussian
-from .. import ops
+from .. import debug, ops
 from .mg_map_policy import MGMapNet, SEM_CLASSES
 
 
@@ -49,7 +47,7 @@ class BasePolicy(nn.Module):
 
     def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False):
         features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
-        if ops.rows_route(features) and os.environ.get("WSMG_FUSED_HEADS", "1") != "0":
+        if ops.rows_route(features) and debug.sw.fused_heads:
             # rollout: progress, critic, action mean, mode / sample and log-probability in one launch (≈20 otherwise); the
             # noise of a sampled action is Normal.sample()'s own draw (same generator, same shape)
             ad = self.action_distribution
@@ -86,7 +84,7 @@ class BasePolicy(nn.Module):
             size = self.net.map_encoder.output_shape[-1]
             dis = observations["gt_path"] if "gt_path" in observations.keys() else observations["waypoint_distribution"]
             att = self.net.att_map_t_m
-            if dis.is_cuda and dis.dtype == torch.float32 and att.dtype == torch.float32 and os.environ.get("WSMG_FUSED_KL", "1") != "0":
+            if dis.is_cuda and dis.dtype == torch.float32 and att.dtype == torch.float32 and debug.sw.fused_kl:
                 kl = ops.path_kl(dis, att, size, cfg.CONTRASTIVE_MONITOR.target_tau)      # one launch per direction
             else:
                 lo, hi = torch.aminmax(dis)  # batch-global normalisation, as the reference does (dis.max(), dis.min()) in one pass
@@ -100,7 +98,7 @@ class BasePolicy(nn.Module):
 
     # -- teacher forcing / DAgger update ---------------------------------------------
     def forward(self, observations, rnn_hidden_states, prev_actions, masks, weights):
-        self.net.skip_pred_map_nchw = os.environ.get("WSMG_FUSED_CE", "1") != "0"   # the only consumer of pred_sem_map is the loss below
+        self.net.skip_pred_map_nchw = debug.sw.fused_ce   # the only consumer of pred_sem_map is the loss below
         gt = observations.get("gt_semantic_map") if (AuxLosses.is_active() and self.model_config.PREDICTION_MONITOR.use) else None
         self.net._gt_semantic_map = gt if (gt is not None and gt.is_cuda and gt.dtype == torch.float32 and gt.dim() == 3) else None
         # the fused classifier tail returns logits that carry no gradient: it may only run when the loss on them is its own
@@ -114,7 +112,7 @@ class BasePolicy(nn.Module):
         # = self.action_distribution(features).mean (policy.py:96-97) without building the Normal: its log-std / exp / expand
         # kernels produce nothing the update path reads (logstd gets no gradient in the reference either)
         fused = (features.is_cuda and features.dtype == torch.float32 and features.shape[1] % 4 == 0
-                 and os.environ.get("WSMG_FUSED_UPDATE_HEADS", "1") != "0")
+                 and debug.sw.fused_update_heads)
         if fused:
             # action mean, tanh progress head and the progress monitor's per-row loss in one launch per direction (≈10 each way)
             progress = observations.get("progress") if (AuxLosses.is_active() and self.model_config.PROGRESS_MONITOR.use) else None

@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from . import _abi
+from .debug import sw
 
 _ws_cache = {}
 
@@ -80,7 +81,7 @@ def _rows_of(dy, C):
     ld = dy.stride(-2) if dy.dim() >= 2 else 0
     ok = (dy.stride(-1) == 1 and ld >= C and ld % 8 == 0 and dy.data_ptr() % 16 == 0 and C % 8 == 0
           and all(dy.stride(i) == dy.stride(i + 1) * dy.shape[i + 1] for i in range(dy.dim() - 2))
-          and _os.environ.get("WSMG_STRIDED_GRADS", "1") != "0")
+          and sw.strided_grads)
     return (dy, ld) if ok else (dy.contiguous(), C)
 
 
@@ -131,23 +132,26 @@ def profile_end():
     torch.cuda.synchronize()
     out = {}
     for name, items in (rec or {}).items():
-        ms = sum(s.elapsed_time(e) for s, e, _ in items)
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in items)
         o = out.setdefault(KERNEL_OF[_prof_key(name)], dict(launches=0, ms_total=0.0, flops_total=0.0, entry=_prof_key(name)))
-        o["launches"] += len(items)      # (the *_stats entry points launch the same kernels: one family)
+        o["launches"] += sum(n for _, _, _, n in items)      # (the *_stats entry points launch the same kernels: one family)
         o["ms_total"] += ms
-        o["flops_total"] += float(sum(f for _, _, f in items))
+        o["flops_total"] += float(sum(f for _, _, f, _ in items))
     return out
 
 
-def _launch(name, flops, *args):
-    if _prof is None or (_prof_only is not None and _prof_key(name) not in _prof_only):
+def _launch(name, flops, *args, prof_as=None):
+    """prof_as: time this launch WITH the family of that entry point, as part of its launches (the ordered slab reduction behind a
+    weight-gradient kernel: its time belongs to the family's total, it is not a launch of the family's kernel)."""
+    key = prof_as or name
+    if _prof is None or (_prof_only is not None and _prof_key(key) not in _prof_only):
         _abi.call(name, *args)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     _abi.call(name, *args)
     e.record()
-    _prof.setdefault(name, []).append((s, e, flops))
+    _prof.setdefault(key, []).append((s, e, flops, 0 if prof_as else 1))
 
 
 # ----------------------------------------------------------------------------- section marks (diagnostics)
@@ -243,16 +247,14 @@ def reset_pass_state():
     """Called at the entry of every policy forward pass.  The end-of-backward callbacks that retire the zero pool and
     join the weight-gradient side stream do not run when backward() raises (a WsmgError from a kernel, OOM): without
     this reset one failed backward would leave them 'armed' for ever — every later request would fall back to a
-    torch.zeros launch and, with WSMG_WGRAD_STREAM=1, optimizer.step could race the side-stream weight gradients."""
+    torch.zeros launch, and the optimizer could race gradients that a leaf stream is still writing."""
     TokenGradSink.check_none_pending()
     _prelaid.clear()
-    _pass_seen.clear()
-    _pass_shared.clear()
     if any(z["armed"] for z in _zero_pool.values()):
         _zero_pool_retire()
     if _side_join_armed:
         for main_id, side_id in list(_side_join_armed):
-            for side in list(_wgrad_side.values()) + list(_reduce_side.values()) + _leaf_streams:
+            for side in _leaf_streams:
                 if side.cuda_stream == side_id:
                     torch.cuda.current_stream().wait_stream(side)
         _side_join_armed.clear()
@@ -294,121 +296,45 @@ def _weight_grad_oihw(dw_ohwi, I):
 # Deterministic weight gradients (C ABI: wsmg_conv2d_bwd_weight[_bf16]_plan / _slabs + wsmg_weight_grad_reduce_oihw): the
 # weight-gradient kernels' workgroups STORE their partial tiles into slabs of a workspace and one more launch adds the slabs in
 # a fixed order while it re-lays dW out as OIHW — no float atomics, no zero-fill of dW, bit-identical gradients from run to
-# run (the reference sets cudnn.deterministic, run.py:107-108).  WSMG_WGRAD_ATOMICS=1 restores the atomic form (A/B).
-_wgrad_ws = {}        # (device, stream, layer geometry or None) -> float32 workspace
-_reduce_side = {}     # device -> the stream the slab reductions run on (beside the backward pass's next convolution kernels)
+# run (the reference sets cudnn.deterministic, run.py:107-108).  debug.sw.wgrad_atomics restores the atomic form (A/B).
+_wgrad_ws = {}        # (device, stream) -> float32 workspace
 
 
-def _wgrad_workspace(device, floats, layer=None):
-    """layer=None: one workspace per stream, shared by the layers (launches of one stream use it one after the other);
-    layer=key: that layer's own workspace (its reduction runs on another stream while the next layer's kernel fills its own)."""
-    key = (device.index, _raw_stream(), layer)
+def _wgrad_workspace(device, floats):
+    """One slab workspace per stream, shared by the layers (launches of one stream use it one after the other)."""
+    key = (device.index, _raw_stream())
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < floats:
         if ws is not None:
             ws.record_stream(torch.cuda.current_stream())      # launches that still read the old one are queued on this stream
-        ws = torch.empty(max(int(floats), 1 << 24) if layer is None else int(floats), device=device, dtype=torch.float32)
+        ws = torch.empty(max(int(floats), 1 << 24), device=device, dtype=torch.float32)
         _wgrad_ws[key] = ws
     return ws
 
 
-def _reduce_stream(device, param):
-    """The side stream for the slab reductions, or None.  The reduction of a layer is pure HBM traffic (its slabs: 25-75 MB) with
-    nothing but the optimizer waiting for it: on a second stream it runs beside the backward pass's next convolution kernels,
-    which are bound by the matrix pipe and the L2 -> LDS path.  Conditions: inside a backward pass (the join is an
-    end-of-backward callback), one process (the gradient all-reduce hooks read p.grad on the main stream as soon as it is
-    accumulated), and a parameter whose gradient is SET, not added to, by this pass — autograd's accumulation into an existing
-    .grad would run on the main stream before the reduction has finished.
-    OPT-IN (WSMG_WGRAD_REDUCE_STREAM=1): measured on MI355X in two interleaved pairs of 40-update runs it LOSES — 11.53 / 11.62 ms per
-    update against 11.41 / 11.46 ms with the reductions on the backward pass's own stream: the 1 GB of slab reads per update take
-    bandwidth and CU slots from the convolution kernels they run beside (which are bound by the L2 -> LDS path, not idle), and the
-    20 cross-stream event pairs cost more than the 0.18 ms of reduction time they hide."""
-    if param is None or param.grad is not None or _os.environ.get("WSMG_WGRAD_REDUCE_STREAM", "0") != "1":
-        return None
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        return None
-    if id(param) in _pass_shared:
-        return None
-    s = _reduce_side.get(device.index)
-    if s is None:
-        s = _reduce_side[device.index] = torch.cuda.Stream(device)
-    return s
-
-
-_pass_seen, _pass_shared = set(), set()    # parameters used by one / by several convolutions of the running pass
-
-
-def _note_param_use(w):
-    k = id(w)
-    if k in _pass_seen:
-        _pass_shared.add(k)
-    _pass_seen.add(k)
-
-
-def _weight_grad(sfx, x, dy, dims, fl, Cin_w, param=None):
-    """OIHW float32 weight gradient [Cout, Cin_w, KH, KW] of the convolution `dims` from x [B,H,W,Cin] and dy [B,OH,OW,Cout].
-    param: the parameter this gradient is for, when the caller knows it (see _reduce_stream)."""
+def _weight_grad(sfx, x, dy, dims, fl, Cin_w):
+    """OIHW float32 weight gradient [Cout, Cin_w, KH, KW] of the convolution `dims` from x [B,H,W,Cin] and dy [B,OH,OW,Cout]: the
+    weight-gradient kernel's workgroups store their partial tiles into slabs, one more launch adds the slabs in a fixed order and
+    lays dW out as OIHW (bit-reproducible).  debug.sw.wgrad_atomics: the float-atomics form (A/B)."""
     B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW = dims
-    if _os.environ.get("WSMG_WGRAD_ATOMICS", "0") == "1":
+    if sw.wgrad_atomics:
         dw_ohwi = _zeros_f32((Cout, KH, KW, Cin), x.device)
         _launch("wsmg_conv2d_bwd_weight" + sfx, fl, _p(x), _p(dy), _p(dw_ohwi), *dims, _stream())
         return _weight_grad_oihw(dw_ohwi, Cin_w)
     nsplit, floats = ctypes.c_int(0), ctypes.c_longlong(0)
     _abi.call("wsmg_conv2d_bwd_weight" + sfx + "_plan", *dims, ctypes.cast(ctypes.byref(nsplit), ctypes.c_void_p),
               ctypes.cast(ctypes.byref(floats), ctypes.c_void_p))
-    side = _reduce_stream(x.device, param)
-    if side is not None:
-        main = torch.cuda.current_stream()
-        try:
-            _join_side_at_end(main, side, strict=True)     # raises outside a backward pass
-        except RuntimeError:
-            side = None
-    ws = _wgrad_workspace(x.device, floats.value, None if side is None else (tuple(dims), sfx))
+    ws = _wgrad_workspace(x.device, floats.value)
     _launch("wsmg_conv2d_bwd_weight" + sfx + "_slabs", fl, _p(x), _p(dy), _p(ws), nsplit.value, floats.value, *dims, _stream())
-    if side is None:
-        out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_weight_grad_reduce_oihw", _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream())
-        return out
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
-        _abi.call("wsmg_weight_grad_reduce_oihw", _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream())
-    out.record_stream(main)        # consumed on the main stream behind the end-of-backward join
+    out = torch.empty(Cout, Cin_w, KH, KW, device=x.device, dtype=torch.float32)
+    # (timed with the family it belongs to: ADVICE r03 — its 0.18 ms per update were left out of the weight-gradient family's total)
+    _launch("wsmg_weight_grad_reduce_oihw", 0.0, _p(ws), nsplit.value, Cout, Cin_w, KH, KW, Cin, _p(out), _stream(),
+            prof_as="wsmg_conv2d_bwd_weight" + sfx + "_slabs")
     return out
 
 
-_wgrad_side = {}
 _side_join_armed = set()
-_leaf_streams = []     # other streams that join the main stream at the end of a backward pass (wsmgmap.recurrent's leaf stream)
-
-
-def _wgrad_side_stream(flops=0.0, param=None):
-    """The side stream a layer's weight-gradient launches (kernel + ordered reduce) run on, or None for the backward pass's own.
-    A weight gradient is a leaf of the backward graph — nothing but the optimizer waits for it — so beside the backward-data
-    chain it fills what that chain leaves idle: the tails of its launches and the stretches of small kernels.  Measured (round 3,
-    interleaved 40-update runs, three rounds on one box): layers below 30 / 60 / 100 GFLOP on the side stream 11.44 / 11.46 / 11.42 ms
-    per update against 11.61 without, 11.50 / 11.46 / 11.54 against 11.53 / 11.54 / 11.65 in a second call; from 150 GFLOP up it LOSES
-    (11.82, 11.74 with every layer: two chip-filling kernels side by side only share the chip).  OPT-IN all the same
-    (WSMG_WGRAD_STREAM=2: layers below WSMG_WGRAD_STREAM_GF = 100 GFLOP; =1: every layer; default 0): the gain is 0.1 ms, the
-    family's own launches get 13 % LONGER under the overlap (0.30 -> 0.26 of the bf16 peak by the bench's per-launch clock, which
-    is the figure the roofline object reports), and a HIP-graph capture of the update with this stream in it crashed in
-    capture_end (record_stream on tensors of the capture's pool) — under capture it is always off.  Conditions, as for the reduce stream above: one process (with a process group the gradient all-reduce hooks read
-    p.grad on the main stream as soon as it is accumulated), and a leaf parameter whose .grad this pass SETS — autograd's add into
-    an existing .grad, or into the gradient of a weight that several convolutions share, would run on the main stream before the
-    side stream has finished.  The main stream waits for the side stream once, when the backward pass ends."""
-    mode = _os.environ.get("WSMG_WGRAD_STREAM", "0")
-    if mode not in ("1", "2") or (mode == "2" and flops >= float(_os.environ.get("WSMG_WGRAD_STREAM_GF", "100")) * 1e9):
-        return None
-    if torch.cuda.is_current_stream_capturing():
-        return None
-    if param is None or param.grad is not None or id(param) in _pass_shared:
-        return None
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        return None
-    dev = torch.cuda.current_device()
-    if dev not in _wgrad_side:
-        _wgrad_side[dev] = torch.cuda.Stream()
-    return _wgrad_side[dev]
+_leaf_streams = []     # streams that join the main stream at the end of a backward pass (wsmgmap.recurrent's leaf stream)
 
 
 def _join_side_at_end(main, side, strict=False):
@@ -497,8 +423,6 @@ class _Conv2d(torch.autograd.Function):
                 _abi.call("wsmg_relu_fwd", _p(y), _p(y), y.numel(), _stream())
         ctx.save_for_backward(x, w_ihwo, y if relu else None)
         ctx.cfg = dims + (bias is not None, sfx, Cin_w)
-        ctx.w_param = w_oihw if w_oihw.is_leaf else None     # (a leaf: its .grad is where the weight gradient goes)
-        _note_param_use(w_oihw)
         ctx.bias_grad_zero = bool(bias_grad_zero)
         ctx.relu_sink = relu_sink if relu else None
         if ctx.relu_sink is not None:
@@ -531,25 +455,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
-            side = _wgrad_side_stream(fl, ctx.w_param)
-            if side is not None:
-                try:
-                    _join_side_at_end(torch.cuda.current_stream(), side, strict=True)   # raises outside a backward pass
-                except RuntimeError:
-                    side = None
-            if side is None:
-                dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w, ctx.w_param)
-            else:
-                # the weight gradient is a leaf of the backward graph: it runs on a side stream beside the backward-data
-                # chain and fills the tails of its launches (1.8-3.6 waves of workgroups each); the main stream joins the
-                # side stream once, at the end of the backward pass
-                main = torch.cuda.current_stream()
-                side.wait_stream(main)
-                x.record_stream(side)
-                dy.record_stream(side)
-                with torch.cuda.stream(side):
-                    dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
-                dw.record_stream(main)         # consumed on the main stream (the optimizer) behind the end-of-backward join
+            dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
@@ -611,86 +517,14 @@ def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=Fal
     return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats, relu_sink)
 
 
-class _Conv2dCat(torch.autograd.Function):
-    """conv2d(cat(xs, channel axis), w) + b without the concatenation (bf16 engine): one launch per part over the
-    matching input-channel slice of w, parts after the first accumulate into y in the epilogue (flag bit 2), the optional
-    ReLU runs in the last part's epilogue.  Backward: one backward-data and one backward-weight launch per part on the
-    parts themselves, so no gradient slice of a concatenated tensor is ever copied out.  Only the last part may carry
-    zero-padded channels beyond the weight's."""
-
-    @staticmethod
-    def forward(ctx, w_oihw, bias, stride, pad, bias_grad_zero, relu, *xs):
-        _req(w_oihw, bias, *xs)
-        _f32(w_oihw, bias)
-        B, H, W, _ = xs[0].shape
-        Cout, Cin_w, KH, KW = w_oihw.shape
-        OH, OW = _conv_out(H, KH, stride, pad), _conv_out(W, KW, stride, pad)
-        y = torch.empty(B, OH, OW, Cout, device=xs[0].device, dtype=torch.bfloat16)
-        parts, c0 = [], 0
-        for i, x in enumerate(xs):
-            if x.dtype != torch.bfloat16 or tuple(x.shape[:3]) != (B, H, W):
-                raise _abi.WsmgError("conv2d_cat: parts must be bf16 NHWC tensors of one spatial size")
-            Ci = x.shape[3]
-            Ci_w = min(Ci, Cin_w - c0)
-            if Ci_w <= 0 or (Ci_w < Ci and i != len(xs) - 1):
-                raise _abi.WsmgError("conv2d_cat: only the last part may have padded channels")
-            w, w_ihwo = _weight_layouts(w_oihw[:, c0:c0 + Ci_w].contiguous(), Ci, torch.bfloat16, ctx.needs_input_grad[6 + i])
-            fl = 2.0 * B * OH * OW * Cout * Ci * KH * KW
-            dims = (B, H, W, Ci, Cout, KH, KW, stride, pad, OH, OW)
-            flags = (4 if i else 0) | (2 if relu and i == len(xs) - 1 else 0)
-            _launch("wsmg_conv2d_fwd_bf16", fl, _p(x), _p(w), _p(bias if i == 0 else None), _p(y), flags, *dims, _stream())
-            parts.append((dims, fl, Ci_w, w_ihwo))
-            c0 += Ci_w
-        if c0 != Cin_w:
-            raise _abi.WsmgError(f"conv2d_cat: parts cover {c0} of the weight's {Cin_w} input channels")
-        ctx.save_for_backward(*xs, *[p[3] for p in parts if p[3] is not None], *([y] if relu else []))
-        ctx.parts = [(p[0], p[1], p[2], p[3] is not None) for p in parts]
-        ctx.has_bias, ctx.bias_grad_zero, ctx.relu = bias is not None, bool(bias_grad_zero), bool(relu)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        saved = list(ctx.saved_tensors)
-        n = len(ctx.parts)
-        xs, rest = saved[:n], saved[n:]
-        dy = dy.contiguous()
-        if ctx.relu:
-            y = rest.pop()
-            masked = torch.empty_like(dy)
-            _abi.call("wsmg_relu_bwd_bf16", _p(dy), _p(y), _p(masked), dy.numel(), _stream())
-            dy = masked
-        dxs, dws = [], []
-        for i, (x, (dims, fl, Ci_w, has_ihwo)) in enumerate(zip(xs, ctx.parts)):
-            B, H, W, Ci, Cout, KH, KW, stride, pad, OH, OW = dims
-            dx = None
-            if has_ihwo:
-                w_ihwo = rest.pop(0)
-                dx = torch.empty_like(x)
-                _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
-            dxs.append(dx)
-            if ctx.needs_input_grad[0]:
-                dws.append(_weight_grad("_bf16", x, dy, tuple(dims), fl, Ci_w))
-        dw = torch.cat(dws, dim=1) if dws else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[1]:
-            Cout = ctx.parts[0][0][4]
-            db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
-        return (dw, db, None, None, None, None, *dxs)
-
-
 def conv2d_cat(xs, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, relu_sink=None):
-    """conv2d over the channel concatenation of the NHWC tensors `xs` (see _Conv2dCat); float32 activations take the
-    plain route (torch.cat + conv2d)."""
+    """conv2d over the channel concatenation of the NHWC tensors `xs`: one vectorised concatenation (wsmg_cat_channels), then the
+    convolution.  (Running the convolution part by part over the weight's input-channel slices — no concatenated tensor — was
+    built and measured in round 2: 15.30-15.39 vs 15.14 ms per update; two shorter reductions, two epilogues and twice the
+    weight-gradient launches cost more than the copies they remove.  The code is gone, the measurement is in DESIGN.md section 7.)"""
     xs = list(xs)
-    if len(xs) == 1:
-        return conv2d(xs[0], weight_oihw, bias, stride, pad, bias_grad_zero, relu, relu_sink=relu_sink)
-    # measured on the T=64 x N=8 update: 15.30-15.39 ms with the part-by-part route against 15.14 ms with torch.cat + one
-    # conv — two shorter reductions, two epilogues (the second re-reads y) and twice the weight-gradient launches cost
-    # more than the 0.35 ms of concatenation and slice copies they remove — so the part-by-part route is opt-in
-    if xs[0].dtype != torch.bfloat16 or _os.environ.get("WSMG_CONV_CAT", "0") != "1":
-        x = cat_channels(xs[0], xs[1]) if len(xs) == 2 else torch.cat(xs, dim=-1)
-        return conv2d(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, relu_sink=relu_sink)
-    return _Conv2dCat.apply(weight_oihw, bias, stride, pad, bias_grad_zero, relu, *xs)
+    x = xs[0] if len(xs) == 1 else (cat_channels(xs[0], xs[1]) if len(xs) == 2 else torch.cat(xs, dim=-1))
+    return conv2d(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, relu_sink=relu_sink)
 
 
 _splitk_plans = {}    # layer geometry -> (ksplit, partial floats) from wsmg_conv2d_splitk_plan
@@ -712,7 +546,7 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False, ad
     (one launch; used by the frozen encoders with eval-mode BatchNorm folded into weight and bias).
     add_to: a tensor of the output's shape and type that the result is ADDED to, in place, before the ReLU (the identity branch
     of a residual block) — it is returned.  Layers too small to fill the chip run split-K (wsmg_conv2d_fwd_bf16_splitk);
-    WSMG_CONV_SPLITK=0 turns that off."""
+    debug.sw.conv_splitk = False turns that off."""
     _req(x, w_ohwi_bf16, bias, add_to)
     if x.dtype != torch.bfloat16 or w_ohwi_bf16.dtype != torch.bfloat16:
         raise _abi.WsmgError("conv2d_infer_bf16 needs bf16 activations and weights")
@@ -730,7 +564,7 @@ def conv2d_infer_bf16(x, w_ohwi_bf16, bias, stride, pad, relu, out_f32=False, ad
     flags = (2 if relu else 0) | (1 if out_f32 else 0) | (4 if add_to is not None else 0)
     fl = 2.0 * B * OH * OW * Cout * Cin * KH * KW
     dims = (B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)
-    ks, floats = _splitk_plan(B, OH, OW, Cin, Cout, KH, KW) if _os.environ.get("WSMG_CONV_SPLITK", "1") != "0" else (1, 0)
+    ks, floats = _splitk_plan(B, OH, OW, Cin, Cout, KH, KW) if sw.conv_splitk else (1, 0)
     if ks > 1:
         part = torch.empty(floats, device=x.device, dtype=torch.float32)
         _launch("wsmg_conv2d_fwd_bf16_splitk", fl, _p(x), _p(w_ohwi_bf16), _p(bias), _p(y), flags, ks, _p(part), *dims, _stream())
@@ -781,9 +615,9 @@ ROWS_MAX = 16     # rollout-size dense layers: up to this many rows go through l
 
 def rows_route(x):
     """True when a dense layer on x [B, ...] should take the one-launch rollout route: no autograd, float32 on the GPU, at most
-    ROWS_MAX rows.  WSMG_ROWS_LINEAR=0 turns it off (the nn.Linear modules run)."""
+    ROWS_MAX rows.  debug.sw.rows_linear = False turns it off (the nn.Linear modules run)."""
     return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.shape[0] <= ROWS_MAX
-            and _os.environ.get("WSMG_ROWS_LINEAR", "1") != "0")
+            and sw.rows_linear)
 
 
 @torch.no_grad()
@@ -918,9 +752,9 @@ _bn_slabs = {}
 def bn_stats_slabs(key, C, device):
     """Float64 [BN_SLABS, 2, C] accumulator a convolution's epilogue adds its output's per-channel sums into and the
     following train-mode BatchNorm consumes AND CLEARS (wsmg_bn_act_fwd_bf16_pre) — one persistent buffer per BatchNorm
-    layer, zero between uses.  Returns None when the fused statistics are off (WSMG_BN_FUSED_STATS=0) .  If a forward pass
+    layer, zero between uses.  Returns None when the fused statistics are off (debug.sw.bn_fused_stats).  If a forward pass
     died between the two launches the buffer is dirty: `in_use` catches that and it is zeroed again."""
-    if _os.environ.get("WSMG_BN_FUSED_STATS", "1") == "0":
+    if not sw.bn_fused_stats:
         return None
     k = (key, C, device.index)
     e = _bn_slabs.get(k)
@@ -965,7 +799,7 @@ class _MaxPool(torch.autograd.Function):
         OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty(B, OH, OW, C, device=x.device, dtype=x.dtype)
         ctx.dims = (B, H, W, C, OH, OW)
-        if x.dtype == torch.bfloat16 and x.requires_grad and _os.environ.get("WSMG_MAXPOOL_IDX", "1") != "0":
+        if x.dtype == torch.bfloat16 and x.requires_grad:
             # training: keep every output element's winning tap (one byte) — the backward then reads four taps per input element
             # instead of recomputing four windows' arg-max from x
             idx = torch.empty(B, OH, OW, C // 4, device=x.device, dtype=torch.int32)
@@ -1250,7 +1084,7 @@ class _ClsTail(torch.autograd.Function):
 def cls_tail_ok(y2, classes):
     """Can `cls_tail` take this activation?  bf16 [B, H, W, 32] with H even and W a multiple of 16, at most 32 classes."""
     return (y2.is_cuda and y2.dtype == torch.bfloat16 and y2.dim() == 4 and y2.shape[3] == 32 and y2.shape[1] % 2 == 0
-            and y2.shape[2] % 16 == 0 and classes <= 32 and _os.environ.get("WSMG_FUSED_CLS_TAIL", "1") != "0")
+            and y2.shape[2] % 16 == 0 and classes <= 32 and sw.fused_cls_tail)
 
 
 def cls_tail(y2, stats, bn, conv1x1, gt=None):
@@ -1530,7 +1364,7 @@ class _Fanout3(torch.autograd.Function):
 
 def fanout3(x):
     """(x, x, x) for an activation with three consumers, whose gradients then meet in one launch (see _Fanout3)."""
-    if not (x.requires_grad and torch.is_grad_enabled()) or _os.environ.get("WSMG_FANOUT3", "1") == "0":
+    if not (x.requires_grad and torch.is_grad_enabled()):
         return x, x, x
     return _Fanout3.apply(x)
 
@@ -1565,8 +1399,7 @@ class _Up2Cat(torch.autograd.Function):
 def upsample2x_cat(a, b):
     """cat([upsample2x(a), b], channels) of bf16 NHWC activations in one launch (wsmg_upsample2x_cat_bf16: the upsampled tensor
     is never materialised), forward and — round 3 — under autograd.  Other types / channel counts: the two separate operators."""
-    if (a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.shape[-1] % 8 or b.shape[-1] % 8
-            or _os.environ.get("WSMG_UPCAT", "1") == "0"):
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.shape[-1] % 8 or b.shape[-1] % 8:
         return cat_channels(upsample2x(a), b)
     _req(a, b)
     B, H, W, Ca = a.shape
@@ -1764,23 +1597,19 @@ def attention_fp8_shared(q, k_sets, v_sets, lengths, inverse, scale=1.0 / 16, sc
 
 
 def _rnn_workspace(nbytes, device):
-    """Barrier words + exchange image of the persistent RNN kernels.  WSMG_RNN_POISON=1 (stress tool) fills
+    """Barrier words + exchange image of the persistent RNN kernels.  debug.sw.rnn_poison (stress tool) fills
     it with NaN first so that any stale or missed hand-off read poisons the results visibly."""
     ws = torch.empty((int(nbytes) + 3) // 4, device=device, dtype=torch.float32)
-    if _POISON:
+    if sw.rnn_poison:
         ws.fill_(float("nan"))
     return ws
 
-
-import os as _os
-_POISON = _os.environ.get("WSMG_RNN_POISON", "0") == "1"
-_RNN_CHECK = _os.environ.get("WSMG_RNN_CHECK", "0") == "1"   # debug: synchronise and check after every persistent launch
 
 check_rnn_status = _abi.check_rnn_status
 
 
 def _rnn_launched():
-    if _RNN_CHECK:
+    if sw.rnn_check:          # debug: synchronise and check after every persistent launch
         torch.cuda.current_stream().synchronize()
         _abi.check_rnn_status()
 
@@ -1866,12 +1695,8 @@ class _BiLSTM(torch.autograd.Function):
         # one direction's gate gradients as a contiguous [U L, 4H] matrix first: on the strided view dg[:, :, d] (row pitch 8H)
         # the GEMM library picked a 32 x 16 tile kernel that took 340 us for this 0.7 GFLOP product (beside the map stack's
         # backward, on the instruction stream)
-        if _os.environ.get("WSMG_LSTM_DW_CONTIG", "1") != "0":
-            dgd = dg.permute(2, 0, 1, 3).contiguous().view(2, U * L, 4 * H)
-            dw = torch.stack([dgd[0].t() @ hprev_f.reshape(U * L, H), dgd[1].t() @ hprev_r.reshape(U * L, H)])
-        else:
-            dw = torch.stack([dg[:, :, 0].reshape(U * L, 4 * H).t() @ hprev_f.reshape(U * L, H),
-                              dg[:, :, 1].reshape(U * L, 4 * H).t() @ hprev_r.reshape(U * L, H)])
+        dgd = dg.permute(2, 0, 1, 3).contiguous().view(2, U * L, 4 * H)
+        dw = torch.stack([dgd[0].t() @ hprev_f.reshape(U * L, H), dgd[1].t() @ hprev_r.reshape(U * L, H)])
         db = dg.sum(dim=(0, 1))
         return dg, dw, db, None
 
@@ -1963,7 +1788,7 @@ def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12, planes=False):
 def map_retrieve(global_map, gps, compass, E, resolution=0.12, fused=None):
     """fused: crop + rotation in one launch, bit-identical to the two.  Default: for small batches only (B E^2 C / 4 <= 500 000
     work items: 11 vs 16 us at B = 1; at B = 8 the 16 gathers per item already cost more than the crop's round trip through memory —
-    35 vs 26 us, 311 vs 219 us at cfg4); WSMG_BEV_RETRIEVE_FUSED=0 / 1 forces either."""
+    35 vs 26 us, 311 vs 219 us at cfg4); `fused` = True / False forces either."""
     _req(global_map, gps, compass)
     B = gps.shape[0]
     _check_global_map(global_map, B, global_map.shape[3] if global_map.dim() == 4 else -1, gps, compass)
@@ -1972,8 +1797,7 @@ def map_retrieve(global_map, gps, compass, E, resolution=0.12, fused=None):
     G, C = global_map.shape[1], global_map.shape[3]
     out = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
     if fused is None:
-        ev = _os.environ.get("WSMG_BEV_RETRIEVE_FUSED")
-        fused = (B * E * E * (C // 4) <= 500_000) if ev is None else ev != "0"
+        fused = B * E * E * (C // 4) <= 500_000
     if fused:
         _abi.call("wsmg_map_retrieve_fused", _p(global_map), _p(gps), _p(compass), B, C, E, G, float(resolution), _p(out), _stream())
         return out
