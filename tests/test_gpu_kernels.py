@@ -532,8 +532,9 @@ def test_rnn_handoff_under_concurrent_load(ops, Tn):
     ref = run()
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(t).all()) for t in ref)
-    old = ops._POISON
-    ops._POISON = True
+    from wsmgmap.debug import sw
+    old = sw.rnn_poison
+    sw.rnn_poison = True
     try:
         side = torch.cuda.Stream()
         x = torch.randn(256, 24, 24, 256, device="cuda").to(torch.bfloat16)
@@ -547,7 +548,7 @@ def test_rnn_handoff_under_concurrent_load(ops, Tn):
                 assert torch.equal(a, b), f"repeat {i}: {name} differs under load (max {float((a - b).abs().max()):.3e})"
         torch.cuda.synchronize()
     finally:
-        ops._POISON = old
+        sw.rnn_poison = old
 
 
 # ------------------------------------------------------------------ fp8 text attention (configs[4])
