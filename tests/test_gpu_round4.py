@@ -394,3 +394,25 @@ def test_instruction_dedup_in_one_launch_matches_torch_unique(dtype):
         first = [int((inverse.cpu() == u).nonzero()[0]) for u in range(uniq.shape[0])]
         assert first == sorted(first)                                              # order of first appearance
         assert torch.equal(len_host, (uniq.cpu() != 0).sum(1)) and torch.equal(len_dev.cpu(), len_host)
+
+
+def test_feeder_streams_a_recoded_cache_bit_identically():
+    """the same episodes stored the reference's way (zlib(msgpack_numpy)) and recoded (raw, uncompressed) come
+    out of DeviceFeeder — worker processes, shared-memory ring, device collate — as bit-identical batches, in the same order."""
+    from oracle import data_cases as dc
+    from wsmgmap.data import DeviceFeeder, TrajectoryDataset, pack_record, recode_record
+    lengths = (dc.DATASET_LENGTHS * 2)[:32]
+    blobs = [pack_record(*dc.episode(2000 + i, n)) for i, n in enumerate(lengths)]
+    raws = [recode_record(b) for b in blobs]
+
+    def run(store):
+        ds = TrajectoryDataset(_Store(store), len(store), batch_size=4, rank=0, world_size=1)
+        out = []
+        for ob, prev, masks, corr, wts in DeviceFeeder(ds, 4, "cuda", num_workers=2, prefetch=2, seed=3):
+            out.append(({k: v.cpu() for k, v in ob.items()}, prev.cpu(), masks.cpu(), corr.cpu(), wts.cpu()))
+        return out
+    a, b = run(blobs), run(raws)
+    assert len(a) == len(b) and len(a) > 0
+    for (oa, *ra), (ob_, *rb) in zip(a, b):
+        assert list(oa) == list(ob_) and all(torch.equal(oa[k], ob_[k]) for k in oa)
+        assert all(torch.equal(x, y) for x, y in zip(ra, rb))

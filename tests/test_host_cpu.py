@@ -518,3 +518,38 @@ def test_feeder_worker_sends_an_oversize_batch_outside_the_ring_and_waits_for_th
     th.join(timeout=10)
     torch.set_num_threads(nthreads)
     assert not th.is_alive() and big >= 1 and len(got) == len(sizes) and sorted(got) == sorted(sizes)
+
+
+def test_recoded_raw_records_decode_to_the_same_arrays_and_collate_identically():
+    """`tools/recode_cache.py` rewrites the reference's zlib(msgpack_numpy) values (dagger_trainer.py:336-343)
+    once into an uncompressed layout; a recoded record must give the same arrays (dtype, shape, bytes) and the same batch from
+    the reference-semantics collate, so the feeder streams it with no decode."""
+    sys_path_tools = os.path.join(ROOT, "tools")
+    import sys
+    if sys_path_tools not in sys.path:
+        sys.path.insert(0, sys_path_tools)
+    import recode_cache
+    from oracle import data_cases as dc
+    from wsmgmap.data import collate_fn, is_raw_record, pack_record, pack_record_raw, recode_record, unpack_record
+    eps = [dc.episode(300 + i, n) for i, n in enumerate(dc.COLLATE_LENGTHS + dc.LONG_LENGTHS)]
+    blobs = [pack_record(*e) for e in eps]
+    store_out = {}
+    nin, nout = recode_cache.recode_store(lambda i: blobs[i], len(blobs), store_out.__setitem__, workers=2, chunk=2)
+    assert nin == sum(map(len, blobs)) and nout == sum(len(v) for v in store_out.values()) and len(store_out) == len(blobs)
+    for i, e in enumerate(eps):
+        raw = store_out[i]
+        assert is_raw_record(raw) and not is_raw_record(blobs[i])
+        assert recode_record(raw) == raw and raw == pack_record_raw(*e)
+        a, b = unpack_record(blobs[i]), unpack_record(memoryview(raw))       # (LMDB hands out memoryviews with buffers=True)
+        assert list(a[0]) == list(b[0])
+        for k in a[0]:
+            assert a[0][k].dtype == b[0][k].dtype and a[0][k].shape == b[0][k].shape and a[0][k].tobytes() == b[0][k].tobytes(), k
+        assert a[1].tobytes() == b[1].tobytes() and a[2].tobytes() == b[2].tobytes()
+    mk = lambda recs: [(r[0], r[1], r[2], torch.ones(len(r[1]))) for r in recs]    # noqa: E731
+    want = collate_fn(mk([unpack_record(x) for x in blobs[:3]]))
+    got = collate_fn(mk([unpack_record(store_out[i]) for i in range(3)]))
+    assert all(torch.equal(want[0][k], got[0][k]) for k in want[0]) and all(torch.equal(x, y) for x, y in zip(want[1:], got[1:]))
+    # the 200-step cap of the collate applies to raw records alike
+    long_w = collate_fn(mk([unpack_record(x) for x in blobs[3:]]))
+    long_g = collate_fn(mk([unpack_record(store_out[i]) for i in (3, 4)]))
+    assert all(torch.equal(long_w[0][k], long_g[0][k]) for k in long_w[0])

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ws-mgmap_amd"))
 import numpy as np
 import torch
-from wsmgmap.data import pack_record, unpack_record, collate_fn, DeviceCollator
+from wsmgmap.data import pack_record, pack_record_raw, unpack_record, collate_fn, DeviceCollator
 
 N, T = 8, 64
 rng = np.random.RandomState(0)
@@ -74,24 +74,25 @@ def host_side_and_collate():
 # to the workers), every worker decodes whole batches of its shard, the consumer does what a training loop does with a batch:
 # waits for it on its stream.  Reported next to the compute rate of the update (bench.py: ~42 k steps/s).
 class SynthStore:
-    def __init__(self, n_records, seed=0):
-        self.n, self.seed, self._blobs = n_records, seed, None
+    def __init__(self, n_records, seed=0, raw_records=False):
+        self.n, self.seed, self._blobs, self.raw_records = n_records, seed, None, raw_records
 
     def __getstate__(self):
-        return dict(n=self.n, seed=self.seed, _blobs=None)
+        return dict(n=self.n, seed=self.seed, _blobs=None, raw_records=self.raw_records)
 
     def __call__(self, i):
         if self._blobs is None:
             global rng
             rng = np.random.RandomState(self.seed)
-            self._blobs = [pack_record(*episode(), level=1) for _ in range(4)]
+            # raw_records: the recoded cache of tools/recode_cache.py (uncompressed, zero-copy decode)
+            self._blobs = [(pack_record_raw(*episode()) if self.raw_records else pack_record(*episode(), level=1)) for _ in range(4)]
         return self._blobs[i % len(self._blobs)]
 
 
-def feeder_rate(workers, batches_per_worker=6, transport="ring"):
+def feeder_rate(workers, batches_per_worker=6, transport="ring", raw_records=False):
     from wsmgmap.data import TrajectoryDataset, DeviceFeeder
     nw = max(workers, 1)
-    ds = TrajectoryDataset(SynthStore(N * batches_per_worker * nw), N * batches_per_worker * nw, batch_size=N)
+    ds = TrajectoryDataset(SynthStore(N * batches_per_worker * nw, raw_records=raw_records), N * batches_per_worker * nw, batch_size=N)
     fd = DeviceFeeder(ds, N, "cuda", num_workers=workers, prefetch=2, workers=transport, slot_bytes=int(raw * 1.05) + (1 << 20))
     t_first, n, steps = None, 0, 0
     for ob, prev, masks, corr, wts in fd:
@@ -120,5 +121,13 @@ if __name__ == "__main__" and os.environ.get("WSMG_FEEDER_E2E", "1") != "0":
             print(f"  ring, {w:2d} decode processes: not run — {str(e).splitlines()[-1][:300]}")
             continue
         print(f"  ring, {w:2d} decode processes: {r:8.0f} steps/s  ({n} batches; ring pinned: {pinned}; {r / max(w, 1):.0f} steps/s per worker)")
+    print("the same from a RECODED cache (tools/recode_cache.py: uncompressed raw records, no inflate / msgpack parse):")
+    for w in [min(int(x), 32) for x in os.environ.get("WSMG_FEEDER_WORKERS_RAW", "1,4,8,16").split(",")]:
+        try:
+            r, n, pinned = feeder_rate(w, batches_per_worker=12, raw_records=True)
+        except RuntimeError as e:
+            print(f"  raw ring, {w:2d} worker processes: not run — {str(e).splitlines()[-1][:300]}")
+            continue
+        print(f"  raw ring, {w:2d} worker processes: {r:8.0f} steps/s  ({n} batches; ring pinned: {pinned}; {r / max(w, 1):.0f} steps/s per worker)")
     r, n, _ = feeder_rate(8, transport="dataloader")
     print(f"  torch DataLoader transport, 8 workers (batches pickled through a pipe): {r:8.0f} steps/s")

@@ -61,9 +61,77 @@ def pack_record(observations, prev_actions, oracle_actions, level=-1):
     return zlib.compress(payload, level)
 
 
+# ---- the recoded ("raw") record: the same arrays, uncompressed, behind a small index ------------------------------------------
+# The reference's value format costs one zlib inflate + one msgpack parse of 92 MB per episode on every epoch: 228 policy steps/s
+# per host core (profiles/r03_feeder.txt), i.e. ~200 cores of decode to keep ONE MI355X fed (the update consumes > 45 k steps/s).
+# `tools/recode_cache.py` rewrites a cache ONCE into this layout; reading a record is then a header parse and zero-copy views
+# into the stored bytes — the arrays keep their on-disk dtypes (common_trainer.py:514-532), so a recoded record collates
+# bit-identically to the original (tests/test_host_cpu.py, tests/test_gpu_round4.py).
+#
+#   bytes 0-7   b"WSMGRAW1"
+#   bytes 8-11  little-endian uint32: length H of the index
+#   12 .. 12+H  msgpack [[name, dtype.str, shape, offset, nbytes] ...] for the observations in their stored order, then the
+#               entries "__prev" and "__oracle" (prev_actions, oracle_actions); offsets are relative to the payload
+#   payload     starts at the next multiple of 64 bytes; every array starts on a multiple of 64 bytes
+RAW_MAGIC = b"WSMGRAW1"
+
+
+def pack_record_raw(observations, prev_actions, oracle_actions):
+    """The recoded form of one record (see above).  Arrays are stored as they are (no dtype change: cast first with
+    change_data_type, as the reference does before it writes)."""
+    items = [(k, np.ascontiguousarray(np.asarray(v))) for k, v in observations.items() if k != "ep_id"]
+    items += [("__prev", np.ascontiguousarray(np.asarray(prev_actions))), ("__oracle", np.ascontiguousarray(np.asarray(oracle_actions)))]
+    index, off = [], 0
+    for k, a in items:
+        if a.dtype.kind == "V" or a.dtype.kind == "O":
+            raise TypeError(f"cannot store {k} of dtype {a.dtype} in a raw record")
+        index.append([k, a.dtype.str, list(a.shape), off, a.nbytes])
+        off += (a.nbytes + 63) & ~63
+    head = msgpack.packb(index, use_bin_type=True)
+    start = (12 + len(head) + 63) & ~63
+    out = bytearray(start + off)
+    out[0:8] = RAW_MAGIC
+    out[8:12] = len(head).to_bytes(4, "little")
+    out[12:12 + len(head)] = head
+    for (k, a), (_, _, _, o, nb) in zip(items, index):
+        out[start + o:start + o + nb] = a.reshape(-1).view(np.uint8).data
+    return bytes(out)
+
+
+def is_raw_record(blob):
+    return len(blob) >= 12 and bytes(blob[0:8]) == RAW_MAGIC
+
+
+def _unpack_raw(blob):
+    mv = memoryview(blob)
+    hlen = int.from_bytes(mv[8:12], "little")
+    index = msgpack.unpackb(bytes(mv[12:12 + hlen]), raw=False)
+    start = (12 + hlen + 63) & ~63
+    obs, prev, oracle = {}, None, None
+    for name, dt, shape, off, nbytes in index:
+        a = np.frombuffer(mv, dtype=np.dtype(dt), count=nbytes // np.dtype(dt).itemsize, offset=start + off).reshape(shape)
+        if name == "__prev":
+            prev = a
+        elif name == "__oracle":
+            oracle = a
+        else:
+            obs[name] = a
+    return [obs, prev, oracle]
+
+
+def recode_record(blob, level=None):
+    """zlib(msgpack_numpy) value -> raw value (a raw value is returned unchanged)."""
+    if is_raw_record(blob):
+        return bytes(blob)
+    return pack_record_raw(*unpack_record(blob))
+
+
 def unpack_record(blob):
     """-> [observations, prev_actions, oracle_actions]; arrays are read-only views of the decompressed buffer
-    (no copy), which is what the pinned staging of DeviceCollator copies from."""
+    (no copy), which is what the pinned staging of DeviceCollator copies from.  Accepts the reference's value format
+    (zlib(msgpack_numpy)) and the recoded raw format (views straight into `blob`)."""
+    if is_raw_record(blob):
+        return _unpack_raw(blob)
     rec = msgpack.unpackb(zlib.decompress(blob), object_hook=_decode, raw=False, strict_map_key=False)
     if isinstance(rec[0], dict):
         rec[0].pop("ep_id", None)   # dagger_trainer.py:180-181
