@@ -463,6 +463,16 @@ int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const flo
                  const float* y, const float* save_r, const float* save_z, const float* save_n,
                  const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
                  void* sync_ws, wsmg_stream_t stream);
+/* wsmg_gru_fwd / wsmg_gru_bwd on a workspace the caller OWNS: zeroed once at allocation and used by nothing but these two entry
+ * points of this process — the per-launch clear is skipped (tags are launch-unique within a process; one launch less in front of
+ * each of the 16 chunk launches of the pipelined update, wsmgmap/recurrent.py).  After a reported timeout (wsmg_rnn_status != 0)
+ * the owner zeroes the workspace again (the error word in it is sticky).  Concurrent launches need separate workspaces. */
+int wsmg_gru_fwd_owned(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                       int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                       float* save_ghn, void* sync_ws, wsmg_stream_t stream);
+int wsmg_gru_bwd_owned(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                       const float* y, const float* save_r, const float* save_z, const float* save_n, const float* save_ghn,
+                       int T, int N, int hidden, float* dgi, float* dgh, float* dh0, void* sync_ws, wsmg_stream_t stream);
 
 /* ============================ persistent packed bidirectional LSTM ============================ */
 /* nn.LSTM(50 -> 128, bidirectional) over packed instructions (instruction_encoder.py:80-92): row b is

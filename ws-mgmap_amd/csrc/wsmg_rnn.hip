@@ -796,17 +796,15 @@ extern "C" int64_t wsmg_gru_workspace_bytes(int T) {
   return 256 + (fwd > bwd ? fwd : bwd);
 }
 
-extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
-                            int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
-                            float* save_ghn, void* sync_ws, wsmg_stream_t stream) {
+static int gru_fwd_launch(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks, int T, int N, int hidden,
+                          float* y, float* save_r, float* save_z, float* save_n, float* save_ghn, void* sync_ws, hipStream_t s, bool clear) {
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
-  hipStream_t s = wsmg_s(stream);
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
   if (T > 1023) return WSMG_EINVAL;
+  hipError_t e = hipSuccess;
   // the control words AND the {value, tag} image are cleared: tags are launch-unique within a process, but device
   // memory handed to a new process can still hold a previous process's image with the same epoch numbers
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)T * NWG * NB * UNITS_WG * 8, s);
-  if (e != hipSuccess) return (int)e;
+  if (clear && (e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)T * NWG * NB * UNITS_WG * 8, s)) != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
   if (WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B)
@@ -817,17 +815,31 @@ extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_h
   WSMG_RETURN_LAUNCH();
 }
 
-extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
-                            const float* y, const float* save_r, const float* save_z, const float* save_n,
-                            const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
-                            void* sync_ws, wsmg_stream_t stream) {
+extern "C" int wsmg_gru_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                            int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                            float* save_ghn, void* sync_ws, wsmg_stream_t stream) {
+  return gru_fwd_launch(gi, w_hh, b_hh, h0, masks, T, N, hidden, y, save_r, save_z, save_n, save_ghn, sync_ws, wsmg_s(stream), true);
+}
+
+// The same launch on a workspace the CALLER owns for good: zeroed once when it was allocated and never used by anything but this
+// process's wsmg_gru_*_owned calls.  Tags are launch-unique within a process, so words left by earlier launches can never match:
+// the per-launch clear (one more launch in front of every one of the 16 chunk launches of the pipelined update) is not needed.
+// After a reported timeout (wsmg_rnn_status) the owner must zero the workspace again: the error word in it is sticky.
+extern "C" int wsmg_gru_fwd_owned(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                                  int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                                  float* save_ghn, void* sync_ws, wsmg_stream_t stream) {
+  return gru_fwd_launch(gi, w_hh, b_hh, h0, masks, T, N, hidden, y, save_r, save_z, save_n, save_ghn, sync_ws, wsmg_s(stream), false);
+}
+
+static int gru_bwd_launch(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks, const float* y,
+                          const float* save_r, const float* save_z, const float* save_n, const float* save_ghn, int T, int N, int hidden,
+                          float* dgi, float* dgh, float* dh0, void* sync_ws, hipStream_t s, bool clear) {
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
-  hipStream_t s = wsmg_s(stream);
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
   if (T > 1023) return WSMG_EINVAL;
+  hipError_t e = hipSuccess;
   // control words and the ring of {value, tag} words are cleared (see wsmg_gru_fwd)
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)BWD_RING * XP_SLOT * 8, s);
-  if (e != hipSuccess) return (int)e;
+  if (clear && (e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)BWD_RING * XP_SLOT * 8, s)) != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
   if (WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B)
@@ -836,6 +848,20 @@ extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh
   }
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
   WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_gru_bwd(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                            const float* y, const float* save_r, const float* save_z, const float* save_n,
+                            const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
+                            void* sync_ws, wsmg_stream_t stream) {
+  return gru_bwd_launch(dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, T, N, hidden, dgi, dgh, dh0, sync_ws, wsmg_s(stream), true);
+}
+
+extern "C" int wsmg_gru_bwd_owned(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                                  const float* y, const float* save_r, const float* save_z, const float* save_n,
+                                  const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
+                                  void* sync_ws, wsmg_stream_t stream) {
+  return gru_bwd_launch(dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, T, N, hidden, dgi, dgh, dh0, sync_ws, wsmg_s(stream), false);
 }
 
 // =================================================================================================

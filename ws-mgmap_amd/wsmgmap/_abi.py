@@ -130,6 +130,8 @@ _SIG["wsmg_collate_pad"] = [c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_p, c_p]
 _SIG["wsmg_gru_workspace_bytes"] = [c_i]
 _SIG["wsmg_gru_fwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_p]
 _SIG["wsmg_gru_bwd"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_p]
+_SIG["wsmg_gru_fwd_owned"] = list(_SIG["wsmg_gru_fwd"])
+_SIG["wsmg_gru_bwd_owned"] = list(_SIG["wsmg_gru_bwd"])
 _SIG["wsmg_lstm_workspace_bytes"] = [c_i]
 _SIG["wsmg_lstm_fwd"] = [c_p] * 4 + [c_i] * 3 + [c_p] * 4 + [c_p]
 _SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
@@ -188,12 +190,17 @@ def call(name, *args):
         raise WsmgError(f"{name} failed: {kind}")
 
 
+rnn_timeouts = 0      # persistent-RNN timeouts reported so far in this process
+
+
 def check_rnn_status():
     """Raise WsmgError if a persistent RNN kernel reported a timeout since the last check.  Reads a word in host-mapped
     pinned memory: no device synchronisation.  Called at the host's natural sync points (the instruction dedup
     read-back of every forward pass, GradAllReducer.finish(), the end of an update in bench / tests)."""
+    global rnn_timeouts
     v = lib().wsmg_rnn_status(1)
     if v:
+        rnn_timeouts += 1       # (owners of persistent, never-cleared RNN workspaces re-zero them: the error word in them is sticky)
         names = [n for b, n in ((1, "gru_fwd"), (2, "gru_bwd"), (4, "lstm_fwd"), (8, "lstm_bwd")) if v & b]
         raise WsmgError("persistent RNN kernel(s) timed out waiting for their cooperating workgroups: " + ", ".join(names) +
                         " — their outputs were filled with NaN; results since the previous check are invalid "

@@ -31,6 +31,18 @@ from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _st
 MAX_BATCH = 8          # batch slots of the persistent GRU kernels
 
 
+_owned = {}      # (device index, role) -> [workspace, bytes, timeouts seen]: the GRU chunk launches' persistent exchange images
+
+
+def _owned_ws(dev, role, nbytes):
+    """A zeroed workspace that only this role's launches ever use (wsmg_gru_*_owned: no clear per launch).  One per role — GRU 1 /
+    GRU 2, forward / backward: launches of one role follow each other on one stream, launches of different roles overlap."""
+    e = _owned.get((dev.index, role))
+    if e is None or e[1] < nbytes or e[2] != _abi.rnn_timeouts:
+        e = _owned[(dev.index, role)] = [torch.zeros((int(nbytes) + 3) // 4, device=dev, dtype=torch.float32), int(nbytes), _abi.rnn_timeouts]
+    return e[0]
+
+
 def _prow(t, row):
     """Pointer to row `row` of a contiguous tensor (a view object per kernel argument costs more host time than the launch)."""
     return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
@@ -125,12 +137,16 @@ class _RecurrentBlock(torch.autograd.Function):
         elif text_ev is not None:
             main.wait_event(text_ev)
 
-        def gru(gi, w_hh, b_hh, h0, y, sv, k):
+        # chunk launches run on workspaces this module owns (no clear in front of every launch); a HIP-graph capture bakes the
+        # launch-unique tags in, so replays need the clearing form
+        owned = not torch.cuda.is_current_stream_capturing()
+
+        def gru(gi, w_hh, b_hh, h0, y, sv, k, role):
             t0 = k * Tc
             hk = h0 if k == 0 else y[t0 - 1]
-            ws = _rnn_workspace(nbytes, dev)
-            _abi.call("wsmg_gru_fwd", _p(gi[t0:]), _p(w_hh), _p(b_hh), _p(hk), _p(m[t0:]), Tc, N, H, _p(y[t0:]),
-                      *[_p(s[t0:]) for s in sv], _p(ws), _stream())
+            ws = _owned_ws(dev, role, nbytes) if owned else _rnn_workspace(nbytes, dev)
+            _abi.call("wsmg_gru_fwd_owned" if owned else "wsmg_gru_fwd", _prow(gi, t0), _p(w_hh), _p(b_hh), _p(hk), _prow(m, t0), Tc, N, H,
+                      _prow(y, t0), *[_prow(s_, t0) for s_ in sv], _p(ws), _stream())
             _rnn_launched()
 
         gi1v, gi2v = gi1.view(T, N, 3 * H), gi2.view(T, N, 3 * H)
@@ -141,7 +157,7 @@ class _RecurrentBlock(torch.autograd.Function):
         # instead of eight times (the host has < 1.5 ms of lead over the GPU in this part of an update)
         ev1, eva = [], []
         for k in range(K):
-            gru(gi1v, w_hh1, b_hh1, h01, y1, sv1, k)                                   # main
+            gru(gi1v, w_hh1, b_hh1, h01, y1, sv1, k, "f1")                             # main
             _ops.mark("f.g1.%d" % k)
             if multi:
                 e1 = torch.cuda.Event()
@@ -176,7 +192,7 @@ class _RecurrentBlock(torch.autograd.Function):
             for k in range(K):
                 if multi:
                     sg.wait_event(eva[k])
-                gru(gi2v, w_hh2, b_hh2, h02, y2, sv2, k)
+                gru(gi2v, w_hh2, b_hh2, h02, y2, sv2, k, "f2")
                 _ops.mark("f.g2.%d" % k)
         if sg is not main:
             main.wait_stream(sg)
@@ -264,21 +280,23 @@ class _RecurrentBlock(torch.autograd.Function):
         dstate_r = dstate.view(B, H)
         dgi2r = dgi2.view(B, 3 * H)
 
-        def gru_bwd(dy, w_hh, h0, y, sv, dgi, dgh, dh0_out, carry, k):
+        owned = not torch.cuda.is_current_stream_capturing()
+
+        def gru_bwd(dy, w_hh, h0, y, sv, dgi, dgh, dh0_out, carry, k, role):
             t0 = k * Tc
             hk = h0 if k == 0 else y[t0 - 1]
             dhT = None if k == K - 1 else carry[(k + 1) & 1]
             out = dh0_out if k == 0 else carry[k & 1]
-            ws = _rnn_workspace(nbytes, dev)
-            _abi.call("wsmg_gru_bwd", _p(dy[t0:]), _p(dhT), _p(w_hh), _p(hk), _p(m[t0:]), _p(y[t0:]), *[_p(s[t0:]) for s in sv],
-                      Tc, N, H, _p(dgi[t0:]), _p(dgh[t0:]), _p(out), _p(ws), _stream())
+            ws = _owned_ws(dev, role, nbytes) if owned else _rnn_workspace(nbytes, dev)
+            _abi.call("wsmg_gru_bwd_owned" if owned else "wsmg_gru_bwd", _prow(dy, t0), _p(dhT), _p(w_hh), _p(hk), _prow(m, t0), _prow(y, t0),
+                      *[_prow(s_, t0) for s_ in sv], Tc, N, H, _prow(dgi, t0), _prow(dgh, t0), _p(out), _p(ws), _stream())
             _rnn_launched()
 
         # stream by stream, as in forward: GRU 2's chunks (last chunk first), the attention stage's, GRU 1's
         ev2, eva = {}, {}
         with torch.cuda.stream(sg):
             for k in range(K - 1, -1, -1):
-                gru_bwd(dy2, w_hh2, h02, y2, (sr2, sz2, sn2, sg2), dgi2, dgh2, dh02, carry2, k)
+                gru_bwd(dy2, w_hh2, h02, y2, (sr2, sz2, sn2, sg2), dgi2, dgh2, dh02, carry2, k, "b2")
                 _ops.mark("b.g2.%d" % k)
                 if multi:
                     ev2[k] = torch.cuda.Event()
@@ -312,7 +330,7 @@ class _RecurrentBlock(torch.autograd.Function):
         for k in range(K - 1, -1, -1):
             if multi:
                 main.wait_event(eva[k])
-            gru_bwd(dstate, w_hh1, h01, y1, (sr1, sz1, sn1, sg1), dgi1, dgh1, dh01, carry1, k)      # main
+            gru_bwd(dstate, w_hh1, h01, y1, (sr1, sz1, sn1, sg1), dgi1, dgh1, dh01, carry1, k, "b1")      # main
             _ops.mark("b.g1.%d" % k)
         d_state_in = torch.mm(dgi1.view(B, 3 * H), w_ih1) if ctx.needs_input_grad[1] else None
         # gradients of the shared instruction sets (they feed the instruction branch's backward, on ITS stream): after the last
