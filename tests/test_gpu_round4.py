@@ -416,3 +416,55 @@ def test_feeder_streams_a_recoded_cache_bit_identically():
     for (oa, *ra), (ob_, *rb) in zip(a, b):
         assert list(oa) == list(ob_) and all(torch.equal(oa[k], ob_[k]) for k in oa)
         assert all(torch.equal(x, y) for x, y in zip(ra, rb))
+
+
+# ----------------------------------------------------------------------------- small-channel 3 x 3 weight gradients out of the LDS window
+@pytest.mark.parametrize("shape", [
+    (130, 24, 64, 64),          # conv_original_size1: 64 co x 64 ci, two waves per tile pair (V222), ragged image ranges
+    (115, 24, 256, 64),         # conv_original_size0: four input-channel tiles
+    (120, (24, 23), 192, 64),   # conv_original_size2: three input-channel tiles, a row length whose padded rows leave a partial k-step
+    (131, 24, 32, 128),         # map_classified_linear: 128 co x 32 ci (V412)
+    (67, 48, 32, 32),           # the classifier's 32 -> 32 layer at 48 x 48: eight waves on one tile pair (V118)
+    (33, (47, 43), 32, 96),     # V118 with three output-channel tiles and a ragged image
+    (259, 16, 32, 32),          # narrowest rows the window kernels take
+], ids=["orig1", "orig0", "orig2", "classified", "cls48", "cls-ragged", "w16"])
+def test_small_channel_window_weight_gradients_3x3(shape):
+    """wsmg_conv_win3_wgrad.hip, round-4 tile shapes (pixel-split tile pairs whose partial sums meet in LDS): the atomic form and the
+    slab form against a float64 weight gradient of the same bf16 operands and against the generic kernel (window kernels off);
+    the slab form is bit-identical over repeated launches."""
+    import ctypes
+    import torch.nn.functional as F
+    from wsmgmap import _abi, ops
+    B, H, Cin, Cout = shape
+    H, W = H if isinstance(H, tuple) else (H, H)
+    torch.manual_seed(B + Cin)
+    x = torch.relu(torch.randn(B, H, W, Cin, device="cuda")).bfloat16()
+    gy = (torch.randn(B, H, W, Cout, device="cuda") * 0.1).bfloat16()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())   # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _abi.lib().wsmg_conv_debug_win3_tile(1) in (0, 1, 256, 512)
+    ns, fl = ctypes.c_int(0), ctypes.c_longlong(0)
+    dims = (B, H, W, Cin, Cout, 3, 3, 1, 1, H, W)
+    _abi.call("wsmg_conv2d_bwd_weight_bf16_plan", *dims, ctypes.cast(ctypes.byref(ns), ctypes.c_void_p), ctypes.cast(ctypes.byref(fl), ctypes.c_void_p))
+    assert 1 <= ns.value <= 256, f"{ns.value} slabs: the layer did not take the window kernel's plan"
+
+    def atomic(tile):
+        prev = _abi.lib().wsmg_conv_debug_win3_tile(tile)
+        try:
+            dw = torch.zeros(Cout, 3, 3, Cin, device="cuda")
+            _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(gy), P(dw), *dims, st)
+            torch.cuda.synchronize()
+            return dw
+        finally:
+            _abi.lib().wsmg_conv_debug_win3_tile(prev)
+    dw = atomic(1)
+    w = torch.zeros(Cout, Cin, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double(), w, padding=1).backward(gy.permute(0, 3, 1, 2).double())
+    ref = w.grad.permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((dw.double() - ref).abs().max()) <= 2e-5 * scale, float((dw.double() - ref).abs().max()) / scale
+    assert float((dw - atomic(0)).abs().max()) <= 2e-5 * scale
+    slabs = [ops._weight_grad("_bf16", x, gy, dims, 0.0, Cin) for _ in range(3)]      # [Cout, Cin, 3, 3]
+    torch.cuda.synchronize()
+    assert torch.equal(slabs[0], slabs[1]) and torch.equal(slabs[0], slabs[2])
+    assert float((slabs[0].permute(0, 2, 3, 1).double() - ref).abs().max()) <= 2e-5 * scale

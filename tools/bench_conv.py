@@ -23,9 +23,15 @@ LAYERS = [
     ("orig2_k3", 192, 64, 3, 1, 1, 24, True),
     ("convT_adj_k4s2", 32, 64, 4, 2, 1, 48, True),
     ("cls_k3_48", 32, 32, 3, 1, 1, 48, True),
-    ("cls_1x1_48", 32, 32, 1, 1, 0, 48, True),
     ("classified_k3", 32, 128, 3, 1, 1, 24, True),
     ("cated_k3", 256, 256, 3, 1, 1, 24, True),
+    ("l0_1x1_12", 64, 64, 1, 1, 0, 12, True),
+    ("l1_1x1_6", 64, 64, 1, 1, 0, 6, True),
+]
+# Not in the update any more, kept for --only: the classifier's 1 x 1 head runs inside the fused tail (csrc/wsmg_cls_tail.hip) and
+# text_map_k_layer is folded into the attention's query (ops.attention_folded); the tables of rounds 1-3 still listed them.
+EXTRA = [
+    ("cls_1x1_48", 32, 32, 1, 1, 0, 48, True),
     ("mapk_1x1", 256, 256, 1, 1, 0, 24, True),
 ]
 
@@ -49,6 +55,9 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--B", type=int, default=512)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--wgrad", default="slabs", choices=["slabs", "atomics"],
+                    help="slabs (default): the product's deterministic form, ops._weight_grad = slab launch + ordered reduce launch; "
+                         "atomics: the A/B form (float atomics into a zeroed dW; the tables of rounds 1-3 timed this one)")
     ap.add_argument("--data", default="randn", choices=["randn", "relu"],
                     help="relu: x and dy half zeros, as the update's post-ReLU activations and masked gradients are (the kernels' clock, "
                          "and with it their ranking, depends on the data)")
@@ -57,7 +66,7 @@ def main():
     st = ops._stream
     tot = {"fwd": 0.0, "bwdD": 0.0, "wgrad": 0.0}
     print(f"{'layer':18s} {'GF':>8s} | {'fwd ms':>8s} {'TF':>6s} | {'bwdD ms':>8s} {'TF':>6s} | {'wgrad ms':>8s} {'TF':>6s}")
-    for name, Cin, Cout, k, s, p, H, need_dx in LAYERS:
+    for name, Cin, Cout, k, s, p, H, need_dx in LAYERS + (EXTRA if a.only else []):
         if a.only and a.only not in name: continue
         OH = (H + 2 * p - k) // s + 1
         dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -78,7 +87,10 @@ def main():
         if a.dtype == "bf16":
             t_f = timeit(lambda: _abi.call("wsmg_conv2d_fwd_bf16", P(x), P(w), None, P(y), 0, *args, st()), a.reps)
             t_d = timeit(lambda: _abi.call("wsmg_conv2d_bwd_data_bf16", P(dy), P(wi), P(dx), 0, *args, st()), a.reps) if need_dx else 0.0
-            t_w = timeit(lambda: _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(dy), P(dw), *args, st()), a.reps)
+            if a.wgrad == "slabs":
+                t_w = timeit(lambda: ops._weight_grad("_bf16", x, dy, args, 0.0, Cin), a.reps)
+            else:
+                t_w = timeit(lambda: _abi.call("wsmg_conv2d_bwd_weight_bf16", P(x), P(dy), P(dw), *args, st()), a.reps)
         else:
             t_f = timeit(lambda: _abi.call("wsmg_conv2d_fwd", P(x), P(w), None, P(y), *args, st()), a.reps)
             t_d = timeit(lambda: _abi.call("wsmg_conv2d_bwd_data", P(dy), P(wi), P(dx), *args, st()), a.reps) if need_dx else 0.0

@@ -52,9 +52,8 @@ struct W3wArgs {
   unsigned x_bytes, dy_bytes;
 };
 
-constexpr int KS = 48;       // entries per k-step
-constexpr int XCAP = 104;    // window rows (KS + 2 (W + 3) <= XCAP: W <= 24)
 constexpr int NSTG = 3;
+constexpr int RED_BYTES = 4 * 9 * 16 * 64 * 4;   // the closing reduction of a pixel-split tile: four waves' nine accumulator tiles (144 KB)
 constexpr int OOB = (int)0x80000000;
 
 __device__ __forceinline__ int xcd_swizzle_w(int bid, int nb) {
@@ -70,17 +69,23 @@ __device__ __forceinline__ bf16x4 tr_read(const unsigned char* p) {
 // 64-byte quarter swizzle of a row of `pitch` bytes (see the header)
 template <int PITCH>
 __device__ __forceinline__ int quarter_xor(int row) {
-  static_assert(PITCH == 256 || PITCH == 128, "row pitches of 4 or 2 channel tiles");
-  return PITCH == 256 ? (row & 3) : ((row >> 1) & 1);
+  static_assert(PITCH == 256 || PITCH == 128 || PITCH == 64, "row pitches of 4, 2 or 1 channel tiles");
+  return PITCH == 256 ? (row & 3) : (PITCH == 128 ? ((row >> 1) & 1) : 0);   // 64-byte rows: four consecutive rows ARE one bank row
 }
 
-template <int WCO, int WCI, int NLW>   // NLW: waves that issue the DMA pieces (8: all; 4: waves 0-3, one per SIMD)
+// WCO x WCI: 32-channel tiles of dY / X per workgroup; WK: waves that share one (co, ci) tile pair and split the k-step's 16-entry
+// slices between them (small-channel layers, round 4: with Cout x Cin = 32 x 32 there is ONE tile pair — eight waves take one
+// eighth of the entries each and their accumulators meet in LDS when the workgroup is done); SL: slices per wave and k-step;
+// XCAP: window rows (KS + 2 (W + 3) <= XCAP); NLW: waves that issue the DMA pieces (8: all; 4: waves 0-3, one per SIMD)
+template <int WCO, int WCI, int WK, int SL, int XCAP, int NLW>
 __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
-  static_assert(WCO * WCI == 8, "8 waves");
+  static_assert(WCO * WCI * WK == 8, "8 waves");
+  constexpr int KS = 16 * WK * SL;                          // entries per k-step
+  constexpr int NPAIR = WCO * WCI;
   constexpr int DP = 64 * WCO, XP = 64 * WCI;               // row pitches (bytes)
   constexpr int D_STAGE = KS * DP, X_STAGE = XCAP * XP, STAGE = D_STAGE + X_STAGE;
   constexpr int ND = D_STAGE / 1024, NX = X_STAGE / 1024;   // 1 KB DMA pieces per stage
-  
+  static_assert(D_STAGE % 1024 == 0 && X_STAGE % 1024 == 0, "whole DMA pieces");
   constexpr int DRPP = 1024 / DP, XRPP = 1024 / XP;         // rows per piece
   constexpr int DSL = DP / 16, XSL = XP / 16;               // 16-byte slots per row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -162,12 +167,14 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
 
   // ---- MFMA roles: wave -> (output-channel tile tco, input-channel tile tci); transposing-read lane map as in
   // conv_wgrad_bf16_kernel: the lane supplies row 8 h + q4 (+ 4 for the second read) and channels 16 half16 + 4 p4 .. + 3
-  const int tco = wave % WCO, tci = wave / WCO;
+  const int pair = wave % NPAIR, wk = wave / NPAIR;
+  const int tco = pair % WCO, tci = pair / WCO;
   const int li = lane & 15, q4 = li >> 2, p4 = li & 3;
   const int half16 = (lane >> 4) & 1, h = lane >> 5;
   const int chan_off = (half16 * 16 + p4 * 4) * 2;
   // dY: row 16 c + 8 h + q4 (+ 4): row & 3 == q4 (256-B rows), (row >> 1) & 1 == q4 >> 1 (128-B rows)
-  const int a_off = (8 * h + q4) * DP + ((tco ^ quarter_xor<DP>(q4)) << 6) + chan_off;
+  // (wave wk of a tile pair owns slices wk SL .. wk SL + SL - 1 of every k-step: a multiple of 16 rows, which leaves the swizzle alone)
+  const int a_off = (16 * SL * wk + 8 * h + q4) * DP + ((tco ^ quarter_xor<DP>(q4)) << 6) + chan_off;
   // X: row 16 c + 8 h + q4 (+ 4) + (W + 3) + shift(tap): the part that is not a multiple of 4 is q4 + (W + 3) + shift
   // (two 16-bit offsets per register: the nine accumulators leave no room for nine address registers)
   unsigned b_pack[5];
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
     for (int k = 0; k < 2; ++k) {
       const int tap = 2 * tp + k < 9 ? 2 * tp + k : 8;
       const int o = q4 + PW + 1 + (tap / 3 - 1) * PW + (tap % 3 - 1);
-      v |= (unsigned)(D_STAGE + (8 * h + o) * XP + ((tci ^ quarter_xor<XP>(o)) << 6) + chan_off) << (16 * k);
+      v |= (unsigned)(D_STAGE + (16 * SL * wk + 8 * h + o) * XP + ((tci ^ quarter_xor<XP>(o)) << 6) + chan_off) << (16 * k);
     }
     b_pack[tp] = v;
   }
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
     // 27 MFMAs per wave and step, each with its own B fragment (2 transposing reads): read -> use back to back leaves the
     // LDS round trip exposed 27 times per step, so the fragments run PD MFMAs ahead in a small register ring, and the
     // interleave is pinned (1 MFMA, 2 reads, ...): left alone, hipcc groups the reads and waits for all of them.
-    constexpr int NI = (KS / 16) * 9, PD = 4;   // (depth 2 / 4 / 6 measured within 1 % of each other)
+    constexpr int NI = SL * 9, PD = 4;   // (depth 2 / 4 / 6 measured within 1 % of each other)
     auto rdA = [&](int c) {
       const bf16x4 l = tr_read(sb + a_off + (16 * c) * DP), hh = tr_read(sb + a_off + (16 * c + 4) * DP);
       return __builtin_shufflevector(l, hh, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -220,15 +227,42 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
     for (int i = 0; i < NI; ++i) {
       acc[i % 9] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[i % PD], acc[i % 9], 0, 0, 0);
       if (i + PD < NI) bq[i % PD] = rdB(i + PD);
-      if (i % 9 == 4 && i / 9 + 1 < KS / 16) afn = rdA(i / 9 + 1);   // next slice's dY fragment, half a slice ahead
+      if (i % 9 == 4 && i / 9 + 1 < SL) afn = rdA(i / 9 + 1);   // next slice's dY fragment, half a slice ahead
       if (i % 9 == 8) af = afn;
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
-      if (i % 9 == 4 && i / 9 + 1 < KS / 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      if (i % 9 == 4 && i / 9 + 1 < SL) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- pixel-split tiles: the WK partial sums of a tile pair meet in LDS (the stages are dead), upper half into lower half, in a
+  // fixed order (bit-reproducible); the pair's wave 0 then flushes alone
+  if constexpr (WK > 1) {
+    __syncthreads();
+    float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int rr = WK / 2; rr >= 1; rr >>= 1) {
+      if (wk >= rr && wk < 2 * rr) {
+        float* const dst = red + (size_t)(((wk - rr) * NPAIR + pair) * 144) * 64 + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) dst[(tap * 16 + g) * 64] = acc[tap][g];
+      }
+      __syncthreads();
+      if (wk < rr) {
+        const float* const src = red + (size_t)((wk * NPAIR + pair) * 144) * 64 + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) acc[tap][g] += src[(tap * 16 + g) * 64];
+      }
+      __syncthreads();
+    }
+    if (wk != 0) return;
+  }
 
   // ---- one flush per workgroup: lane r = input channel (consecutive lanes -> 128-byte segments of an OHWI row)
   const int r = lane & 31;
@@ -265,72 +299,98 @@ int w3w_cus() {
   return cus;
 }
 
+// The tile shapes (WCO, WCI, WK, SL, XCAP):
+//   V421: 128 co x 64 ci, 48-entry k-steps — the wide layers (cated 256 -> 256, enc6 128 -> 256, encoded_lin 256 -> 128), W <= 24
+//   V222:  64 co x 64 ci, two waves per tile pair, 64-entry k-steps — the decoder's 64-output-channel layers (256 / 192 / 64 -> 64), W <= 24
+//   V412: 128 co x 32 ci, two waves per pair, 64-entry k-steps — map_classified_linear (32 -> 128), W <= 24
+//   V118:  32 co x 32 ci, eight waves on the one pair, 256-entry k-steps — the classifier's 32 -> 32 layer at 48 x 48, W <= 48
+// (round 4: the generic kernel ran these small-channel layers at 240-680 TFLOP/s — it re-fetches X once per tap through the vector
+//  memory path, and with 32 channels half of its 64-wide dY tile is padding; out of the window they are bound by the bytes of x and
+//  dy, read once.)
+enum W3wVariant { V_NONE = 0, V421, V222, V412, V118 };
+
+struct W3wShape { int wco, wci, ks, xcap; };
+constexpr W3wShape kShape[5] = {{0, 0, 0, 0}, {4, 2, 48, 104}, {2, 2, 64, 120}, {4, 1, 64, 128}, {1, 1, 256, 368}};
+
+W3wVariant w3w_variant(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H < 1 || W < 16) return V_NONE;   // W < 16: the pad columns and the last k-step's unused entries cost more than
+                                                  // the window saves (12 x 12: 0.091 vs 0.052 ms)
+  if ((size_t)B * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return V_NONE;
+  const unsigned PW = (unsigned)(W + 2);
+  const uint64_t nmax = (uint64_t)(H + 4) * PW + 256 + 368;   // (largest k-step + window of the shapes above)
+  if (nmax * PW >= (1ull << 32)) return V_NONE;
+  auto fits = [&](W3wVariant v) { return kShape[v].ks + 2 * (W + 3) <= kShape[v].xcap; };
+  if (Cout % 128 == 0 && Cin % 64 == 0) return fits(V421) ? V421 : V_NONE;
+  // WSMG_WIN3W_SMALL: bit 0 = V222, bit 1 = V412, bit 2 = V118 (A/B: 0 keeps the generic kernel for the small-channel layers)
+  const int small = WSMG_TUNE("WSMG_WIN3W_SMALL", 7);
+  if (Cout % 64 == 0 && Cin % 64 == 0) return ((small & 1) && fits(V222)) ? V222 : V_NONE;
+  if (Cout % 128 == 0 && Cin % 32 == 0) return ((small & 2) && fits(V412)) ? V412 : V_NONE;
+  if (Cout % 32 == 0 && Cin % 32 == 0) return ((small & 4) && fits(V118)) ? V118 : V_NONE;
+  return V_NONE;
+}
+
 // image ranges: one workgroup per CU (its LDS), every range the same number of images (no range is empty)
-template <int WCO, int WCI>
-void plan_w3w(W3wArgs& a) {
-  a.gco = a.Cout / (32 * WCO);
-  a.gci = a.Cin / (32 * WCI);
+void plan_w3w(W3wArgs& a, W3wVariant v) {
+  a.gco = a.Cout / (32 * kShape[v].wco);
+  a.gci = a.Cin / (32 * kShape[v].wci);
   const int ntile = a.gco * a.gci;
   int gz = w3w_cus() / ntile;
-  if (const int v = WSMG_TUNE("WSMG_WIN3W_SPLITS", 0); v > 0) gz = v;
+  if (const int t = WSMG_TUNE("WSMG_WIN3W_SPLITS", 0); t > 0) gz = t;
   if (gz < 1) gz = 1;
   if (gz > a.B) gz = a.B;
   a.imgs = (a.B + gz - 1) / gz;
   a.gz = (a.B + a.imgs - 1) / a.imgs;
 }
 
-template <int WCO, int WCI, int NLW>
-int launch_w3w(W3wArgs& a, hipStream_t s) {
-  constexpr int LDS = NSTG * (KS * 64 * WCO + XCAP * 64 * WCI) + 1024;
+template <int WCO, int WCI, int WK, int SL, int XCAP, int NLW>
+int launch_w3w(W3wArgs& a, W3wVariant v, hipStream_t s) {
+  constexpr int STAGES = NSTG * (16 * WK * SL * 64 * WCO + XCAP * 64 * WCI) + 1024;
+  constexpr int LDS = (WK > 1 && RED_BYTES > STAGES) ? RED_BYTES : STAGES;
+  static_assert(LDS <= 160 * 1024, "LDS of one CU");
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_wgrad_kernel<WCO, WCI, NLW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_wgrad_kernel<WCO, WCI, WK, SL, XCAP, NLW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  plan_w3w<WCO, WCI>(a);
+  plan_w3w(a, v);
   const int ntile = a.gco * a.gci;
-  hipLaunchKernelGGL((conv_win3_wgrad_kernel<WCO, WCI, NLW>), dim3((unsigned)(ntile * a.gz)), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((conv_win3_wgrad_kernel<WCO, WCI, WK, SL, XCAP, NLW>), dim3((unsigned)(ntile * a.gz)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
 
 }  // namespace
 
-// dW of a 3 x 3 / stride 1 / pad 1 convolution on bf16 NHWC with 16 <= W <= 24, Cout % 128 == 0 and Cin % 64 == 0; WSMG_EINVAL
-// otherwise (the caller then uses the generic kernel).
-static bool w3w_fits(int B, int H, int W, int Cin, int Cout) {
-  if (B <= 0 || H < 1 || W < 16 || KS + 2 * (W + 3) > XCAP) return false;   // W < 16: the pad columns and the last k-step's
-                                                                            // unused entries cost more than the window saves (12 x 12: 0.091 vs 0.052 ms)
-  if ((size_t)B * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 >= (1ull << 31)) return false;
-  const unsigned PW = (unsigned)(W + 2);
-  const uint64_t nmax = (uint64_t)(H + 4) * PW + KS + XCAP;
-  if (nmax * PW >= (1ull << 32)) return false;
-  return Cout % 128 == 0 && Cin % 64 == 0;
-}
-
 // image ranges (= slabs of the deterministic form) this kernel would use for the layer; 0: the layer is not this kernel's
 int wsmg_conv_win3_wgrad_splits(int B, int H, int W, int Cin, int Cout) {
-  if (!w3w_fits(B, H, W, Cin, Cout)) return 0;
+  const W3wVariant v = w3w_variant(B, H, W, Cin, Cout);
+  if (v == V_NONE) return 0;
   W3wArgs a{nullptr, nullptr, nullptr, 0, B, H, W, Cin, Cout, 0, 0, 0, 0, 0, 0, 0};
-  plan_w3w<4, 2>(a);
+  plan_w3w(a, v);
   return a.gz;
 }
 
-// slab_floats == 0: dW (OHWI float32) is ACCUMULATED INTO with float atomics (the caller zeroes it); slab_floats > 0: `dw_ohwi` is a
-// workspace of wsmg_conv_win3_wgrad_splits() slabs of that many floats, every one written whole (see W3wArgs::slab).
+// dW of a 3 x 3 / stride 1 / pad 1 convolution on bf16 NHWC for the shapes w3w_variant() names; WSMG_EINVAL otherwise (the caller
+// then uses the generic kernel).  slab_floats == 0: dW (OHWI float32) is ACCUMULATED INTO with float atomics (the caller zeroes it);
+// slab_floats > 0: `dw_ohwi` is a workspace of wsmg_conv_win3_wgrad_splits() slabs of that many floats, every one written whole
+// (see W3wArgs::slab).
 int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,
                               hipStream_t s) {
-  if (!w3w_fits(B, H, W, Cin, Cout)) return WSMG_EINVAL;
+  const W3wVariant v = w3w_variant(B, H, W, Cin, Cout);
+  if (v == V_NONE) return WSMG_EINVAL;
   const unsigned PW = (unsigned)(W + 2);
   W3wArgs a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, (int64_t)slab_floats, B, H, W, Cin, Cout, 0, 0, 0, 0, (unsigned)((1ull << 32) / PW + 1),
             (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * H * W * Cout * 2)};
-  // waves 0-3 load (measured at B = 512: 0.373 / 0.205 / 0.206 ms on the 256->256, 128->256 and 256->128 layers against 0.404 /
+  // V421: waves 0-3 load (measured at B = 512: 0.373 / 0.205 / 0.206 ms on the 256->256, 128->256 and 256->128 layers against 0.404 /
   // 0.216 / 0.216 with all eight loading, and 0.421 / 0.247 / 0.225 for the generic kernel); WSMG_WIN3W_LOADERS=8: all eight (A/B).
-  // (A 64 x 128-channel tile <2, 4> for the 64-output-channel layers was slower than the generic kernel — 0.175 vs 0.137 ms on
-  // 256->64: its 26 KB window per step feeds two output-channel tiles only — and is not built.)
   const int nlw = WSMG_TUNE("WSMG_WIN3W_LOADERS", 4);
-  if (Cout % 128 == 0 && Cin % 64 == 0) return nlw == 8 ? launch_w3w<4, 2, 8>(a, s) : launch_w3w<4, 2, 4>(a, s);
-  return WSMG_EINVAL;
+  switch (v) {
+    case V421: return nlw == 8 ? launch_w3w<4, 2, 1, 3, 104, 8>(a, v, s) : launch_w3w<4, 2, 1, 3, 104, 4>(a, v, s);
+    case V222: return launch_w3w<2, 2, 2, 2, 120, 8>(a, v, s);
+    case V412: return launch_w3w<4, 1, 2, 2, 128, 8>(a, v, s);
+    case V118: return launch_w3w<1, 1, 8, 2, 368, 8>(a, v, s);
+    default: return WSMG_EINVAL;
+  }
 }
-
