@@ -292,15 +292,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         warm_prof = ops.profile_end()
     dom_entry = None
     if warm_prof:
-        # forward and backward-weight are within a few per cent of each other (3.1 vs 3.2 ms per update; rocprofv3 ranks
-        # backward-weight first in every trace of this round) and one warm-up sample can rank them either way: families
-        # within 15 % of the largest count as tied and the tie goes to the backward-weight family, so that the `roofline`
-        # object names the same kernel from run to run and round to round (round 3: the slab-reduced weight gradients brought
-        # that family to 2.5 ms per update against 2.7-2.8 ms of forward; `kernels` carries every family's figures either way)
-        top = max(r["ms_total"] for r in warm_prof.values())
-        tied = [r for r in warm_prof.values() if r["ms_total"] >= 0.85 * top]
-        tied.sort(key=lambda r: (r["entry"] != "wsmg_conv2d_bwd_weight_bf16", -r["ms_total"]))
-        dom_entry = tied[0]["entry"]
+        # the family with the most time in the last warm-up update, no tie rule (rounds 2-3 gave ties within 15 % to
+        # the backward-weight family); `kernels` carries every family's figures either way
+        dom_entry = max(warm_prof.values(), key=lambda r: r["ms_total"])["entry"]
     # Pre-timing spin of real updates (reported as `prewarm_s` / `prewarm_updates`; `warmup` stays what the caller passed): on a
     # fresh lease the first ~20 updates after 5 warm-up ones ran 14.6 / 11.8 ms against a steady 11.4 (BENCH_r03 `windows`) — the GPU
     # comes out of idle clocks, the allocator is still growing after profile_end(), the per-stream workspaces see first use.
@@ -557,7 +551,7 @@ def main():
             # passes over this very command (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM counters in separate runs, folded by
             # tools/pmc_traffic.py / tools/pmc_mfma.py; tools/refresh_profiles.sh): PMC collection cannot run inside a timed
             # bench, so the figures are read from profiles/ (newest round), not measured live
-            fams = {"wsmg_conv2d_bwd_weight_bf16": ["conv_wgrad_bf16_kernel", "conv_win_wgrad_kernel", "conv_win3_wgrad_kernel"],
+            fams = {"wsmg_conv2d_bwd_weight_bf16": ["conv_wgrad_bf16_kernel", "conv_win_wgrad_kernel", "conv_win3_wgrad_kernel", "conv_s2_wgrad_kernel"],
                     "wsmg_conv2d_fwd_bf16": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel"],
                     "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel"],
                     "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>", "conv_win3_kernel"]}.get(r.get("entry"), [dom.replace("<*>", "")])

@@ -468,3 +468,39 @@ def test_small_channel_window_weight_gradients_3x3(shape):
     torch.cuda.synchronize()
     assert torch.equal(slabs[0], slabs[1]) and torch.equal(slabs[0], slabs[2])
     assert float((slabs[0].permute(0, 2, 3, 1).double() - ref).abs().max()) <= 2e-5 * scale
+
+
+# ----------------------------------------------------------------------------- stride-2 window weight gradients (k5 64->128, k7 256->64)
+@pytest.mark.parametrize("geom", [
+    (37, 50, 64, 128, 5, 1),     # MapEncoder.cnn[3]: 8 waves, 5 kernel-row roles, 3 tiles of 8 x 24 pixels per image
+    (3, 50, 64, 128, 5, 1),      # fewer tiles than tile groups
+    (45, 24, 256, 64, 7, 3),     # MapDecoder conv1: 4 waves, 7 x 4 roles (kernel row x 64-channel chunk), one 12 x 12 tile per image
+    (2, 24, 256, 64, 7, 3),
+], ids=["enc3", "enc3-few", "stem", "stem-few"])
+def test_stride2_window_weight_gradients(geom):
+    """wsmg_conv_s2_wgrad.hip against the float64 weight gradient of the same bf16 operands: the atomic form, and the slab form
+    (bit-identical over repeated launches), with post-ReLU inputs and a gradient that is zero on a band of rows (tile edges)."""
+    import ctypes
+    from wsmgmap import _abi, ops
+    B, H, Cin, Cout, K, pad = geom
+    OH = (H + 2 * pad - K) // 2 + 1
+    g = torch.Generator(device="cuda"); g.manual_seed(B * 13 + K)
+    x = torch.relu(torch.randn(B, H, H, Cin, device="cuda", generator=g)).bfloat16()
+    dy = (torch.randn(B, OH, OH, Cout, device="cuda", generator=g) * 0.1)
+    dy[:, OH // 2] = 0
+    dy = dy.bfloat16()
+    dims = (B, H, H, Cin, Cout, K, K, 2, pad, OH, OH)
+    ns, fl = ctypes.c_int(0), ctypes.c_longlong(0)
+    _abi.call("wsmg_conv2d_bwd_weight_bf16_plan", *dims, ctypes.cast(ctypes.byref(ns), ctypes.c_void_p), ctypes.cast(ctypes.byref(fl), ctypes.c_void_p))
+    assert ns.value % 8 == 0 and ns.value <= 48, f"{ns.value} slabs: not the stride-2 window kernel's plan"
+    want = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, K, K), dy.double().permute(0, 3, 1, 2), stride=2, padding=pad)
+    scale = float(want.abs().max())
+    dw = torch.zeros(Cout, K, K, Cin, device="cuda")
+    _abi.call("wsmg_conv2d_bwd_weight_bf16", ops._p(x), ops._p(dy), ops._p(dw), *dims, ops._stream())
+    torch.cuda.synchronize()
+    err = float((dw.permute(0, 3, 1, 2).double() - want).abs().max())
+    assert err <= 2e-5 * scale, err / scale
+    slabs = [ops._weight_grad("_bf16", x, dy, dims, 0.0, Cin) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(slabs[0], slabs[1]) and torch.equal(slabs[0], slabs[2])
+    assert float((slabs[0].double() - want).abs().max()) <= 2e-5 * scale

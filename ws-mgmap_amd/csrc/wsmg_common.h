@@ -82,6 +82,11 @@ int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias,
 int wsmg_conv_win_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,
                              int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s);
 int wsmg_conv_win_wgrad_splits(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW);
+// wsmg_conv_s2_wgrad.hip: weight gradient of the k5 s2 (64 -> 128 at 50 x 50) and k7 s2 (256 -> 64 at 24 x 24) layers out of an
+// LDS-resident input window; WSMG_EINVAL / 0 splits for any other shape
+int wsmg_conv_s2_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,
+                            int KH, int KW, int stride, int pad, int OH, int OW, hipStream_t s);
+int wsmg_conv_s2_wgrad_splits(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW);
 // wsmg_conv_win3.hip: 3 x 3 / stride 1 / pad 1 out of a zero-padded LDS pixel window (forward / backward-data), N % 128 == 0,
 // Kc % 32 == 0, mt = 512 or 256 pixels per workgroup; WSMG_EINVAL otherwise
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,

@@ -833,7 +833,7 @@ namespace {
 // Which kernel takes the weight gradient of a layer, and over how many partial sums (pixel chunks / image ranges / tile groups) its
 // reduction is split — the number of slabs of the deterministic form.
 struct WgradPlan {
-  int kind;      // 0 generic (conv_wgrad_bf16_kernel), 1 stem window kernel, 2 3 x 3 window kernel
+  int kind;      // 0 generic (conv_wgrad_bf16_kernel), 1 k8 stem window kernel, 2 3 x 3 window kernel, 3 k5 / k7 stride-2 window kernel
   int nsplit;
   int tc, tu, gx, gy;
   int64_t chunk;
@@ -845,6 +845,8 @@ WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW
   if (WSMG_TUNE("WSMG_WGRAD_WIN", 1)) {
     if (const int n = wsmg_conv_win_wgrad_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) { p.kind = 1; p.nsplit = n; return p; }
   }
+  // the other two stride-2 layers (k5 64 -> 128, k7 256 -> 64): wsmg_conv_s2_wgrad.hip; WSMG_WGRAD_S2WIN=0 keeps the generic kernel (A/B)
+  if (const int n = wsmg_conv_s2_wgrad_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) { p.kind = 3; p.nsplit = n; return p; }
   // 3 x 3 stride-1 layers: zero-padded LDS window (wsmg_conv_win3_wgrad.hip); WSMG_WGRAD_WIN3=0 (or the tests' tile switch = 0)
   // keeps the generic kernel (A/B)
   const int use_w3w = WSMG_TUNE("WSMG_WGRAD_WIN3", 1);
@@ -887,6 +889,7 @@ int launch_wgrad_bf16(const void* x, const void* dy, float* dw, long long slab_f
   const WgradPlan p = wgrad_plan_bf16(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW);
   if (p.kind == 1) return wsmg_conv_win_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
   if (p.kind == 2) return wsmg_conv_win3_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, stream);
+  if (p.kind == 3) return wsmg_conv_s2_wgrad_bf16(x, dy, dw, slab_floats, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
   WgradArgsB a{(const bf16_t*)x, (const bf16_t*)dy, dw, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, 0, 0, 0,
                (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * OH * OW * Cout * 2), 0, 0, (int64_t)slab_floats};
   a.units = KH * KW * (Cin / 32);
