@@ -56,8 +56,6 @@ constexpr int XROW = S * PC * PITCH;   // one window row: 2 parity planes
 constexpr int X_BYTES = TH * XROW;     // 53 760
 constexpr int NPX = 128;               // K axis of a tile: 125 pixels + 3 padding
 constexpr int D_BYTES = NPX * PITCH;   // 24 576
-constexpr int XPIECES = TH * WC * 8;   // 2240 16-byte pieces
-constexpr int XPER = (XPIECES + 255) / 256;   // 9
 constexpr int DPER = NPX * 8 / 256;    // 4
 
 __global__ __launch_bounds__(256, 2) void conv_win_wgrad_kernel(WinWgradArgs a) {
@@ -75,56 +73,63 @@ __global__ __launch_bounds__(256, 2) void conv_win_wgrad_kernel(WinWgradArgs a) 
   const int ntiles = a.B * tpi;
   const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes), dr = make_rsrc(a.dy, a.dy_bytes);
 
-  // ---- staging roles: X piece c = tid + 256 j -> (row jr, column wc, 16-byte chunk ch); dY piece -> (pixel q, chunk ch).
-  // The role arithmetic is redone per tile (a few dozen VALU instructions against 64 MFMAs per wave): kept in registers it
-  // cost 27 VGPRs, which the fragment double buffer below needs.
-  u32x4 rx[XPER], rd[DPER];
+  // ---- staging (round 4: dealt by window ROW, as in wsmg_conv_s2_wgrad.hip).  A window row is 56 columns x 8 pieces = 448 pieces:
+  // thread t owns piece (column t >> 3, chunk t & 7) and, for t < 192, the piece 32 columns further, of EVERY window row — the
+  // columns' validity and byte offsets are computed once per tile, a row then costs one scalar base.  The dY pieces of a thread
+  // (pixel (t >> 3) + 32 j of the 5 x 25 block) sit at per-thread constant offsets from the block's first pixel.  (Rounds 1-3 mapped
+  // piece c = t + 256 j -> (row, column) by multiply-shift divisions per piece and tile, in gload AND in lstore: 26 pieces' worth of
+  // address arithmetic beside a tile's 64 MFMAs.)
+  constexpr int XPER2 = 2 * TH;
+  const int wc0 = tid >> 3, pch = tid & 7;
+  const bool has1 = tid < (WC - 32) * 8;
+  const int xl0 = ((wc0 & 1) * PC + (wc0 >> 1)) * PITCH + pch * 16;            // LDS offsets within a window row (wc0 + 32 has wc0's parity)
+  const int xl1 = xl0 + 16 * PITCH;
+  int doff[DPER];       // dY piece j: byte offset from the block's first pixel, or -1 for the 3 padding pixels
+#pragma unroll
+  for (int j = 0; j < DPER; ++j) {
+    const int q = wc0 + 32 * j;
+    const int qr = (q * 41) >> 10;              // q / 25 for q < 128
+    doff[j] = q < TH * TW ? ((qr * a.OW + q - qr * TW) * 64) * 2 + pch * 16 : -1;
+  }
+  u32x4 rx[XPER2], rd[DPER];
   auto gload = [&](int tile) {
     const int b = tile / tpi, t = tile - b * tpi;
-    const int oy0 = (t / a.tiles_x) * TH, ox0 = (t % a.tiles_x) * TW;
+    const int ty = t / a.tiles_x;
+    const int oy0 = ty * TH, ox0 = (t - ty * a.tiles_x) * TW;
     const int ix0 = ox0 * S - P, iyb = oy0 * S - P + ky;
     const bool live = tile < ntiles;
-    int tl = tid;
-    asm volatile("" : "+v"(tl));   // opaque per call: hipcc otherwise hoists the 26 loop-invariant piece coordinates out of the
-                                   // tile loop, spills them, and the scratch reloads (vmcnt(0)) drain the prefetch every tile
+    const int c0 = ix0 + wc0, c1 = c0 + 32;
+    const bool ok0 = (unsigned)c0 < (unsigned)a.W, ok1 = has1 && (unsigned)c1 < (unsigned)a.W;
+    const int cb0 = c0 * 128 + pch * 16, cb1 = cb0 + 32 * 128;
 #pragma unroll
-    for (int j = 0; j < XPER; ++j) {
-      const int c = tl + 256 * j;
-      const int pix = c >> 3;
-      const int jr = (pix * 1171) >> 16;          // pix / 56 for pix < 3 * 65536 / 8
-      const int wc = pix - jr * WC;
-      const int iy = iyb + jr * S, ix = ix0 + wc;
-      const bool ok = live && c < XPIECES && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const int off = (((b * a.H + iy) * a.W + ix) * 64) * 2 + (c & 7) * 16;
-      rx[j] = buf_load16(xr, ok ? off : (int)0x80000000);
+    for (int j = 0; j < TH; ++j) {
+      const int iy = iyb + j * S;                                               // (uniform)
+      const bool rowok = live && (unsigned)iy < (unsigned)a.H;
+      const int base = ((b * a.H + iy) * a.W) * 128;
+      rx[2 * j] = buf_load16(xr, (rowok && ok0) ? base + cb0 : (int)0x80000000);
+      rx[2 * j + 1] = buf_load16(xr, (rowok && ok1) ? base + cb1 : (int)0x80000000);
     }
+    // (a block may hang over the right / bottom edge only where OW, OH are not multiples of 25 / 5: the map encoder's 50 x 50 is)
+    const bool whole = live && oy0 + TH <= a.OH && ox0 + TW <= a.OW;
+    const int dbase = (((b * a.OH + oy0) * a.OW + ox0) * 64) * 2;
 #pragma unroll
     for (int j = 0; j < DPER; ++j) {
-      const int c = tl + 256 * j;
-      const int q = c >> 3;
-      const int qr = (q * 41) >> 10;              // q / 25 for q < 128
-      const int oy = oy0 + qr, ox = ox0 + q - qr * TW;
-      const bool ok = live && q < TH * TW && oy < a.OH && ox < a.OW;
-      const int off = (((b * a.OH + oy) * a.OW + ox) * 64) * 2 + (c & 7) * 16;
-      rd[j] = buf_load16(dr, ok ? off : (int)0x80000000);
+      bool ok = whole && doff[j] >= 0;
+      if (!whole && live && doff[j] >= 0) {     // edge block: per-pixel test (never taken at 50 x 50)
+        const int q = wc0 + 32 * j, qr = (q * 41) >> 10;
+        ok = oy0 + qr < a.OH && ox0 + q - qr * TW < a.OW;
+      }
+      rd[j] = buf_load16(dr, ok ? dbase + doff[j] : (int)0x80000000);
     }
   };
   auto lstore = [&]() {
-    int tl = tid;
-    asm volatile("" : "+v"(tl));
 #pragma unroll
-    for (int j = 0; j < XPER; ++j) {
-      const int c = tl + 256 * j;
-      const int pix = c >> 3;
-      const int jr = (pix * 1171) >> 16;
-      const int wc = pix - jr * WC;
-      if (c < XPIECES) *reinterpret_cast<u32x4*>(xs + jr * XROW + ((wc & 1) * PC + (wc >> 1)) * PITCH + (c & 7) * 16) = rx[j];
+    for (int j = 0; j < TH; ++j) {
+      *reinterpret_cast<u32x4*>(xs + j * XROW + xl0) = rx[2 * j];
+      if (has1) *reinterpret_cast<u32x4*>(xs + j * XROW + xl1) = rx[2 * j + 1];
     }
 #pragma unroll
-    for (int j = 0; j < DPER; ++j) {
-      const int c = tl + 256 * j;
-      *reinterpret_cast<u32x4*>(ds + (c >> 3) * PITCH + (c & 7) * 16) = rd[j];
-    }
+    for (int j = 0; j < DPER; ++j) *reinterpret_cast<u32x4*>(ds + (wc0 + 32 * j) * PITCH + pch * 16) = rd[j];
   };
 
   // ---- transposing-read lane map (as conv_wgrad_bf16_kernel): the lane supplies the address of pixel 8 h + q (+ 4 for
