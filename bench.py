@@ -233,6 +233,10 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
 
     T, N = args.T, args.N
     obs, prev, masks, weights = synth_batch(T, N, dev, 1000 + rank)
+    # the synthetic batch is resident and complete from here on: say so (what DeviceCollator says of every batch it hands over), so that
+    # the forward's one host read-back — the instruction dedup, still launched and read back in every update — need not wait for
+    # the previous update to finish on the GPU (wsmgmap/ops/core.py, "input readiness")
+    ops.mark_inputs_ready(obs["instruction"])
     AuxLosses.activate()
 
     def update():
@@ -334,9 +338,26 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
     marks = []
     import gc
-    if os.environ.get("WSMG_BENCH_GC") == "0":      # diagnostic: are the slow updates the host's garbage collector?
+    # The host's cyclic garbage collector stays as it is in the timed region.  Measured (profiles/r04_gc_ab.txt, 3 x 300 updates each,
+    # interleaved, 5-update windows): collector on as usual — no window more than 3 % over the median; heap frozen after the warm-up
+    # (gc.freeze) — 1 / 9 / 1 such windows; collector off — 2 / 4 / 23 and 11.6 ms per update in the third run: the autograd graphs
+    # are reference cycles, and without the collector their tensors go back to the allocator late (it grows, and growing stalls).
+    # WSMG_BENCH_GC=0 / freeze reproduce the other two arms; WSMG_BENCH_HOSTTIME=2 logs collections and slow updates.
+    gc_mode = os.environ.get("WSMG_BENCH_GC", "plain")
+    if gc_mode == "0":
         gc.collect()
         gc.disable()
+    elif gc_mode == "freeze":
+        gc.collect()
+        gc.freeze()
+    gc_log, host_each = [], []
+    if os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
+        def _gc_cb(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((len(host_each), info.get("generation"), round((time.perf_counter() - _t[0]) * 1e3, 2), info.get("collected")))
+        gc.callbacks.append(_gc_cb)
     t0 = time.perf_counter()
     host = 0.0
     for i in range(steps):
@@ -347,6 +368,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         h0 = time.perf_counter()
         loss = update()
         host += time.perf_counter() - h0
+        host_each.append(time.perf_counter() - h0)
     if marks:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
@@ -365,6 +387,14 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
                                  ms_per_update_second_half=round(sum(tail) / len(tail), 3),
                                  note="HIP-event time of consecutive 50-update windows inside the same timed region")
     gc.enable()
+    gc.unfreeze()
+    if gc_log or os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
+        gc.callbacks[:] = [c for c in gc.callbacks if getattr(c, "__name__", "") != "_gc_cb"]
+        if rank == 0:
+            med = sorted(host_each)[len(host_each) // 2]
+            slow = [(i, round(v * 1e3, 2)) for i, v in enumerate(host_each) if v > 1.5 * med]
+            print("host per update: median %.2f ms; updates over 1.5 x median: %s" % (med * 1e3, slow[:40]), file=sys.stderr)
+            print("collections (update index, generation, ms, collected): %s" % [g for g in gc_log if g[1] >= 1 or g[2] > 1.0][:60], file=sys.stderr)
     if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
         print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
     if args.dp:

@@ -440,6 +440,13 @@ int wsmg_ce_nhwc_bwd_bf16(const void* logits, const int64_t* target, const float
  * observations, 0 for actions and weights, :85-91). */
 int wsmg_collate_pad(const void* const* src, const int* lengths, int N, int T, int64_t elems, int src_dtype,
                      float pad, float* dst, wsmg_stream_t stream);
+/* The same collate for the cached ego map when the map stack runs in bf16 (round 4): src episodes float16 [length_n][C][HW]
+ * (common_trainer.py:514-532 stores rgb_ego_map as float16), dst bf16 [T][N][HW][C] — channels-last, i.e. the layout and
+ * dtype the map encoder's first convolution reads, so the policy's NCHW float32 -> NHWC bf16 pass (1.3 GB read + 0.65 GB
+ * written per update at B = 512) does not exist on the feeder route.  Values are bit-identical to wsmg_collate_pad followed by
+ * wsmg_nchw_to_nhwc_bf16 (float16 -> float32 is exact, then one rounding to bf16).  C % 64 == 0, HW % 4 == 0, T * N <= 65535. */
+int wsmg_collate_pad_nhwc_bf16(const void* const* src, const int* lengths, int N, int T, int C, int HW, float pad, void* dst,
+                               wsmg_stream_t stream);
 
 /* ============================ persistent masked-GRU state encoders ============================ */
 /* habitat-lab RNNStateEncoder (GRU, hidden 512) as used at mg_map_policy.py:118-123,147-152,220-227,242-249:

@@ -504,3 +504,73 @@ def test_stride2_window_weight_gradients(geom):
     torch.cuda.synchronize()
     assert torch.equal(slabs[0], slabs[1]) and torch.equal(slabs[0], slabs[2])
     assert float((slabs[0].double() - want).abs().max()) <= 2e-5 * scale
+
+
+# ----------------------------------------------------------------------------- feeder route: ego map as channels-last bf16; input readiness
+def test_collate_emits_the_ego_map_as_channels_last_bf16_bit_identically():
+    """DeviceCollator(ego_map_nhwc_bf16=True) writes `rgb_ego_map` padded, episode-interleaved, channels-last
+    and bf16 in ONE pass (wsmg_collate_pad_nhwc_bf16); the values are those of the float32 collate followed by the policy's NCHW
+    float32 -> NHWC bf16 conversion, bit for bit (float16 -> float32 -> bf16 either way), the padding steps hold bf16(1.0), every
+    other sensor is untouched — and the policy takes the tensor as it is (no layout / dtype launch)."""
+    import test_gpu_round2 as r2
+    from wsmgmap import ops
+    from wsmgmap.data import DeviceCollator
+    rng = np.random.RandomState(5)
+    lengths, C, E = [7, 3, 5], 64, 10
+    batch = []
+    for n in lengths:
+        obs = {"instruction": rng.randint(0, 27, size=(n, 6)).astype(np.int64),
+               "rgb_ego_map": (rng.randn(n, C, E, E) * 3).astype(np.float16),
+               "progress": rng.rand(n, 1).astype(np.float32)}
+        batch.append((obs, rng.randn(n, 2).astype(np.float32), rng.randn(n, 2).astype(np.float32), torch.ones(n)))
+    ref_obs, *ref_rest = DeviceCollator("cuda")(batch)
+    new_obs, *new_rest = DeviceCollator("cuda", ego_map_nhwc_bf16=True)(batch)
+    torch.cuda.synchronize()
+    for a, b in zip(ref_rest, new_rest):
+        assert torch.equal(a, b)
+    assert torch.equal(ref_obs["instruction"], new_obs["instruction"]) and torch.equal(ref_obs["progress"], new_obs["progress"])
+    ego = new_obs["rgb_ego_map"]
+    T, N = max(lengths), len(lengths)
+    assert ego.dtype == torch.bfloat16 and tuple(ego.shape) == (T * N, C, E, E) and ego.permute(0, 2, 3, 1).is_contiguous()
+    want = ops.to_nhwc(ref_obs["rgb_ego_map"].contiguous(), C, dtype=torch.bfloat16)          # [T*N, E, E, C]
+    assert torch.equal(ego.permute(0, 2, 3, 1), want)
+    pad_rows = [t * N + n for n, ln in enumerate(lengths) for t in range(ln, T)]
+    assert pad_rows and bool((ego[pad_rows].float() == 1.0).all())
+    # the policy reads it in place
+    pol = r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state())
+    x = pol.net._ego_to_nhwc(ego)
+    assert x.data_ptr() == ego.data_ptr() and x.dtype == torch.bfloat16 and tuple(x.shape) == (T * N, E, E, C)
+    # and the tokens carry their readiness event
+    assert ops.inputs_ready_event(new_obs["instruction"]) is not None
+
+
+def test_early_instruction_dedup_changes_no_result(monkeypatch):
+    """ops.mark_inputs_ready: with the tokens marked complete, the instruction dedup and its host read-back run on a stream that
+    does not wait for the previous update (wsmgmap/ops/core.py); losses, logits and every gradient of three consecutive updates are
+    bit-identical to the route that waits, and the persistent kernels' status stays clean."""
+    import bench
+    import test_gpu_round2 as r2
+    from wsmgmap import debug, ops
+    from wsmgmap.optim import Adam
+    T, N = 16, 4
+
+    def run(early):
+        monkeypatch.setattr(debug.sw, "early_dedup", early)
+        torch.manual_seed(3)
+        pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+        opt = Adam(pol.parameters(), lr=2.5e-4)
+        obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 91)
+        ops.mark_inputs_ready(obs["instruction"])
+        out = []
+        for _ in range(3):
+            a = _one_update(pol, obs, prev, masks, weights, N, 4)
+            opt.step()
+            out.append(a)
+        ops.check_rnn_status()
+        return out, getattr(pol.net, "_early_stream", None) is not None
+    (a, used_a), (b, used_b) = run(True), run(False)
+    assert used_a and not used_b
+    for x, y in zip(a, b):
+        assert torch.equal(x[0], y[0]) and x[1] == y[1]
+        for k, g in x[4].items():
+            assert (g is None) == (y[4][k] is None) and (g is None or torch.equal(g, y[4][k])), k

@@ -59,6 +59,46 @@ __global__ __launch_bounds__(256) void collate_pad_kernel(const void* const* __r
   }
 }
 
+// The cached ego map for the bf16 map stack (round 4): padded, episode-interleaved AND channels-last bf16 in one pass —
+// dst[t][n][p][c] = bf16(src_n[t][c][p]) (float16 on disk -> float32 -> bf16, the roundings of wsmg_collate_pad followed by the
+// policy's NCHW float32 -> NHWC bf16 conversion, so the values are bit-identical to that route) or bf16(pad) for t >= length_n.
+// 64-channel x 64-pixel tiles through LDS: 8-byte loads along the pixel axis, 16-byte stores along the channel axis.
+__global__ __launch_bounds__(256) void collate_pad_nhwc_bf16_kernel(const void* const* __restrict__ src, const int* __restrict__ lengths,
+                                                                    int N, int C, int HW, float pad, bf16_t* __restrict__ dst) {
+  __shared__ float tile[64][65];
+  const int row = blockIdx.z, t = row / N, n = row - t * N;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  const bool live = t < lengths[n];
+  if (live) {
+    const _Float16* s = reinterpret_cast<const _Float16*>(src[n]) + (size_t)t * C * HW;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int id = tid + 256 * j;         // 1024 pieces of 4 pixels: 16 per channel row
+      const int c = id >> 4, pq = (id & 15) * 4;
+      h4 v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+      if (p0 + pq < HW) v = *reinterpret_cast<const h4*>(s + (size_t)(c0 + c) * HW + p0 + pq);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tile[c][pq + k] = (float)v[k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int id = tid + 256 * j;           // 512 pieces of 8 channels: 8 per pixel
+    const int p = id >> 3, cs = (id & 7) * 8;
+    if (p0 + p < HW) {
+      f32x4 lo, hi;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { lo[k] = live ? tile[cs + k][p] : pad; hi[k] = live ? tile[cs + 4 + k][p] : pad; }
+      bf16_t* o = dst + ((size_t)row * HW + p0 + p) * C + c0 + cs;
+      st4(o, lo);
+      st4(o + 4, hi);
+    }
+  }
+}
+
 template <int DT>
 int launch(const void* const* src, const int* lengths, int N, int T, int64_t elems, float pad, float* dst, hipStream_t s) {
   const bool v4 = (elems % 4) == 0;
@@ -85,4 +125,12 @@ extern "C" int wsmg_collate_pad(const void* const* src, const int* lengths, int 
     case DT_F32: return launch<DT_F32>(src, lengths, N, T, elems, pad, dst, s);
     default: return WSMG_EINVAL;
   }
+}
+
+extern "C" int wsmg_collate_pad_nhwc_bf16(const void* const* src, const int* lengths, int N, int T, int C, int HW, float pad, void* dst,
+                                          wsmg_stream_t stream) {
+  if (N <= 0 || T <= 0 || C <= 0 || HW <= 0 || (C % 64) || (HW % 4) || (int64_t)T * N > 65535) return WSMG_EINVAL;
+  hipLaunchKernelGGL(collate_pad_nhwc_bf16_kernel, dim3((unsigned)wsmg_cdiv(HW, 64), (unsigned)(C / 64), (unsigned)(T * N)), dim3(256), 0,
+                     wsmg_s(stream), src, lengths, N, C, HW, pad, (bf16_t*)dst);
+  WSMG_RETURN_LAUNCH();
 }

@@ -127,6 +127,7 @@ _SIG["wsmg_ce_nhwc_bwd"] = [c_p, c_p, c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_ce_nhwc_fwd_bf16"] = list(_SIG["wsmg_ce_nhwc_fwd"])
 _SIG["wsmg_ce_nhwc_bwd_bf16"] = list(_SIG["wsmg_ce_nhwc_bwd"])
 _SIG["wsmg_collate_pad"] = [c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_p, c_p]
+_SIG["wsmg_collate_pad_nhwc_bf16"] = [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]
 _SIG["wsmg_gru_workspace_bytes"] = [c_i]
 _SIG["wsmg_gru_fwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_p]
 _SIG["wsmg_gru_bwd"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_p]

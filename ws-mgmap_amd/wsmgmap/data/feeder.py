@@ -111,7 +111,7 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
 
 class DeviceFeeder:
     def __init__(self, dataset, batch_size, device="cuda", num_workers=0, prefetch=2, workers="ring", slot_bytes=None,
-                 slots_per_worker=2, seed=None):
+                 slots_per_worker=2, seed=None, ego_map_nhwc_bf16=False):
         """slot_bytes: capacity of one ring slot (default: sized from one batch this process plans itself — it decodes one batch
         of the first shard for that — with 50 % headroom, capped at the true upper bound batch_size x 200 steps; a larger batch
         travels outside the ring, counted in `oversize_batches`).
@@ -125,6 +125,7 @@ class DeviceFeeder:
             raise ValueError("workers: 'ring' or 'dataloader'")
         self.slot_bytes, self.slots_per_worker = slot_bytes, max(2, int(slots_per_worker))
         self.seed = None if seed is None else int(seed)
+        self.ego_map_nhwc_bf16 = bool(ego_map_nhwc_bf16)   # DeviceCollator's option: rgb_ego_map as channels-last bf16 (bf16 policies)
         self.epoch = 0                # iterators created so far (ring transport)
         self.oversize_batches = 0     # batches that did not fit a ring slot and travelled as their own shared-memory block
         self.pinned_ring = None       # True / False once a ring exists: could the shared slots be registered as pinned memory
@@ -154,7 +155,7 @@ class DeviceFeeder:
         loader = torch.utils.data.DataLoader(self.dataset, batch_size=self.batch_size, collate_fn=_identity,
                                              num_workers=self.num_workers, drop_last=True)
         side = torch.cuda.Stream(self.device)
-        slots = [[DeviceCollator(self.device), None] for _ in range(self.prefetch + 1)]   # [collator, last event]
+        slots = [[DeviceCollator(self.device, self.ego_map_nhwc_bf16), None] for _ in range(self.prefetch + 1)]   # [collator, last event]
         pending = collections.deque()
         for i, batch in enumerate(loader):
             slot = slots[i % len(slots)]
@@ -254,7 +255,7 @@ class DeviceFeeder:
             procs.append(p)
         self._trace("%d workers started" % W)
         side = torch.cuda.Stream(self.device)
-        coll = DeviceCollator(self.device)
+        coll = DeviceCollator(self.device, self.ego_map_nhwc_bf16)
         pending = collections.deque()          # (out, event, worker, slot)
         live = [True] * W
         try:

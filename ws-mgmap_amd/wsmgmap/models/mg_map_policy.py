@@ -141,13 +141,14 @@ class MGMapNet(nn.Module):
 
     # -- operator 2 --------------------------------------------------------------
     def _ego_to_nhwc(self, ego_map):
-        ego_map = ego_map.float()
         c = ego_map.shape[1]
         cpad = (c + 31) // 32 * 32   # the conv engine works on multiples of 32 channels (cfg4: 40 -> 64)
         nhwc_view = ego_map.permute(0, 2, 3, 1)
-        if nhwc_view.is_contiguous() and cpad == c:  # channels-last storage (what our BEV kernels emit)
-            return nhwc_view.to(self.compute_dtype)
-        return ops.to_nhwc(ego_map.contiguous(), cpad, dtype=self.compute_dtype)
+        if nhwc_view.is_contiguous() and cpad == c:
+            # channels-last storage: what our BEV kernels emit (float32) and what DeviceCollator(ego_map_nhwc_bf16=True) emits
+            # (already bf16: nothing to do — the feeder route has no layout / dtype pass at all)
+            return nhwc_view if nhwc_view.dtype == self.compute_dtype else nhwc_view.to(self.compute_dtype)
+        return ops.to_nhwc(ego_map.float().contiguous(), cpad, dtype=self.compute_dtype)
 
     _token_sink = None
 
@@ -294,10 +295,27 @@ class MGMapNet(nn.Module):
             self._side_stream = torch.cuda.Stream()
         side = self._side_stream
         side.wait_event(entry)
+        dd = observations.get("instruction_dedup")
+        tok = observations["instruction"]
+        ready = ops.inputs_ready_event(tok) if (dd is None and tok.is_cuda and torch.is_grad_enabled() and debug.sw.early_dedup
+                                                and not torch.cuda.is_current_stream_capturing()) else None
+        if ready is not None:
+            # the producer of the tokens told us when they were complete (ops.mark_inputs_ready): the dedup — parameter-free — runs on a
+            # stream that waits for that alone, and its read-back does not wait for the previous update (see ops/core.py)
+            if getattr(self, "_early_stream", None) is None:
+                self._early_stream = torch.cuda.Stream(priority=-1)
+            early_s = self._early_stream
+            early_s.wait_event(ready)
+            with torch.cuda.stream(early_s):
+                tok.record_stream(early_s)
+                dd = self.instruction_encoder.dedup(tok)
+            side.wait_stream(early_s)
+            for t in dd:
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)
         with torch.cuda.stream(side):
             after = getattr(self, "_encoder_done", None)
-            instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(observations["instruction"],
-                                                                             dedup=observations.get("instruction_dedup"), lstm_after=after)
+            instr_u, mask_u, inverse = self.instruction_encoder.encode_unique(tok, dedup=dd, lstm_after=after)
             text_k_u = self._key_projection(self.state_text_k_layer, instr_u)
             # the B rows attend over the U unique sets in place (ops.attention_shared): no per-row copies
             text = (text_k_u.contiguous(), instr_u.contiguous(), mask_u.to(torch.uint8).contiguous(), inverse.contiguous())

@@ -193,6 +193,37 @@ def mark(name, tensor=None):
         tensor.register_hook(hook)
 
 
+# ----------------------------------------------------------------------------- input readiness (round 4)
+# A tensor handed to BasePolicy.forward is, by PyTorch's stream rules, complete only in the ORDER of the caller's stream — behind the
+# previous update's optimizer step.  The one host read-back of a forward pass (the number of distinct instructions) therefore made the
+# host wait, every update, until the GPU had finished the update before: the host never ran more than a fraction of an update
+# ahead, and any hiccup of a few milliseconds on the host (scheduler, page faults: 17-25 ms outliers on some boxes) reached the GPU.
+# A producer that KNOWS when an input was complete — the feeder's collate stream, a trainer that built the batch long ago — says so
+# here; the policy then runs the data-dependent, parameter-free part of its forward (the instruction dedup) on a stream that
+# waits for THAT event only, and the read-back returns while the GPU is still busy with the previous update.
+import weakref
+
+_inputs_ready = {}      # id(tensor) -> (weak reference to the tensor, event): by identity (tensors compare element-wise)
+
+
+def mark_inputs_ready(tensor, event=None):
+    """`tensor` (an observation about to be passed to the policy) is complete once `event` has happened; default: an event
+    recorded now on the current stream.  Returns the event."""
+    if not tensor.is_cuda:
+        return None
+    if event is None:
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(tensor.device))
+    key = id(tensor)
+    _inputs_ready[key] = (weakref.ref(tensor, lambda _r, key=key: _inputs_ready.pop(key, None)), event)
+    return event
+
+
+def inputs_ready_event(tensor):
+    e = _inputs_ready.get(id(tensor))
+    return e[1] if e is not None and e[0]() is tensor else None
+
+
 # ----------------------------------------------------------------------------- state of one forward / backward pass
 _prelaid = {}     # (data_ptr, version, cin_pad, dtype) -> (OHWI, IHWO) laid out by conv.prelayout_conv_weights for THIS forward pass
 
