@@ -338,12 +338,14 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
     marks = []
     import gc
-    # The host's cyclic garbage collector stays as it is in the timed region.  Measured (profiles/r04_gc_ab.txt, 3 x 300 updates each,
-    # interleaved, 5-update windows): collector on as usual — no window more than 3 % over the median; heap frozen after the warm-up
-    # (gc.freeze) — 1 / 9 / 1 such windows; collector off — 2 / 4 / 23 and 11.6 ms per update in the third run: the autograd graphs
-    # are reference cycles, and without the collector their tensors go back to the allocator late (it grows, and growing stalls).
-    # WSMG_BENCH_GC=0 / freeze reproduce the other two arms; WSMG_BENCH_HOSTTIME=2 logs collections and slow updates.
-    gc_mode = os.environ.get("WSMG_BENCH_GC", "plain")
+    # The host's cyclic garbage collector and the timed region.  The collector stays ON (off, the autograd graphs — reference cycles —
+    # give their tensors back late and the allocator grows: 2 / 4 / 23 windows more than 3 % over the median and 11.6 ms per update in
+    # the third run of profiles/r04_gc_ab.txt).  But a full (generation-2) collection walks every tracked object of the process — the
+    # import-time heap of torch included — and takes 100-170 ms here; it comes once every ~360 updates (profiles/
+    # r04_host_stalls_and_collections.txt: update 334-338 of every 500-update run, one window at 31-46 ms).  The heap that exists after
+    # the warm-up is therefore moved to the permanent generation (gc.freeze) after one full collection: later collections look at what
+    # the updates themselves allocate, and a full one takes about a millisecond.  WSMG_BENCH_GC=plain: no freeze; =0: collector off.
+    gc_mode = os.environ.get("WSMG_BENCH_GC", "freeze")
     if gc_mode == "0":
         gc.collect()
         gc.disable()
