@@ -299,6 +299,23 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         # the family with the most time in the last warm-up update, no tie rule (rounds 2-3 gave ties within 15 % to
         # the backward-weight family); `kernels` carries every family's figures either way
         dom_entry = max(warm_prof.values(), key=lambda r: r["ms_total"])["entry"]
+    import gc
+    # The host's cyclic garbage collector and the timed region.  The collector stays ON (off, the autograd graphs — reference cycles —
+    # give their tensors back late and the allocator grows: 2 / 4 / 23 windows more than 3 % over the median and 11.6 ms per update in
+    # the third run of profiles/r04_gc_ab.txt).  But a full (generation-2) collection walks every tracked object of the process — the
+    # import-time heap of torch included — and takes 100-170 ms here; it comes once every ~360 updates (profiles/
+    # r04_host_stalls_and_collections.txt: update 334-338 of every 500-update run, one window at 31-46 ms).  The heap that exists after
+    # the warm-up is therefore moved to the permanent generation (gc.freeze) after one full collection: later collections look at what
+    # the updates themselves allocate, and a full one takes about a millisecond.  WSMG_BENCH_GC=plain: no freeze; =0: collector off.
+    # (Done HERE, before the pre-timing spin: the full collection takes ~110 ms of host time, the GPU drains and clocks down meanwhile, and
+    # right in front of the timed region that showed as a first window 0.3-0.5 ms per update above the rest.)
+    gc_mode = os.environ.get("WSMG_BENCH_GC", "freeze")
+    if gc_mode == "0":
+        gc.collect()
+        gc.disable()
+    elif gc_mode == "freeze":
+        gc.collect()
+        gc.freeze()
     # Pre-timing spin of real updates (reported as `prewarm_s` / `prewarm_updates`; `warmup` stays what the caller passed): on a
     # fresh lease the first ~20 updates after 5 warm-up ones ran 14.6 / 11.8 ms against a steady 11.4 (BENCH_r03 `windows`) — the GPU
     # comes out of idle clocks, the allocator is still growing after profile_end(), the per-stream workspaces see first use.
@@ -337,21 +354,6 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     if os.environ.get("WSMG_BENCH_WINDOW"):        # diagnostic: another window length (1 = an event per update)
         WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
     marks = []
-    import gc
-    # The host's cyclic garbage collector and the timed region.  The collector stays ON (off, the autograd graphs — reference cycles —
-    # give their tensors back late and the allocator grows: 2 / 4 / 23 windows more than 3 % over the median and 11.6 ms per update in
-    # the third run of profiles/r04_gc_ab.txt).  But a full (generation-2) collection walks every tracked object of the process — the
-    # import-time heap of torch included — and takes 100-170 ms here; it comes once every ~360 updates (profiles/
-    # r04_host_stalls_and_collections.txt: update 334-338 of every 500-update run, one window at 31-46 ms).  The heap that exists after
-    # the warm-up is therefore moved to the permanent generation (gc.freeze) after one full collection: later collections look at what
-    # the updates themselves allocate, and a full one takes about a millisecond.  WSMG_BENCH_GC=plain: no freeze; =0: collector off.
-    gc_mode = os.environ.get("WSMG_BENCH_GC", "freeze")
-    if gc_mode == "0":
-        gc.collect()
-        gc.disable()
-    elif gc_mode == "freeze":
-        gc.collect()
-        gc.freeze()
     gc_log, host_each = [], []
     if os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
         def _gc_cb(phase, info, _t=[0.0]):

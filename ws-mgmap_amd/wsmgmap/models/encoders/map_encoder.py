@@ -226,6 +226,26 @@ class MapDecoder(nn.Module):
         y = conv_bn_relu(x, blk.conv1, blk.bn1, train)
         return conv_bn_relu(y, blk.conv2, blk.bn2, train, relu=True, residual=x)
 
+    def side_stream(self, x):
+        """The stream the full-resolution branch runs on beside the resnet branch, or None for one stream (debug.sw.decoder_streams
+        = 0, CPU tensors, ranks sharing a GPU)."""
+        import torch
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        # Under a process group the side stream is used when every rank of this node has a GPU to itself — the launcher's
+        # LOCAL_WORLD_SIZE <= visible GPUs, the only configuration of the target (one process per GPU, README.md:80-84 of the
+        # reference).  Two ranks SHARING one GPU (the functional test on a 1-GPU box) went from 49 ms to 4.3 s per update with
+        # this third stream per process beside the collective library's own: hardware-queue oversubscription between two
+        # processes' persistent RNN kernels; there the decoder stays on one stream.  The stream is worth 0.25 ms per update
+        # (12.36 vs 12.62 ms, single process, one run).
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+        shared = multi and not (0 < lws <= torch.cuda.device_count())
+        mode = int(debug.sw.decoder_streams)     # 0: one stream; 2: side stream even when ranks share a GPU (experiments)
+        if not (x.is_cuda and mode != 0 and (not shared or mode == 2)):
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def forward(self, x, fold=None):
         import torch
         # x: the encoded map, or (alias for the full-resolution branch, alias for the stem) of it — ops.fanout3 in MGMapNet._map_stack
@@ -239,21 +259,9 @@ class MapDecoder(nn.Module):
         # the resnet branch is mostly launch-latency-bound (6x6 and 12x12 maps: ~15 us kernels that leave the chip idle):
         # the full-resolution branch runs on a side stream beside it — in backward too, where autograd replays every node
         # on its forward stream.  WSMG_DECODER_STREAMS=0: one stream.
-        side = None
-        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-        # Under a process group the side stream is used when every rank of this node has a GPU to itself — the launcher's
-        # LOCAL_WORLD_SIZE <= visible GPUs, the only configuration of the target (one process per GPU, README.md:80-84 of the
-        # reference).  Two ranks SHARING one GPU (the functional test on a 1-GPU box) went from 49 ms to 4.3 s per update with
-        # this third stream per process beside the collective library's own: hardware-queue oversubscription between two
-        # processes' persistent RNN kernels; there the decoder stays on one stream.  The stream is worth 0.25 ms per update
-        # (12.36 vs 12.62 ms, single process, one run).
-        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
-        shared = multi and not (0 < lws <= torch.cuda.device_count())
-        mode = int(debug.sw.decoder_streams)     # 0: one stream; 2: side stream even when ranks share a GPU (experiments)
-        if x.is_cuda and mode != 0 and (not shared or mode == 2):
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            side, main = self._side, torch.cuda.current_stream()
+        side = self.side_stream(x)
+        if side is not None:
+            main = torch.cuda.current_stream()
             side.wait_stream(main)
             x_full.record_stream(side)   # saved for the side-stream backward of these layers: no reuse of its memory before that ran
             with torch.cuda.stream(side):
