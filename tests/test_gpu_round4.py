@@ -574,3 +574,23 @@ def test_early_instruction_dedup_changes_no_result(monkeypatch):
         assert torch.equal(x[0], y[0]) and x[1] == y[1]
         for k, g in x[4].items():
             assert (g is None) == (y[4][k] is None) and (g is None or torch.equal(g, y[4][k])), k
+
+
+def test_cls_tail_poisons_the_loss_row_of_an_out_of_range_label():
+    """the reference's F.cross_entropy (policy.py:61-66) faults on a label outside [0, classes); the fused classifier tail
+    returns NaN for that sample's loss row — and only for that one — instead of a finite number computed from a padded channel."""
+    import torch.nn as nn
+    from wsmgmap import ops
+    B, H, classes = 4, 48, 27
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    y2 = (torch.randn(B, H, H, 32, device="cuda", generator=g) * 1.5).to(torch.bfloat16)
+    bn, conv = nn.BatchNorm2d(32).cuda().train(), nn.Conv2d(32, classes, 1).cuda()
+    gt = torch.randint(0, classes, (B, 100, 100), device="cuda", generator=g).float()
+    gt[1, 50, 50] = float(classes)       # one past the last class
+    gt[3, 0, 0] = -1.0
+    st = torch.zeros(ops.BN_SLABS, 2, 32, device="cuda", dtype=torch.float64)
+    f = y2.double().reshape(-1, 32)
+    st[0, 0], st[0, 1] = f.sum(0), (f * f).sum(0)
+    _, _, ce = ops.cls_tail(y2, st, bn, conv, gt)
+    torch.cuda.synchronize()
+    assert torch.isnan(ce).tolist() == [False, True, False, True], ce

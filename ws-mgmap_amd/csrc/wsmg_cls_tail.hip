@@ -215,7 +215,9 @@ __global__ __launch_bounds__(512) void cls_tail_fwd_kernel(TailArgs a) {
       }
       s += __shfl_xor(s, 32, 64);
       vt += __shfl_xor(vt, 32, 64);
-      if (h == 0) loss += (mx + logf(s)) - vt;
+      // a label outside [0, classes): F.cross_entropy of the reference (policy.py:61-66) faults on it; here the sample's loss row
+      // becomes NaN — loud in the loss and in every gradient behind it — instead of a finite, wrong number
+      if (h == 0) loss += ((unsigned)tlab < (unsigned)a.classes) ? (mx + logf(s)) - vt : __builtin_nanf("");
     }
     // the logits as the unfused path stores them (bf16), and their 2 x 2 average
     float vr[16];

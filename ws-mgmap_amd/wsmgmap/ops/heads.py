@@ -136,7 +136,10 @@ def cls_tail_ok(y2, classes):
 def cls_tail(y2, stats, bn, conv1x1, gt=None):
     """-> (logits [B,H,W,32] bf16 — not differentiable, for inspection / pred_sem_map —, pooled [B,H/2,W/2,32] bf16, ce_rows [B] or
     None): train-mode `bn` (nn.BatchNorm2d(32), statistics in `stats` from the producing convolution's epilogue) + ReLU + `conv1x1`
-    (nn.Conv2d(32, classes, 1)) + the prediction monitor's per-sample cross-entropy against gt [B,Hg,Wg] + AvgPool2d(2)."""
+    (nn.Conv2d(32, classes, 1)) + the prediction monitor's per-sample cross-entropy against gt [B,Hg,Wg] + AvgPool2d(2).
+    A label outside [0, classes) — `F.cross_entropy` of the reference faults on it — makes that sample's loss row NaN (and with it
+    the loss and the gradients behind it): loud, not a finite wrong number.  The loss is taken from the float32 logits; the
+    unfused route takes it from the stored bf16 logits (the difference is inside the 5e-3 bar of the tests)."""
     w, b = conv1x1.weight, conv1x1.bias
     return _ClsTail.apply(y2.contiguous(), stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                           w.contiguous(), b, None if gt is None else gt.contiguous())
