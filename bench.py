@@ -346,7 +346,13 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # timed live (HIP events around every launch, inside the timed region): the family with the most time, and the weight-gradient
     # family whichever it is — rounds 1-3 reported that one, and its kernels are what round 4 rebuilt; a line must show both
     WG = "wsmg_conv2d_bwd_weight_bf16" if dtype == "bf16" else "wsmg_conv2d_bwd_weight"
-    ops.profile_begin(only=sorted({dom_entry, WG}) if dom_entry else None)
+    # Every timed launch is two HIP event records on its stream (~1.5 us of GPU time each): with both families timed on every update
+    # the line itself cost 0.1-0.2 ms per update (10.58 / 10.67 vs 10.46 / 10.46 ms, profiles/r04_first_window_and_event_cost.txt).
+    # So: the largest family on every update, as in rounds 1-3; the weight-gradient family, when it is not the largest, on every
+    # 4th update of the timed region (a sample of the same region).  WSMG_BENCH_NOPROF=1: no events at all (diagnostic).
+    both = sorted({dom_entry, WG}) if dom_entry else None
+    if os.environ.get("WSMG_BENCH_NOPROF") != "1":
+        ops.profile_begin(only=[dom_entry] if dom_entry else None)
     # an event every WIN updates (no synchronisation): `sustained` for --steps >= 200 (50-update windows), and `windows` for every
     # run (a quarter of the run each), so that a transient stall inside the timed region — one run in ~40 on this pool came out at
     # 14-19 ms per update for no reason the process could see — shows in the line as what it is
@@ -369,6 +375,8 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
+        if dom_entry and dom_entry != WG:
+            ops.profile_set_only(both if i % 4 == 0 else [dom_entry])
         h0 = time.perf_counter()
         loss = update()
         host += time.perf_counter() - h0
@@ -406,6 +414,12 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = ops.profile_end()
+    if dom_entry and dom_entry != WG:
+        for r in prof.values():       # the sampled family: its totals are over every 4th update
+            if r.get("entry") == WG:
+                r["per_steps"] = (steps + 3) // 4
+                r["phase"] = "timed region"
+                r["sampled"] = "every 4th update of the timed region"
     ops.check_rnn_status()        # a persistent-RNN timeout anywhere in the run invalidates it: fail loudly
     if reducer:
         reducer.check()
@@ -584,7 +598,7 @@ def main():
             r = prof[fam]
             ach = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-            o = dict(bound="mfma", kernel=fam, achieved=round(ach, 3), peak=peak, unit="TFLOP/s",
+            o = dict(bound="mfma", kernel=fam, achieved=round(ach, 3), peak=peak, unit="TFLOP/s", timed=r.get("sampled", "every update of the timed region"),
                      frac=round(ach / peak, 4), traffic=None,
                      avg_launch_ms=round(r["ms_total"] / r["launches"], 4), launches=r["launches"],
                      alg_gflop_per_launch=round(r["flops_total"] / r["launches"] / 1e9, 3))

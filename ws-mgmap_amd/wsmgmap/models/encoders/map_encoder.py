@@ -243,7 +243,7 @@ class MapDecoder(nn.Module):
         if not (x.is_cuda and mode != 0 and (not shared or mode == 2)):
             return None
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = ops.helper_stream("decoder")
         return self._side
 
     def forward(self, x, fold=None):

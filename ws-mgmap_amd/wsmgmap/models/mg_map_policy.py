@@ -217,7 +217,7 @@ class MGMapNet(nn.Module):
             entry = getattr(self, "_entry_event", None)
             if entry is not None and self.recurrent_chunks > 0 and not torch.cuda.is_current_stream_capturing():
                 if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream()
+                    self._side_stream = ops.helper_stream("instruction")
                 self._side_stream.wait_event(entry)          # the optimizer's writes to the parameters are complete there
                 with torch.cuda.stream(self._side_stream):
                     ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
@@ -306,7 +306,7 @@ class MGMapNet(nn.Module):
         unique instructions), and while the host waits for it the GPU still has the map-stack forward to run,
         instead of draining (measured: 0.9 ms of idle GPU per update when the read-back came first)."""
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
+            self._side_stream = ops.helper_stream("instruction")
         side = self._side_stream
         side.wait_event(entry)
         dd = observations.get("instruction_dedup")
@@ -317,7 +317,7 @@ class MGMapNet(nn.Module):
             # the producer of the tokens told us when they were complete (ops.mark_inputs_ready): the dedup — parameter-free — runs on a
             # stream that waits for that alone, and its read-back does not wait for the previous update (see ops/core.py)
             if getattr(self, "_early_stream", None) is None:
-                self._early_stream = torch.cuda.Stream(priority=-1)
+                self._early_stream = ops.helper_stream("early", priority=-1)
             early_s = self._early_stream
             early_s.wait_event(ready)
             with torch.cuda.stream(early_s):
@@ -386,7 +386,7 @@ class MGMapNet(nn.Module):
                        and not capturing)
         if dense_early:
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
+                self._side_stream = ops.helper_stream("instruction")
             self._side_stream.wait_event(entry)
             with torch.cuda.stream(self._side_stream):
                 state_in = dense_inputs()

@@ -129,6 +129,14 @@ def profile_begin(only=None):
     _prof_only = set(only) if only else None
 
 
+def profile_set_only(only):
+    """Change which entry points are timed WITHOUT dropping what has been collected (bench.py times a second family on a sample
+    of its timed region's updates: every timed launch is two event records on the stream, ~1.5 us of GPU time each)."""
+    global _prof_only
+    if _prof is not None:
+        _prof_only = set(only) if only else None
+
+
 def profile_end():
     """-> {kernel: dict(launches, ms_total, flops_total)}; synchronises."""
     global _prof, _prof_only
@@ -191,6 +199,25 @@ def mark(name, tensor=None):
                 _marks.append(("b:" + name, ev))
             return g
         tensor.register_hook(hook)
+
+
+# ----------------------------------------------------------------------------- helper streams (round 4)
+# A process has four hardware queues by default (GPU_MAX_HW_QUEUES) and HIP deals its streams onto them round-robin.  The update
+# uses the caller's stream plus three helpers — "instruction" (instruction branch, weight layout, dense inputs, recurrent-core
+# stages), "decoder" (the decoder's full-resolution branch, map_encoded_linear) and "early" (input preprocessing behind the
+# producer's event) — and these are PROCESS-WIDE, one per device and name: a second policy object in the same process (bench.py's
+# float32 leg behind its bf16 leg, an evaluation policy beside a training one) shares them instead of creating three more and
+# landing two "independent" streams on one queue (the float32 leg ran 69 ms per update behind the bf16 leg, 56.5 alone).
+_helper_streams = {}
+
+
+def helper_stream(name, device=None, priority=0):
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, name)
+    s = _helper_streams.get(key)
+    if s is None:
+        s = _helper_streams[key] = torch.cuda.Stream(device=dev, priority=priority)
+    return s
 
 
 # ----------------------------------------------------------------------------- input readiness (round 4)
