@@ -471,7 +471,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         measure.graphed = dict(ms_per_step=round(gdt / steps * 1e3, 3), value=round(T * N * steps / gdt, 2), unit="policy steps/s", steps=steps,
                                loss=round(float(gloss), 5),
                                note="the same update (zero_grad + forward + loss + backward + Adam) as one captured HIP graph per "
-                                    "input signature, replayed; only the instruction dedup stays eager")
+                                    "input signature, replayed; only the instruction dedup stays eager.  The batch is registered as the "
+                                    "graph's static inputs: a trainer fed by the feeder pays one more copy of it per update (the "
+                                    "cached ego map alone is 1.3 GB), which this figure does not contain")
     del policy, opt, obs
     torch.cuda.empty_cache()
     return dt, prof, final_loss, state_cpu
