@@ -311,8 +311,13 @@ class MGMapNet(nn.Module):
         side.wait_event(entry)
         dd = observations.get("instruction_dedup")
         tok = observations["instruction"]
+        # (not under a process group: with the host free to run ahead of the GPU, the data-parallel bench path — one-rank RCCL
+        #  communicator, the only form a 1-GPU box can host — ran 17.7 ms per update instead of 11.3, on the GPU's own clock
+        #  (profiles/r04_dp1_early_dedup.txt); not understood, so the exchange keeps the round-3 behaviour: one read-back per update
+        #  that waits for the previous update)
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized()
         ready = ops.inputs_ready_event(tok) if (dd is None and tok.is_cuda and torch.is_grad_enabled() and debug.sw.early_dedup
-                                                and not torch.cuda.is_current_stream_capturing()) else None
+                                                and not multi and not torch.cuda.is_current_stream_capturing()) else None
         if ready is not None:
             # the producer of the tokens told us when they were complete (ops.mark_inputs_ready): the dedup — parameter-free — runs on a
             # stream that waits for that alone, and its read-back does not wait for the previous update (see ops/core.py)
