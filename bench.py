@@ -387,6 +387,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         marks.append(ev)
     torch.cuda.synchronize()
     measure.sustained = measure.windows = None
+    measure.host_ms = round(host / steps * 1e3, 3)      # wall time of the update() calls of the timed region, per update
     if len(marks) >= 2:
         spans = [(min(WIN, steps - j * WIN), marks[j].elapsed_time(marks[j + 1])) for j in range(len(marks) - 1)]
         per = [ms / n for n, ms in spans if n > 0]
@@ -567,6 +568,7 @@ def main():
 
     T, N = args.T, args.N
     dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)
+    measure.host_ms_main = getattr(measure, "host_ms", None)
     dp_info = measure.dp_info
     graphed = getattr(measure, "graphed", None)
     sustained = getattr(measure, "sustained", None)
@@ -661,6 +663,10 @@ def main():
             "graphed_update": graphed,
             "sustained": sustained,
             "windows": windows,
+            "host_ms_per_update": getattr(measure, "host_ms_main", None),
+            "host_ms_note": "host wall time inside update() per timed update: enqueueing the launches plus whatever the host waits for "
+                            "(single process: only the instruction dedup's read-back on the early stream; under a process group the "
+                            "read-back waits for the previous update, so the figure is then the update's own time)",
             "roofline": roofline,
             "roofline_weight_gradient_family": roofline_wgrad,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
