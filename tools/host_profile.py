@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""GPU-box tool: where the HOST's time goes in one update (both threads: the caller's and autograd's), by torch.profiler's CPU
+activity — self CPU time per operator / Function over a few updates of the bench workload.   python tools/host_profile.py [updates]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ws-mgmap_amd"))
+import torch
+import bench
+from wsmgmap import ops
+from wsmgmap.common.aux_losses import AuxLosses
+from wsmgmap.config import default_model_config
+from wsmgmap.models.policy import BasePolicy
+from wsmgmap.optim import Adam
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+dev = torch.device("cuda")
+T, N = 64, 8
+
+
+class Box:
+    shape = (2,)
+
+
+pol = BasePolicy(None, Box(), default_model_config(num_proc=N, compute_dtype="bf16")).to(dev)
+pol.train(); pol.net.depth_encoder.eval(); pol.net.rgb_encoder.eval()
+opt = Adam(pol.parameters(), lr=2.5e-4)
+obs, prev, masks, weights = bench.synth_batch(T, N, dev, 1000)
+ops.mark_inputs_ready(obs["instruction"])
+AuxLosses.activate()
+
+
+def update():
+    opt.zero_grad(set_to_none=True)
+    AuxLosses.clear()
+    h0 = torch.zeros(pol.net.num_recurrent_layers, N, 512, device=dev)
+    o = dict(obs)
+    pred, aux = pol(o, h0, prev, masks, weights)
+    loss = bench.dagger_loss(pred, aux, o["waypoint"], weights)
+    loss.backward()
+    opt.step()
+
+
+for _ in range(10):
+    update()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU], record_shapes=False) as prof:
+    for _ in range(n):
+        update()
+    torch.cuda.synchronize()
+ka = prof.key_averages()
+rows = sorted(ka, key=lambda e: -e.self_cpu_time_total)[:45]
+tot = sum(e.self_cpu_time_total for e in ka)
+print("self CPU time over %d updates: %.2f ms per update (both threads)" % (n, tot / n / 1e3))
+for e in rows:
+    print("%-70s %8.3f ms/update  %6.1f calls/update  %6.1f us/call" % (e.key[:70], e.self_cpu_time_total / n / 1e3, e.count / n, e.self_cpu_time_total / max(e.count, 1)))
