@@ -230,15 +230,10 @@ class MapDecoder(nn.Module):
         """The stream the full-resolution branch runs on beside the resnet branch, or None for one stream (debug.sw.decoder_streams
         = 0, CPU tensors, ranks sharing a GPU)."""
         import torch
-        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
-        # Under a process group the side stream is used when every rank of this node has a GPU to itself — the launcher's
-        # LOCAL_WORLD_SIZE <= visible GPUs, the only configuration of the target (one process per GPU, README.md:80-84 of the
-        # reference).  Two ranks SHARING one GPU (the functional test on a 1-GPU box) went from 49 ms to 4.3 s per update with
-        # this third stream per process beside the collective library's own: hardware-queue oversubscription between two
-        # processes' persistent RNN kernels; there the decoder stays on one stream.  The stream is worth 0.25 ms per update
-        # (12.36 vs 12.62 ms, single process, one run).
-        lws = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
-        shared = multi and not (0 < lws <= torch.cuda.device_count())
+        # Under a process group the side stream is used when every rank of this node has a GPU to itself (ops.ranks_share_gpu: the
+        # launcher's LOCAL_WORLD_SIZE <= visible GPUs, the only configuration of the target — one process per GPU, README.md:80-84
+        # of the reference).  The stream is worth 0.25 ms per update (12.36 vs 12.62 ms, single process, one run).
+        shared = ops.ranks_share_gpu()
         mode = int(debug.sw.decoder_streams)     # 0: one stream; 2: side stream even when ranks share a GPU (experiments)
         if not (x.is_cuda and mode != 0 and (not shared or mode == 2)):
             return None

@@ -424,7 +424,7 @@ class MGMapNet(nn.Module):
         n1 = self.state_encoder.num_recurrent_layers
         ops.mark("state_in", state_in)
         n_env = rnn_hidden_states.size(1)
-        if (self.recurrent_chunks > 0 and torch.is_grad_enabled() and not rows and "map" in self._inputs and n1 == 1
+        if (self.recurrent_chunks > 0 and not ops.ranks_share_gpu() and torch.is_grad_enabled() and not rows and "map" in self._inputs and n1 == 1
                 and rnn_hidden_states.size(0) == 2 and recurrent.usable(state_in, map_tokens, n_env, text)):
             # GRU 1 -> text attention -> map attention -> compress -> GRU 2 as one autograd node, pipelined over time chunks on three
             # streams, parameter gradients off the chain (wsmgmap/recurrent.py); same kernels, same arithmetic row for row

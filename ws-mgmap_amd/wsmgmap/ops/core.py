@@ -220,6 +220,20 @@ def helper_stream(name, device=None, priority=0):
     return s
 
 
+def ranks_share_gpu():
+    """True under a process group whose ranks of this node outnumber its visible GPUs (the launcher's LOCAL_WORLD_SIZE): the
+    functional tests of the data-parallel path on a 1-GPU box.  Two processes' persistent RNN kernels and helper streams on ONE
+    GPU oversubscribe its hardware queues (round 1: 49 ms -> 4.3 s per update with one extra stream per process; round 4, with
+    the recurrent core pipelined over three streams: 36 ms -> 0.24-1.9 s): there the update runs on the caller's stream plus
+    the instruction branch's, one persistent kernel at a time, as in round 3.  One process per GPU — the target's only
+    configuration — is never affected."""
+    import os
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+        return False
+    lws = int(os.environ.get("LOCAL_WORLD_SIZE", "0") or 0)
+    return not (0 < lws <= torch.cuda.device_count())
+
+
 # ----------------------------------------------------------------------------- input readiness (round 4)
 # A tensor handed to BasePolicy.forward is, by PyTorch's stream rules, complete only in the ORDER of the caller's stream — behind the
 # previous update's optimizer step.  The one host read-back of a forward pass (the number of distinct instructions) therefore made the
