@@ -594,3 +594,42 @@ def test_cls_tail_poisons_the_loss_row_of_an_out_of_range_label():
     _, _, ce = ops.cls_tail(y2, st, bn, conv, gt)
     torch.cuda.synchronize()
     assert torch.isnan(ce).tolist() == [False, True, False, True], ce
+
+
+def test_collate_hands_over_the_instruction_dedup():
+    """DeviceCollator computes the instruction dedup of the padded, time-major batch on the HOST (plan_batch, in the decode worker) and
+    attaches it to the token tensor (ops.attach_instruction_dedup): it equals what the device kernel + read-back compute — distinct rows
+    in order of first appearance, inverse map, lengths — and the policy's forward pass, which then launches no dedup kernel and reads
+    nothing back, gives bit-identical logits, loss and gradients."""
+    import bench
+    import test_gpu_round2 as r2
+    from wsmgmap import ops
+    from wsmgmap.data import DeviceCollator
+    from wsmgmap.models.encoders.instruction_encoder import InstructionEncoder
+    rng = np.random.RandomState(9)
+    lengths, L = [7, 3, 5, 7], 12
+    instr = [np.concatenate([rng.randint(1, 27, size=rng.randint(3, L)), np.zeros(L, np.int64)])[:L].astype(np.int64) for _ in lengths]
+    instr[3] = instr[0].copy()                                  # two episodes with the same instruction
+    batch = []
+    for n, tok in zip(lengths, instr):
+        obs = {"instruction": np.repeat(tok[None], n, 0), "progress": rng.rand(n, 1).astype(np.float32)}
+        batch.append((obs, rng.randn(n, 2).astype(np.float32), rng.randn(n, 2).astype(np.float32), torch.ones(n)))
+    obs, *_ = DeviceCollator("cuda")(batch)
+    torch.cuda.synchronize()
+    dd = ops.attached_instruction_dedup(obs["instruction"])
+    assert dd is not None and "instruction_dedup" not in obs
+    ref = InstructionEncoder._dedup_fused(obs["instruction"].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(dd[0], ref[0]) and torch.equal(dd[1], ref[1])
+    assert torch.equal(dd[2], ref[2].cpu()) and torch.equal(dd[3].cpu(), ref[3].cpu())
+    assert dd[0].shape[0] == 4          # three distinct instructions + the all-ones padding row
+    # in the policy: same update with and without the attached dedup
+    T, N = 16, 4
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+    o, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 93)
+    a = _one_update(pol, o, prev, masks, weights, N, 4)
+    ops.attach_instruction_dedup(o["instruction"], pol.net.instruction_encoder.dedup(o["instruction"]))
+    b = _one_update(pol, o, prev, masks, weights, N, 4)
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    for k, g in a[4].items():
+        assert (g is None) == (b[4][k] is None) and (g is None or torch.equal(g, b[4][k])), k

@@ -64,7 +64,37 @@ def plan_batch(batch):
             total += a.nbytes
         sensors.append((name, tuple(arrs[0].shape[1:]), _DT[arrs[0].dtype], float(pad)))
     meta = dict(N=N, T=T, lengths=[min(n, T) for n in lengths], offsets=offs, total=total + 16, sensors=sensors)
+    dd = _host_dedup(plan, meta)
+    if dd is not None:
+        meta["dedup"] = dd
     return plan, meta
+
+
+def _host_dedup(plan, meta):
+    """The instruction dedup of the padded time-major batch, computed HERE — in the decode worker, from the token arrays that are on the
+    host anyway — instead of by a kernel + host read-back in every forward pass (models/encoders/instruction_encoder.py::_dedup_fused
+    computes the same thing on the device): distinct rows of the [T*N, L] token matrix (row t*N + n = episode n's step t, or the pad
+    value 1 past its end) in order of first appearance, the inverse map, and each distinct row's count of non-zero tokens.  Small and
+    picklable: (uniq rows as a list of lists, inverse list, lengths list).  None when the batch has no integer `instruction` sensor."""
+    ent = next((e for e in plan if e[0] == "instruction"), None)
+    if ent is None or not np.issubdtype(ent[1][0].dtype, np.integer) or ent[1][0].ndim != 2:
+        return None
+    _, arrs, pad = ent
+    T, N, L = meta["T"], meta["N"], arrs[0].shape[1]
+    tok = np.full((T, N, L), int(pad), dtype=np.int64)
+    for n, a in enumerate(arrs):
+        tok[:a.shape[0], n] = a
+    rows = tok.reshape(T * N, L)
+    seen, uniq, inverse = {}, [], np.empty(T * N, dtype=np.int64)
+    for i in range(T * N):
+        k = rows[i].tobytes()
+        j = seen.get(k)
+        if j is None:
+            j = seen[k] = len(uniq)
+            uniq.append(rows[i])
+        inverse[i] = j
+    u = np.stack(uniq)
+    return dict(uniq=u.tolist(), inverse=inverse.tolist(), lengths=(u != 0).sum(1).tolist())
 
 
 def pack_batch(plan, meta, host_u8):
@@ -93,6 +123,7 @@ class DeviceCollator:
         self.device = torch.device(device)
         self._pinned = None
         self.ego_map_nhwc_bf16 = bool(ego_map_nhwc_bf16)
+        self.host_dedup = True        # hand the batch's instruction dedup (computed on the host by plan_batch) to the policy
 
     def _staging(self, nbytes):
         if self._pinned is None or self._pinned.numel() < nbytes:
@@ -148,4 +179,13 @@ class DeviceCollator:
         if "instruction" in obs:     # the policy's parameter-free preprocessing may start as soon as the collate has run (ops/core.py)
             from ..ops import mark_inputs_ready
             mark_inputs_ready(obs["instruction"], ready)
+        dd = meta.get("dedup")
+        if dd is not None and self.host_dedup:
+            # the dedup came with the batch (plan_batch): the policy finds it beside the token tensor (ops.attach_instruction_dedup) and runs neither
+            # the dedup kernel nor its host read-back — a forward pass without a single host synchronisation
+            with torch.cuda.stream(stream):
+                up = lambda v: torch.tensor(v, dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)   # noqa: E731
+                lens = torch.tensor(dd["lengths"], dtype=torch.int64)
+                from ..ops import attach_instruction_dedup
+                attach_instruction_dedup(obs["instruction"], (up(dd["uniq"]), up(dd["inverse"]), lens, lens.pin_memory().to(self.device, non_blocking=True)))
         return obs, prev.view(-1, 2), masks.view(-1, 1), corr, wts

@@ -309,8 +309,20 @@ class MGMapNet(nn.Module):
             self._side_stream = ops.helper_stream("instruction")
         side = self._side_stream
         side.wait_event(entry)
-        dd = observations.get("instruction_dedup")
         tok = observations["instruction"]
+        dd = observations.get("instruction_dedup")
+        if dd is None and torch.is_tensor(tok):
+            dd = ops.attached_instruction_dedup(tok)      # computed on the host by the feeder's collate: no kernel, no read-back
+            if dd is not None:
+                # (made on the collate stream: this branch's stream waits for the producer's event, and the persistent kernels'
+                #  status word — otherwise read behind the dedup's read-back — is read here)
+                ev = ops.inputs_ready_event(tok)
+                if ev is not None:
+                    side.wait_event(ev)
+                for t in dd:
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(side)
+                ops.check_rnn_status()
         # (not under a process group: with the host free to run ahead of the GPU, the data-parallel bench path — one-rank RCCL
         #  communicator, the only form a 1-GPU box can host — ran 17.7 ms per update instead of 11.3, on the GPU's own clock
         #  (profiles/r04_dp1_early_dedup.txt); not understood, so the exchange keeps the round-3 behaviour: one read-back per update

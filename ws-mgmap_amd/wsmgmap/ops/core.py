@@ -260,6 +260,23 @@ def mark_inputs_ready(tensor, event=None):
     return event
 
 
+_inputs_dedup = {}      # id(instruction tensor) -> (weak reference, dedup tuple): see attach_instruction_dedup
+
+
+def attach_instruction_dedup(tensor, dedup):
+    """A producer that has the tokens on the host (DeviceCollator: plan_batch computes it in the decode worker) hands the policy the
+    instruction dedup of `tensor` — (unique rows [U, L] int64, inverse [B] int64, lengths on the host, lengths on the device), what
+    InstructionEncoder.dedup returns: the forward pass then runs neither the dedup kernel nor its host read-back.  Kept beside the
+    tensor (by identity), not inside the observations dict, whose keys stay the reference's."""
+    key = id(tensor)
+    _inputs_dedup[key] = (weakref.ref(tensor, lambda _r, key=key: _inputs_dedup.pop(key, None)), dedup)
+
+
+def attached_instruction_dedup(tensor):
+    e = _inputs_dedup.get(id(tensor))
+    return e[1] if e is not None and e[0]() is tensor else None
+
+
 def inputs_ready_event(tensor):
     e = _inputs_ready.get(id(tensor))
     return e[1] if e is not None and e[0]() is tensor else None
