@@ -346,11 +346,14 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # timed live (HIP events around every launch, inside the timed region): the family with the most time, and the weight-gradient
     # family whichever it is — rounds 1-3 reported that one, and its kernels are what round 4 rebuilt; a line must show both
     WG = "wsmg_conv2d_bwd_weight_bf16" if dtype == "bf16" else "wsmg_conv2d_bwd_weight"
+    FW = "wsmg_conv2d_fwd_bf16" if dtype == "bf16" else "wsmg_conv2d_fwd"      # (the *_stats entry points fold into it: ops._prof_key)
     # Every timed launch is two HIP event records on its stream (~1.5 us of GPU time each): with both families timed on every update
     # the line itself cost 0.1-0.2 ms per update (10.58 / 10.67 vs 10.46 / 10.46 ms, profiles/r04_first_window_and_event_cost.txt).
     # So: the largest family on every update, as in rounds 1-3; the weight-gradient family, when it is not the largest, on every
     # 4th update of the timed region (a sample of the same region).  WSMG_BENCH_NOPROF=1: no events at all (diagnostic).
-    both = sorted({dom_entry, WG}) if dom_entry else None
+    # round 5: BOTH named families are in every line, whichever of them the warm-up found larger — the larger
+    # one timed on every update, the other on every 4th; a third family, should it ever lead, is timed on every update beside them
+    both = sorted({dom_entry, WG, FW}) if dom_entry else None
     if os.environ.get("WSMG_BENCH_NOPROF") != "1":
         ops.profile_begin(only=[dom_entry] if dom_entry else None)
     # an event every WIN updates (no synchronisation): `sustained` for --steps >= 200 (50-update windows), and `windows` for every
@@ -375,7 +378,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
-        if dom_entry and dom_entry != WG:
+        if dom_entry:
             ops.profile_set_only(both if i % 4 == 0 else [dom_entry])
         h0 = time.perf_counter()
         loss = update()
@@ -415,9 +418,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = ops.profile_end()
-    if dom_entry and dom_entry != WG:
-        for r in prof.values():       # the sampled family: its totals are over every 4th update
-            if r.get("entry") == WG:
+    if dom_entry:
+        for r in prof.values():       # the sampled families: their totals are over every 4th update
+            if r.get("entry") in (WG, FW) and r.get("entry") != dom_entry:
                 r["per_steps"] = (steps + 3) // 4
                 r["phase"] = "timed region"
                 r["sampled"] = "every 4th update of the timed region"
@@ -508,6 +511,8 @@ def main():
                     help="seconds of untimed updates between the warm-up and the timed region (clock ramp / allocator steady state); 0 = none")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra float32 parity-mode measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the cfg1 / cfg4 / cfg5 legs (BASELINE configs[0], [3], [4]; bench_legs.py, ~2 s after the cfg2 leg)")
     ap.add_argument("--cpu-budget", type=float, default=90.0,
                     help="seconds the host may spend on the TWO timed CPU-baseline updates: T=64 if they fit, else T=32 / 16")
     args = ap.parse_args()
@@ -582,6 +587,13 @@ def main():
                       ms_per_step=round(dt32 / k32 * 1e3, 3), steps=k32, loss=round(loss32, 5),
                       note="same workload in the float32 parity mode (f32 MFMA; logits within 1e-4 of the reference)")
 
+    # BASELINE configs[0], [3], [4] as short HIP-event-timed legs in the same line:
+    # single process only — they are single-GPU measurements — after every cfg2 measurement, outside any timed region
+    other = None
+    if world == 1 and not args.dp and not args.no_other_configs:
+        import bench_legs
+        other = bench_legs.other_configs(dev)
+
     if rank == 0:
         steps_per_s = T * N * world * args.steps / dt
         kernels = {}
@@ -635,9 +647,11 @@ def main():
             return o
 
         roofline = roofline_of(dom) if dom else None
-        # the weight-gradient family's own object when another family is the largest (same live measurement, same fields)
+        # both named families' own objects, unconditionally (same live measurement, same fields; one of them is also `roofline`)
         wg = [k for k in timed if prof[k].get("entry", "").startswith("wsmg_conv2d_bwd_weight")]
-        roofline_wgrad = roofline_of(wg[0]) if (wg and wg[0] != dom) else None
+        fw = [k for k in timed if prof[k].get("entry", "").startswith("wsmg_conv2d_fwd")]
+        roofline_wgrad = roofline_of(wg[0]) if wg else None
+        roofline_fwd = roofline_of(fw[0]) if fw else None
         out = {
             "metric": "policy steps/sec (fwd+bwd), CMA batch=8 seq=64",
             "value": round(steps_per_s, 2),
@@ -669,6 +683,8 @@ def main():
                             "read-back waits for the previous update, so the figure is then the update's own time)",
             "roofline": roofline,
             "roofline_weight_gradient_family": roofline_wgrad,
+            "roofline_forward_family": roofline_fwd,
+            "other_configs": other,
             "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -224,3 +224,55 @@ def test_grad_allreduce_layout_agreement_and_inorder_error_paths():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+class BnNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc = torch.nn.Linear(8, 6)
+        self.bn = torch.nn.BatchNorm1d(6)
+
+    def forward(self, x):
+        return self.bn(self.fc(x))
+
+
+def _worker_buffers(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "ws-mgmap_amd"))
+    from wsmgmap.parallel import GradAllReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    net = BnNet().train()
+    red = GradAllReducer(net.parameters(), module=net, broadcast_buffers_every=2)
+    red.broadcast_parameters(net)
+    torch.manual_seed(50 + rank)                 # per-rank batches -> per-rank running statistics
+    same_after = []
+    for it in range(4):
+        net.zero_grad(set_to_none=True)
+        net(torch.randn(16, 8) * (1 + rank)).square().mean().backward()
+        red.finish()
+        mine = torch.cat([net.bn.running_mean, net.bn.running_var, net.bn.num_batches_tracked.float().view(1)])
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        same_after.append(bool(torch.equal(got[0], got[1])))
+    # every 2nd finish() ends with rank 0's buffers everywhere (DDP's C4 behaviour, opt-in); in between they drift apart
+    ok = same_after == [False, True, False, True]
+    q.put((rank, ok, same_after))
+    dist.destroy_process_group()
+
+
+def test_broadcast_buffers_every_n_updates_gloo():
+    """VERDICT r04 missing 6 / SURVEY C4: `GradAllReducer(module=..., broadcast_buffers_every=n)` gives every rank rank 0's
+    BatchNorm statistics at the end of every n-th update (reference: DDP's per-forward buffer broadcast, common_trainer.py:61-66)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_buffers, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res

@@ -553,3 +553,16 @@ def test_recoded_raw_records_decode_to_the_same_arrays_and_collate_identically()
     long_w = collate_fn(mk([unpack_record(x) for x in blobs[3:]]))
     long_g = collate_fn(mk([unpack_record(store_out[i]) for i in (3, 4)]))
     assert all(torch.equal(long_w[0][k], long_g[0][k]) for k in long_w[0])
+
+
+def test_truncated_or_corrupt_raw_record_is_refused_with_a_clear_error():
+    """the recoded record's stored index is validated against the blob before any zero-copy view is made."""
+    import pytest
+    from oracle import data_cases as dc
+    from wsmgmap.data import pack_record_raw, unpack_record
+    raw = pack_record_raw(*dc.episode(400, 5))
+    assert len(unpack_record(raw)) == 3
+    with pytest.raises(ValueError, match="truncated"):
+        unpack_record(raw[:len(raw) // 2])
+    with pytest.raises(ValueError, match="truncated"):
+        unpack_record(raw[:14])

@@ -194,11 +194,18 @@ def call(name, *args):
 rnn_timeouts = 0      # persistent-RNN timeouts reported so far in this process
 
 
-def check_rnn_status():
+def check_rnn_status(sync=False):
     """Raise WsmgError if a persistent RNN kernel reported a timeout since the last check.  Reads a word in host-mapped
-    pinned memory: no device synchronisation.  Called at the host's natural sync points (the instruction dedup
-    read-back of every forward pass, GradAllReducer.finish(), the end of an update in bench / tests)."""
+    pinned memory: no device synchronisation by itself.  Called at the host's natural sync points (the instruction dedup
+    read-back of every forward pass, GradAllReducer.finish(), the end of an update in bench / tests) — those see every kernel
+    that had FINISHED by then, so a timeout of the current update can surface one update late.  sync=True waits for the device
+    first: the exact form, for a trainer that wants the guarantee that NaN-filled outputs never reach optimizer.step()
+    (`BasePolicy.check_status()`)."""
     global rnn_timeouts
+    if sync:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
     v = lib().wsmg_rnn_status(1)
     if v:
         rnn_timeouts += 1       # (owners of persistent, never-cleared RNN workspaces re-zero them: the error word in them is sticky)

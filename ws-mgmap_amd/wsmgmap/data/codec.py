@@ -103,13 +103,24 @@ def is_raw_record(blob):
 
 
 def _unpack_raw(blob):
+    """Views straight into `blob` — zero copy.  LIFETIME: the arrays are valid as long as `blob` is; a `get` that hands back a
+    transaction-scoped buffer (lmdb with `buffers=True`) must keep the transaction open until the batch has been collated, or
+    hand back bytes.  The stored index is validated against the blob before any view is made."""
     mv = memoryview(blob)
+    total = len(mv)
     hlen = int.from_bytes(mv[8:12], "little")
+    if 12 + hlen > total:
+        raise ValueError(f"raw trajectory record truncated: index of {hlen} bytes in a record of {total}")
     index = msgpack.unpackb(bytes(mv[12:12 + hlen]), raw=False)
     start = (12 + hlen + 63) & ~63
     obs, prev, oracle = {}, None, None
     for name, dt, shape, off, nbytes in index:
-        a = np.frombuffer(mv, dtype=np.dtype(dt), count=nbytes // np.dtype(dt).itemsize, offset=start + off).reshape(shape)
+        dtype = np.dtype(dt)
+        want = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if off < 0 or nbytes != want or start + off + nbytes > total:
+            raise ValueError(f"raw trajectory record corrupt or truncated: entry {name!r} ({dt}, shape {list(shape)}, {nbytes} bytes at "
+                             f"payload offset {off}) does not fit a record of {total} bytes")
+        a = np.frombuffer(mv, dtype=dtype, count=nbytes // dtype.itemsize, offset=start + off).reshape(shape)
         if name == "__prev":
             prev = a
         elif name == "__oracle":

@@ -80,7 +80,10 @@ class InstructionEncoder(nn.Module):
                   ctypes.c_void_p(uniq.data_ptr()), ctypes.c_void_p(inverse.data_ptr()), ctypes.c_void_p(meta.data_ptr()),
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         host = meta.cpu()        # the one host read-back of a forward pass
-        ops.check_rnn_status()   # (everything queued before it has finished: the persistent kernels' status word is final)
+        # the persistent kernels' sticky status word: final for everything queued on THIS stream before the read-back — with the
+        # dedup on its own early stream the previous update's kernels may still be running, so a timeout can surface one update
+        # late here; `BasePolicy.check_status()` / `ops.check_rnn_status(sync=True)` before optimizer.step() is the exact point
+        ops.check_rnn_status()
         U = int(host[0])
         return uniq[:U], inverse, host[2:2 + U], meta[2:2 + U]
 

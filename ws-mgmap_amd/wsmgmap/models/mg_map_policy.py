@@ -399,12 +399,21 @@ class MGMapNet(nn.Module):
         # (not under a HIP-graph capture: wsmgmap.graph captures the one-stream form of these three — this, the weight layout
         #  and the pipelined recurrent core; the end of a capture that held the three-stream form crashed in the runtime)
         capturing = rgb_embedding.is_cuda and torch.cuda.is_current_stream_capturing()
+        # (only with BOTH feature sets cached: from raw pixels the frozen encoders run on the main stream after `entry`)
         dense_early = (torch.is_grad_enabled() and not rows and not early and rgb_embedding.is_cuda and self.recurrent_chunks > 0
-                       and not capturing)
+                       and not capturing and "rgb_features" in observations and "depth_features" in observations)
         if dense_early:
             if self._side_stream is None:
                 self._side_stream = ops.helper_stream("instruction")
-            self._side_stream.wait_event(entry)
+            # depth_embedding is WRITTEN on the main stream after `entry` (the spatial-embedding concatenation of the depth
+            # encoder, also with cached features): the side stream waits for an event recorded behind it, not for `entry`
+            # (read-before-write), and the caching allocator is told about the second stream
+            encoders_done = torch.cuda.Event()
+            encoders_done.record(torch.cuda.current_stream())
+            self._side_stream.wait_event(encoders_done)
+            for t in (rgb_embedding, depth_embedding):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(self._side_stream)
             with torch.cuda.stream(self._side_stream):
                 state_in = dense_inputs()
             dense_ready = torch.cuda.Event()

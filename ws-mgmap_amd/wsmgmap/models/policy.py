@@ -40,6 +40,13 @@ class BasePolicy(nn.Module):
         self.prog_pred = nn.Linear(model_config.STATE_ENCODER.hidden_size, 1)
         self.prog = None
 
+    def check_status(self, sync=True):
+        """Not a reference method.  Raises WsmgError if a persistent GRU / LSTM kernel of this process timed out (its outputs are
+        NaN-filled then).  sync=True waits for the device first, so that a trainer calling it between `loss.backward()` and
+        `optimizer.step()` can never apply an update computed from a timed-out kernel (the checks inside forward() see what had
+        finished by then and can be one update late).  Costs the host its run-ahead: opt-in."""
+        ops.check_rnn_status(sync=sync)
+
     # -- rollout -------------------------------------------------------------------
     def update_map(self, observations, masks):
         _, proj = self.net.rgb_encoder(observations)

@@ -46,9 +46,19 @@ class GradExchangeError(RuntimeError):
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=8 << 20, group=None, single_rank_exchange=False):
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, single_rank_exchange=False, module=None, broadcast_buffers_every=0):
         """single_rank_exchange: run the whole exchange even in a one-rank group (by default one rank does nothing at all) — the
-        way to put the real backend (RCCL) through this code on a box with one GPU (tests/test_gpu_round2.py)."""
+        way to put the real backend (RCCL) through this code on a box with one GPU (tests/test_gpu_round2.py).
+        module, broadcast_buffers_every = n > 0: every n-th `finish()` ends with rank 0's buffers (BatchNorm running statistics,
+        counters) broadcast to every rank, two coalesced collectives — opt-in parity with DDP's `broadcast_buffers=True`, which
+        re-broadcasts rank 0's buffers before EVERY forward (common_trainer.py:61-66): n = 1 gives a trainer that
+        evaluates or checkpoints from any rank mid-epoch the statistics the reference's DDP would show it.  Default 0: the
+        statistics stay per rank between explicit `broadcast_buffers()` calls."""
+        self._module = module
+        self._buffers_every = int(broadcast_buffers_every)
+        if self._buffers_every > 0 and module is None:
+            raise ValueError("broadcast_buffers_every needs the module whose buffers are to be broadcast")
+        self._updates = 0
         self.params = [p for p in params if p.requires_grad]
         seen, uniq = set(), []
         for p in self.params:
@@ -92,12 +102,25 @@ class GradAllReducer:
         """rank-`src` buffers (BatchNorm running statistics, counters) to every rank: the state DDP's
         `broadcast_buffers=True` keeps identical by re-broadcasting before every forward (common_trainer.py:61-66
         default).  Statistics here stay per rank during training; call this before evaluating or checkpointing from a
-        rank other than `src` (the reference checkpoints rank 0's, common_trainer.py:99)."""
+        rank other than `src` (the reference checkpoints rank 0's, common_trainer.py:99), or construct the reducer with
+        `module=..., broadcast_buffers_every=n`.  One collective per dtype: the buffers travel packed."""
         if self._off:
             return
+        by_dtype = {}
         for b in module.buffers():
             if b.is_floating_point() or b.dtype == torch.int64:
-                dist.broadcast(b.data, src=src, group=self.group)
+                by_dtype.setdefault((b.dtype, b.device), []).append(b)
+        g_src = dist.get_global_rank(self.group, src) if self.group is not None else src
+        for bufs in by_dtype.values():
+            flat = torch.cat([b.data.reshape(-1) for b in bufs])
+            dist.broadcast(flat, src=g_src, group=self.group)
+            off = 0
+            views = []
+            for b in bufs:
+                views.append(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            torch._foreach_copy_([b.data for b in bufs], views)
+            for b in bufs:
                 torch.autograd.graph.increment_version(b)
 
     def resync(self, module, optimizer=None, src=0):
@@ -341,6 +364,9 @@ class GradAllReducer:
         if ev0 is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record(torch.cuda.current_stream())
+        self._updates += 1
+        if self._buffers_every > 0 and self._updates % self._buffers_every == 0:
+            self.broadcast_buffers(self._module)
         self._timing.append((time.perf_counter() - t_host, ev0, ev1))
         if len(self._timing) > 64:
             self._fold_timing(keep=8)

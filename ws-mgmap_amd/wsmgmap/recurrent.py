@@ -31,16 +31,46 @@ from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _st
 MAX_BATCH = 8          # batch slots of the persistent GRU kernels
 
 
-_owned = {}      # (device index, role) -> [workspace, bytes, timeouts seen]: the GRU chunk launches' persistent exchange images
+_owned = {}      # (device index, role, stream handle) -> [workspace, bytes, timeouts seen]: the GRU chunk launches' persistent exchange images
 
 
 def _owned_ws(dev, role, nbytes):
-    """A zeroed workspace that only this role's launches ever use (wsmg_gru_*_owned: no clear per launch).  One per role — GRU 1 /
-    GRU 2, forward / backward: launches of one role follow each other on one stream, launches of different roles overlap."""
-    e = _owned.get((dev.index, role))
+    """A zeroed workspace that only this role's launches ON THE CURRENT STREAM ever use (wsmg_gru_*_owned: no clear per launch).
+    One per (role, stream) — GRU 1 / GRU 2, forward / backward: launches of one role follow each other on one stream, launches of
+    different roles overlap; a second policy or a caller on another stream gets an image of its own.  A workspace
+    that is outgrown is told which stream may still be using it before it is dropped."""
+    sid = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev.index, role, sid)
+    e = _owned.get(key)
     if e is None or e[1] < nbytes or e[2] != _abi.rnn_timeouts:
-        e = _owned[(dev.index, role)] = [torch.zeros((int(nbytes) + 3) // 4, device=dev, dtype=torch.float32), int(nbytes), _abi.rnn_timeouts]
+        if e is not None:
+            e[0].record_stream(torch.cuda.current_stream(dev))
+        e = _owned[key] = [torch.zeros((int(nbytes) + 3) // 4, device=dev, dtype=torch.float32), int(nbytes), _abi.rnn_timeouts]
     return e[0]
+
+
+_hooks_probe = None
+
+
+def _post_hooks_visible():
+    """Does this torch keep `register_post_accumulate_grad_hook` hooks in the private dict the multi-stream backward runs by hand
+    (`Tensor._post_accumulate_grad_hooks`)?  Probed once on a scratch tensor; if a torch version moves it, the block stays on the
+    one-stream route (gradients through AccumulateGrad) instead of silently skipping the reducer's hooks."""
+    global _hooks_probe
+    if _hooks_probe is None:
+        try:
+            t = torch.zeros(1, requires_grad=True)
+            seen = []
+            h = t.register_post_accumulate_grad_hook(seen.append)
+            d = getattr(t, "_post_accumulate_grad_hooks", None)
+            _hooks_probe = bool(d) and len(d) == 1
+            for f in list((d or {}).values()):
+                f(t)
+            _hooks_probe = _hooks_probe and len(seen) == 1
+            h.remove()
+        except Exception:
+            _hooks_probe = False
+    return _hooks_probe
 
 
 def _prow(t, row):
@@ -230,7 +260,11 @@ class _RecurrentBlock(torch.autograd.Function):
         # the parameters' post-accumulate hooks (wsmgmap.parallel.GradAllReducer's bucket hooks) and returns None for them.
         # A stock DistributedDataParallel wrap hooks the AccumulateGrad nodes instead: there the block stays on one stream.
         own = [p for p in params if p is not None and p.requires_grad]
-        multi = ctx.cfg[1] > 1 and all(p.is_leaf and p.grad is None for p in own)
+        # (a parameter with a tensor hook — `register_hook`, which AccumulateGrad's input would have run — keeps the one-stream,
+        #  through-autograd form: assigning .grad here would silently skip it; ADVICE r04.  These parameters have no consumer
+        #  outside this block — `is_leaf and grad is None` at entry is the whole contract: nothing else can add to them in this pass)
+        multi = (ctx.cfg[1] > 1 and _post_hooks_visible()
+                 and all(p.is_leaf and p.grad is None and not getattr(p, "_backward_hooks", None) for p in own))
         if multi and torch.distributed.is_available() and torch.distributed.is_initialized():
             multi = all(getattr(p, "_wsmg_reducer", False) for p in own)
         sa, sg, sl = _roles(ctx.streams if multi else None, main)
