@@ -226,7 +226,11 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     from wsmgmap.optim import Adam as WsmgAdam
     opt = (torch.optim.Adam if os.environ.get("WSMG_STOCK_ADAM") == "1" else WsmgAdam)(policy.parameters(), lr=2.5e-4)
     reducer = GradAllReducer(policy.parameters(), bucket_bytes=int(float(os.environ.get("WSMG_DP_BUCKET_MB", "8")) * (1 << 20)),
-                             single_rank_exchange=True) if args.dp else None
+                             single_rank_exchange=True,
+                             # round 5: the exchange on the policy's instruction-branch stream, synchronous RCCL collectives (no stream
+                             # beyond the policy's own; profiles/r05_dp_exchange_ab.txt); WSMG_DP_EXCHANGE=hook: the round-2 form
+                             exchange_stream={"hook": None, "": None}.get(os.environ.get("WSMG_DP_EXCHANGE", "instruction"),
+                                                                          os.environ.get("WSMG_DP_EXCHANGE", "instruction"))) if args.dp else None
     if reducer:
         reducer.broadcast_parameters(policy)
     measure.dp_info = None
@@ -430,6 +434,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         st = reducer.stats()
         measure.dp_info = dict(ranks_in_process_group=dist.get_world_size(), backend=dist.get_backend(),
                                gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+                               exchange=os.environ.get("WSMG_DP_EXCHANGE", "instruction"), early_dedup=bool(debug.sw.early_dedup_dp),
                                live_gradient_bytes=reducer.live_bytes, buckets=reducer.num_buckets,
                                devices_visible=torch.cuda.device_count(),
                                exposed_allreduce_ms=st["exposed_allreduce_ms"], exposed_allreduce_max_ms=st["exposed_allreduce_max_ms"],

@@ -607,6 +607,29 @@ int wsmg_mean_rows(const float* x, int64_t R, int n, float* out, wsmg_stream_t s
 int wsmg_instruction_dedup(const void* tokens, int is_f32, int B, int L, long long* uniq, long long* inverse, long long* meta,
                            wsmg_stream_t stream);
 
+/* ---- dense layers of the recurrent core's attention stage on a chunk of rows (csrc/wsmg_rows_gemm.hip, round 5) -------------
+ * Replaces, one launch each, the nn.Linear calls between the two recurrences of MGMapNet.forward (mg_map_policy.py:229-245:
+ * state_text_q_layer, text_map_q_layer (+ the folded text_map_k_layer), second_state_compress over cat(state, text_embedding,
+ * map_embedding) + ReLU, the second GRU's input projection) and their backward products, at 32-512 rows, float32:
+ *     C = epilogue( [A0 | A1 | A2] W^T )   w_is_kn == 0: W [N][K] row-major, row stride ldw (an nn.Linear weight; forward)
+ *     C = epilogue( [A0 | A1 | A2] W   )   w_is_kn != 0: W [K][N] row-major, row stride ldw (the same weight in dX = dY W)
+ * A: up to three column segments a_i [M][ka_i] (row stride lda_i; ka1 = ka2 = 0: one operand) — the reference's torch.cat;
+ * C: up to three column segments c_i [M][nc_i] (row stride ldc_i) — the split of d(cat) into its parts;
+ * epilogue, in this order: + bias[N] (may be NULL), + cin_i (same segmentation as C, may be NULL: beta = 1), ReLU (relu != 0),
+ * zero where mask[M][N] <= 0 (row stride ldmask, may be NULL: threshold_backward of the ReLU).
+ * K % 32 == 0, ka_i % 8 == 0, nc_i % 32 == 0, strides % 4 == 0; WSMG_EINVAL otherwise.  Deterministic (fixed reduction order). */
+int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const float* a1, int lda1, int ka1, const float* a2, int lda2, int ka2,
+                       const float* w, int ldw, int w_is_kn, const float* bias, const float* mask, int ldmask, int relu,
+                       float* c0, int ldc0, int nc0, float* c1, int ldc1, int nc1, float* c2, int ldc2, int nc2,
+                       const float* cin0, int ldcin0, const float* cin1, int ldcin1, const float* cin2, int ldcin2,
+                       int M, wsmg_stream_t stream);
+
+/* Tests: hold `n_workgroups` whole compute units (1 024 threads + lds_bytes of LDS each) until *stop_flag != 0 (host-mapped or
+ * device memory) or max_ms milliseconds have passed; `arrived` (device word, zero on entry) counts the workgroups that started.
+ * What the collective library's ring kernels do to the persistent GRU / LSTM kernels' co-residency on a multi-GPU node, on a box with
+ * one GPU (tests/test_gpu_round5.py).  No reference counterpart.  n_workgroups <= 256, max_ms <= 10 000. */
+int wsmg_debug_occupy(int n_workgroups, int lds_bytes, int max_ms, const int* stop_flag, unsigned* arrived, wsmg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,338 @@
+"""GPU tests, round 5 (VERDICT r04 "Next round" + ADVICE r04): the recurrent core's dense layers as one launch each, the persistent
+kernels beside pinned compute units, the gradient exchange on a policy stream, the race-free early dense inputs, the mixed-tile
+window convolution."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _aux_losses_off():
+    from wsmgmap.common.aux_losses import AuxLosses
+    AuxLosses.deactivate()
+    AuxLosses.clear()
+    yield
+    AuxLosses.deactivate()
+    AuxLosses.clear()
+
+
+# ----------------------------------------------------------------------------- wsmg_rows_gemm_f32
+@pytest.mark.parametrize("M", [128, 64, 37, 512])
+def test_rows_gemm_matches_float64(M):
+    """csrc/wsmg_rows_gemm.hip against the reference's lines in float64 (mg_map_policy.py:229-245: Linear layers over a
+    concatenation, ReLU; and their backward products): both weight layouts, one and three operand / output segments, bias,
+    accumulate-into (in place), ReLU, the ReLU-backward mask; row counts that are not multiples of the 32-row tile; rows addressed
+    at an offset inside full-batch tensors, as wsmgmap/recurrent.py calls it.  Deterministic bit for bit."""
+    from wsmgmap import recurrent
+    g = torch.Generator(device="cuda").manual_seed(5 + M)
+    r0 = 32                       # the chunk starts at row 32 of the full-batch tensors
+    Bf = r0 + M + 7
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+
+    def close(got, want, name):
+        d = float((got.double() - want).abs().max())
+        assert d <= 2e-6 * max(1.0, float(want.abs().max())), (name, d)
+
+    # forward form: xc = relu(cat(y1, text, map) @ wc^T + bc)  (second_state_compress)
+    y1, text, mp = rnd(Bf, 512), rnd(Bf, 256), rnd(Bf, 256)
+    wc, bc = rnd(512, 1024) * 0.05, rnd(512)
+    xc = torch.full((Bf, 512), float("nan"), device="cuda")
+    recurrent._rg([y1, text, mp], wc, False, [xc], r0, M, bias=bc, relu=True)
+    want = torch.relu(torch.cat([y1, text, mp], 1).double() @ wc.double().t() + bc.double())[r0:r0 + M]
+    close(xc[r0:r0 + M], want, "compress")
+    assert torch.isnan(xc[:r0]).all() and torch.isnan(xc[r0 + M:]).all()          # rows outside the chunk untouched
+    xc2 = torch.empty_like(xc)
+    recurrent._rg([y1, text, mp], wc, False, [xc2], r0, M, bias=bc, relu=True)
+    assert torch.equal(xc[r0:r0 + M], xc2[r0:r0 + M])
+    # plain NT with bias (state_text_q_layer) and the GRU input projection's width
+    wq, bq = rnd(256, 512) * 0.05, rnd(256)
+    q1 = torch.empty(Bf, 256, device="cuda")
+    recurrent._rg([y1], wq, False, [q1], r0, M, bias=bq)
+    close(q1[r0:r0 + M], (y1.double() @ wq.double().t() + bq.double())[r0:r0 + M], "q1")
+    wih, bih = rnd(1536, 512) * 0.05, rnd(1536)
+    gi = torch.empty(Bf, 1536, device="cuda")
+    xcv = torch.relu(rnd(Bf, 512))
+    recurrent._rg([xcv], wih, False, [gi], r0, M, bias=bih)
+    close(gi[r0:r0 + M], (xcv.double() @ wih.double().t() + bih.double())[r0:r0 + M], "gi2")
+    # backward forms: d(pre-activation) = (dgi @ w_ih) where xc > 0; d(cat) = dxc @ wc split into its three parts; accumulate-into
+    dgi = rnd(Bf, 1536)
+    dxc = torch.empty(Bf, 512, device="cuda")
+    recurrent._rg([dgi], wih, True, [dxc], r0, M, mask=xcv)
+    want = ((dgi.double() @ wih.double()) * (xcv > 0).double())[r0:r0 + M]
+    close(dxc[r0:r0 + M], want, "dxc")
+    ds, dt, dm = torch.empty(Bf, 512, device="cuda"), torch.empty(Bf, 256, device="cuda"), torch.empty(Bf, 256, device="cuda")
+    recurrent._rg([dxc], wc, True, [ds, dt, dm], r0, M)
+    want = (dxc.double() @ wc.double())[r0:r0 + M]
+    close(ds[r0:r0 + M], want[:, :512], "dstate")
+    close(dt[r0:r0 + M], want[:, 512:768], "dtext")
+    close(dm[r0:r0 + M], want[:, 768:], "dmap")
+    dq = rnd(Bf, 256)
+    before = ds.clone()
+    recurrent._rg([dq], wq, True, [ds], r0, M, cin_segs=[ds])                   # in place: ds += dq @ wq
+    close(ds[r0:r0 + M], (before.double() + dq.double() @ wq.double())[r0:r0 + M], "accumulate")
+    assert torch.equal(ds[:r0], before[:r0])
+
+
+def test_rows_gemm_refuses_shapes_it_does_not_take():
+    from wsmgmap import _abi, recurrent
+    a, w, c = torch.zeros(8, 40, device="cuda"), torch.zeros(32, 40, device="cuda"), torch.zeros(8, 32, device="cuda")
+    with pytest.raises(_abi.WsmgError):
+        recurrent._rg([a], w, False, [c], 0, 8)          # K = 40 is not a multiple of 32
+
+
+@pytest.mark.parametrize("chunks", [4, 8])
+def test_recurrent_core_rows_gemm_route_matches_the_gemm_library_route(chunks, monkeypatch):
+    """The pipelined recurrent core with its dense layers on wsmg_rows_gemm_f32 (round 5) against the same core on the GEMM library
+    (round 4), bench workload, 4 and 8 time chunks: logits, loss, attention row, hidden states and every parameter gradient of the
+    core within float32 summation-order noise (2e-5 / 5e-5 of the largest element); bit-identical run to run."""
+    import bench
+    import test_gpu_round2 as r2
+    import test_gpu_round4 as r4
+    from wsmgmap import debug, ops
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+    T, N = 64, 8
+    obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 78)
+    masks = masks.clone()
+    masks.view(T, N)[T // 2 + 1, N - 1] = 0
+    monkeypatch.setattr(debug.sw, "rows_gemm", False)
+    a = r4._one_update(pol, obs, prev, masks, weights, N, chunks)
+    monkeypatch.setattr(debug.sw, "rows_gemm", True)
+    b = r4._one_update(pol, obs, prev, masks, weights, N, chunks)
+    c = r4._one_update(pol, obs, prev, masks, weights, N, chunks)
+    ops.check_rnn_status()
+
+    def close(x, y, name, tol=2e-5):
+        d = float((x.double() - y.double()).abs().max())
+        assert d <= tol * max(1e-6, float(y.double().abs().max())), (name, d, float(y.abs().max()))
+    close(b[0], a[0], "pred")
+    assert abs(a[1] - b[1]) <= 2e-6 * max(1.0, abs(a[1]))
+    close(b[2], a[2], "att_map_t_m")
+    close(b[3], a[3], "rnn_hidden_states")
+    core = ("net.state_encoder.", "net.second_state_encoder.", "net.state_text_q_layer.", "net.text_map_q_layer.", "net.text_map_k_layer.",
+            "net.second_state_compress.", "action_distribution.", "prog_pred.")
+    from util import NULL_GRAD
+    for k, g in a[4].items():
+        if g is None or k in NULL_GRAD:
+            continue
+        if k.startswith(core):
+            close(b[4][k], g, k, tol=5e-5)
+        else:
+            x, y = b[4][k].double().flatten(), g.double().flatten()
+            if float(y.norm()) > 0:
+                assert float((x @ y) / (x.norm() * y.norm())) >= 0.9999, k
+    assert torch.equal(b[0], c[0]) and b[1] == c[1]
+    for k, g in b[4].items():
+        if g is not None:
+            assert torch.equal(g, c[4][k]), k
+
+
+# ----------------------------------------------------------------------------- co-residency beside pinned compute units
+@pytest.mark.parametrize("pinned", [16, 32])
+def test_persistent_kernels_beside_pinned_compute_units(pinned):
+    """What an 8-rank RCCL ring with 8-16 channels does to the rest of the GPU, on a box with one: a dummy persistent kernel holds
+    `pinned` WHOLE compute units (1 024 threads + 160 KB of LDS each, so nothing else fits on them) while the update runs — the
+    pipelined recurrent core's up to three persistent GRU kernels (32 co-resident workgroups each, ordinary launches), the
+    instruction LSTM (16), the decoder / instruction side streams.  Zero RNN timeouts, and the 12 losses equal bit for bit those of
+    the same updates on the free GPU.  Reference: the data-parallel launch of common_trainer.py:35-38,60-66."""
+    import bench
+    import test_gpu_round2 as r2
+    from wsmgmap import _abi, ops
+    from wsmgmap.common.aux_losses import AuxLosses
+    from wsmgmap.optim import Adam
+    T_, N = 16, 8
+    state = r2._default_state()
+    obs, prev, masks, weights = bench.synth_batch(T_, N, torch.device("cuda"), 6)
+
+    def run(n_updates):
+        pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=state))
+        assert pol.net.recurrent_chunks >= 4
+        opt = Adam(pol.parameters(), lr=2.5e-4)
+        AuxLosses.activate()
+        losses = []
+        for _ in range(n_updates):
+            opt.zero_grad(set_to_none=True)
+            AuxLosses.clear()
+            o = dict(obs)
+            pred, aux = pol(o, torch.zeros(2, N, 512, device="cuda"), prev, masks, weights)
+            loss = bench.dagger_loss(pred, aux, o["waypoint"], weights)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize()
+        AuxLosses.deactivate()
+        ops.check_rnn_status()
+        return [float(x) for x in losses]
+
+    free = run(12)
+    stop = torch.zeros(1, dtype=torch.int32, device="cuda")
+    arrived = torch.zeros(1, dtype=torch.int32, device="cuda")
+    occ, flip = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(occ):
+        _abi.call("wsmg_debug_occupy", pinned, 160 * 1024, 8000, ops._p(stop), ops._p(arrived), ops._stream())
+    try:
+        import time
+        t0 = time.time()
+        with torch.cuda.stream(flip):
+            while int(arrived.cpu()) < pinned and time.time() - t0 < 5:
+                time.sleep(0.01)
+            assert int(arrived.cpu()) == pinned, "the occupying workgroups did not all start"
+        held = run(12)
+        with torch.cuda.stream(flip):
+            still = int(arrived.cpu())          # (the kernel is still resident: it only leaves on the flag or after 8 s)
+    finally:
+        with torch.cuda.stream(flip):
+            stop.fill_(1)
+        torch.cuda.synchronize()
+    assert still == pinned
+    assert held == free, [(i, a, b) for i, (a, b) in enumerate(zip(held, free)) if a != b][:4]
+    assert held[-1] < held[0]
+
+
+# ----------------------------------------------------------------------------- gradient exchange on a policy stream
+def _xs_worker(port, q, updates):
+    for p in (ROOT, os.path.join(ROOT, "ws-mgmap_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    try:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        import torch.distributed as dist
+        import bench
+        import test_gpu_round2 as r2
+        from wsmgmap import debug, ops
+        from wsmgmap.common.aux_losses import AuxLosses
+        from wsmgmap.optim import Adam
+        from wsmgmap.parallel import GradAllReducer
+        torch.cuda.set_device(0)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        T_, N = 16, 8
+        state = r2._default_state()
+        obs, prev, masks, weights = bench.synth_batch(T_, N, torch.device("cuda"), 5)
+        ops.mark_inputs_ready(obs["instruction"])
+        AuxLosses.activate()
+
+        def run(xs):
+            pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=state))
+            opt = Adam(pol.parameters(), lr=2.5e-4)
+            red = GradAllReducer(pol.parameters(), bucket_bytes=4 << 20, single_rank_exchange=True, exchange_stream=xs)
+            red.broadcast_parameters(pol)
+            losses = []
+            for _ in range(updates):
+                opt.zero_grad(set_to_none=True)
+                AuxLosses.clear()
+                o = dict(obs)
+                pred, aux = pol(o, torch.zeros(2, N, 512, device="cuda"), prev, masks, weights)
+                loss = bench.dagger_loss(pred, aux, o["waypoint"], weights)
+                loss.backward()
+                red.finish()
+                opt.step()
+                losses.append(loss.detach())
+            torch.cuda.synchronize()
+            ops.check_rnn_status()
+            red.check()
+            return [float(x) for x in losses], red.stats(), bool(debug.sw.early_dedup_dp)
+        hook, _, early0 = run(None)
+        xs, st, early1 = run("instruction")
+        dist.destroy_process_group()
+        q.put(("ok", dict(hook=hook, xs=xs, stats=st, early=(early0, early1))))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("error", traceback.format_exc() + repr(e)))
+
+
+def test_gradient_exchange_on_the_instruction_stream_over_rccl():
+    """VERDICT r04 item 3a.  `GradAllReducer(exchange_stream="instruction")`: the buckets are packed and all-reduced (synchronous RCCL
+    collectives: they run on the caller's current stream, no internal stream) on the policy's own instruction-branch stream, the
+    compute streams never wait for a bucket, the early instruction dedup stays on under the process group — and the 30 losses equal,
+    bit for bit, those of the round-2 form (hook-stream pack + asynchronous collective).  One-rank RCCL communicator: what a 1-GPU box
+    can host of common_trainer.py:60-66."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_xs_worker, args=(port, q, 30))
+    p.start()
+    status, info = q.get(timeout=900)
+    p.join(timeout=120)
+    assert status == "ok", info
+    assert info["early"] == (False, True)
+    assert len(info["xs"]) == 30 and info["xs"] == info["hook"], [(i, a, b) for i, (a, b) in enumerate(zip(info["xs"], info["hook"])) if a != b][:4]
+    assert info["xs"][-1] < info["xs"][0] and info["stats"]["updates"] == 30
+
+
+# ----------------------------------------------------------------------------- early dense inputs
+def test_update_from_raw_depth_does_not_take_the_early_dense_route():
+    """the rgb / depth dense inputs ran on the instruction stream behind `entry` only, while the depth embedding is
+    written on the main stream after it.  Now the side stream waits for an event recorded behind the encoders and the early route
+    needs BOTH cached feature sets: a grad-enabled forward from raw depth (the frozen ResNet50 runs on main) gives the same logits
+    as the same forward with the features cached first."""
+    import bench
+    import test_gpu_round2 as r2
+    from wsmgmap.common.aux_losses import AuxLosses
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+    T, N = 4, 2
+    obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 9)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    depth = torch.rand(T * N, 256, 256, 1, device="cuda", generator=g)
+    with torch.no_grad():
+        feats = pol.net.depth_encoder.visual_encoder({"depth": depth})
+    outs = []
+    for use_raw in (False, True, True):
+        o = dict(obs)
+        if use_raw:
+            del o["depth_features"]
+            o["depth"] = depth
+        else:
+            o["depth_features"] = feats
+        AuxLosses.activate()
+        AuxLosses.clear()
+        pred, aux = pol(o, torch.zeros(2, N, 512, device="cuda"), prev, masks, weights)
+        (pred.sum() + aux).backward()
+        torch.cuda.synchronize()
+        outs.append(pred.detach().clone())
+        for p in pol.parameters():
+            p.grad = None
+    assert torch.equal(outs[1], outs[2])
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * max(1.0, float(outs[0].abs().max()))
+
+
+# ----------------------------------------------------------------------------- two tile sizes in one launch
+@pytest.mark.parametrize("Cin,Cout,B", [(128, 256, 512), (256, 128, 512), (256, 64, 512), (256, 256, 300)])
+def test_mixed_tile_window_convolution_is_bit_identical_to_one_tile_size(Cin, Cout, B):
+    """csrc/wsmg_conv_win3.hip, round 5: whole rounds of 512- / 256-pixel tiles and the remainder as half-size tiles in ONE launch
+    (map_encoder.py:26,94-112 / mg_map_policy.py:89-100 layers at 24 x 24).  A tile's size changes which workgroup computes a pixel,
+    not how: forward and backward-data outputs and the BatchNorm sums' inputs equal the single-tile-size launch bit for bit."""
+    from wsmgmap import _abi, ops
+    g = torch.Generator(device="cuda").manual_seed(Cin + Cout)
+    H = 24
+    x = torch.relu(torch.randn(B, H, H, Cin, device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    dy = torch.randn(B, H, H, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    wi = w.permute(3, 1, 2, 0).contiguous()
+    args = (B, H, H, Cin, Cout, 3, 3, 1, 1, H, H)
+    P, st = ops._p, ops._stream
+    outs = {}
+    for mt in (512, 256, 1):       # 1 = the shape's own choice, which takes the mixed launch where it pays
+        old = _abi.lib().wsmg_conv_debug_win3_tile(mt)
+        try:
+            y = torch.empty(B, H, H, Cout, device="cuda", dtype=torch.bfloat16)
+            dx = torch.empty_like(x)
+            _abi.call("wsmg_conv2d_fwd_bf16", P(x), P(w), None, P(y), 0, *args, st())
+            _abi.call("wsmg_conv2d_bwd_data_bf16", P(dy), P(wi), P(dx), 0, *args, st())
+            torch.cuda.synchronize()
+            outs[mt] = (y, dx)
+        finally:
+            _abi.lib().wsmg_conv_debug_win3_tile(old)
+    for mt in (512, 256):
+        assert torch.equal(outs[1][0], outs[mt][0]) and torch.equal(outs[1][1], outs[mt][1]), mt

@@ -216,16 +216,24 @@ __device__ __forceinline__ Taps rot_taps(int x, int y, int E, Rot r) {
 // ends, so the rotation samples it there (4 LDS reads per output pixel) and only the ROTATED plane goes to memory — NCHW, whole
 // rows, coalesced — instead of plane out, plane in through 4-byte gathers, NHWC out.  map_fuse_planes_kernel consumes the planes.
 // Same arithmetic per output pixel as rotate_nchw_to_nhwc_kernel (tap order nw, ne, sw, se).
+// Round 5 — the rotation's arithmetic diet (cfg4: scatter alone 165 us, scatter + rotation 270-295: the rotation phase was VALU time,
+// not LDS or HBM time — every (pixel, channel) item recomputed the tap geometry with four IEEE divisions (base_coord: 2 / (W - 1)
+// and / W, twice) and an integer division p / E): the two base coordinates come from a table in the LDS left over beside the
+// plane (E floats, the same function's values: bit-identical), y = p / E is a multiply-high by a host-computed magic number.
 template <int WU>
 __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* __restrict__ feat, const int32_t* __restrict__ lin,
                                                                   const float* __restrict__ heading, float sign, int Cf, int HW,
-                                                                  int C, int E, int CG, float* __restrict__ out) {
+                                                                  int C, int E, int CG, unsigned magicE, int table,
+                                                                  float* __restrict__ out) {
   extern __shared__ unsigned tile[];
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * CG;
   const int tid = threadIdx.x;
   const int E2 = E * E;
+  float* const bc = reinterpret_cast<float*>(tile + (size_t)CG * E2);    // [E] base coordinates (only when `table`)
   for (int i = tid; i < CG * E2; i += 1024) tile[i] = 0u;
+  if (table)
+    for (int i = tid; i < E; i += 1024) bc[i] = base_coord(i, E);
   __syncthreads();
   const int32_t* lb = lin + (size_t)b * HW;
   for (int g = 0; g < CG; ++g) {
@@ -247,8 +255,11 @@ __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* _
     const float* pb = reinterpret_cast<const float*>(tile + (size_t)g * E2);
     float* ob = out + ((size_t)b * C + c) * E2;
     for (int p = tid; p < E2; p += 1024) {
-      const int y = p / E, x = p - y * E;
-      Taps tp = rot_taps(x, y, E, r);
+      const int y = (int)__umulhi((unsigned)p, magicE), x = p - y * E;
+      const float bx = table ? bc[x] : base_coord(x, E), by = table ? bc[y] : base_coord(y, E);
+      const float gx = bx * r.c + by * r.s;
+      const float gy = bx * (-r.s) + by * r.c;
+      const Taps tp = make_taps(unnorm(gx, E), unnorm(gy, E));
       bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
       bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
       float v = 0.f;
@@ -697,6 +708,10 @@ extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx
   int CG = (2 * plane <= 80 * 1024 && (int64_t)B * C >= 1024) ? 2 : 1;
   dim3 grid((unsigned)wsmg_cdiv(C, CG), (unsigned)B);
   const int wu = scatter_window(Cf, C);
+  // the base-coordinate table rides in whatever LDS the planes leave (E = 200: 3 840 spare bytes of the 160 KB, 800 needed)
+  const int table = plane * CG + (size_t)E * sizeof(float) <= 160 * 1024 ? 1 : 0;
+  const size_t lds = plane * CG + (table ? (size_t)E * sizeof(float) : 0);
+  const unsigned magicE = (unsigned)((1ull << 32) / (unsigned)E + 1);      // p / E == umulhi(p, magicE) for p < E * E <= 40 960
 #define WSMG_SCATTER(WU_)                                                                                                          \
   {                                                                                                                                \
     static bool attr_set = false;                                                                                                  \
@@ -706,8 +721,8 @@ extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx
       if (e != hipSuccess) return (int)e;                                                                                          \
       attr_set = true;                                                                                                             \
     }                                                                                                                              \
-    hipLaunchKernelGGL(bev_scatter_rotate_kernel<WU_>, grid, dim3(1024), plane * CG, wsmg_s(stream), feat, lin_idx, heading, sign, \
-                       Cf, Hf * Wf, C, E, CG, out_planes);                                                                         \
+    hipLaunchKernelGGL(bev_scatter_rotate_kernel<WU_>, grid, dim3(1024), lds, wsmg_s(stream), feat, lin_idx, heading, sign,        \
+                       Cf, Hf * Wf, C, E, CG, magicE, table, out_planes);                                                          \
   }
   if (wu == 1) WSMG_SCATTER(1) else if (wu == 2) WSMG_SCATTER(2) else if (wu == 3) WSMG_SCATTER(3) else WSMG_SCATTER(4)
 #undef WSMG_SCATTER

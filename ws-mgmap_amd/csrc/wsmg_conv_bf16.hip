@@ -757,7 +757,7 @@ extern "C" int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, con
   }
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 5) == 0) {
     if (const int mt = win3_choice((int64_t)B * OH * OW, Cin, Cout)) {
-      int rc = wsmg_conv_win3_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, mt, wsmg_s(stream));
+      int rc = wsmg_conv_win3_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, mt, win3_tile() == 1, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
     }
   }
@@ -787,7 +787,7 @@ extern "C" int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihw
   if (stats && (nslab <= 0 || (out_f32 & 5) != 0 || (Cin & 7) != 0)) return WSMG_EINVAL;
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 7) == 0) {
     if (const int mt = win3_choice((int64_t)B * H * W, Cout, Cin)) {
-      int rc = wsmg_conv_win3_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cout, Cin, mt, wsmg_s(stream));
+      int rc = wsmg_conv_win3_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cout, Cin, mt, win3_tile() == 1, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
     }
   }

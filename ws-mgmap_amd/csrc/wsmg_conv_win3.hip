@@ -60,6 +60,9 @@ struct Win3Args {
   unsigned src_bytes, wt_bytes;
   double* stats;
   int nslab;
+  // round 5 — two tile sizes in ONE launch: blocks [0, nbig) take MT-pixel tiles from pixel 0, blocks [nbig, nbig + nsmall) take
+  // MT/2-pixel tiles from pixel m_split (0 / 0 / 0: every block is a big tile)
+  int nbig, nsmall, m_split;
 };
 
 constexpr int DK = 32, ROWB = 64, NST = 4;
@@ -84,7 +87,7 @@ constexpr int n_issue(int tap, int npw) { return ((tap % 9 + 9) % 9) < npw ? 2 :
 // 64-channel layers (8 x 1: every wave takes MT / 8 pixels x all 64 channels; waves 4-7 have no weight rows to fetch and issue
 // their weight DMA as a zero-fill into a dummy KB, so that every wave's `vmcnt` counts the same instructions)
 template <int MT, int NPW, int NT>
-__global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
+__device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid, const int nblocks, const int m_base) {
   constexpr int WN = NT >= 128 ? 2 : 1, WM = 8 / WN;   // waves along the channels / along the pixels
   constexpr int NU = NT >= 64 ? 2 : 1;         // 32-column accumulator tiles per wave (NT = 32: one)
   constexpr int TT = MT / (32 * WM);           // 32-row accumulator tiles per wave along the pixels
@@ -97,8 +100,8 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
   static_assert(MT * OPITCH <= OFF_DUMMY, "epilogue staging fits under the k-loop's LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int logical = xcd_swizzle3(blockIdx.x, gridDim.x);
-  const int m0 = (logical / a.ntiles) * MT, n0 = (logical % a.ntiles) * NT;
+  const int logical = xcd_swizzle3(bid, nblocks);
+  const int m0 = m_base + (logical / a.ntiles) * MT, n0 = (logical % a.ntiles) * NT;
   const int H = a.H, W = a.W, PW = W + 2, PP = (H + 2) * PW;
   const int Mtot = a.B * H * W;
 
@@ -279,6 +282,22 @@ __global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
 }
 
 template <int MT, int NPW, int NT>
+__global__ __launch_bounds__(512) void conv_win3_kernel(Win3Args a) {
+  win3_tile_body<MT, NPW, NT>(a, blockIdx.x, gridDim.x, 0);
+}
+
+// Two tile sizes in one launch (round 5).  The wide layers launch 1 152 workgroups of one CU each on 256 CUs: 4.5 rounds, i.e. the
+// last round runs on half the chip for a whole tile's time (5 rounds' time for 4.5 rounds' work: 10 %; the 64-channel layers, 576
+// workgroups, pay 3 rounds for 2.25).  Here the whole rounds keep the big tile and the remainder is cut into tiles of half the
+// pixels — twice the workgroups, each done in about half the time — dispatched last (block order).  Same arithmetic per output
+// element (a tile's size changes which workgroup computes a pixel, not how).
+template <int MT, int NPW, int NPW_S, int NT>
+__global__ __launch_bounds__(512) void conv_win3_mixed_kernel(Win3Args a) {
+  if ((int)blockIdx.x < a.nbig) win3_tile_body<MT, NPW, NT>(a, blockIdx.x, a.nbig, 0);
+  else win3_tile_body<MT / 2, NPW_S, NT>(a, (int)blockIdx.x - a.nbig, a.nsmall, a.m_split);
+}
+
+template <int MT, int NPW, int NT>
 int launch_win3(Win3Args& a, hipStream_t s) {
   constexpr int LDS = 2 * 128 * NPW * ROWB + NST * NT * ROWB + 1024;
   static bool attr = false;
@@ -291,6 +310,51 @@ int launch_win3(Win3Args& a, hipStream_t s) {
   a.mtiles = (int)wsmg_cdiv(M, MT);
   a.ntiles = a.N / NT;
   hipLaunchKernelGGL((conv_win3_kernel<MT, NPW, NT>), dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS, s, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+int g_cus3 = 0;
+int win3_cus() {
+  if (!g_cus3) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    g_cus3 = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      g_cus3 = prop.multiProcessorCount;
+  }
+  return g_cus3;
+}
+
+// Split of a layer's M pixels x (N / NT) channel tiles into whole rounds of MT-pixel tiles and a remainder of MT/2-pixel tiles; false
+// when the plain launch is as good (whole rounds already, fewer than one round, or a remainder that would still need two rounds)
+bool mixed_plan(Win3Args& a, int64_t M, int MT, int NT) {
+  const int cus = win3_cus();
+  const int ntiles = a.N / NT;
+  const int64_t big = wsmg_cdiv(M, MT) * ntiles;
+  const int64_t full = big / cus * cus;
+  const int64_t rem = big - full;
+  if (full == 0 || rem == 0 || 2 * rem > cus || full % ntiles) return false;
+  const int64_t m_split = full / ntiles * MT;               // pixels covered by the whole rounds
+  if (m_split >= M) return false;
+  a.nbig = (int)full;
+  a.m_split = (int)m_split;
+  a.nsmall = (int)(wsmg_cdiv(M - m_split, MT / 2) * ntiles);
+  return true;
+}
+
+template <int MT, int NPW, int NPW_S, int NT>
+int launch_win3_mixed(Win3Args& a, hipStream_t s) {
+  constexpr int LDS = 2 * 128 * NPW * ROWB + NST * NT * ROWB + 1024;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_mixed_kernel<MT, NPW, NPW_S, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  a.ntiles = a.N / NT;
+  a.mtiles = 0;
+  hipLaunchKernelGGL((conv_win3_mixed_kernel<MT, NPW, NPW_S, NT>), dim3((unsigned)(a.nbig + a.nsmall)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -308,18 +372,30 @@ int window_bound(int mt, int H, int W) {
 // 3 x 3 / stride 1 / pad 1, bf16 in / bf16 out, N % 64 == 0 (128-channel tiles when N % 128 == 0), Kc % 32 == 0; WSMG_EINVAL otherwise (the caller then uses the
 // implicit-GEMM kernel).  bwd = 0: forward (src = x, wt = OHWI); 1: backward-data (src = dy, wt = IHWO).
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
-                        int B, int H, int W, int Kc, int N, int mt, hipStream_t s) {
+                        int B, int H, int W, int Kc, int N, int mt, int mixed, hipStream_t s) {
   if (N <= 0 || N % 32 || Kc % DK || B <= 0) return WSMG_EINVAL;
   if ((int64_t)B * (H + 2) * (W + 2) * 1 > (1 << 30) || (int64_t)B * H * W * (Kc > N ? Kc : N) * 2 >= (1ll << 31)) return WSMG_EINVAL;
   Win3Args a{(const bf16_t*)src, (const bf16_t*)wt, bias, (bf16_t*)dst, B, H, W, Kc, N, 0, 0, relu, bwd,
-             (unsigned)((size_t)B * H * W * Kc * 2), (unsigned)((size_t)N * 9 * Kc * 2), stats, nslab};
+             (unsigned)((size_t)B * H * W * Kc * 2), (unsigned)((size_t)N * 9 * Kc * 2), stats, nslab, 0, 0, 0};
+  const int64_t M = (int64_t)B * H * W;
+  // mixed == 0 (a tile size forced through wsmg_conv_debug_win3_tile) or WSMG_CONV_WIN3_MIXED=0: one tile size per launch (rounds 2-4; A/B)
+  const bool mix = mixed && WSMG_TUNE("WSMG_CONV_WIN3_MIXED", 1) != 0;
   if (N % 128 == 0) {
-    if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 128>(a, s);
-    if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 128>(a, s);
+    if (mt == 512 && window_bound(512, H, W) <= 128 * 6) {
+      if (mix && window_bound(256, H, W) <= 128 * 4 && mixed_plan(a, M, 512, 128)) return launch_win3_mixed<512, 6, 4, 128>(a, s);
+      return launch_win3<512, 6, 128>(a, s);
+    }
+    if (mt == 256 && window_bound(256, H, W) <= 128 * 4) {
+      if (mix && window_bound(128, H, W) <= 128 * 2 && mixed_plan(a, M, 256, 128)) return launch_win3_mixed<256, 4, 2, 128>(a, s);
+      return launch_win3<256, 4, 128>(a, s);
+    }
     return WSMG_EINVAL;
   }
   if (N % 64 == 0) {   // 64-channel tiles (N = 64, 192, ...)
-    if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 64>(a, s);
+    if (mt == 512 && window_bound(512, H, W) <= 128 * 6) {
+      if (mix && window_bound(256, H, W) <= 128 * 4 && mixed_plan(a, M, 512, 64)) return launch_win3_mixed<512, 6, 4, 64>(a, s);
+      return launch_win3<512, 6, 64>(a, s);
+    }
     if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 64>(a, s);
     return WSMG_EINVAL;
   }

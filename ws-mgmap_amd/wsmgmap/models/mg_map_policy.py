@@ -327,7 +327,7 @@ class MGMapNet(nn.Module):
         #  communicator, the only form a 1-GPU box can host — ran 17.7 ms per update instead of 11.3, on the GPU's own clock
         #  (profiles/r04_dp1_early_dedup.txt); not understood, so the exchange keeps the round-3 behaviour: one read-back per update
         #  that waits for the previous update)
-        multi = torch.distributed.is_available() and torch.distributed.is_initialized()
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and not debug.sw.early_dedup_dp
         ready = ops.inputs_ready_event(tok) if (dd is None and tok.is_cuda and torch.is_grad_enabled() and debug.sw.early_dedup
                                                 and not multi and not torch.cuda.is_current_stream_capturing()) else None
         if ready is not None:

@@ -46,7 +46,8 @@ class GradExchangeError(RuntimeError):
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=8 << 20, group=None, single_rank_exchange=False, module=None, broadcast_buffers_every=0):
+    def __init__(self, params, bucket_bytes=8 << 20, group=None, single_rank_exchange=False, module=None, broadcast_buffers_every=0,
+                 exchange_stream=None):
         """single_rank_exchange: run the whole exchange even in a one-rank group (by default one rank does nothing at all) — the
         way to put the real backend (RCCL) through this code on a box with one GPU (tests/test_gpu_round2.py).
         module, broadcast_buffers_every = n > 0: every n-th `finish()` ends with rank 0's buffers (BatchNorm running statistics,
@@ -54,6 +55,19 @@ class GradAllReducer:
         re-broadcasts rank 0's buffers before EVERY forward (common_trainer.py:61-66): n = 1 gives a trainer that
         evaluates or checkpoints from any rank mid-epoch the statistics the reference's DDP would show it.  Default 0: the
         statistics stay per rank between explicit `broadcast_buffers()` calls."""
+        # exchange_stream (round 5): a CUDA stream THE CALLER ALREADY USES (the policy's instruction-branch stream, idle for most
+        # of the backward pass: ops.helper_stream("instruction")), or the string naming it.  The buckets are then packed AND
+        # all-reduced on that stream with synchronous collectives (`async_op=False`: this torch runs those on the caller's
+        # current stream, without ProcessGroupNCCL's internal stream), the compute streams never wait for a bucket — only
+        # `finish()` joins the exchange stream into the caller's — and the process has no stream beyond the policy's own.
+        # None: the round-2 form (pack on the stream of the hook that completes a bucket, asynchronous collective on the
+        # backend's internal stream).  DESIGN.md section 4.3 / 5.
+        self._xstream = exchange_stream
+        if exchange_stream is not None:
+            # with no stream beyond the policy's own in the process, the policy may keep its early instruction dedup under a process
+            # group too (mg_map_policy.MGMapNet._encode_instruction; measured: profiles/r05_dp_exchange_ab.txt)
+            from . import debug
+            debug.sw.early_dedup_dp = True
         self._module = module
         self._buffers_every = int(broadcast_buffers_every)
         if self._buffers_every > 0 and module is None:
@@ -201,14 +215,22 @@ class GradAllReducer:
         if self._local_error is None:
             self._local_error = msg
 
+    def _exchange_stream(self):
+        xs = self._xstream
+        if isinstance(xs, str):
+            from . import ops
+            xs = self._xstream = ops.helper_stream(xs, device=self.params[0].device)
+        return xs
+
     def _launch(self, bi):
         b = self._buckets[bi]
+        xs = self._exchange_stream() if b["params"][0].is_cuda else None
         if b["params"][0].is_cuda:
-            # parts of the backward graph run on side streams (instruction branch, decoder branch): this stream packs the bucket, so
-            # it waits for every OTHER stream a gradient of the bucket was produced on.  One event per such stream, recorded now:
+            # parts of the backward graph run on side streams (instruction branch, decoder branch): the stream that packs the bucket
+            # waits for every OTHER stream a gradient of the bucket was produced on.  One event per such stream, recorded now:
             # the hook of each of those gradients ran after its producer was queued, so "everything queued on that stream so
             # far" covers it (an event per gradient was 102 records per update: 1 ms of host time in the backward pass).
-            cur = torch.cuda.current_stream()
+            cur = xs if xs is not None else torch.cuda.current_stream()
             for sid, st in b.pop("streams", {}).items():
                 if sid != cur.cuda_stream:
                     ev = torch.cuda.Event()
@@ -225,9 +247,16 @@ class GradAllReducer:
         # the whole bucket is ready: ONE multi-tensor copy packs it (instead of a copy kernel per parameter), then
         # the exchange starts while backward continues
         dst = [v for v, g in zip(b["views"], grads) if g is not None]
+        b["launched"] = True
+        if xs is not None:
+            with torch.cuda.stream(xs):
+                if dst:
+                    torch._foreach_copy_(dst, [g for g in grads if g is not None])
+                dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)     # synchronous form: runs on `xs` itself
+            self._works.append((bi, None))
+            return
         if dst:
             torch._foreach_copy_(dst, [g for g in grads if g is not None])
-        b["launched"] = True
         self._works.append((bi, dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def _launch_ready(self):
@@ -291,8 +320,11 @@ class GradAllReducer:
             self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
             self._flag_host = torch.zeros(1, dtype=torch.int32, pin_memory=dev.type == "cuda")
         self._flag.fill_(1 if self._local_error else 0)
-        w = dist.all_reduce(self._flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        w.wait()    # NCCL/RCCL: the current stream waits, not the host
+        if dev.type == "cuda" and self._exchange_stream() is not None:
+            dist.all_reduce(self._flag, op=dist.ReduceOp.SUM, group=self.group)        # on the current stream (see exchange_stream)
+        else:
+            w = dist.all_reduce(self._flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()    # NCCL/RCCL: the current stream waits, not the host
         self._flag_host.copy_(self._flag, non_blocking=True)
         if dev.type == "cuda":
             self._flag_event = torch.cuda.Event()
@@ -346,7 +378,10 @@ class GradAllReducer:
                     self._launch(self._next)
                     self._next += 1
             for _, w in self._works:
-                w.wait()
+                if w is not None:
+                    w.wait()
+            if dev.type == "cuda" and self._exchange_stream() is not None:
+                torch.cuda.current_stream().wait_stream(self._exchange_stream())     # the one join of the exchange into the compute stream
             done = [bi for bi, _ in self._works]
         bad = self._exchange_flag(dev)
         inv = 1.0 / self.world

@@ -26,6 +26,7 @@ import torch
 
 from . import _abi
 from . import ops as _ops
+from .debug import sw as _sw
 from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _stream
 
 MAX_BATCH = 8          # batch slots of the persistent GRU kernels
@@ -76,6 +77,24 @@ def _post_hooks_visible():
 def _prow(t, row):
     """Pointer to row `row` of a contiguous tensor (a view object per kernel argument costs more host time than the launch)."""
     return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
+
+
+def _rg(a_segs, w, w_is_kn, out_segs, r0, M, bias=None, cin_segs=None, mask=None, relu=False):
+    """One launch of wsmg_rows_gemm_f32 on rows r0 .. r0 + M of full-batch row-major tensors: C = epilogue([A0|A1|A2] W^T) (w_is_kn
+    False: W an nn.Linear weight [N, K]) or ([A0|A1|A2] W) (True: W [K, N], the backward product dY W).  a_segs / out_segs /
+    cin_segs: lists of up to three 2-D tensors (their column counts are the segment widths); mask: the ReLU-backward mask source."""
+    z = (None, 0, 0)
+    A = [(_prow(t, r0), t.stride(0), t.shape[1]) for t in a_segs] + [z] * (3 - len(a_segs))
+    Cs = [(_prow(t, r0), t.stride(0), t.shape[1]) for t in out_segs] + [z] * (3 - len(out_segs))
+    Ci = [(_prow(t, r0), t.stride(0)) for t in (cin_segs or [])] + [(None, 0)] * (3 - len(cin_segs or []))
+    _abi.call("wsmg_rows_gemm_f32", *A[0], *A[1], *A[2], _p(w), w.stride(0), int(bool(w_is_kn)), _p(bias),
+              None if mask is None else _prow(mask, r0), 0 if mask is None else mask.stride(0), int(bool(relu)),
+              *Cs[0], *Cs[1], *Cs[2], *Ci[0], *Ci[1], *Ci[2], int(M), _stream())
+
+
+def rows_gemm_ok(H, C, in1):
+    """Shapes wsmg_rows_gemm_f32 takes for the attention stage's five products (hidden size H, attention width C, GRU-2 input)."""
+    return _sw.rows_gemm and H % 32 == 0 and C % 32 == 0 and in1 % 32 == 0
 
 
 def _roles(streams, main):
@@ -149,7 +168,9 @@ class _RecurrentBlock(torch.autograd.Function):
         qf = torch.empty(B, C, **f32)
         map_emb = torch.empty(B, C, **f32)
         att_map = torch.empty(B, I, **f32)
-        x = torch.empty(B, wc.shape[1], **f32)
+        x = None            # (the concatenation is an operand of the rows-GEMM route: the leaf pass rebuilds it for dW)
+        if not (rows_gemm_ok(H, C, wc.shape[0]) and wq1.shape[0] % 32 == 0 and wq2.shape[0] % 32 == 0):
+            x = torch.empty(B, wc.shape[1], **f32)
         xc = torch.empty(B, wc.shape[0], **f32)
         gi2 = torch.empty(B, 3 * H, **f32)
         m = masks.reshape(T, N)
@@ -193,26 +214,41 @@ class _RecurrentBlock(torch.autograd.Function):
                 e1 = torch.cuda.Event()
                 e1.record(main)
                 ev1.append(e1)
+        rg = rows_gemm_ok(H, C, wc.shape[0]) and wq1.shape[0] % 32 == 0 and wq2.shape[0] % 32 == 0
         with torch.cuda.stream(sa):
-            q1.copy_(bq1.expand_as(q1))
-            q2.copy_(bq2.expand_as(q2))
-            xc.copy_(bc.expand_as(xc))
-            gi2.copy_(b_ih2.expand_as(gi2))
+            if not rg:
+                q1.copy_(bq1.expand_as(q1))
+                q2.copy_(bq2.expand_as(q2))
+                xc.copy_(bc.expand_as(xc))
+                gi2.copy_(b_ih2.expand_as(gi2))
             for k in range(K):
                 r0, r1 = k * rows, (k + 1) * rows
                 if multi:
                     sa.wait_event(ev1[k])
-                q1[r0:r1].addmm_(y1r[r0:r1], wq1.t())
+                if rg:
+                    # round 5: every dense layer of the stage is ONE launch (csrc/wsmg_rows_gemm.hip): bias, the concatenation, the
+                    # ReLU in the epilogue / operand segments — 7 launches per chunk instead of 9 + 4 pre-fills, each ~4 us
+                    _rg([y1r], wq1, False, [q1], r0, rows, bias=bq1)
+                else:
+                    q1[r0:r1].addmm_(y1r[r0:r1], wq1.t())
                 _abi.call("wsmg_attn_shared_fwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _p(text_mask), _prow(inverse, r0),
                           scale, rows, L, C, _prow(text_emb, r0), _prow(attn_text, r0), _stream())
-                q2[r0:r1].addmm_(text_emb[r0:r1], wq2.t())
-                torch.mm(q2[r0:r1], wk2, out=qf[r0:r1])
+                if rg:
+                    _rg([text_emb], wq2, False, [q2], r0, rows, bias=bq2)
+                    _rg([q2], wk2, True, [qf], r0, rows)
+                else:
+                    q2[r0:r1].addmm_(text_emb[r0:r1], wq2.t())
+                    torch.mm(q2[r0:r1], wk2, out=qf[r0:r1])
                 _abi.call("wsmg_attn_fwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), None, scale, rows, I, C,
                           _prow(map_emb, r0), _prow(att_map, r0), _stream())
-                torch.cat([y1r[r0:r1], text_emb[r0:r1], map_emb[r0:r1]], dim=1, out=x[r0:r1])
-                xc[r0:r1].addmm_(x[r0:r1], wc.t())
-                torch.relu_(xc[r0:r1])
-                gi2[r0:r1].addmm_(xc[r0:r1], w_ih2.t())
+                if rg:
+                    _rg([y1r, text_emb, map_emb], wc, False, [xc], r0, rows, bias=bc, relu=True)
+                    _rg([xc], w_ih2, False, [gi2], r0, rows, bias=b_ih2)
+                else:
+                    torch.cat([y1r[r0:r1], text_emb[r0:r1], map_emb[r0:r1]], dim=1, out=x[r0:r1])
+                    xc[r0:r1].addmm_(x[r0:r1], wc.t())
+                    torch.relu_(xc[r0:r1])
+                    gi2[r0:r1].addmm_(xc[r0:r1], w_ih2.t())
                 _ops.mark("f.at.%d" % k)
                 if multi:
                     ea = torch.cuda.Event()
@@ -228,7 +264,8 @@ class _RecurrentBlock(torch.autograd.Function):
             main.wait_stream(sg)
             main.wait_stream(sa)
         ctx.save_for_backward(state_in, tokens, text_k, text_v, inverse, m, h01, h02, w_ih1, w_hh1, wq1, wq2, wk2, wc, w_ih2, w_hh2,
-                              gi1, y1, *sv1, y2, *sv2, q1, text_emb, attn_text, q2, qf, att_map, x, xc)
+                              gi1, y1, *sv1, y2, *sv2, q1, text_emb, attn_text, q2, qf, att_map, map_emb if x is None else x, xc)
+        ctx.x_is_parts = x is None
         ctx.cfg = (N, K, Tc, scale, sink, tuple(wk.shape), text_mask is not None)
         ctx.params = (w_ih1, b_ih1, w_hh1, b_hh1, wq1, bq1, wq2, bq2, wk, bk, wc, bc, w_ih2, b_ih2, w_hh2, b_hh2)
         h1n, h2n = y1[-1:].clone(), y2[-1:].clone()
@@ -240,6 +277,7 @@ class _RecurrentBlock(torch.autograd.Function):
     def backward(ctx, dy2, datt, _dh1, _dh2):
         (state_in, tokens, text_k, text_v, inverse, m, h01, h02, w_ih1, w_hh1, wq1, wq2, wk2, wc, w_ih2, w_hh2,
          gi1, y1, sr1, sz1, sn1, sg1, y2, sr2, sz2, sn2, sg2, q1, text_emb, attn_text, q2, qf, att_map, x, xc) = ctx.saved_tensors
+        rg = ctx.x_is_parts          # the rows-GEMM route: `x` is map_emb, the concatenation is rebuilt on the leaf stream
         N, K, Tc, scale, sink, wk_shape, _ = ctx.cfg
         T = y1.shape[0]
         H = y1.shape[2]
@@ -291,6 +329,7 @@ class _RecurrentBlock(torch.autograd.Function):
         dxc = torch.empty(B, wc.shape[0], **f32)
         dqf, dq2, dq1 = torch.empty(B, C, **f32), torch.empty(B, wq2.shape[0], **f32), torch.empty(B, wq1.shape[0], **f32)
         dtext = torch.empty(B, C, **f32)
+        dmap_all = torch.empty(B, C, **f32) if rg else None
         dl = torch.empty(B, L, **f32)
         dstate = torch.empty(T, N, H, **f32)
         dtokens = torch.empty_like(tokens)
@@ -304,7 +343,7 @@ class _RecurrentBlock(torch.autograd.Function):
             # — and so do the tensors SAVED by the forward pass: autograd drops them the moment this function returns, long before
             # the leaf stream's GEMMs have read x, xc, q2, text_emb, y1, y2, ... (seen as one wrong weight gradient in ~8 runs of two
             # ranks sharing a GPU, where the leaf stream starts late)
-            keep = [dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dl, dstate, dtokens, dh02, dy2, datt, carry2, carry1,
+            keep = [dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dmap_all, dl, dstate, dtokens, dh02, dy2, datt, carry2, carry1,
                     list(ctx.saved_tensors)]
             torch.autograd.Variable._execution_engine.queue_callback(keep.clear)
             sg.wait_stream(main)
@@ -342,21 +381,36 @@ class _RecurrentBlock(torch.autograd.Function):
                 r0, r1 = k * rows, (k + 1) * rows
                 if multi:
                     sa.wait_event(ev2[k])
-                # ReLU of second_state_compress: d(pre-activation) = d(xc) where xc > 0
-                dxc_k = dxc[r0:r1]
-                torch.ops.aten.threshold_backward.grad_input(torch.mm(dgi2r[r0:r1], w_ih2), xcr[r0:r1], 0.0, grad_input=dxc_k)
-                dstate_a = torch.mm(dxc_k, wc_s)
-                dtext_a = torch.mm(dxc_k, wc_t)
-                dmap = torch.mm(dxc_k, wc_m)
-                _abi.call("wsmg_attn_bwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), _prow(att_map, r0), _p(dmap),
-                          None if datt is None else _prow(datt, r0), scale, rows, I, C, _prow(dqf, r0), _prow(dtokens, r0),
-                          _prow(dtokens, r0), _stream())
-                dq2_k = dq2[r0:r1]
-                torch.mm(dqf[r0:r1], wk2t, out=dq2_k)
-                torch.addmm(dtext_a, dq2_k, wq2, out=dtext[r0:r1])
-                _abi.call("wsmg_attn_shared_bwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _prow(attn_text, r0), _prow(dtext, r0),
-                          None, _prow(inverse, r0), scale, rows, L, C, _prow(dq1, r0), _prow(dl, r0), _stream())
-                torch.addmm(dstate_a, dq1[r0:r1], wq1, out=dstate_r[r0:r1])
+                if rg:
+                    # round 5: five launches of wsmg_rows_gemm_f32 around the two attention kernels (was 9 GEMM-library launches + a
+                    # threshold_backward): the ReLU mask, the split of d(cat) into its three parts and the two accumulate-intos
+                    # (beta = 1, in place) ride in the epilogues
+                    _rg([dgi2r], w_ih2, True, [dxc], r0, rows, mask=xcr)
+                    _rg([dxc], wc, True, [dstate_r, dtext, dmap_all], r0, rows)
+                    _abi.call("wsmg_attn_bwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), _prow(att_map, r0), _prow(dmap_all, r0),
+                              None if datt is None else _prow(datt, r0), scale, rows, I, C, _prow(dqf, r0), _prow(dtokens, r0),
+                              _prow(dtokens, r0), _stream())
+                    _rg([dqf], wk2, False, [dq2], r0, rows)
+                    _rg([dq2], wq2, True, [dtext], r0, rows, cin_segs=[dtext])
+                    _abi.call("wsmg_attn_shared_bwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _prow(attn_text, r0), _prow(dtext, r0),
+                              None, _prow(inverse, r0), scale, rows, L, C, _prow(dq1, r0), _prow(dl, r0), _stream())
+                    _rg([dq1], wq1, True, [dstate_r], r0, rows, cin_segs=[dstate_r])
+                else:
+                    # ReLU of second_state_compress: d(pre-activation) = d(xc) where xc > 0
+                    dxc_k = dxc[r0:r1]
+                    torch.ops.aten.threshold_backward.grad_input(torch.mm(dgi2r[r0:r1], w_ih2), xcr[r0:r1], 0.0, grad_input=dxc_k)
+                    dstate_a = torch.mm(dxc_k, wc_s)
+                    dtext_a = torch.mm(dxc_k, wc_t)
+                    dmap = torch.mm(dxc_k, wc_m)
+                    _abi.call("wsmg_attn_bwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), _prow(att_map, r0), _p(dmap),
+                              None if datt is None else _prow(datt, r0), scale, rows, I, C, _prow(dqf, r0), _prow(dtokens, r0),
+                              _prow(dtokens, r0), _stream())
+                    dq2_k = dq2[r0:r1]
+                    torch.mm(dqf[r0:r1], wk2t, out=dq2_k)
+                    torch.addmm(dtext_a, dq2_k, wq2, out=dtext[r0:r1])
+                    _abi.call("wsmg_attn_shared_bwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _prow(attn_text, r0), _prow(dtext, r0),
+                              None, _prow(inverse, r0), scale, rows, L, C, _prow(dq1, r0), _prow(dl, r0), _stream())
+                    torch.addmm(dstate_a, dq1[r0:r1], wq1, out=dstate_r[r0:r1])
                 _ops.mark("b.at.%d" % k)
                 if multi:
                     eva[k] = torch.cuda.Event()
@@ -385,6 +439,8 @@ class _RecurrentBlock(torch.autograd.Function):
             hp2 = torch.cat([h02.unsqueeze(0), y2[:-1]], dim=0) * m.unsqueeze(-1)
             gh2 = dgh2.view(B, 3 * H)
             dw_hh2, db_hh2 = gh2.t() @ hp2.view(B, H), gh2.sum(0)
+            if rg:
+                x = torch.cat([y1r, text_emb, x], dim=1)          # (x held map_emb)
             dwc, dbc = dxc.t() @ x, dxc.sum(0)
             dwk = (q2.t() @ dqf).reshape(wk_shape)
             # (the key projection's bias adds the same number to every token's logit: it cancels in the softmax, gradient exactly 0)
