@@ -200,7 +200,8 @@ def cfg5_attn_fp8(dev, reps=50):
     out["unit_rate"] = round(B * 1e6 / t_shared, 1)
     out["unit"] = "attention rows/s"
     out["gflops"] = round(flops / t_shared / 1e3, 2)
-    out["launches"] = int(getattr(ops, "ATTENTION_FP8_SHARED_LAUNCHES", 3))
+    from wsmgmap.ops import attention as _att
+    out["launches"] = int(_att.last_fp8_shared_launches)
     out["single_query_form"] = dict(_bw(t_single, alg_single), note="ops.attn_fp8_fused: one token set per row (SURVEY 8d: 82 KB per row), "
                                     "query fold on the f32 matrix pipe + split-row kernel: 2 launches")
     out["note"] = "latency-bound at this size (5 MB, 21 MFLOP): the figure to watch is us, not the fraction"

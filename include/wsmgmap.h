@@ -595,6 +595,20 @@ int wsmg_attn_fp8_prep(const float* q, const float* k_sets, const float* v_sets,
                        float q_scale, float k_scale, float v_scale, uint8_t* q_codes, uint8_t* k_codes, uint8_t* v_codes,
                        float* scales, int* row_ids, int* set_start, unsigned* amax_ws, wsmg_stream_t stream);
 
+/* wsmg_attn_fp8_prep + wsmg_attn_fp8_mfma_fwd as ONE launch (round 5; BASELINE configs[4], mg_map_policy.py:173-178): from float32 q
+ * [B][256], k_sets / v_sets [U][L][256] and inverse [B] — per-tensor scales (x_scale > 0: the caller's, else amax / 448 as above),
+ * e4m3 quantisation on the fly, the rows of a set found by a ranked scan of `inverse`, S = Q K^T on the fp8 matrix pipe, float32
+ * softmax, O = P V.  Results equal the two-step route bit for bit.  workspace: 16 words owned by ONE stream, zero before its first
+ * use and never touched by the caller afterwards; arrivals_before: the sum of wsmg_attn_fp8_mfma_fused_arrivals() over the earlier
+ * launches on this workspace THAT TOOK MAXIMA (mod 2^32); epoch: their count.  A launch with all three scales given uses neither.
+ * scales_out [3] (may be NULL): the scales used.  Not capturable into a HIP graph (the arrival target is a launch argument).
+ * WSMG_EINVAL when maxima are needed and U * ceil(B / 32) > 128 (the caller then takes the two-step route), L > 224, C != 256. */
+int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, const float* v_sets, const int64_t* inverse, const int* lengths,
+                             float q_scale, float k_scale, float v_scale, float scale, int B, int U, int L, int C,
+                             unsigned* workspace, unsigned arrivals_before, int epoch, float* scales_out, float* out, float* attn,
+                             wsmg_stream_t stream);
+int wsmg_attn_fp8_mfma_fused_arrivals(int B, int U, int L, int C);
+
 /* out[r] = mean of x[r][0..n) for R rows of n <= 160 float32 values (contiguous): `nn.AdaptiveAvgPool1d(1)` + `Flatten` in front of
  * rgb_linear (mg_map_policy.py:90-96) over the 7 x 7 positions of the RGB feature. */
 int wsmg_mean_rows(const float* x, int64_t R, int n, float* out, wsmg_stream_t stream);

@@ -66,7 +66,7 @@ def test_rows_gemm_matches_float64(M):
     recurrent._rg([dgi], wih, True, [dxc], r0, M, mask=xcv)
     want = ((dgi.double() @ wih.double()) * (xcv > 0).double())[r0:r0 + M]
     close(dxc[r0:r0 + M], want, "dxc")
-    ds, dt, dm = torch.empty(Bf, 512, device="cuda"), torch.empty(Bf, 256, device="cuda"), torch.empty(Bf, 256, device="cuda")
+    ds, dt, dm = torch.zeros(Bf, 512, device="cuda"), torch.zeros(Bf, 256, device="cuda"), torch.zeros(Bf, 256, device="cuda")
     recurrent._rg([dxc], wc, True, [ds, dt, dm], r0, M)
     want = (dxc.double() @ wc.double())[r0:r0 + M]
     close(ds[r0:r0 + M], want[:, :512], "dstate")
@@ -303,8 +303,12 @@ def test_update_from_raw_depth_does_not_take_the_early_dense_route():
         outs.append(pred.detach().clone())
         for p in pol.parameters():
             p.grad = None
-    assert torch.equal(outs[1], outs[2])
-    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * max(1.0, float(outs[0].abs().max()))
+    # (the frozen ResNet50 runs on stock float32 convolutions, which are not bit-reproducible from call to call: one unit in the last
+    #  place of the logits was seen between two identical forwards; a read-before-write shows as a difference in the first digits)
+    scale = max(1e-3, float(outs[0].abs().max()))
+    assert float((outs[1] - outs[2]).abs().max()) <= 1e-5 * scale
+    d = float((outs[0] - outs[1]).abs().max())
+    assert d <= 1e-4 * scale, (d, scale)
 
 
 # ----------------------------------------------------------------------------- two tile sizes in one launch
@@ -336,3 +340,59 @@ def test_mixed_tile_window_convolution_is_bit_identical_to_one_tile_size(Cin, Co
             _abi.lib().wsmg_conv_debug_win3_tile(old)
     for mt in (512, 256):
         assert torch.equal(outs[1][0], outs[mt][0]) and torch.equal(outs[1][1], outs[mt][1]), mt
+
+
+# ----------------------------------------------------------------------------- configs[4] in one launch
+def test_fp8_shared_attention_in_one_launch_equals_the_three_launch_route(monkeypatch):
+    """VERDICT r04 item 4 / BASELINE configs[4] (`_attn`, mg_map_policy.py:173-178, e4m3 storage): wsmg_attn_fp8_mfma_fused — maxima
+    behind a grid barrier, quantisation on the fly, ranked row scan, attention — against the round-3 route (maxima launch, quantise +
+    group launch, attention launch): context and weights BIT FOR BIT, at configs[4]'s size, at the update path's (512 rows over 8
+    sets: the barrier's largest grid), with ragged lengths and an uneven row-to-set map, with the caller's scales (no barrier),
+    and over repeated launches of alternating shapes on one stream (the arrival counter's bookkeeping).  Larger batches fall back."""
+    from wsmgmap import debug, ops
+    from wsmgmap.ops import attention as att
+    g = torch.Generator(device="cuda").manual_seed(21)
+
+    def case(B, U, L, scales=None):
+        q = torch.randn(B, 256, device="cuda", generator=g)
+        k = torch.randn(U, L, 256, device="cuda", generator=g) * 1.7
+        v = torch.randn(U, L, 256, device="cuda", generator=g) * 0.6
+        inv = torch.randint(0, U, (B,), device="cuda", generator=g)
+        inv[: min(B, U)] = torch.arange(min(B, U), device="cuda")
+        lens = torch.randint(1, L + 1, (U,), device="cuda", generator=g).to(torch.int32)
+        monkeypatch.setattr(debug.sw, "fp8_fused", False)
+        o3, a3 = ops.attention_fp8_shared(q, k, v, lens, inv, 1 / 16, scales=scales)
+        n3 = att.last_fp8_shared_launches
+        monkeypatch.setattr(debug.sw, "fp8_fused", True)
+        o1, a1 = ops.attention_fp8_shared(q, k, v, lens, inv, 1 / 16, scales=scales)
+        n1 = att.last_fp8_shared_launches
+        torch.cuda.synchronize()
+        return (o3, a3, n3), (o1, a1, n1)
+
+    for rep in range(3):
+        for B, U, L, scales, fused in ((64, 8, 160, None, True), (512, 8, 80, None, True), (37, 5, 200, None, True), (3, 3, 33, None, True),
+                                       (64, 8, 160, (0.01, 0.02, 0.005), True), (4096, 64, 160, (0.01, 0.02, 0.005), True),
+                                       (4096, 64, 160, None, False)):
+            (o3, a3, n3), (o1, a1, n1) = case(B, U, L, scales)
+            assert n1 == (1 if fused else 3) and n3 == (2 if scales else 3), (B, U, L, n1, n3)
+            assert torch.equal(a1, a3), (B, U, L, rep, float((a1 - a3).abs().max()))
+            assert torch.equal(o1, o3), (B, U, L, rep, float((o1 - o3).abs().max()))
+            assert torch.isfinite(o1).all()
+
+
+def test_fp8_one_launch_attention_reproduces_the_reference_golden_g5f():
+    """The fused launch against golden g5f — the reference's own `_attn` on e4m3-representable inputs at configs[4]'s size."""
+    import numpy as np
+    from oracle import cases
+    from util import golden
+    from wsmgmap import ops
+    from wsmgmap.ops import attention as att
+    c = cases.attn_fp8_inputs()
+    g = golden("g5f_attn_fp8.npz")
+    q, k, v = (torch.from_numpy(c[n]).cuda() for n in ("q", "k", "v"))
+    out, attn = ops.attention_fp8_shared(q, k, v, torch.from_numpy(c["lengths"]).cuda(), torch.from_numpy(c["inverse"]).cuda(), 1.0 / 16,
+                                         scales=(c["q_scale"], c["k_scale"], c["v_scale"]))
+    assert att.last_fp8_shared_launches == 1
+    ea = float(np.abs(attn.cpu().numpy() - g["attn"]).max())
+    eo = float(np.abs(out.cpu().numpy() - g["out"]).max() / np.abs(g["out"]).max())
+    assert ea <= 3e-5 and eo <= 6e-5, (ea, eo)

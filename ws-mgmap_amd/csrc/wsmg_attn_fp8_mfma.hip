@@ -285,6 +285,286 @@ __global__ __launch_bounds__(256) void attn_fp8_quant_group_kernel(PrepArgs a, i
   reinterpret_cast<unsigned*>(a.codes[t])[k] = (unsigned)w;
 }
 
+// ---- round 5: the whole operator in ONE launch (it was |x| maxima + quantise / group + this kernel = 36 us at
+// B = 64, of which the attention itself 15).  From float32 q / k / v and `inverse`:
+//   phase A (skipped when the caller fixes all three scales): every workgroup — the U x tiles attention workgroups and `nhelp` helper
+//     workgroups that do nothing else — takes a slice of the three tensors, one atomicMax per workgroup and tensor into this
+//     launch's slot of a persistent workspace, then one arrival on a monotonic counter; the attention workgroups spin (bounded) until
+//     all have arrived.  Only the arrivals are waited for, never a workgroup's residency: helpers run and leave, so the launch
+//     cannot deadlock on co-residency as long as the attention workgroups (<= 128: the host's condition) do not fill the GPU.
+//   phase B: the rows of this workgroup's (set, tile) from a ranked scan of `inverse` (rank = position among the set's rows in row
+//     order); no row list in memory.
+//   phase C: attn_fp8_mfma_fwd_kernel's arithmetic, operands quantised on the fly with the quantiser's exact expression — the codes,
+//     and so every result bit, equal the three-launch route's (tests/test_gpu_round5.py).
+struct F8fArgs {
+  const float* q;          // [B][256]
+  const float* k;          // [U][L][256]
+  const float* v;          // [U][L][256]
+  const int64_t* inverse;  // [B]
+  const int* lengths;      // [U] or null
+  float fixed[3];          // > 0: the caller's scale of q / k / v
+  float scale;
+  int B, U, L, tiles, nmain;
+  unsigned* ws;            // [0..2] / [4..6]: |x| maxima of the launch with epoch parity 0 / 1; [8]: arrivals (monotonic)
+  unsigned target;         // value of ws[8] once every workgroup of THIS launch has arrived
+  int parity, need_amax;
+  float* scales_out;       // [3] or null: the scales used (diagnostics / tests)
+  float* out;
+  float* attn;
+};
+
+__device__ __forceinline__ long quant8(const float* p, float inv_scale) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = fminf(fmaxf(x[j] * inv_scale, -448.f), 448.f);
+  int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w0, true);
+  int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], 0, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], w1, true);
+  return (long)(((unsigned long)(unsigned)w1 << 32) | (unsigned long)(unsigned)w0);
+}
+__device__ __forceinline__ float scale_of(float am, float fixed) {
+  return fixed > 0.f ? fixed : (am != am ? am : fmaxf(am * (1.0f / 448.0f), 1e-30f));
+}
+
+__global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
+  __shared__ __attribute__((aligned(16))) float S[32][LMAX + 4];
+  __shared__ __attribute__((aligned(16))) uint8_t V8[2][32][AC + 16];
+  __shared__ int rows[32];
+  __shared__ int wtot[4];
+  __shared__ float wm[4][3];
+  __shared__ float sc3[3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = blockIdx.x;
+  // ---- phase A
+  if (a.need_amax) {
+    const int64_t n4q = (int64_t)a.B * AC / 4, n4k = (int64_t)a.U * a.L * AC / 4;
+    const int64_t tot = n4q + 2 * n4k;
+    float m[3] = {0.f, 0.f, 0.f};
+    constexpr int UA = 4;
+    for (int64_t i0 = (int64_t)wg * 256 + tid; i0 < tot; i0 += (int64_t)gridDim.x * 256 * UA) {
+      f32x4 vv[UA];
+      int tt[UA];
+#pragma unroll
+      for (int uu = 0; uu < UA; ++uu) {
+        const int64_t i = i0 + (int64_t)uu * gridDim.x * 256;
+        const int t = i < n4q ? 0 : i < n4q + n4k ? 1 : 2;
+        tt[uu] = i < tot ? t : -1;
+        const int64_t kk = i - (t == 0 ? 0 : t == 1 ? n4q : n4q + n4k);
+        const float* src = t == 0 ? a.q : t == 1 ? a.k : a.v;
+        vv[uu] = i < tot ? reinterpret_cast<const f32x4*>(src)[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int uu = 0; uu < UA; ++uu) {
+        const f32x4 v = vv[uu];
+        const float mm = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        const bool bad = v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (tt[uu] == t && !(a.fixed[t] > 0.f)) m[t] = (bad || m[t] != m[t]) ? __builtin_nanf("") : fmaxf(m[t], mm);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float v = m[t];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float w = __shfl_xor(v, o, 64);
+        v = (v != v || w != w) ? __builtin_nanf("") : fmaxf(v, w);
+      }
+      m[t] = v;
+    }
+    if (lane == 0) { wm[wave][0] = m[0]; wm[wave][1] = m[1]; wm[wave][2] = m[2]; }
+    __syncthreads();
+    unsigned* const slot = a.ws + 4 * a.parity;
+    if (tid < 3) {
+      float v = wm[0][tid];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float o = wm[w][tid];
+        v = (v != v || o != o) ? __builtin_nanf("") : fmaxf(v, o);
+      }
+      if (v > 0.f || v != v) __hip_atomic_fetch_max(slot + tid, v != v ? 0x7fc00000u : __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_fetch_add(a.ws + 8, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wg >= a.nmain) return;      // a helper: done
+    if (tid == 0) {
+      unsigned spins = 0;
+      bool ok = true;
+      while ((int)(__hip_atomic_load(a.ws + 8, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.target) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1u << 24)) { ok = false; break; }     // (seconds: a workgroup of this launch never ran — results become NaN)
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float am = __uint_as_float(__hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        sc3[t] = ok ? scale_of(am, a.fixed[t]) : __builtin_nanf("");
+      }
+      if (wg == 0) {       // the other slot is the next launch's: hand it over clean (launches on one stream do not overlap)
+        unsigned* const other = a.ws + 4 * (a.parity ^ 1);
+        other[0] = 0u; other[1] = 0u; other[2] = 0u;
+        if (a.scales_out) { a.scales_out[0] = sc3[0]; a.scales_out[1] = sc3[1]; a.scales_out[2] = sc3[2]; }
+      }
+    }
+    __syncthreads();
+  } else {
+    if (wg >= a.nmain) return;
+    if (tid < 3) sc3[tid] = a.fixed[tid];
+    if (wg == 0 && tid < 3 && a.scales_out) a.scales_out[tid] = a.fixed[tid];
+    __syncthreads();
+  }
+  const float sq = sc3[0], sk = sc3[1], sv = sc3[2];
+  const float iq = (float)(1.0 / (double)sq), ik = (float)(1.0 / (double)sk), iv = (float)(1.0 / (double)sv);
+
+  // ---- phase B: this workgroup's rows
+  const int u = wg % a.U, tile = wg / a.U;
+  const int first = tile * 32;
+  if (tid < 32) rows[tid] = -1;
+  __syncthreads();
+  int running = 0;
+  for (int base = 0; base < a.B; base += 256) {
+    const int b = base + tid;
+    bool mine = false;
+    if (b < a.B) {
+      const int64_t su = a.inverse[b];
+      mine = (int)(su < 0 ? 0 : su >= a.U ? a.U - 1 : su) == u;
+    }
+    const unsigned long long bal = __ballot(mine);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; ++w) off += wtot[w];
+    const int rank = off + before;
+    if (mine && rank >= first && rank < first + 32) rows[rank - first] = b;
+    running += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
+  }
+  if (first >= running) return;
+  const int r = lane & 31, h = lane >> 5;
+  const int len = a.lengths ? a.lengths[u] : a.L;
+  const int LP = (a.L + 31) & ~31;
+
+  // ---- phase C: S = Q K^T on the fp8 matrix pipe (operands quantised here)
+  const int my_row = rows[r];
+  const float* qp = a.q + (size_t)(my_row < 0 ? 0 : my_row) * AC + 8 * h;
+  long qa[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) qa[ks] = my_row < 0 ? 0l : quant8(qp + 16 * ks, iq);
+  for (int tt = wave; tt * 32 < LP; tt += 4) {
+    const int tok = tt * 32 + r;
+    const float* kp = a.k + ((size_t)u * a.L + (tok < a.L ? tok : 0)) * AC + 8 * h;
+    f32x16 acc4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc4[c][g] = 0.f;
+    long kb[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) kb[ks] = tok < a.L ? quant8(kp + 16 * ks, ik) : 0l;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc4[ks >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(qa[ks], kb[ks], acc4[ks >> 2], 0, 0, 0);
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = (acc4[0][g] + acc4[1][g]) + (acc4[2][g] + acc4[3][g]);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int m = (g & 3) + 8 * (g >> 2) + 4 * h;
+      float lg = acc[g] * (sq * sk);
+      if (tok >= len) lg -= 1e8f;
+      S[m][tok] = tok < a.L ? lg * a.scale : -INFINITY;
+    }
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 3, sub = tid & 7;
+    float mx = -INFINITY;
+    for (int l = sub; l < LP; l += 8) mx = fmaxf(mx, S[row][l]);
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    float sum = 0.f;
+    for (int l = sub; l < LP; l += 8) {
+      const float e = expf(S[row][l] - mx);
+      S[row][l] = e;
+      sum += e;
+    }
+    sum += __shfl_xor(sum, 4, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 1, 64);
+    const float inv = 1.f / sum;
+    const int gr = rows[row];
+    for (int l = sub; l < LP; l += 8) {
+      const float p = S[row][l] * inv;
+      S[row][l] = p;
+      if (gr >= 0 && l < a.L) a.attn[(size_t)gr * a.L + l] = p;
+    }
+  }
+  __syncthreads();
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) o[t][g] = 0.f;
+  const int nchunk = LP / 32;
+  auto stage = [&](int c, int buf) {      // tokens 32 c .. + 31 of set u, quantised -> V8[buf]: 512 pieces of 16 codes, two per thread
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int idx = tid + 256 * half;
+      const int tk = idx >> 4, piece = idx & 15;
+      const int l = 32 * c + tk;
+      u32x4v val = {0u, 0u, 0u, 0u};
+      if (l < a.L) {
+        const float* vp = a.v + ((size_t)u * a.L + l) * AC + 16 * piece;
+        const long lo = quant8(vp, iv), hi = quant8(vp + 8, iv);
+        val[0] = (unsigned)(lo & 0xffffffffl); val[1] = (unsigned)((unsigned long)lo >> 32);
+        val[2] = (unsigned)(hi & 0xffffffffl); val[3] = (unsigned)((unsigned long)hi >> 32);
+      }
+      *reinterpret_cast<u32x4v*>(&V8[buf][tk][16 * piece]) = val;
+    }
+  };
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 1 < nchunk) stage(c + 1, (c + 1) & 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ks = 2 * c + kk;
+      bf16x8 phi, plo;
+#pragma unroll
+      for (int s_ = 0; s_ < 8; ++s_) {
+        const float p = S[r][16 * ks + 8 * h + s_];
+        const unsigned short hi = f2bf(p);
+        phi[s_] = (short)hi;
+        plo[s_] = (short)f2bf(p - bf2f(hi));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ch = 64 * wave + 32 * t + r;
+        bf16x8 vb;
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) vb[s_] = (short)f2bf(e4m3_to_f32(V8[c & 1][16 * kk + 8 * h + s_][ch]));
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phi, vb, o[t], 0, 0, 0);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plo, vb, o[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int m = (g & 3) + 8 * (g >> 2) + 4 * h;
+      const int gr = rows[m];
+      if (gr >= 0) a.out[(size_t)gr * AC + 64 * wave + 32 * t + r] = o[t][g] * sv;
+    }
+}
+
 }  // namespace
 
 extern "C" int wsmg_attn_fp8_prep(const float* q, const float* k_sets, const float* v_sets, const int64_t* inverse, int B, int U, int L,
@@ -322,4 +602,45 @@ extern "C" int wsmg_attn_fp8_mfma_fwd(const uint8_t* q_codes, const float* q_sca
   F8mArgs a{q_codes, k_codes, v_codes, q_scale, k_scale, v_scale, lengths, row_ids, set_start, scale, B, U, L, out, attn};
   hipLaunchKernelGGL(attn_fp8_mfma_fwd_kernel, dim3((unsigned)U, (unsigned)wsmg_cdiv(B, 32)), dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, const float* v_sets, const int64_t* inverse, const int* lengths,
+                                        float q_scale, float k_scale, float v_scale, float scale, int B, int U, int L, int C,
+                                        unsigned* workspace, unsigned arrivals_before, int epoch, float* scales_out, float* out, float* attn,
+                                        wsmg_stream_t stream) {
+  if (!q || !k_sets || !v_sets || !inverse || !workspace || !out || !attn) return WSMG_EINVAL;
+  if (B <= 0 || U <= 0 || U > 1024 || L <= 0 || L > LMAX || C != AC) return WSMG_EINVAL;
+  const int tiles = (int)wsmg_cdiv(B, 32);
+  const int64_t nmain = (int64_t)U * tiles;
+  const int need = !(q_scale > 0.f && k_scale > 0.f && v_scale > 0.f);
+  if (need && nmain > 128) return WSMG_EINVAL;       // the spinning workgroups must leave room for the helpers (see the kernel)
+  if (nmain > (1 << 20)) return WSMG_EINVAL;
+  int nhelp = 0;
+  if (need) {     // ~8 KB of float32 per workgroup in the |x| pass, at most one workgroup per CU in all
+    const int64_t tot4 = ((int64_t)B * C + 2ll * U * L * C) / 4;
+    int64_t want = wsmg_cdiv(tot4, 256 * 4);
+    if (want > 224) want = 224;
+    nhelp = want > nmain ? (int)(want - nmain) : 0;
+  }
+  F8fArgs a;
+  a.q = q; a.k = k_sets; a.v = v_sets; a.inverse = inverse; a.lengths = lengths;
+  a.fixed[0] = q_scale; a.fixed[1] = k_scale; a.fixed[2] = v_scale;
+  a.scale = scale; a.B = B; a.U = U; a.L = L; a.tiles = tiles; a.nmain = (int)nmain;
+  a.ws = workspace; a.target = arrivals_before + (unsigned)(nmain + nhelp); a.parity = epoch & 1; a.need_amax = need;
+  a.scales_out = scales_out; a.out = out; a.attn = attn;
+  hipLaunchKernelGGL(attn_fp8_mfma_fused_kernel, dim3((unsigned)(nmain + nhelp)), dim3(256), 0, wsmg_s(stream), a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+/* workgroups wsmg_attn_fp8_mfma_fused launches for this shape when it has to take the maxima itself (= the arrivals one launch adds
+ * to its workspace's counter); 0 when it would refuse the shape */
+extern "C" int wsmg_attn_fp8_mfma_fused_arrivals(int B, int U, int L, int C) {
+  if (B <= 0 || U <= 0 || U > 1024 || L <= 0 || L > LMAX || C != AC) return 0;
+  const int64_t nmain = (int64_t)U * wsmg_cdiv(B, 32);
+  if (nmain > 128) return 0;
+  const int64_t tot4 = ((int64_t)B * C + 2ll * U * L * C) / 4;
+  int64_t want = wsmg_cdiv(tot4, 256 * 4);
+  if (want > 224) want = 224;
+  return (int)(want > nmain ? want : nmain);
 }

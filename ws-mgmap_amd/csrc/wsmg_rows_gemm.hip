@@ -12,10 +12,10 @@
 // in the epilogue: bias, ReLU, the ReLU mask of the backward pass, an accumulate-into (beta = 1), the concatenation as up to
 // three column segments of A, and the split of a backward product's columns into up to three output tensors.
 //
-// Tile = 32 rows x 32 columns per workgroup on v_mfma_f32_32x32x2f32 (bit-for-bit an fmaf chain in k order per wave), the four
-// waves split K (each a contiguous quarter) and meet in LDS in a fixed order: deterministic.  Operands go global -> registers with
-// 16-byte loads along K (lane (r, h) takes k0 + 4 h .. + 3 of row r: the four values feed four consecutive MFMAs, A and W with the
-// same k assignment), 32 k values in flight per wave.  At M = 128 a layer is 32-192 workgroups of 0.26-1 MFLOP each: ~3-5 us.
+// Tile = 32 rows x 32 columns per workgroup on v_mfma_f32_32x32x2f32 (bit-for-bit an fmaf chain in k order per wave), the
+// workgroup's 4-16 waves split K (each a contiguous share) and meet in LDS in a fixed order: deterministic.  Operands go global ->
+// registers with 16-byte loads along K (lane (r, h) takes k0 + 4 h .. + 3 of row r: the four values feed four consecutive MFMAs,
+// A and W with the same k assignment).  At M = 128 a layer is 32-192 workgroups of 0.26-1 MFLOP each.
 #include "wsmg_common.h"
 
 namespace {
@@ -38,43 +38,50 @@ struct RowsGemmArgs {
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-__global__ __launch_bounds__(256) void rows_gemm_f32_kernel(RowsGemmArgs a) {
-  __shared__ float red[4][16][64];
+// WAVES waves per workgroup split K: each takes a contiguous K / WAVES = rounds x 8 U and issues ALL loads of a round (U eight-deep
+// chunks: 2 U 16-byte loads per lane) before its first MFMA — one memory round trip per round.  Everything in the k-loop is
+// branch-free (host: K % (WAVES x 8 U) == 0; the operand segment of a chunk is a pointer SELECT): the first version guarded its
+// loads with `ok ? load : 0`, which hipcc turned into a branch and an `s_waitcnt vmcnt(0)` per load — a chain of dependent round
+// trips, 10-30 us per product.
+template <int WAVES, int U, bool NN>
+__global__ __launch_bounds__(64 * WAVES) void rows_gemm_f32_kernel(RowsGemmArgs a) {
+  __shared__ float red[WAVES][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  const int kq = a.K >> 2;                          // this wave's share of the reduction (host: K % 32 == 0)
+  const int kq = a.K / WAVES;                       // this wave's share of the reduction
   const int kbeg = wave * kq, kend = kbeg + kq;
   const int row = m0 + r < a.M ? m0 + r : a.M - 1;  // rows past M are computed on the last row and never stored
   const int s1 = a.ka[0], s2 = a.ka[0] + a.ka[1];
+  const float* const p0 = a.a[0] + (size_t)row * a.lda[0];
+  const float* const p1 = a.a[1] + (size_t)row * a.lda[1] - s1;      // (never dereferenced below s1: pointer arithmetic only)
+  const float* const p2 = a.a[2] + (size_t)row * a.lda[2] - s2;
+  const float* const wrow = NN ? a.w + n0 + r : a.w + (size_t)(n0 + r) * a.ldw;
   f32x16 acc;
 #pragma unroll
   for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-
-  auto a_ptr = [&](int k) -> const float* {          // &A[row][k], k a multiple of 4 inside one segment (host: segments % 8 == 0)
-    if (k < s1) return a.a[0] + (size_t)row * a.lda[0] + k;
-    if (k < s2) return a.a[1] + (size_t)row * a.lda[1] + (k - s1);
-    return a.a[2] + (size_t)row * a.lda[2] + (k - s2);
-  };
-  constexpr int U = 4;                               // 8-deep chunks in flight
   for (int k0 = kbeg; k0 < kend; k0 += 8 * U) {
     f32x4 av[U], wv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int k = k0 + 8 * u + 4 * h;
-      const bool ok = k0 + 8 * u < kend;
-      av[u] = ok ? ldg4(a_ptr(k)) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!a.nn) {
-        wv[u] = ok ? ldg4(a.w + (size_t)(n0 + r) * a.ldw + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int k = k0 + 8 * u + 4 * h;             // k .. k + 3 lie in one segment (host: segment widths % 8 == 0)
+      const float* const ap = k < s1 ? p0 : (k < s2 ? p1 : p2);
+      av[u] = ldg4(ap + k);
+      if constexpr (!NN) {
+        wv[u] = ldg4(wrow + k);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wv[u][j] = ok ? a.w[(size_t)(k + j) * a.ldw + n0 + r] : 0.f;
+        for (int j = 0; j < 4; ++j) wv[u][j] = wrow[(size_t)(k + j) * a.ldw];
       }
     }
+    // (left alone, hipcc sinks every load to just in front of the MFMA that uses it — fewer live registers, one exposed round trip
+    //  per MFMA: all loads of the round are issued above this line)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], wv[u][j], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int g = 0; g < 16; ++g) red[wave][g][lane] = acc[g];
@@ -84,11 +91,12 @@ __global__ __launch_bounds__(256) void rows_gemm_f32_kernel(RowsGemmArgs a) {
   if (cn >= a.nc[0]) { cn -= a.nc[0]; seg = 1; if (cn >= a.nc[1]) { cn -= a.nc[1]; seg = 2; } }
   float* const cb = a.c[seg];
   const float* const ib = a.cin ? a.cin_seg[seg] : nullptr;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int e = tid + 256 * i, g = e >> 6, l = e & 63;
+  for (int e = tid; e < 1024; e += 64 * WAVES) {
+    const int g = e >> 6, l = e & 63;
     const int orow = m0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), col = l & 31;
-    float v = ((red[0][g][l] + red[1][g][l]) + red[2][g][l]) + red[3][g][l];
+    float v = red[0][g][l];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) v += red[w][g][l];     // fixed order: deterministic
     if (orow >= a.M) continue;
     if (a.bias) v += a.bias[n0 + col];
     if (ib) v += ib[(size_t)orow * a.ldcin[seg] + cn + col];
@@ -96,6 +104,12 @@ __global__ __launch_bounds__(256) void rows_gemm_f32_kernel(RowsGemmArgs a) {
     if (a.mask) v = a.mask[(size_t)orow * a.ldmask + n0 + col] > 0.f ? v : 0.f;
     cb[(size_t)orow * a.ldc[seg] + cn + col] = v;
   }
+}
+
+template <int WAVES, int U>
+void launch_rows(const RowsGemmArgs& g, dim3 grid, hipStream_t s) {
+  if (g.nn) hipLaunchKernelGGL((rows_gemm_f32_kernel<WAVES, U, true>), grid, dim3(64 * WAVES), 0, s, g);
+  else hipLaunchKernelGGL((rows_gemm_f32_kernel<WAVES, U, false>), grid, dim3(64 * WAVES), 0, s, g);
 }
 
 // ---- debug: hold n workgroups' worth of CUs (whole CUs: 1 024 threads and `lds_bytes` of LDS each) until *stop != 0 or max_us passed
@@ -137,7 +151,17 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
   g.cin_seg[0] = cin0; g.cin_seg[1] = cin1; g.cin_seg[2] = cin2;
   g.ldcin[0] = ldcin0; g.ldcin[1] = ldcin1; g.ldcin[2] = ldcin2;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.nn = w_is_kn;
-  hipLaunchKernelGGL(rows_gemm_f32_kernel, dim3((unsigned)(N / 32), (unsigned)wsmg_cdiv(M, 32)), dim3(256), 0, wsmg_s(stream), g);
+  const dim3 grid((unsigned)(N / 32), (unsigned)wsmg_cdiv(M, 32));
+  // (waves, chunks per round): the first shape that divides K — K = 1024: 16 x 8 (one round), 512: 8 x 8, 256: 4 x 8, 1536: 16 x 6 (two
+  // rounds); anything else that is a multiple of 32: 4 x 1.  WSMG_ROWS_GEMM_WAVES caps the waves (A/B).
+  const int cap = WSMG_TUNE("WSMG_ROWS_GEMM_WAVES", 16);
+  hipStream_t st = wsmg_s(stream);
+  if (cap >= 16 && K % (16 * 64) == 0) launch_rows<16, 8>(g, grid, st);
+  else if (cap >= 16 && K % (16 * 48) == 0) launch_rows<16, 6>(g, grid, st);
+  else if (cap >= 8 && K % (8 * 64) == 0) launch_rows<8, 8>(g, grid, st);
+  else if (K % (4 * 64) == 0) launch_rows<4, 8>(g, grid, st);
+  else if (K % (4 * 32) == 0) launch_rows<4, 4>(g, grid, st);
+  else launch_rows<4, 1>(g, grid, st);
   WSMG_RETURN_LAUNCH();
 }
 

@@ -246,6 +246,21 @@ def attention_fp8(q, w_k, b_k, x, lengths, scale=1.0 / 16):
     return _AttnFp8.apply(q, w_k, b_k, x.contiguous(), lengths, scale)
 
 
+last_fp8_shared_launches = 0      # launches the last attention_fp8_shared call took (1: the fused kernel)
+_fp8_fused_ws = {}
+
+
+def _fp8_fused_state(dev):
+    """[workspace (16 zeroed words), arrivals so far, launches that took maxima so far] of wsmg_attn_fp8_mfma_fused for the current
+    stream: the kernel's grid barrier counts arrivals on a monotonic counter, so the host tells every launch where the counter
+    stands (one workspace per stream: launches on one stream do not overlap)."""
+    key = (dev.index, _raw_stream())
+    st = _fp8_fused_ws.get(key)
+    if st is None:
+        st = _fp8_fused_ws[key] = [torch.zeros(16, device=dev, dtype=torch.int32), 0, 0]
+    return st
+
+
 @torch.no_grad()
 def attention_fp8_shared(q, k_sets, v_sets, lengths, inverse, scale=1.0 / 16, scales=None):
     """BASELINE configs[4] on the matrix cores (csrc/wsmg_attn_fp8_mfma.hip): `_attn` (mg_map_policy.py:173-178) of B rows over U
@@ -265,6 +280,25 @@ def attention_fp8_shared(q, k_sets, v_sets, lengths, inverse, scale=1.0 / 16, sc
         inverse = inverse.long()
     q, k_sets, v_sets, inverse = q.contiguous(), k_sets.contiguous(), v_sets.contiguous(), inverse.contiguous()
     s3 = [float(x) if x is not None else 0.0 for x in (scales or (None, None, None))]
+    lens = None if lengths is None else lengths.to(torch.int32).contiguous()
+    global last_fp8_shared_launches
+    # round 5: ONE launch (scales, codes, row grouping and the attention: wsmg_attn_fp8_mfma_fused) whenever the maxima pass's grid
+    # barrier is safe (<= 128 attention workgroups) or the caller fixed the scales; not under a HIP-graph capture (the arrival target
+    # of the barrier is a launch argument)
+    need = not all(x > 0.0 for x in s3)
+    arrivals = int(_abi.lib().wsmg_attn_fp8_mfma_fused_arrivals(B, U, L, C)) if need else 0
+    if sw.fp8_fused and (not need or arrivals > 0) and not torch.cuda.is_current_stream_capturing():
+        st = _fp8_fused_state(dev)
+        out = torch.empty(B, C, device=dev, dtype=torch.float32)
+        attn = torch.empty(B, L, device=dev, dtype=torch.float32)
+        _abi.call("wsmg_attn_fp8_mfma_fused", _p(q), _p(k_sets), _p(v_sets), _p(inverse), _p(lens), s3[0], s3[1], s3[2], float(scale),
+                  B, U, L, C, _p(st[0]), st[1], st[2], None, _p(out), _p(attn), _stream())
+        if need:
+            st[1] = (st[1] + arrivals) & 0xffffffff
+            st[2] += 1
+        last_fp8_shared_launches = 1
+        return out, attn
+    last_fp8_shared_launches = 3 if need else 2
     # scales, codes and the row grouping in two launches (wsmg_attn_fp8_prep) instead of ~25 stock ones
     qc = torch.empty(B, C, device=dev, dtype=torch.uint8)
     kc = torch.empty(U, L, C, device=dev, dtype=torch.uint8)
@@ -276,7 +310,6 @@ def attention_fp8_shared(q, k_sets, v_sets, lengths, inverse, scale=1.0 / 16, sc
     _abi.call("wsmg_attn_fp8_prep", _p(q), _p(k_sets), _p(v_sets), _p(inverse), B, U, L, C, s3[0], s3[1], s3[2], _p(qc), _p(kc), _p(vc),
               _p(sc), _p(order), _p(start), _p(ws), _stream())
     qs, ks, vs = sc[0:1], sc[1:2], sc[2:3]
-    lens = None if lengths is None else lengths.to(torch.int32).contiguous()
     out = torch.empty(B, C, device=dev, dtype=torch.float32)
     attn = torch.empty(B, L, device=dev, dtype=torch.float32)
     _abi.call("wsmg_attn_fp8_mfma_fwd", _p(qc), _p(qs), _p(kc), _p(ks), _p(vc), _p(vs), _p(lens), _p(order), _p(start), float(scale),
