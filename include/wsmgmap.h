@@ -447,6 +447,14 @@ int wsmg_collate_pad(const void* const* src, const int* lengths, int N, int T, i
  * wsmg_nchw_to_nhwc_bf16 (float16 -> float32 is exact, then one rounding to bf16).  C % 64 == 0, HW % 4 == 0, T * N <= 65535. */
 int wsmg_collate_pad_nhwc_bf16(const void* const* src, const int* lengths, int N, int T, int C, int HW, float pad, void* dst,
                                wsmg_stream_t stream);
+/* The same tensor from the SPARSE record form of the ego map (round 5; the recoded trajectory cache of wsmgmap/data/codec.py —
+ * dagger_trainer.py:336-343 stores the dense float16 map, 55-80 % of which is zero): per episode n, bits[n] = uint64 [T_n][HW]
+ * (bit c of pixel p's word: channel c is non-zero), off[n] = uint32 [T_n][HW] (non-zeros of the step in front of pixel p),
+ * base[n] = int64 [T_n + 1] (non-zeros of the episode in front of step t), vals[n] = float16 non-zero values in (step, pixel,
+ * channel) order; lengths [N]; dst bf16 [T][N][HW][64], pad for t >= lengths[n].  C == 64, T * N <= 65535. */
+int wsmg_collate_ego_sparse_nhwc_bf16(const void* const* bits, const void* const* off, const void* const* base,
+                                      const void* const* vals, const int* lengths, int N, int T, int C, int HW, float pad,
+                                      void* dst, wsmg_stream_t stream);
 
 /* ============================ persistent masked-GRU state encoders ============================ */
 /* habitat-lab RNNStateEncoder (GRU, hidden 512) as used at mg_map_policy.py:118-123,147-152,220-227,242-249:
@@ -515,6 +523,23 @@ int wsmg_group_norm_nhwc_bf16(const void* x, int x_f32, const void* residual, co
  * cannot time out; mg_map_policy.py:220-227,242-249, instruction_encoder.py:80-92 are the replaced call sites).
  * wsmg_rnn_debug_spin_limit(n): bound every spin by n polls (0 = default, 2^20) — test hook to force a timeout. */
 int wsmg_rnn_status(int clear);
+/* Whole-sequence GRU launches chained by time chunk to kernels on other streams (round 5: the recurrent core of the update as
+ * three concurrent kernel chains instead of 16 chunk launches; mg_map_policy.py:220-249).  As wsmg_gru_fwd_owned / _bwd_owned, plus:
+ * steps_per_chunk divides T; in_count (may be NULL): one device counter per chunk that must reach in_target before the chunk's
+ * inputs (gi, resp. dy) are read — filled by wsmg_rows_gemm_f32's `signal_count` or by the other recurrence's out_count;
+ * out_count (may be NULL): one counter per chunk to which this launch adds wsmg_gru_chain_workgroups() arrivals when the chunk's
+ * outputs (y and the saved gates, resp. dgi / dgh) are complete.  The caller zeroes the counters before the pass and enqueues a
+ * waiter AFTER its producers. */
+int wsmg_gru_fwd_chain(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                       int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                       float* save_ghn, void* sync_ws, int steps_per_chunk, const unsigned* in_count, unsigned in_target,
+                       unsigned* out_count, wsmg_stream_t stream);
+int wsmg_gru_bwd_chain(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                       const float* y, const float* save_r, const float* save_z, const float* save_n,
+                       const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
+                       void* sync_ws, int steps_per_chunk, const unsigned* in_count, unsigned in_target, unsigned* out_count,
+                       wsmg_stream_t stream);
+int wsmg_gru_chain_workgroups(void);
 int wsmg_rnn_debug_spin_limit(unsigned limit);
 
 /* ---- the update path's heads, auxiliary-loss reduction and trainer loss (csrc/wsmg_heads.hip) ----------------------------
@@ -631,12 +656,20 @@ int wsmg_instruction_dedup(const void* tokens, int is_f32, int B, int L, long lo
  * C: up to three column segments c_i [M][nc_i] (row stride ldc_i) — the split of d(cat) into its parts;
  * epilogue, in this order: + bias[N] (may be NULL), + cin_i (same segmentation as C, may be NULL: beta = 1), ReLU (relu != 0),
  * zero where mask[M][N] <= 0 (row stride ldmask, may be NULL: threshold_backward of the ReLU).
- * K % 32 == 0, ka_i % 8 == 0, nc_i % 32 == 0, strides % 4 == 0; WSMG_EINVAL otherwise.  Deterministic (fixed reduction order). */
+ * K % 64 == 0 (K / 16 a multiple of 16, or of 4, times 1-4, 6 or 8), ka_i % 16 == 0, nc_i % 16 == 0, strides % 4 == 0; WSMG_EINVAL
+ * otherwise.  Deterministic (fixed reduction order).
+ * Chaining to the whole-sequence GRU launches (wsmg_gru_fwd_chain / _bwd_chain): wait_count (may be NULL): every workgroup waits,
+ * bounded, until *wait_count >= wait_target before it reads its operands (they are produced by a kernel still running on another
+ * stream, enqueued earlier); a timeout sets bit `fail_bit` of the persistent kernels' status word (wsmg_rnn_status) and fills the
+ * output with NaN.  signal_count (may be NULL): every workgroup adds one arrival when its tile is stored. */
 int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const float* a1, int lda1, int ka1, const float* a2, int lda2, int ka2,
                        const float* w, int ldw, int w_is_kn, const float* bias, const float* mask, int ldmask, int relu,
                        float* c0, int ldc0, int nc0, float* c1, int ldc1, int nc1, float* c2, int ldc2, int nc2,
                        const float* cin0, int ldcin0, const float* cin1, int ldcin1, const float* cin2, int ldcin2,
-                       int M, wsmg_stream_t stream);
+                       int M, const unsigned* wait_count, unsigned wait_target, unsigned* signal_count, int fail_bit,
+                       wsmg_stream_t stream);
+/* workgroups one wsmg_rows_gemm_f32 launch of M rows x N columns runs (= the arrivals it adds to signal_count) */
+int wsmg_rows_gemm_workgroups(int M, int N);
 
 /* Tests: hold `n_workgroups` whole compute units (1 024 threads + lds_bytes of LDS each) until *stop_flag != 0 (host-mapped or
  * device memory) or max_ms milliseconds have passed; `arrived` (device word, zero on entry) counts the workgroups that started.

@@ -350,7 +350,8 @@ def test_fp8_shared_attention_in_one_launch_equals_the_three_launch_route(monkey
     sets: the barrier's largest grid), with ragged lengths and an uneven row-to-set map, with the caller's scales (no barrier),
     and over repeated launches of alternating shapes on one stream (the arrival counter's bookkeeping).  Larger batches fall back."""
     from wsmgmap import debug, ops
-    from wsmgmap.ops import attention as att
+    import importlib
+    att = importlib.import_module("wsmgmap.ops.attention")
     g = torch.Generator(device="cuda").manual_seed(21)
 
     def case(B, U, L, scales=None):
@@ -386,7 +387,8 @@ def test_fp8_one_launch_attention_reproduces_the_reference_golden_g5f():
     from oracle import cases
     from util import golden
     from wsmgmap import ops
-    from wsmgmap.ops import attention as att
+    import importlib
+    att = importlib.import_module("wsmgmap.ops.attention")
     c = cases.attn_fp8_inputs()
     g = golden("g5f_attn_fp8.npz")
     q, k, v = (torch.from_numpy(c[n]).cuda() for n in ("q", "k", "v"))
@@ -396,3 +398,71 @@ def test_fp8_one_launch_attention_reproduces_the_reference_golden_g5f():
     ea = float(np.abs(attn.cpu().numpy() - g["attn"]).max())
     eo = float(np.abs(out.cpu().numpy() - g["out"]).max() / np.abs(g["out"]).max())
     assert ea <= 3e-5 and eo <= 6e-5, (ea, eo)
+
+
+# ----------------------------------------------------------------------------- the chained recurrent core
+@pytest.mark.parametrize("chunks,T,N", [(4, 64, 8), (8, 64, 8), (4, 12, 3)])
+def test_chained_recurrent_core_is_bit_identical_to_the_chunk_launch_route(chunks, T, N, monkeypatch):
+    """Round 5: each recurrence of the pipelined core as ONE whole-sequence launch, chained to the attention stage's kernels on the
+    other streams by per-chunk arrival counters (device-side waits: csrc/wsmg_rnn.hip chain_wait, wsmg_rows_gemm_f32's wait / signal)
+    instead of K launches per recurrence ordered by events (mg_map_policy.py:220-249).  Same kernels, same arithmetic in the same
+    order: logits, loss, attention row, hidden states and every gradient are equal BIT FOR BIT, three times in a row (a missed
+    wait would read a chunk before it is written)."""
+    import bench
+    import test_gpu_round2 as r2
+    import test_gpu_round4 as r4
+    from wsmgmap import debug, ops
+    pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+    obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 79)
+    masks = masks.clone()
+    masks.view(T, N)[T // 2 + 1, N - 1] = 0
+    monkeypatch.setattr(debug.sw, "recurrent_chain", False)
+    a = r4._one_update(pol, obs, prev, masks, weights, N, chunks)
+    monkeypatch.setattr(debug.sw, "recurrent_chain", True)
+    for rep in range(3):
+        b = r4._one_update(pol, obs, prev, masks, weights, N, chunks)
+        ops.check_rnn_status()
+        assert torch.equal(a[0], b[0]) and a[1] == b[1], rep
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), rep
+        for k, g in a[4].items():
+            if g is not None:
+                assert torch.equal(g, b[4][k]), (rep, k)
+
+
+# ----------------------------------------------------------------------------- sparse ego map through the device collate
+def test_sparse_ego_map_collates_bit_identically_to_the_dense_record():
+    """a recoded record with the sparse ego map (codec.sparse_pack_ego: presence bits + packed non-zeros, 0.4-0.6 x
+    the PCIe bytes of the float16 map of dagger_trainer.py:336-343) goes through DeviceCollator(ego_map_nhwc_bf16=True) — one expansion
+    kernel, wsmg_collate_ego_sparse_nhwc_bf16 — to the SAME padded channels-last bf16 tensor, bit for bit, as the dense record through
+    wsmg_collate_pad_nhwc_bf16 (ragged batch, the 200-step cap, a fully empty and a fully dense step, -0.0); every other sensor is
+    untouched; a float32 collator refuses the sparse record instead of guessing."""
+    from wsmgmap import _abi
+    from wsmgmap.data import DeviceCollator, pack_record_raw, unpack_record
+    rng = np.random.RandomState(8)
+    lengths, C, E = [9, 203, 4], 64, 10
+    dense, sparse = [], []
+    for n in lengths:
+        ego = np.maximum(rng.randn(n, C, E, E), 0.6).astype(np.float16) - np.float16(0.6)
+        ego[0] = 0
+        ego[1] = (rng.randn(C, E, E) + 3).astype(np.float16)
+        ego[2, 7, 3, 3] = np.float16(-0.0)
+        obs = {"instruction": rng.randint(0, 27, size=(n, 6)).astype(np.int64), "rgb_ego_map": ego,
+               "progress": rng.rand(n, 1).astype(np.float32)}
+        rec = (obs, rng.randn(n, 2).astype(np.float32), rng.randn(n, 2).astype(np.float32))
+        dense.append(rec + (torch.ones(n),))
+        o2, p2, a2 = unpack_record(pack_record_raw(*rec, sparse_ego=True))
+        sparse.append(({k: np.asarray(v) for k, v in o2.items()}, np.asarray(p2), np.asarray(a2), torch.ones(n)))
+    want_obs, *want_rest = DeviceCollator("cuda", ego_map_nhwc_bf16=True)(dense)
+    got_obs, *got_rest = DeviceCollator("cuda", ego_map_nhwc_bf16=True)(sparse)
+    torch.cuda.synchronize()
+    for a, b in zip(want_rest, got_rest):
+        assert torch.equal(a, b)
+    assert set(want_obs) == set(got_obs)
+    for k in want_obs:
+        assert want_obs[k].dtype == got_obs[k].dtype and want_obs[k].shape == got_obs[k].shape, k
+        assert torch.equal(want_obs[k].contiguous().view(torch.int16) if want_obs[k].dtype == torch.bfloat16 else want_obs[k],
+                           got_obs[k].contiguous().view(torch.int16) if got_obs[k].dtype == torch.bfloat16 else got_obs[k]), k
+    ego = got_obs["rgb_ego_map"]
+    assert ego.dtype == torch.bfloat16 and ego.permute(0, 2, 3, 1).is_contiguous() and ego.shape[0] == 200 * 3
+    with pytest.raises(_abi.WsmgError):
+        DeviceCollator("cuda")(sparse)

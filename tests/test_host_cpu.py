@@ -566,3 +566,36 @@ def test_truncated_or_corrupt_raw_record_is_refused_with_a_clear_error():
         unpack_record(raw[:len(raw) // 2])
     with pytest.raises(ValueError, match="truncated"):
         unpack_record(raw[:14])
+
+
+def test_sparse_ego_map_record_round_trips_bit_for_bit():
+    """Round 5 (VERDICT r04 item 8): the recoded cache may hold `rgb_ego_map` (dagger_trainer.py:336-343 stores the dense float16 map;
+    55-80 % of it is zero) as presence bits + packed non-zeros (codec.sparse_pack_ego).  The expansion is bit-exact (-0.0 included),
+    cutting an episode to its first steps works on the packed form, a raw record with the sparse map decodes to the same dense map, and
+    the reference-semantics host collate gives the same batch from either record."""
+    from wsmgmap.data import collate_fn, pack_record_raw, unpack_record, sparse_pack_ego, sparse_expand_ego, densify, has_sparse_ego
+    rng = np.random.RandomState(3)
+    eps = []
+    for n in (6, 3):
+        ego = np.maximum(rng.randn(n, 64, 7, 9), 0.5).astype(np.float16) - np.float16(0.5)
+        ego[0, 5, 2, 3] = np.float16(-0.0)
+        obs = {"rgb_ego_map": ego, "progress": rng.rand(n, 1).astype(np.float32), "instruction": rng.randint(0, 9, size=(n, 5)).astype(np.int64)}
+        eps.append((obs, rng.randn(n, 2).astype(np.float32), rng.randn(n, 2).astype(np.float32)))
+    for obs, prev, orc in eps:
+        sp = sparse_pack_ego(obs["rgb_ego_map"])
+        assert sp["rgb_ego_map__vals"].size < 0.5 * obs["rgb_ego_map"].size
+        assert np.array_equal(sparse_expand_ego(sp).view(np.uint16), obs["rgb_ego_map"].view(np.uint16))
+        assert np.array_equal(sparse_expand_ego(sp, 2).view(np.uint16), obs["rgb_ego_map"][:2].view(np.uint16))
+        raw = pack_record_raw(obs, prev, orc, sparse_ego=True)
+        assert len(raw) < 0.75 * len(pack_record_raw(obs, prev, orc))
+        o2, p2, a2 = unpack_record(raw)
+        assert has_sparse_ego(o2) and "rgb_ego_map" not in o2
+        d2 = densify(o2)
+        assert set(d2) == set(obs) and all(np.array_equal(np.asarray(d2[k]), obs[k]) for k in obs)
+        assert np.array_equal(d2["rgb_ego_map"].view(np.uint16), obs["rgb_ego_map"].view(np.uint16))
+    mk = lambda recs: [(r[0], r[1], r[2], torch.ones(len(r[1]))) for r in recs]    # noqa: E731
+    want = collate_fn(mk(eps))
+    got = collate_fn(mk([unpack_record(pack_record_raw(*e, sparse_ego=True)) for e in eps]))
+    assert set(want[0]) == set(got[0]) and all(torch.equal(want[0][k], got[0][k]) for k in want[0])
+    with pytest.raises(TypeError):
+        sparse_pack_ego(np.zeros((2, 32, 4, 4), np.float16))

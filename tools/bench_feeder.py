@@ -65,6 +65,25 @@ def host_side_and_collate():
     a, b = ref_path(), dev_path()
     assert all(torch.equal(a[0][k], b[0][k]) for k in a[0]) and all(torch.equal(x, y) for x, y in zip(a[1:], b[1:]))
     print("both paths produce identical tensors")
+    # one batch through the bf16 / channels-last collate, dense and sparse ego map (round 5), synchronously: staging copy, H2D, kernels
+    from wsmgmap.data import pack_record_raw as _pr, unpack_record as _ur
+    from wsmgmap.data.collate import plan_batch, pack_batch
+    for sp in (False, True):
+        recs2 = [_ur(_pr(r[0], r[1], r[2], sparse_ego=sp)) for r in recs]
+        batch2 = [({k: np.asarray(v) for k, v in r[0].items()}, np.asarray(r[1]), np.asarray(r[2]), torch.ones(T)) for r in recs2]
+        c2 = DeviceCollator("cuda", ego_map_nhwc_bf16=True)
+        plan, meta = plan_batch(batch2)
+        host = c2._staging(meta["total"])
+        t0 = time.time(); pack_batch(plan, meta, host.numpy()); t_pack = time.time() - t0
+        c2.launch(meta, host); torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            th = time.time(); c2.launch(meta, host); t_host = time.time() - th
+            torch.cuda.synchronize()
+        dt = (time.time() - t0) / 5
+        print(f"one batch, ego map {'sparse' if sp else 'dense '} -> NHWC bf16: {meta['total'] / 1e6:6.0f} MB staged; worker-side pack (memcpy into the slot) "
+              f"{t_pack * 1e3:6.1f} ms; consumer-side launch() host {t_host * 1e3:5.1f} ms; H2D + kernels to completion {dt * 1e3:6.1f} ms "
+              f"= {N * T / dt:7.0f} steps/s if nothing overlapped")
 
 
 
@@ -74,26 +93,29 @@ def host_side_and_collate():
 # to the workers), every worker decodes whole batches of its shard, the consumer does what a training loop does with a batch:
 # waits for it on its stream.  Reported next to the compute rate of the update (bench.py: ~42 k steps/s).
 class SynthStore:
-    def __init__(self, n_records, seed=0, raw_records=False):
-        self.n, self.seed, self._blobs, self.raw_records = n_records, seed, None, raw_records
+    def __init__(self, n_records, seed=0, raw_records=False, sparse_ego=False):
+        self.n, self.seed, self._blobs, self.raw_records, self.sparse_ego = n_records, seed, None, raw_records, sparse_ego
 
     def __getstate__(self):
-        return dict(n=self.n, seed=self.seed, _blobs=None, raw_records=self.raw_records)
+        return dict(n=self.n, seed=self.seed, _blobs=None, raw_records=self.raw_records, sparse_ego=self.sparse_ego)
 
     def __call__(self, i):
         if self._blobs is None:
             global rng
             rng = np.random.RandomState(self.seed)
             # raw_records: the recoded cache of tools/recode_cache.py (uncompressed, zero-copy decode)
-            self._blobs = [(pack_record_raw(*episode()) if self.raw_records else pack_record(*episode(), level=1)) for _ in range(4)]
+            self._blobs = [(pack_record_raw(*episode(), sparse_ego=self.sparse_ego) if self.raw_records else pack_record(*episode(), level=1))
+                           for _ in range(4)]
         return self._blobs[i % len(self._blobs)]
 
 
-def feeder_rate(workers, batches_per_worker=6, transport="ring", raw_records=False):
+def feeder_rate(workers, batches_per_worker=6, transport="ring", raw_records=False, sparse_ego=False, nhwc_bf16=False):
     from wsmgmap.data import TrajectoryDataset, DeviceFeeder
     nw = max(workers, 1)
-    ds = TrajectoryDataset(SynthStore(N * batches_per_worker * nw, raw_records=raw_records), N * batches_per_worker * nw, batch_size=N)
-    fd = DeviceFeeder(ds, N, "cuda", num_workers=workers, prefetch=2, workers=transport, slot_bytes=int(raw * 1.05) + (1 << 20))
+    ds = TrajectoryDataset(SynthStore(N * batches_per_worker * nw, raw_records=raw_records, sparse_ego=sparse_ego), N * batches_per_worker * nw,
+                           batch_size=N)
+    fd = DeviceFeeder(ds, N, "cuda", num_workers=workers, prefetch=2, workers=transport, slot_bytes=int(raw * 1.05) + (1 << 20),
+                      ego_map_nhwc_bf16=nhwc_bf16 or sparse_ego)
     t_first, n, steps = None, 0, 0
     for ob, prev, masks, corr, wts in fd:
         torch.cuda.current_stream().synchronize()
@@ -129,5 +151,18 @@ if __name__ == "__main__" and os.environ.get("WSMG_FEEDER_E2E", "1") != "0":
             print(f"  raw ring, {w:2d} worker processes: not run — {str(e).splitlines()[-1][:300]}")
             continue
         print(f"  raw ring, {w:2d} worker processes: {r:8.0f} steps/s  ({n} batches; ring pinned: {pinned}; {r / max(w, 1):.0f} steps/s per worker)")
+    print("the same with the ego map SPARSE in the recoded cache (recode_cache.py --sparse-ego: presence bits + packed non-zeros; this synthetic map "
+          "is 20 % non-zero, real ones 20-45 %) and channels-last bf16 out of the collate (what the bf16 policy reads):")
+    e0 = episode()
+    b_dense, b_sparse = len(pack_record_raw(*e0)), len(pack_record_raw(*e0, sparse_ego=True))
+    print(f"  bytes per step over PCIe: dense {b_dense / T / 1e6:.3f} MB, sparse {b_sparse / T / 1e6:.3f} MB")
+    for w in [min(int(x), 32) for x in os.environ.get("WSMG_FEEDER_WORKERS_RAW", "1,4,8,16").split(",")]:
+        for sp in (False, True):
+            try:
+                r, n, pinned = feeder_rate(w, batches_per_worker=12, raw_records=True, sparse_ego=sp, nhwc_bf16=True)
+            except RuntimeError as e:
+                print(f"  raw ring, {w:2d} workers, sparse={sp}: not run — {str(e).splitlines()[-1][:300]}")
+                continue
+            print(f"  raw ring, {w:2d} worker processes, ego map {'sparse' if sp else 'dense '} -> NHWC bf16: {r:8.0f} steps/s  ({n} batches)")
     r, n, _ = feeder_rate(8, transport="dataloader")
     print(f"  torch DataLoader transport, 8 workers (batches pickled through a pipe): {r:8.0f} steps/s")

@@ -17,14 +17,14 @@ sys.path.insert(0, os.path.join(ROOT, "ws-mgmap_amd"))
 from wsmgmap.data.codec import recode_record  # noqa: E402
 
 
-def recode_store(get, n, put, workers=8, chunk=64):
+def recode_store(get, n, put, workers=8, chunk=64, sparse_ego=False):
     """Recode records 0 .. n-1 of `get` into `put`; zlib releases the GIL, so threads scale the inflate.  -> (bytes in, bytes out)."""
     nin = nout = 0
     with ThreadPoolExecutor(max(1, workers)) as ex:
         for base in range(0, n, chunk):
             ids = list(range(base, min(n, base + chunk)))
             blobs = [bytes(get(i)) for i in ids]
-            for i, b, r in zip(ids, blobs, ex.map(recode_record, blobs)):
+            for i, b, r in zip(ids, blobs, ex.map(lambda x: recode_record(x, sparse_ego=sparse_ego), blobs)):
                 put(i, r)
                 nin += len(b)
                 nout += len(r)
@@ -37,6 +37,9 @@ def main():
     ap.add_argument("dst")
     ap.add_argument("--map-size-gb", type=float, default=2000.0)
     ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--sparse-ego", action="store_true",
+                    help="store rgb_ego_map as presence bits + packed non-zeros (codec.sparse_pack_ego): 0.4-0.6 x the bytes per step; "
+                         "needs DeviceCollator / DeviceFeeder(ego_map_nhwc_bf16=True), i.e. a bf16 policy")
     a = ap.parse_args()
     import lmdb
     src = lmdb.open(a.src, readonly=True, lock=False)
@@ -52,7 +55,7 @@ def main():
                 for k, v in pending:
                     t.put(k, v)
             pending.clear()
-    nin, nout = recode_store(lambda i: txn_r.get(str(i).encode()), n, put, a.workers)
+    nin, nout = recode_store(lambda i: txn_r.get(str(i).encode()), n, put, a.workers, sparse_ego=a.sparse_ego)
     if pending:
         with dst.begin(write=True) as t:
             for k, v in pending:

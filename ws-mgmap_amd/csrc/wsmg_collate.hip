@@ -99,6 +99,49 @@ __global__ __launch_bounds__(256) void collate_pad_nhwc_bf16_kernel(const void* 
   }
 }
 
+// The same tensor from the SPARSE record form (round 5; wsmgmap/data/codec.py): per episode n the presence bits [T_n][HW] (one 8-byte
+// word per pixel: bit c = channel c), the per-pixel exclusive prefix of non-zeros inside its step off[T_n][HW], the per-step prefix
+// base[T_n + 1], and the packed non-zero float16 values.  One wave per pixel, lane = channel: the word is a broadcast load, lane c's
+// value sits at base + off + popcount(word & lanes below c) — 64 lanes read <= 64 consecutive values — and the 128-byte channel run
+// of the pixel is one coalesced store.  float16 -> float32 -> bf16 as in the dense kernel: bit-identical output.
+__global__ __launch_bounds__(256) void collate_ego_sparse_nhwc_bf16_kernel(const void* const* __restrict__ bits, const void* const* __restrict__ off,
+                                                                           const void* const* __restrict__ base, const void* const* __restrict__ vals,
+                                                                           const int* __restrict__ lengths, int N, int HW, float pad,
+                                                                           bf16_t* __restrict__ dst) {
+  const int row = blockIdx.y, t = row / N, n = row - t * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = t < lengths[n];
+  const unsigned long long* const bw = reinterpret_cast<const unsigned long long*>(bits[n]) + (size_t)t * HW;
+  const unsigned* const ow = reinterpret_cast<const unsigned*>(off[n]) + (size_t)t * HW;
+  const _Float16* const vv = reinterpret_cast<const _Float16*>(vals[n]);
+  const long long b0 = live ? reinterpret_cast<const long long*>(base[n])[t] : 0;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  constexpr int PPW = 16, U = 4;                       // pixels per wave and workgroup trip; loads of U pixels in flight
+  const int p0 = (blockIdx.x * 4 + wave) * PPW;
+  for (int i = 0; i < PPW; i += U) {
+    unsigned long long w[U];
+    unsigned o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + i + u;
+      const bool ok = live && p < HW;
+      w[u] = ok ? bw[p] : 0ull;
+      o[u] = ok ? ow[p] : 0u;
+    }
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool bit = (w[u] >> lane) & 1ull;
+      v[u] = bit ? (float)vv[b0 + (long long)o[u] + __popcll(w[u] & below)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + i + u;
+      if (p < HW) dst[((size_t)row * HW + p) * 64 + lane] = (bf16_t)(live ? v[u] : pad);
+    }
+  }
+}
+
 template <int DT>
 int launch(const void* const* src, const int* lengths, int N, int T, int64_t elems, float pad, float* dst, hipStream_t s) {
   const bool v4 = (elems % 4) == 0;
@@ -132,5 +175,16 @@ extern "C" int wsmg_collate_pad_nhwc_bf16(const void* const* src, const int* len
   if (N <= 0 || T <= 0 || C <= 0 || HW <= 0 || (C % 64) || (HW % 4) || (int64_t)T * N > 65535) return WSMG_EINVAL;
   hipLaunchKernelGGL(collate_pad_nhwc_bf16_kernel, dim3((unsigned)wsmg_cdiv(HW, 64), (unsigned)(C / 64), (unsigned)(T * N)), dim3(256), 0,
                      wsmg_s(stream), src, lengths, N, C, HW, pad, (bf16_t*)dst);
+  WSMG_RETURN_LAUNCH();
+}
+
+/* The padded, episode-interleaved channels-last bf16 ego map [T][N][HW][64] from the SPARSE record form (wsmgmap/data/codec.py:
+ * bits / off / base / vals per episode); values bit-identical to wsmg_collate_pad_nhwc_bf16 on the dense map. */
+extern "C" int wsmg_collate_ego_sparse_nhwc_bf16(const void* const* bits, const void* const* off, const void* const* base,
+                                                 const void* const* vals, const int* lengths, int N, int T, int C, int HW, float pad,
+                                                 void* dst, wsmg_stream_t stream) {
+  if (N <= 0 || T <= 0 || C != 64 || HW <= 0 || (int64_t)T * N > 65535) return WSMG_EINVAL;
+  hipLaunchKernelGGL(collate_ego_sparse_nhwc_bf16_kernel, dim3((unsigned)wsmg_cdiv(HW, 64), (unsigned)(T * N)), dim3(256), 0, wsmg_s(stream),
+                     bits, off, base, vals, lengths, N, HW, pad, (bf16_t*)dst);
   WSMG_RETURN_LAUNCH();
 }

@@ -96,3 +96,6 @@ int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* b
 int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,
                               hipStream_t s);
 int wsmg_conv_win3_wgrad_splits(int B, int H, int W, int Cin, int Cout);
+// wsmg_rnn.hip: device pointer of the process-wide persistent-kernel status word (host-mapped; bits 1 gru_fwd, 2 gru_bwd, 4 lstm_fwd,
+// 8 lstm_bwd), for kernels of other files that wait on a chain counter (wsmg_rows_gemm.hip)
+unsigned* wsmgi_rnn_status_dev();

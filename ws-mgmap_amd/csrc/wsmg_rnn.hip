@@ -84,6 +84,44 @@ __device__ __forceinline__ bool grid_barrier(unsigned* sync, unsigned target, in
   return *ok_lds != 0;
 }
 
+// ---- round 5: chaining a whole-sequence launch to kernels on OTHER streams by time chunk (wsmgmap/recurrent.py) -------------------
+// The pipelined recurrent core cut each recurrence into K launches so that the attention stage of chunk k could start when the
+// first recurrence had finished chunk k, and the second recurrence's chunk k when the attention stage had: every chunk launch paid
+// the ~10 us prologue (W_hh into registers) and a launch gap again, 16 times per update.  Chained, a recurrence is ONE launch:
+//   * a PRODUCER (in_cnt == null side) adds one arrival per workgroup to out_cnt[k] when the outputs of its chunk k are complete
+//     (all threads' stores drained -> workgroup barrier -> agent-scope release -> add);
+//   * a CONSUMER spins (bounded, thread 0) at the first step of chunk k until in_cnt[k] has reached in_target, then an
+//     agent-scope acquire; the kernels that fill its inputs run on another stream, enqueued BEFORE it, and signal the same way
+//     (wsmg_rows_gemm_f32's `signal`).
+// Counters are zeroed by the host once per pass.  A waiter is always enqueued after its producers, so whatever hardware queues the
+// streams share, the producer is never stuck behind its own waiter.
+__device__ __forceinline__ bool chain_wait(const unsigned* cnt, unsigned target, unsigned* sync, unsigned limit, int tid) {
+  int bad = 0;
+  if (tid == 0) {
+    unsigned n = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(32);      // (~1 us between polls: 32 waiting workgroups must not compete with the running recurrence's exchange)
+      if (++n >= limit || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return !__syncthreads_or(bad);
+}
+__device__ __forceinline__ void chain_signal(unsigned* cnt, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // cross-lane exchange with lane ^ D at VALU rate where the ISA has a pattern for it: xor 1 / xor 2 =
 // DPP quad_perm, xor 8 = DPP row rotate by 8; xor 4 falls back to ds_bpermute
 template <int D>
@@ -138,6 +176,11 @@ struct GruFwdArgs {
   unsigned tagbase;    // launch-unique tag bits (epoch << 10); a word is valid for step t when tag == tagbase | (t + 1)
   unsigned* status;    // host-mapped process status word (rnn_fail)
   unsigned spin;       // spin bound
+  // chaining by time chunk (see chain_wait): steps per chunk (0: none), the counters gi's chunks are ready behind / this launch reports on
+  int Tc;
+  const unsigned* in_cnt;
+  unsigned in_target;
+  unsigned* out_cnt;
 };
 
 // Flag-in-data exchange (forward): every h value travels as one 8-byte {value, tag} word written with a
@@ -347,6 +390,11 @@ __global__ __launch_bounds__(512) void gru_fwd8_kernel(GruFwdArgs a) {
   const int sw = tid >> 4, sb = (tid >> 1) & 7, sh = tid & 1;
   const int xw = (blockIdx.x * NB + my_b) * UNITS_WG + wave * UNITS_WAVE + grp;
   for (int t = 0; t < a.T; ++t) {
+    if (a.in_cnt && t % a.Tc == 0 && !chain_wait(a.in_cnt + t / a.Tc, a.in_target, a.sync, a.spin, tid)) {   // gi of this chunk is not there yet
+      rnn_fail(a.status, 1u);
+      rnn_poison(a.y, (size_t)a.T * a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
+      return;
+    }
     float (*hcur)[H] = hs[t & 1];
     float gr = 0.f, gz = 0.f, gn = 0.f;
     const size_t orow = (size_t)t * a.N + my_b;
@@ -425,6 +473,7 @@ __global__ __launch_bounds__(512) void gru_fwd8_kernel(GruFwdArgs a) {
       a.sn[orow * H + my_unit] = nn;
       a.sghn[orow * H + my_unit] = ghn;
     }
+    if (a.out_cnt && (t + 1) % a.Tc == 0) chain_signal(a.out_cnt + t / a.Tc, tid);   // y of this chunk is complete (this workgroup's part)
   }
 }
 
@@ -448,6 +497,11 @@ struct GruBwdArgs {
   unsigned tagbase;    // launch-unique tag bits; a word belongs to step t when tag == tagbase | (t + 1)
   unsigned* status;    // host-mapped process status word (rnn_fail)
   unsigned spin;       // spin bound
+  // chaining by time chunk (see chain_wait): steps per chunk (0: none), the counters dy's chunks are ready behind / this launch reports on
+  int Tc;
+  const unsigned* in_cnt;
+  unsigned in_target;
+  unsigned* out_cnt;
 };
 
 // Backward exchange: PARTIAL SUMS of dh, not gate gradients.  dh_{t-1}[k] needs sum over all 3H gate rows of
@@ -625,6 +679,15 @@ __global__ __launch_bounds__(512) void gru_bwd8_kernel(GruBwdArgs a) {
 
   float direct = 0.f, mk_next = 0.f;
   for (int t = a.T - 1; t >= -1; --t) {
+    if (a.in_cnt && t >= 0 && t % a.Tc == a.Tc - 1 && !chain_wait(a.in_cnt + t / a.Tc, a.in_target, a.sync, a.spin, tid)) {   // dy of this chunk
+      rnn_fail(a.status, 2u);
+      for (int g = 0; g < 3; ++g) {
+        rnn_poison(a.dgi, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
+        rnn_poison(a.dgh, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
+      }
+      rnn_poison(a.dh0, (size_t)a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
+      return;
+    }
     float dyv = 0.f, r = 0.f, z = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, mk = 0.f;
     size_t row = 0;
     if (worker && t >= 0) {
@@ -738,6 +801,7 @@ __global__ __launch_bounds__(512) void gru_bwd8_kernel(GruBwdArgs a) {
         __hip_atomic_store(dst + b * UNITS_WG + 1, tag | __float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    if (a.out_cnt && t % a.Tc == 0) chain_signal(a.out_cnt + t / a.Tc, tid);   // dgi / dgh of this chunk are complete (this workgroup's part)
   }
 }
 
@@ -797,7 +861,8 @@ extern "C" int64_t wsmg_gru_workspace_bytes(int T) {
 }
 
 static int gru_fwd_launch(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks, int T, int N, int hidden,
-                          float* y, float* save_r, float* save_z, float* save_n, float* save_ghn, void* sync_ws, hipStream_t s, bool clear) {
+                          float* y, float* save_r, float* save_z, float* save_n, float* save_ghn, void* sync_ws, hipStream_t s, bool clear,
+                          int Tc = 0, const unsigned* in_cnt = nullptr, unsigned in_target = 0, unsigned* out_cnt = nullptr) {
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
   if (T > 1023) return WSMG_EINVAL;
@@ -806,8 +871,8 @@ static int gru_fwd_launch(const float* gi, const float* w_hh, const float* b_hh,
   // memory handed to a new process can still hold a previous process's image with the same epoch numbers
   if (clear && (e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)T * NWG * NB * UNITS_WG * 8, s)) != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
-               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
-  if (WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B)
+               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin, Tc, in_cnt, in_target, out_cnt};
+  if (Tc > 0 || WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B; not chained)
     hipLaunchKernelGGL(gru_fwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
     WSMG_RETURN_LAUNCH();
   }
@@ -833,7 +898,8 @@ extern "C" int wsmg_gru_fwd_owned(const float* gi, const float* w_hh, const floa
 
 static int gru_bwd_launch(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks, const float* y,
                           const float* save_r, const float* save_z, const float* save_n, const float* save_ghn, int T, int N, int hidden,
-                          float* dgi, float* dgh, float* dh0, void* sync_ws, hipStream_t s, bool clear) {
+                          float* dgi, float* dgh, float* dh0, void* sync_ws, hipStream_t s, bool clear,
+                          int Tc = 0, const unsigned* in_cnt = nullptr, unsigned in_target = 0, unsigned* out_cnt = nullptr) {
   if (hidden != H || T <= 0 || N <= 0 || N > NB) return WSMG_EINVAL;
   if (((uintptr_t)sync_ws & 127) != 0) return WSMG_EINVAL;
   if (T > 1023) return WSMG_EINVAL;
@@ -841,8 +907,8 @@ static int gru_bwd_launch(const float* dy, const float* dhT, const float* w_hh, 
   // control words and the ring of {value, tag} words are cleared (see wsmg_gru_fwd)
   if (clear && (e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)BWD_RING * XP_SLOT * 8, s)) != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
-               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin};
-  if (WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B)
+               (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin, Tc, in_cnt, in_target, out_cnt};
+  if (Tc > 0 || WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B; not chained)
     hipLaunchKernelGGL(gru_bwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
     WSMG_RETURN_LAUNCH();
   }
@@ -863,6 +929,31 @@ extern "C" int wsmg_gru_bwd_owned(const float* dy, const float* dhT, const float
                                   void* sync_ws, wsmg_stream_t stream) {
   return gru_bwd_launch(dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, T, N, hidden, dgi, dgh, dh0, sync_ws, wsmg_s(stream), false);
 }
+
+// Whole-sequence launches chained by time chunk to kernels on other streams (round 5; see chain_wait): steps_per_chunk divides T;
+// in_count (may be NULL): one counter per chunk that must reach in_target before the chunk's inputs (gi, resp. dy) are read;
+// out_count (may be NULL): one counter per chunk this launch adds its 32 workgroups' arrivals to when the chunk's outputs (y and
+// the saved gates, resp. dgi / dgh) are complete.  Counters are the caller's, zeroed before the pass.  Workspace as *_owned.
+extern "C" int wsmg_gru_fwd_chain(const float* gi, const float* w_hh, const float* b_hh, const float* h0, const float* masks,
+                                  int T, int N, int hidden, float* y, float* save_r, float* save_z, float* save_n,
+                                  float* save_ghn, void* sync_ws, int steps_per_chunk, const unsigned* in_count, unsigned in_target,
+                                  unsigned* out_count, wsmg_stream_t stream) {
+  if (steps_per_chunk <= 0 || T % steps_per_chunk) return WSMG_EINVAL;
+  return gru_fwd_launch(gi, w_hh, b_hh, h0, masks, T, N, hidden, y, save_r, save_z, save_n, save_ghn, sync_ws, wsmg_s(stream), false,
+                        steps_per_chunk, in_count, in_target, out_count);
+}
+extern "C" int wsmg_gru_bwd_chain(const float* dy, const float* dhT, const float* w_hh, const float* h0, const float* masks,
+                                  const float* y, const float* save_r, const float* save_z, const float* save_n,
+                                  const float* save_ghn, int T, int N, int hidden, float* dgi, float* dgh, float* dh0,
+                                  void* sync_ws, int steps_per_chunk, const unsigned* in_count, unsigned in_target, unsigned* out_count,
+                                  wsmg_stream_t stream) {
+  if (steps_per_chunk <= 0 || T % steps_per_chunk) return WSMG_EINVAL;
+  return gru_bwd_launch(dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, T, N, hidden, dgi, dgh, dh0, sync_ws, wsmg_s(stream), false,
+                        steps_per_chunk, in_count, in_target, out_count);
+}
+extern "C" int wsmg_gru_chain_workgroups(void) { return NWG; }
+// (wsmg_rows_gemm_f32's wait reports a timeout through the same process-wide status word)
+__attribute__((visibility("hidden"))) unsigned* wsmgi_rnn_status_dev() { return rnn_status_dev(); }
 
 // =================================================================================================
 // Persistent packed bidirectional LSTM (instruction encoder, hidden 128 per direction, U <= 8 unique

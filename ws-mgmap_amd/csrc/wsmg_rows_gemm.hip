@@ -12,10 +12,8 @@
 // in the epilogue: bias, ReLU, the ReLU mask of the backward pass, an accumulate-into (beta = 1), the concatenation as up to
 // three column segments of A, and the split of a backward product's columns into up to three output tensors.
 //
-// Tile = 32 rows x 32 columns per workgroup on v_mfma_f32_32x32x2f32 (bit-for-bit an fmaf chain in k order per wave), the
-// workgroup's 4-16 waves split K (each a contiguous share) and meet in LDS in a fixed order: deterministic.  Operands go global ->
-// registers with 16-byte loads along K (lane (r, h) takes k0 + 4 h .. + 3 of row r: the four values feed four consecutive MFMAs,
-// A and W with the same k assignment).  At M = 128 a layer is 32-192 workgroups of 0.26-1 MFLOP each.
+// Tile = 16 rows x 16 columns per workgroup on v_mfma_f32_16x16x4f32 (float32 products and sums), the workgroup's 4-16 waves split K
+// (each a contiguous share) and meet in LDS in a fixed order: deterministic.  At M = 128 a layer is 128-768 workgroups.
 #include "wsmg_common.h"
 
 namespace {
@@ -34,75 +32,105 @@ struct RowsGemmArgs {
   const float* cin_seg[3];
   int ldcin[3];
   int M, N, K, relu, nn;
+  // chaining to the persistent recurrences (wsmg_rnn.hip, chain_wait / chain_signal): every workgroup waits (bounded) until *wait_cnt
+  // has reached wait_target before it reads anything, and adds one arrival to *signal_cnt when its tile is stored
+  const unsigned* wait_cnt;
+  unsigned wait_target;
+  unsigned* signal_cnt;
+  unsigned* status;      // process-wide status word (a wait that times out sets bit `fail_bit` and the tile becomes NaN)
+  unsigned fail_bit;
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// WAVES waves per workgroup split K: each takes a contiguous K / WAVES = rounds x 8 U and issues ALL loads of a round (U eight-deep
-// chunks: 2 U 16-byte loads per lane) before its first MFMA — one memory round trip per round.  Everything in the k-loop is
-// branch-free (host: K % (WAVES x 8 U) == 0; the operand segment of a chunk is a pointer SELECT): the first version guarded its
-// loads with `ok ? load : 0`, which hipcc turned into a branch and an `s_waitcnt vmcnt(0)` per load — a chain of dependent round
-// trips, 10-30 us per product.
+// Tile = 16 rows x 16 columns per workgroup (v_mfma_f32_16x16x4f32), WAVES waves split K: each takes a contiguous K / WAVES = 16 U
+// and issues ALL its loads (U 16-deep chunks: 2 U 16-byte loads per lane; lane (r, kg) takes k0 + 4 kg .. + 3 of row r, the four values
+// feed four consecutive MFMAs, A and W with the same k assignment) before its first MFMA — one memory round trip per launch.
+// Everything in the k-loop is branch-free (the operand segment of a chunk is a pointer SELECT).  History of this kernel (round 5):
+//   * `ok ? load : 0` guards became a branch and an `s_waitcnt vmcnt(0)` per load — a chain of dependent round trips, 10-30 us per
+//     product; without the sched_barrier below hipcc sinks every load to just in front of its MFMA, same effect;
+//   * 32 x 32 tiles (v_mfma_f32_32x32x2f32, 64 cycles each) put a product on 32-192 workgroups whose K / 2 dependent MFMAs share the
+//     CU's four matrix pipes: K x 8 cycles = 3.9 us at K = 1024 however the waves split it, 10-15 us per product in the trace; at
+//     16 x 16 the same product is 4x the workgroups (256 for the compress layer: the whole chip) with a quarter of the MFMA time each.
 template <int WAVES, int U, bool NN>
 __global__ __launch_bounds__(64 * WAVES) void rows_gemm_f32_kernel(RowsGemmArgs a) {
-  __shared__ float red[WAVES][16][64];
+  __shared__ float red[WAVES][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  const int kq = a.K / WAVES;                       // this wave's share of the reduction
-  const int kbeg = wave * kq, kend = kbeg + kq;
+  const int r = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int kbeg = wave * 16 * U;                   // this wave's share of the reduction (host: K == WAVES x 16 U)
   const int row = m0 + r < a.M ? m0 + r : a.M - 1;  // rows past M are computed on the last row and never stored
   const int s1 = a.ka[0], s2 = a.ka[0] + a.ka[1];
+  bool timed_out = false;
+  if (a.wait_cnt) {       // the operands are produced by a kernel that is still running on another stream (enqueued before this one)
+    int bad = 0;
+    if (tid == 0) {
+      unsigned n = 0;
+      while (__hip_atomic_load(a.wait_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.wait_target) {
+        __builtin_amdgcn_s_sleep(32);                     // (~1 us: a poll per workgroup and microsecond, not a stream of them)
+        if (++n >= (1u << 21)) { bad = 1; break; }        // (seconds)
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (bad && a.status) __hip_atomic_fetch_or(a.status, a.fail_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    timed_out = __syncthreads_or(bad) != 0;
+  }
   const float* const p0 = a.a[0] + (size_t)row * a.lda[0];
   const float* const p1 = a.a[1] + (size_t)row * a.lda[1] - s1;      // (never dereferenced below s1: pointer arithmetic only)
   const float* const p2 = a.a[2] + (size_t)row * a.lda[2] - s2;
   const float* const wrow = NN ? a.w + n0 + r : a.w + (size_t)(n0 + r) * a.ldw;
-  f32x16 acc;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 av[U], wv[U];
 #pragma unroll
-  for (int g = 0; g < 16; ++g) acc[g] = 0.f;
-  for (int k0 = kbeg; k0 < kend; k0 += 8 * U) {
-    f32x4 av[U], wv[U];
+  for (int u = 0; u < U; ++u) {
+    const int k = kbeg + 16 * u + 4 * kg;           // k .. k + 3 lie in one segment (host: segment widths % 16 == 0)
+    const float* const ap = k < s1 ? p0 : (k < s2 ? p1 : p2);
+    av[u] = ldg4(ap + k);
+    if constexpr (!NN) {
+      wv[u] = ldg4(wrow + k);
+    } else {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = k0 + 8 * u + 4 * h;             // k .. k + 3 lie in one segment (host: segment widths % 8 == 0)
-      const float* const ap = k < s1 ? p0 : (k < s2 ? p1 : p2);
-      av[u] = ldg4(ap + k);
-      if constexpr (!NN) {
-        wv[u] = ldg4(wrow + k);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wv[u][j] = wrow[(size_t)(k + j) * a.ldw];
-      }
+      for (int j = 0; j < 4; ++j) wv[u][j] = wrow[(size_t)(k + j) * a.ldw];
     }
-    // (left alone, hipcc sinks every load to just in front of the MFMA that uses it — fewer live registers, one exposed round trip
-    //  per MFMA: all loads of the round are issued above this line)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][j], wv[u][j], acc, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
   }
+  __builtin_amdgcn_sched_barrier(0);                // all loads are issued above this line
 #pragma unroll
-  for (int g = 0; g < 16; ++g) red[wave][g][lane] = acc[g];
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][j], wv[u][j], acc, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) red[wave][g][lane] = acc[g];
   __syncthreads();
-  // column segment of this tile (host: segment widths % 32 == 0, so a tile lies in one segment)
+  // column segment of this tile (host: segment widths % 16 == 0, so a tile lies in one segment)
   int seg = 0, cn = n0;
   if (cn >= a.nc[0]) { cn -= a.nc[0]; seg = 1; if (cn >= a.nc[1]) { cn -= a.nc[1]; seg = 2; } }
   float* const cb = a.c[seg];
   const float* const ib = a.cin ? a.cin_seg[seg] : nullptr;
-  for (int e = tid; e < 1024; e += 64 * WAVES) {
-    const int g = e >> 6, l = e & 63;
-    const int orow = m0 + (g & 3) + 8 * (g >> 2) + 4 * (l >> 5), col = l & 31;
+  if (tid < 256) {
+    const int g = tid >> 6, l = tid & 63;
+    const int orow = m0 + 4 * (l >> 4) + g, col = l & 15;   // D of v_mfma_f32_16x16x4f32: lane l, register g -> row 4 (l / 16) + g, column l % 16
     float v = red[0][g][l];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) v += red[w][g][l];     // fixed order: deterministic
-    if (orow >= a.M) continue;
-    if (a.bias) v += a.bias[n0 + col];
-    if (ib) v += ib[(size_t)orow * a.ldcin[seg] + cn + col];
-    if (a.relu) v = v > 0.f ? v : 0.f;
-    if (a.mask) v = a.mask[(size_t)orow * a.ldmask + n0 + col] > 0.f ? v : 0.f;
-    cb[(size_t)orow * a.ldc[seg] + cn + col] = v;
+    if (orow < a.M) {
+      if (a.bias) v += a.bias[n0 + col];
+      if (ib) v += ib[(size_t)orow * a.ldcin[seg] + cn + col];
+      if (a.relu) v = v > 0.f ? v : 0.f;
+      if (a.mask) v = a.mask[(size_t)orow * a.ldmask + n0 + col] > 0.f ? v : 0.f;
+      const float ov = timed_out ? __uint_as_float(0x7fc00000u) : v;
+      float* const op = cb + (size_t)orow * a.ldc[seg] + cn + col;
+      // a signalling launch writes its tile THROUGH to the memory side (agent-scope stores): a waiter on another XCD must find it
+      // there, and the alternative — an agent-scope release fence (an L2 write-back) in each of the launch's 256-768 workgroups —
+      // made the second GRU's input projection 23 us instead of 9 (profiles/r05_update_timeline.txt)
+      if (a.signal_cnt) __hip_atomic_store(op, ov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *op = ov;
+    }
+  }
+  if (a.signal_cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.signal_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -130,13 +158,14 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
                                   const float* w, int ldw, int w_is_kn, const float* bias, const float* mask, int ldmask, int relu,
                                   float* c0, int ldc0, int nc0, float* c1, int ldc1, int nc1, float* c2, int ldc2, int nc2,
                                   const float* cin0, int ldcin0, const float* cin1, int ldcin1, const float* cin2, int ldcin2,
-                                  int M, wsmg_stream_t stream) {
+                                  int M, const unsigned* wait_count, unsigned wait_target, unsigned* signal_count, int fail_bit,
+                                  wsmg_stream_t stream) {
   if (!a0 || !w || !c0 || M <= 0 || ka0 <= 0 || nc0 <= 0) return WSMG_EINVAL;
   if ((ka1 > 0 && !a1) || (ka2 > 0 && !a2) || (nc1 > 0 && !c1) || (nc2 > 0 && !c2) || ka1 < 0 || ka2 < 0 || nc1 < 0 || nc2 < 0) return WSMG_EINVAL;
   if (ka2 > 0 && ka1 <= 0) return WSMG_EINVAL;
   if (nc2 > 0 && nc1 <= 0) return WSMG_EINVAL;
   const int K = ka0 + ka1 + ka2, N = nc0 + nc1 + nc2;
-  if (K % 32 || ka0 % 8 || ka1 % 8 || ka2 % 8 || nc0 % 32 || nc1 % 32 || nc2 % 32) return WSMG_EINVAL;
+  if (K % 64 || ka0 % 16 || ka1 % 16 || ka2 % 16 || nc0 % 16 || nc1 % 16 || nc2 % 16) return WSMG_EINVAL;
   if ((lda0 | lda1 | lda2 | ldw) & 3) return WSMG_EINVAL;       // 16-byte loads along K (NT) / rows of A
   const bool any_cin = cin0 != nullptr;
   if (any_cin && ((nc1 > 0 && !cin1) || (nc2 > 0 && !cin2))) return WSMG_EINVAL;
@@ -151,19 +180,41 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
   g.cin_seg[0] = cin0; g.cin_seg[1] = cin1; g.cin_seg[2] = cin2;
   g.ldcin[0] = ldcin0; g.ldcin[1] = ldcin1; g.ldcin[2] = ldcin2;
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.nn = w_is_kn;
-  const dim3 grid((unsigned)(N / 32), (unsigned)wsmg_cdiv(M, 32));
-  // (waves, chunks per round): the first shape that divides K — K = 1024: 16 x 8 (one round), 512: 8 x 8, 256: 4 x 8, 1536: 16 x 6 (two
-  // rounds); anything else that is a multiple of 32: 4 x 1.  WSMG_ROWS_GEMM_WAVES caps the waves (A/B).
+  g.wait_cnt = wait_count; g.wait_target = wait_target; g.signal_cnt = signal_count;
+  g.status = wait_count ? wsmgi_rnn_status_dev() : nullptr; g.fail_bit = (unsigned)fail_bit;
+  const dim3 grid((unsigned)(N / 16), (unsigned)wsmg_cdiv(M, 16));
+  // (waves, chunks per wave) with waves x 16 x chunks == K: K = 256: 16 x 1, 512: 16 x 2, 1024: 16 x 4, 1536: 16 x 6 — every product of
+  // the recurrent core is one round of loads; other multiples of 64: 4 waves; WSMG_ROWS_GEMM_WAVES caps the waves (A/B)
   const int cap = WSMG_TUNE("WSMG_ROWS_GEMM_WAVES", 16);
   hipStream_t st = wsmg_s(stream);
-  if (cap >= 16 && K % (16 * 64) == 0) launch_rows<16, 8>(g, grid, st);
-  else if (cap >= 16 && K % (16 * 48) == 0) launch_rows<16, 6>(g, grid, st);
-  else if (cap >= 8 && K % (8 * 64) == 0) launch_rows<8, 8>(g, grid, st);
-  else if (K % (4 * 64) == 0) launch_rows<4, 8>(g, grid, st);
-  else if (K % (4 * 32) == 0) launch_rows<4, 4>(g, grid, st);
-  else launch_rows<4, 1>(g, grid, st);
+  const int c16 = K / 16;                           // 16-deep chunks in all
+  if (cap >= 16 && c16 % 16 == 0 && c16 / 16 <= 8) {
+    switch (c16 / 16) {
+      case 1: launch_rows<16, 1>(g, grid, st); break;
+      case 2: launch_rows<16, 2>(g, grid, st); break;
+      case 3: launch_rows<16, 3>(g, grid, st); break;
+      case 4: launch_rows<16, 4>(g, grid, st); break;
+      case 6: launch_rows<16, 6>(g, grid, st); break;
+      case 8: launch_rows<16, 8>(g, grid, st); break;
+      default: return WSMG_EINVAL;                  // (K = 1280, 1792: not a shape of this path)
+    }
+  } else if (c16 % 4 == 0 && c16 / 4 <= 8) {
+    switch (c16 / 4) {
+      case 1: launch_rows<4, 1>(g, grid, st); break;
+      case 2: launch_rows<4, 2>(g, grid, st); break;
+      case 3: launch_rows<4, 3>(g, grid, st); break;
+      case 4: launch_rows<4, 4>(g, grid, st); break;
+      case 6: launch_rows<4, 6>(g, grid, st); break;
+      case 8: launch_rows<4, 8>(g, grid, st); break;
+      default: return WSMG_EINVAL;
+    }
+  } else {
+    return WSMG_EINVAL;
+  }
   WSMG_RETURN_LAUNCH();
 }
+
+extern "C" int wsmg_rows_gemm_workgroups(int M, int N) { return (M <= 0 || N <= 0) ? 0 : (N / 16) * (int)wsmg_cdiv(M, 16); }
 
 extern "C" int wsmg_debug_occupy(int n_workgroups, int lds_bytes, int max_ms, const int* stop_flag, unsigned* arrived, wsmg_stream_t stream) {
   if (n_workgroups <= 0 || n_workgroups > 256 || lds_bytes < 0 || lds_bytes > 160 * 1024 || max_ms <= 0 || max_ms > 10000 || !stop_flag || !arrived)

@@ -148,9 +148,15 @@ _SIG["wsmg_path_kl_fwd"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_
 _SIG["wsmg_path_kl_bwd"] = [c_p, c_p, c_p, c_i, c_i, c_p, c_p]
 _SIG["wsmg_adam_step_multi"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_double, ctypes.c_double, c_p]
 _SIG["wsmg_adam_step_multi_dev"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
-_SIG["wsmg_rows_gemm_f32"] = ([c_p, c_i, c_i] * 3 + [c_p, c_i, c_i, c_p, c_p, c_i, c_i] + [c_p, c_i, c_i] * 3 + [c_p, c_i] * 3 + [c_i, c_p])
+_SIG["wsmg_rows_gemm_f32"] = ([c_p, c_i, c_i] * 3 + [c_p, c_i, c_i, c_p, c_p, c_i, c_i] + [c_p, c_i, c_i] * 3 + [c_p, c_i] * 3
+                              + [c_i, c_p, ctypes.c_uint, c_p, c_i, c_p])
+_SIG["wsmg_rows_gemm_workgroups"] = [c_i, c_i]
+_SIG["wsmg_gru_fwd_chain"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_i, c_p, ctypes.c_uint, c_p, c_p]
+_SIG["wsmg_gru_bwd_chain"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_i, c_p, ctypes.c_uint, c_p, c_p]
+_SIG["wsmg_gru_chain_workgroups"] = []
 _SIG["wsmg_attn_fp8_mfma_fused"] = [c_p] * 5 + [c_f] * 4 + [c_i] * 4 + [c_p, ctypes.c_uint, c_i, c_p, c_p, c_p, c_p]
 _SIG["wsmg_attn_fp8_mfma_fused_arrivals"] = [c_i] * 4
+_SIG["wsmg_collate_ego_sparse_nhwc_bf16"] = [c_p] * 5 + [c_i] * 4 + [c_f, c_p, c_p]
 _SIG["wsmg_debug_occupy"] = [c_i, c_i, c_i, c_p, c_p, c_p]
 _RESTYPE = {"wsmg_cls_tail_workspace_floats": c_l, "wsmg_attn_fp8_workspace_bytes": c_l, "wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
 

@@ -14,6 +14,7 @@ from .. import _abi
 
 LIMITED_LEN_BY_GPU = 200   # dagger_trainer.py:82
 _DT = {np.dtype(np.float16): 0, np.dtype(np.uint8): 1, np.dtype(np.int64): 2, np.dtype(np.float32): 3}
+_SPARSE = "rgb_ego_map__"      # the sparse ego map's arrays (codec.sparse_pack_ego): they travel as raw bytes, one kernel expands them
 
 
 def _pad(t, max_len, fill):
@@ -26,8 +27,9 @@ def _pad(t, max_len, fill):
 def collate_fn(batch):
     """[(obs, prev_actions, oracle_actions, weights)] -> (obs [T*N, ...], prev_actions [T*N, 2], not_done_masks [T*N, 1],
     corrected_actions [T, N, 2], weights [T, N]) on the host, dtypes as stored."""
+    from .codec import densify
     as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.array(a))  # noqa: E731
-    obs_l = [{k: as_t(v) for k, v in b[0].items()} for b in batch]
+    obs_l = [{k: as_t(v) for k, v in densify(b[0]).items()} for b in batch]
     prev_l, corr_l, w_l = [as_t(b[1]) for b in batch], [as_t(b[2]) for b in batch], [as_t(b[3]) for b in batch]
     T = min(max(p.size(0) for p in prev_l), LIMITED_LEN_BY_GPU)
     obs = {}
@@ -50,7 +52,18 @@ def plan_batch(batch):
     lengths = [int(len(b[1])) for b in batch]
     T = min(max(lengths), LIMITED_LEN_BY_GPU)
     # episodes longer than T are cut before they travel
-    plan = [(k, [np.ascontiguousarray(np.asarray(b[0][k])[:T]) for b in batch], 1.0) for k in batch[0][0]]
+    plan = [(k, [np.ascontiguousarray(np.asarray(b[0][k])[:T]) for b in batch], 1.0) for k in batch[0][0] if not k.startswith(_SPARSE)]
+    sparse = None
+    if _SPARSE + "bits" in batch[0][0]:
+        # the sparse ego map (codec.sparse_pack_ego): bits / off cut to T steps, base to T + 1, the values to what those steps hold
+        C, H, W = (int(x) for x in np.asarray(batch[0][0][_SPARSE + "shape"]))
+        cut = [min(n, T) for n in lengths]
+        plan.append((_SPARSE + "bits", [np.ascontiguousarray(np.asarray(b[0][_SPARSE + "bits"])[:c]) for b, c in zip(batch, cut)], 1.0))
+        plan.append((_SPARSE + "off", [np.ascontiguousarray(np.asarray(b[0][_SPARSE + "off"])[:c]).view(np.uint8) for b, c in zip(batch, cut)], 1.0))
+        plan.append((_SPARSE + "base", [np.ascontiguousarray(np.asarray(b[0][_SPARSE + "base"])[:c + 1]) for b, c in zip(batch, cut)], 1.0))
+        plan.append((_SPARSE + "vals", [np.ascontiguousarray(np.asarray(b[0][_SPARSE + "vals"])[:int(np.asarray(b[0][_SPARSE + "base"])[c])])
+                                         for b, c in zip(batch, cut)], 1.0))
+        sparse = dict(C=C, H=H, W=W)
     plan.append(("__prev", [np.ascontiguousarray(np.asarray(b[1], dtype=np.float32)[:T]) for b in batch], 0.0))
     plan.append(("__corr", [np.ascontiguousarray(np.asarray(b[2], dtype=np.float32)[:T]) for b in batch], 0.0))
     plan.append(("__wts", [np.ascontiguousarray(np.asarray(b[3], dtype=np.float32)[:T]) for b in batch], 0.0))
@@ -64,6 +77,8 @@ def plan_batch(batch):
             total += a.nbytes
         sensors.append((name, tuple(arrs[0].shape[1:]), _DT[arrs[0].dtype], float(pad)))
     meta = dict(N=N, T=T, lengths=[min(n, T) for n in lengths], offsets=offs, total=total + 16, sensors=sensors)
+    if sparse is not None:
+        meta["sparse_ego"] = sparse
     dd = _host_dedup(plan, meta)
     if dd is not None:
         meta["dedup"] = dd
@@ -152,7 +167,12 @@ class DeviceCollator:
             ptrs_dev = torch.tensor([base + o for o in offs], dtype=torch.int64).pin_memory().to(self.device, non_blocking=True)
             dev.copy_(host[:total], non_blocking=True)
             out, row = {}, 0
+            sp_rows = {}
             for name, shape, code, pad in meta["sensors"]:
+                if name.startswith(_SPARSE):         # raw bytes of the sparse ego map: expanded by one kernel below
+                    sp_rows[name[len(_SPARSE):]] = row
+                    row += N
+                    continue
                 elems = int(np.prod(shape, dtype=np.int64))
                 if (self.ego_map_nhwc_bf16 and name == "rgb_ego_map" and code == _DT[np.dtype(np.float16)] and len(shape) == 3
                         and shape[0] % 64 == 0 and (shape[1] * shape[2]) % 4 == 0 and T * N <= 65535):
@@ -169,6 +189,17 @@ class DeviceCollator:
                           ctypes.c_void_p(stream.cuda_stream))
                 row += N
                 out[name] = dst
+            if sp_rows:
+                sp = meta["sparse_ego"]
+                if not self.ego_map_nhwc_bf16:
+                    raise _abi.WsmgError("a trajectory cache with the sparse ego map needs DeviceCollator(ego_map_nhwc_bf16=True) "
+                                         "(the bf16 policy's channels-last input); recode it without --sparse-ego for float32 policies")
+                C, HW = sp["C"], sp["H"] * sp["W"]
+                dst = torch.empty((T, N, sp["H"], sp["W"], C), dtype=torch.bfloat16, device=self.device)
+                at = lambda k: ctypes.c_void_p(ptrs_dev.data_ptr() + 8 * sp_rows[k])  # noqa: E731
+                _abi.call("wsmg_collate_ego_sparse_nhwc_bf16", at("bits"), at("off"), at("base"), at("vals"), ctypes.c_void_p(lens_dev.data_ptr()),
+                          N, T, C, HW, 1.0, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(stream.cuda_stream))
+                out["rgb_ego_map"] = dst.permute(0, 1, 4, 2, 3)
             dev.record_stream(stream)
             masks = torch.ones(T, N, dtype=torch.float32, device=self.device)
             masks[0] = 0

@@ -16,6 +16,7 @@ _TABLE = [
     ("recurrent_chunks", "WSMG_RECURRENT_CHUNKS", 4, int, "time chunks of the pipelined recurrent core (wsmgmap/recurrent.py); 0 = the staged route"),
     ("rows_gemm", "WSMG_ROWS_GEMM", True, bool, "the recurrent core's dense layers as one launch each (csrc/wsmg_rows_gemm.hip); 0: the GEMM library"),
     ("fp8_fused", "WSMG_FP8_FUSED", True, bool, "ops.attention_fp8_shared as one launch (wsmg_attn_fp8_mfma_fused) where its grid barrier is safe"),
+    ("recurrent_chain", "WSMG_RECURRENT_CHAIN", True, bool, "each recurrence of the pipelined core as ONE launch chained to the attention stage by device-side counters"),
     ("decoder_streams", "WSMG_DECODER_STREAMS", 1, int, "0: map decoder on one stream; 1: side stream unless ranks share a GPU; 2: always"),
     ("early_dedup", "WSMG_EARLY_DEDUP", True, bool, "instruction dedup on its own stream when the producer marked the tokens ready (ops.mark_inputs_ready)"),
     ("early_dedup_dp", "WSMG_EARLY_DEDUP_DP", False, bool, "the early dedup also under a process group (needs the exchange on a policy stream: GradAllReducer(exchange_stream=...))"),

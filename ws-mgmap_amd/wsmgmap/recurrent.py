@@ -79,22 +79,26 @@ def _prow(t, row):
     return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
 
 
-def _rg(a_segs, w, w_is_kn, out_segs, r0, M, bias=None, cin_segs=None, mask=None, relu=False):
+def _rg(a_segs, w, w_is_kn, out_segs, r0, M, bias=None, cin_segs=None, mask=None, relu=False, wait=None, signal=None, fail_bit=1):
     """One launch of wsmg_rows_gemm_f32 on rows r0 .. r0 + M of full-batch row-major tensors: C = epilogue([A0|A1|A2] W^T) (w_is_kn
     False: W an nn.Linear weight [N, K]) or ([A0|A1|A2] W) (True: W [K, N], the backward product dY W).  a_segs / out_segs /
-    cin_segs: lists of up to three 2-D tensors (their column counts are the segment widths); mask: the ReLU-backward mask source."""
+    cin_segs: lists of up to three 2-D tensors (their column counts are the segment widths); mask: the ReLU-backward mask source.
+    wait = (counter address, target): every workgroup waits for it before reading (operands produced by a chained GRU launch that
+    is still running); signal = counter address: every workgroup adds an arrival when its tile is stored."""
     z = (None, 0, 0)
     A = [(_prow(t, r0), t.stride(0), t.shape[1]) for t in a_segs] + [z] * (3 - len(a_segs))
     Cs = [(_prow(t, r0), t.stride(0), t.shape[1]) for t in out_segs] + [z] * (3 - len(out_segs))
     Ci = [(_prow(t, r0), t.stride(0)) for t in (cin_segs or [])] + [(None, 0)] * (3 - len(cin_segs or []))
     _abi.call("wsmg_rows_gemm_f32", *A[0], *A[1], *A[2], _p(w), w.stride(0), int(bool(w_is_kn)), _p(bias),
               None if mask is None else _prow(mask, r0), 0 if mask is None else mask.stride(0), int(bool(relu)),
-              *Cs[0], *Cs[1], *Cs[2], *Ci[0], *Ci[1], *Ci[2], int(M), _stream())
+              *Cs[0], *Cs[1], *Cs[2], *Ci[0], *Ci[1], *Ci[2], int(M),
+              None if wait is None else ctypes.c_void_p(wait[0]), 0 if wait is None else int(wait[1]),
+              None if signal is None else ctypes.c_void_p(signal), int(fail_bit), _stream())
 
 
 def rows_gemm_ok(H, C, in1):
     """Shapes wsmg_rows_gemm_f32 takes for the attention stage's five products (hidden size H, attention width C, GRU-2 input)."""
-    return _sw.rows_gemm and H % 32 == 0 and C % 32 == 0 and in1 % 32 == 0
+    return _sw.rows_gemm and H % 256 == 0 and C % 256 == 0 and in1 % 256 == 0
 
 
 def _roles(streams, main):
@@ -169,7 +173,7 @@ class _RecurrentBlock(torch.autograd.Function):
         map_emb = torch.empty(B, C, **f32)
         att_map = torch.empty(B, I, **f32)
         x = None            # (the concatenation is an operand of the rows-GEMM route: the leaf pass rebuilds it for dW)
-        if not (rows_gemm_ok(H, C, wc.shape[0]) and wq1.shape[0] % 32 == 0 and wq2.shape[0] % 32 == 0):
+        if not (rows_gemm_ok(H, C, wc.shape[0]) and wq1.shape[0] % 256 == 0 and wq2.shape[0] % 256 == 0):
             x = torch.empty(B, wc.shape[1], **f32)
         xc = torch.empty(B, wc.shape[0], **f32)
         gi2 = torch.empty(B, 3 * H, **f32)
@@ -203,18 +207,33 @@ class _RecurrentBlock(torch.autograd.Function):
         gi1v, gi2v = gi1.view(T, N, 3 * H), gi2.view(T, N, 3 * H)
         y1r = y1.view(B, H)
         multi = sa is not main
+        rg = rows_gemm_ok(H, C, wc.shape[0]) and wq1.shape[0] % 256 == 0 and wq2.shape[0] % 256 == 0
+        # round 5 — chained: each recurrence is ONE whole-sequence launch; the attention stage's first product of chunk k waits (on the
+        # device) for the first recurrence's arrivals on counter k, its last product signals counter K + k, which the second
+        # recurrence waits for at the first step of chunk k (csrc/wsmg_rnn.hip chain_wait).  No chunk prologues (W_hh into registers:
+        # ~10 us, 16 times per update), no launch gaps, no events; a waiter is enqueued after its producers.
+        chain = multi and rg and owned and _sw.recurrent_chain and K > 1
+        cnt = None
+        if chain:
+            cnt = torch.zeros(2 * K, device=dev, dtype=torch.int32)
+            nwg = int(lib.wsmg_gru_chain_workgroups())
+            sa.wait_stream(main)         # (the counters are zeroed on main)
+            sg.wait_stream(main)
+            _abi.call("wsmg_gru_fwd_chain", _p(gi1), _p(w_hh1), _p(b_hh1), _p(h01), _p(m), T, N, H, _p(y1), *[_p(s_) for s_ in sv1],
+                      _p(_owned_ws(dev, "f1", lib.wsmg_gru_workspace_bytes(T))), Tc, None, 0, _p(cnt), _stream())
+            _rnn_launched()
+            _ops.mark("f.g1")
         # Enqueue order: stream by stream (all of GRU 1's chunks, then all attention chunks, then all of GRU 2's) — the dependencies are
         # events, so the GPU sees the same pipeline as with a chunk-by-chunk order, and the host changes its current stream twice
         # instead of eight times (the host has < 1.5 ms of lead over the GPU in this part of an update)
         ev1, eva = [], []
-        for k in range(K):
+        for k in range(0 if chain else K):
             gru(gi1v, w_hh1, b_hh1, h01, y1, sv1, k, "f1")                             # main
             _ops.mark("f.g1.%d" % k)
             if multi:
                 e1 = torch.cuda.Event()
                 e1.record(main)
                 ev1.append(e1)
-        rg = rows_gemm_ok(H, C, wc.shape[0]) and wq1.shape[0] % 32 == 0 and wq2.shape[0] % 32 == 0
         with torch.cuda.stream(sa):
             if not rg:
                 q1.copy_(bq1.expand_as(q1))
@@ -223,12 +242,12 @@ class _RecurrentBlock(torch.autograd.Function):
                 gi2.copy_(b_ih2.expand_as(gi2))
             for k in range(K):
                 r0, r1 = k * rows, (k + 1) * rows
-                if multi:
+                if multi and not chain:
                     sa.wait_event(ev1[k])
                 if rg:
                     # round 5: every dense layer of the stage is ONE launch (csrc/wsmg_rows_gemm.hip): bias, the concatenation, the
                     # ReLU in the epilogue / operand segments — 7 launches per chunk instead of 9 + 4 pre-fills, each ~4 us
-                    _rg([y1r], wq1, False, [q1], r0, rows, bias=bq1)
+                    _rg([y1r], wq1, False, [q1], r0, rows, bias=bq1, wait=(cnt.data_ptr() + 4 * k, nwg) if chain else None, fail_bit=1)
                 else:
                     q1[r0:r1].addmm_(y1r[r0:r1], wq1.t())
                 _abi.call("wsmg_attn_shared_fwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _p(text_mask), _prow(inverse, r0),
@@ -243,19 +262,25 @@ class _RecurrentBlock(torch.autograd.Function):
                           _prow(map_emb, r0), _prow(att_map, r0), _stream())
                 if rg:
                     _rg([y1r, text_emb, map_emb], wc, False, [xc], r0, rows, bias=bc, relu=True)
-                    _rg([xc], w_ih2, False, [gi2], r0, rows, bias=b_ih2)
+                    _rg([xc], w_ih2, False, [gi2], r0, rows, bias=b_ih2, signal=cnt.data_ptr() + 4 * (K + k) if chain else None)
                 else:
                     torch.cat([y1r[r0:r1], text_emb[r0:r1], map_emb[r0:r1]], dim=1, out=x[r0:r1])
                     xc[r0:r1].addmm_(x[r0:r1], wc.t())
                     torch.relu_(xc[r0:r1])
                     gi2[r0:r1].addmm_(xc[r0:r1], w_ih2.t())
                 _ops.mark("f.at.%d" % k)
-                if multi:
+                if multi and not chain:
                     ea = torch.cuda.Event()
                     ea.record(sa)
                     eva.append(ea)
         with torch.cuda.stream(sg):
-            for k in range(K):
+            if chain:
+                _abi.call("wsmg_gru_fwd_chain", _p(gi2), _p(w_hh2), _p(b_hh2), _p(h02), _p(m), T, N, H, _p(y2), *[_p(s_) for s_ in sv2],
+                          _p(_owned_ws(dev, "f2", lib.wsmg_gru_workspace_bytes(T))), Tc, ctypes.c_void_p(cnt.data_ptr() + 4 * K),
+                          int(lib.wsmg_rows_gemm_workgroups(rows, 3 * H)), None, _stream())
+                _rnn_launched()
+                _ops.mark("f.g2")
+            for k in range(0 if chain else K):
                 if multi:
                     sg.wait_event(eva[k])
                 gru(gi2v, w_hh2, b_hh2, h02, y2, sv2, k, "f2")
@@ -266,6 +291,7 @@ class _RecurrentBlock(torch.autograd.Function):
         ctx.save_for_backward(state_in, tokens, text_k, text_v, inverse, m, h01, h02, w_ih1, w_hh1, wq1, wq2, wk2, wc, w_ih2, w_hh2,
                               gi1, y1, *sv1, y2, *sv2, q1, text_emb, attn_text, q2, qf, att_map, map_emb if x is None else x, xc)
         ctx.x_is_parts = x is None
+        ctx.chain = chain
         ctx.cfg = (N, K, Tc, scale, sink, tuple(wk.shape), text_mask is not None)
         ctx.params = (w_ih1, b_ih1, w_hh1, b_hh1, wq1, bq1, wq2, bq2, wk, bk, wc, bc, w_ih2, b_ih2, w_hh2, b_hh2)
         h1n, h2n = y1[-1:].clone(), y2[-1:].clone()
@@ -367,8 +393,22 @@ class _RecurrentBlock(torch.autograd.Function):
 
         # stream by stream, as in forward: GRU 2's chunks (last chunk first), the attention stage's, GRU 1's
         ev2, eva = {}, {}
+        chain = multi and rg and owned and ctx.chain and K > 1
+        cnt = None
+        if chain:     # (see forward: one launch per recurrence, device-side waits on per-chunk arrival counters)
+            cnt = torch.zeros(2 * K, device=dev, dtype=torch.int32)
+            keep.append(cnt)
+            nwg = int(lib.wsmg_gru_chain_workgroups())
+            sg.wait_stream(main)
+            sa.wait_stream(main)
         with torch.cuda.stream(sg):
-            for k in range(K - 1, -1, -1):
+            if chain:
+                _abi.call("wsmg_gru_bwd_chain", _p(dy2), None, _p(w_hh2), _p(h02), _p(m), _p(y2), _p(sr2), _p(sz2), _p(sn2), _p(sg2), T, N, H,
+                          _p(dgi2), _p(dgh2), _p(dh02), _p(_owned_ws(dev, "b2", lib.wsmg_gru_workspace_bytes(T))), Tc, None, 0, _p(cnt),
+                          _stream())
+                _rnn_launched()
+                _ops.mark("b.g2")
+            for k in range(K - 1 if not chain else -1, -1, -1):
                 gru_bwd(dy2, w_hh2, h02, y2, (sr2, sz2, sn2, sg2), dgi2, dgh2, dh02, carry2, k, "b2")
                 _ops.mark("b.g2.%d" % k)
                 if multi:
@@ -379,13 +419,13 @@ class _RecurrentBlock(torch.autograd.Function):
             wk2t = wk2.t()
             for k in range(K - 1, -1, -1):
                 r0, r1 = k * rows, (k + 1) * rows
-                if multi:
+                if multi and not chain:
                     sa.wait_event(ev2[k])
                 if rg:
                     # round 5: five launches of wsmg_rows_gemm_f32 around the two attention kernels (was 9 GEMM-library launches + a
                     # threshold_backward): the ReLU mask, the split of d(cat) into its three parts and the two accumulate-intos
                     # (beta = 1, in place) ride in the epilogues
-                    _rg([dgi2r], w_ih2, True, [dxc], r0, rows, mask=xcr)
+                    _rg([dgi2r], w_ih2, True, [dxc], r0, rows, mask=xcr, wait=(cnt.data_ptr() + 4 * k, nwg) if chain else None, fail_bit=2)
                     _rg([dxc], wc, True, [dstate_r, dtext, dmap_all], r0, rows)
                     _abi.call("wsmg_attn_bwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), _prow(att_map, r0), _prow(dmap_all, r0),
                               None if datt is None else _prow(datt, r0), scale, rows, I, C, _prow(dqf, r0), _prow(dtokens, r0),
@@ -394,7 +434,7 @@ class _RecurrentBlock(torch.autograd.Function):
                     _rg([dq2], wq2, True, [dtext], r0, rows, cin_segs=[dtext])
                     _abi.call("wsmg_attn_shared_bwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _prow(attn_text, r0), _prow(dtext, r0),
                               None, _prow(inverse, r0), scale, rows, L, C, _prow(dq1, r0), _prow(dl, r0), _stream())
-                    _rg([dq1], wq1, True, [dstate_r], r0, rows, cin_segs=[dstate_r])
+                    _rg([dq1], wq1, True, [dstate_r], r0, rows, cin_segs=[dstate_r], signal=cnt.data_ptr() + 4 * (K + k) if chain else None)
                 else:
                     # ReLU of second_state_compress: d(pre-activation) = d(xc) where xc > 0
                     dxc_k = dxc[r0:r1]
@@ -412,10 +452,16 @@ class _RecurrentBlock(torch.autograd.Function):
                               None, _prow(inverse, r0), scale, rows, L, C, _prow(dq1, r0), _prow(dl, r0), _stream())
                     torch.addmm(dstate_a, dq1[r0:r1], wq1, out=dstate_r[r0:r1])
                 _ops.mark("b.at.%d" % k)
-                if multi:
+                if multi and not chain:
                     eva[k] = torch.cuda.Event()
                     eva[k].record(sa)
-        for k in range(K - 1, -1, -1):
+        if chain:
+            _abi.call("wsmg_gru_bwd_chain", _p(dstate), None, _p(w_hh1), _p(h01), _p(m), _p(y1), _p(sr1), _p(sz1), _p(sn1), _p(sg1), T, N, H,
+                      _p(dgi1), _p(dgh1), _p(dh01), _p(_owned_ws(dev, "b1", lib.wsmg_gru_workspace_bytes(T))), Tc,
+                      ctypes.c_void_p(cnt.data_ptr() + 4 * K), int(lib.wsmg_rows_gemm_workgroups(rows, H)), None, _stream())
+            _rnn_launched()
+            _ops.mark("b.g1")
+        for k in range(K - 1 if not chain else -1, -1, -1):
             if multi:
                 main.wait_event(eva[k])
             gru_bwd(dstate, w_hh1, h01, y1, (sr1, sz1, sn1, sg1), dgi1, dgh1, dh01, carry1, k, "b1")      # main
