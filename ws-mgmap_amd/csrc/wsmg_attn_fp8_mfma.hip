@@ -17,6 +17,8 @@
 //
 // One workgroup = one set and one tile of 32 of its rows (rows are addressed through a list grouped by set).  On inputs that are
 // exactly e4m3 numbers the result equals the reference's float32 `_attn` up to summation order — golden g5f.
+#include <stdio.h>
+
 #include "wsmg_common.h"
 
 namespace {
@@ -108,6 +110,9 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fwd_kernel(F8mArgs a) {
   // ---- softmax over the tokens: 8 lanes per row, float32; attention weights to global, P stays in LDS
   {
     const int row = tid >> 3, sub = tid & 7;
+    // (rows of the tile that hold no query — 24 of 32 at B = 64 over 8 sets — are skipped: their logits are never read as results, and
+    //  the softmax is 3.7 of the kernel's 30 us there)
+    if (rows[row] >= 0) {
     float mx = -INFINITY;
     for (int l = sub; l < LP; l += 8) mx = fmaxf(mx, S[row][l]);
     mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fwd_kernel(F8mArgs a) {
       const float p = S[row][l] * inv;
       S[row][l] = p;
       if (gr >= 0 && l < a.L) a.attn[(size_t)gr * a.L + l] = p;
+    }
     }
   }
   __syncthreads();
@@ -311,6 +317,7 @@ struct F8fArgs {
   float* scales_out;       // [3] or null: the scales used (diagnostics / tests)
   float* out;
   float* attn;
+  float* trace;            // WSMG_FP8_TRACE=1 (diagnostic): microseconds since the start of workgroup 0 at its phase boundaries
 };
 
 __device__ __forceinline__ long quant8(const float* p, float inv_scale) {
@@ -328,16 +335,98 @@ __device__ __forceinline__ float scale_of(float am, float fixed) {
   return fixed > 0.f ? fixed : (am != am ? am : fmaxf(am * (1.0f / 448.0f), 1e-30f));
 }
 
+// quantiser's expression on 8 values already in registers (the codes wsmg_attn_fp8_prep writes)
+__device__ __forceinline__ long quant8r(const f32x4 a, const f32x4 b, float inv_scale) {
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = fminf(fmaxf(x[j] * inv_scale, -448.f), 448.f);
+  int w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w0, true);
+  int w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], 0, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], w1, true);
+  return (long)(((unsigned long)(unsigned)w1 << 32) | (unsigned long)(unsigned)w0);
+}
+
+// Order inside an attention workgroup (second form of this kernel; the first — maxima, barrier, then every operand loaded and
+// quantised where it was needed — took 32 us at B = 64, as long as the three launches it replaced: the value chunks alone were five
+// dependent load -> convert -> LDS -> barrier rounds, 12 us): the rows of the (set, tile) first — they need `inverse` only —, then ALL
+// float32 loads that do not depend on a scale are ISSUED (the tile's queries, the set's values: up to 350 registers per lane, one
+// wave per SIMD has 512), then the maxima pass and the grid barrier run while those loads are in flight; after the barrier the
+// registers are quantised (queries to MFMA operands, values to the LDS image of all chunks at once) and only the keys are loaded
+// behind it.  The arithmetic per element is unchanged.
+constexpr int NCHMAX = LMAX / 32;      // 7 value chunks of 32 tokens at most
+
 __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
-  __shared__ __attribute__((aligned(16))) float S[32][LMAX + 4];
-  __shared__ __attribute__((aligned(16))) uint8_t V8[2][32][AC + 16];
+  // (dynamic: 29 KB of logits + 60 KB of value codes are more than the 64 KB a kernel may declare statically without an attribute)
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+  float (*S)[LMAX + 4] = reinterpret_cast<float (*)[LMAX + 4]>(fused_lds);
+  uint8_t (*V8)[32][AC + 16] = reinterpret_cast<uint8_t (*)[32][AC + 16]>(fused_lds + 32 * (LMAX + 4) * 4);
   __shared__ int rows[32];
   __shared__ int wtot[4];
   __shared__ float wm[4][3];
   __shared__ float sc3[3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = blockIdx.x;
-  // ---- phase A
+  const unsigned long long t_start = wall_clock64();
+  auto stamp = [&](int i) { if (a.trace && wg == 0 && tid == 0) a.trace[i] = (float)(wall_clock64() - t_start) * 0.01f; };
+  const bool main_wg = wg < a.nmain;
+  const int u = main_wg ? wg % a.U : 0, tile = main_wg ? wg / a.U : 0;
+  const int first = tile * 32;
+  const int r = lane & 31, h = lane >> 5;
+  const int LP = (a.L + 31) & ~31;
+  const int nchunk = LP / 32;
+  // ---- the rows of this workgroup's (set, tile): rank = position among the set's rows in row order
+  int running = 0;
+  if (main_wg) {
+    if (tid < 32) rows[tid] = -1;
+    __syncthreads();
+    for (int base = 0; base < a.B; base += 256) {
+      const int b = base + tid;
+      bool mine = false;
+      if (b < a.B) {
+        const int64_t su = a.inverse[b];
+        mine = (int)(su < 0 ? 0 : su >= a.U ? a.U - 1 : su) == u;
+      }
+      const unsigned long long bal = __ballot(mine);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wtot[wave] = __popcll(bal);
+      __syncthreads();
+      int off = running;
+      for (int w = 0; w < wave; ++w) off += wtot[w];
+      const int rank = off + before;
+      if (mine && rank >= first && rank < first + 32) rows[rank - first] = b;
+      running += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      __syncthreads();
+    }
+  }
+  const bool active = main_wg && first < running;      // (uniform) this workgroup has rows to attend for
+  stamp(0);
+  // ---- issue the scale-independent loads: this lane's query channels, this thread's pieces of the set's values
+  f32x4 qraw[16][2];
+  f32x4 vraw[NCHMAX][2][4];
+  const int my_row = active ? rows[r] : -1;
+  if (active) {
+    const float* qp = a.q + (size_t)(my_row < 0 ? 0 : my_row) * AC + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      qraw[ks][0] = *reinterpret_cast<const f32x4*>(qp + 16 * ks);
+      qraw[ks][1] = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+    }
+#pragma unroll
+    for (int c = 0; c < NCHMAX; ++c)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int idx = tid + 256 * half;
+        const int tk = idx >> 4, piece = idx & 15;
+        const int l = 32 * c + tk;
+        const bool ok = c < nchunk && l < a.L;
+        const float* vp = a.v + ((size_t)u * a.L + (ok ? l : 0)) * AC + 16 * piece;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vraw[c][half][j] = ok ? *reinterpret_cast<const f32x4*>(vp + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+  stamp(1);
+  // ---- phase A: the |x| maxima (every workgroup) and the grid barrier (attention workgroups)
   if (a.need_amax) {
     const int64_t n4q = (int64_t)a.B * AC / 4, n4k = (int64_t)a.U * a.L * AC / 4;
     const int64_t tot = n4q + 2 * n4k;
@@ -392,7 +481,9 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
       __threadfence();
       __hip_atomic_fetch_add(a.ws + 8, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (wg >= a.nmain) return;      // a helper: done
+    stamp(2);
+    if (!main_wg) return;           // a helper: done
+    if (!active && wg != 0) return; // no rows for this (set, tile): it has arrived, nothing else to do (workgroup 0 cleans up below)
     if (tid == 0) {
       unsigned spins = 0;
       bool ok = true;
@@ -413,49 +504,42 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
     }
     __syncthreads();
   } else {
-    if (wg >= a.nmain) return;
+    if (!main_wg) return;
     if (tid < 3) sc3[tid] = a.fixed[tid];
     if (wg == 0 && tid < 3 && a.scales_out) a.scales_out[tid] = a.fixed[tid];
     __syncthreads();
   }
+  if (!active) return;
+  stamp(3);
   const float sq = sc3[0], sk = sc3[1], sv = sc3[2];
   const float iq = (float)(1.0 / (double)sq), ik = (float)(1.0 / (double)sk), iv = (float)(1.0 / (double)sv);
-
-  // ---- phase B: this workgroup's rows
-  const int u = wg % a.U, tile = wg / a.U;
-  const int first = tile * 32;
-  if (tid < 32) rows[tid] = -1;
-  __syncthreads();
-  int running = 0;
-  for (int base = 0; base < a.B; base += 256) {
-    const int b = base + tid;
-    bool mine = false;
-    if (b < a.B) {
-      const int64_t su = a.inverse[b];
-      mine = (int)(su < 0 ? 0 : su >= a.U ? a.U - 1 : su) == u;
-    }
-    const unsigned long long bal = __ballot(mine);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wtot[wave] = __popcll(bal);
-    __syncthreads();
-    int off = running;
-    for (int w = 0; w < wave; ++w) off += wtot[w];
-    const int rank = off + before;
-    if (mine && rank >= first && rank < first + 32) rows[rank - first] = b;
-    running += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    __syncthreads();
-  }
-  if (first >= running) return;
-  const int r = lane & 31, h = lane >> 5;
   const int len = a.lengths ? a.lengths[u] : a.L;
-  const int LP = (a.L + 31) & ~31;
 
-  // ---- phase C: S = Q K^T on the fp8 matrix pipe (operands quantised here)
-  const int my_row = rows[r];
-  const float* qp = a.q + (size_t)(my_row < 0 ? 0 : my_row) * AC + 8 * h;
+  // ---- quantise what is in registers: the queries to MFMA operands, the values to the LDS image of all chunks
   long qa[16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) qa[ks] = my_row < 0 ? 0l : quant8(qp + 16 * ks, iq);
+  for (int ks = 0; ks < 16; ++ks) qa[ks] = my_row < 0 ? 0l : quant8r(qraw[ks][0], qraw[ks][1], iq);
+#pragma unroll
+  for (int c = 0; c < NCHMAX; ++c) {
+    if (c < nchunk) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int idx = tid + 256 * half;
+        const int tk = idx >> 4, piece = idx & 15;
+        const int l = 32 * c + tk;
+        u32x4v val = {0u, 0u, 0u, 0u};
+        if (l < a.L) {
+          const long lo = quant8r(vraw[c][half][0], vraw[c][half][1], iv), hi = quant8r(vraw[c][half][2], vraw[c][half][3], iv);
+          val[0] = (unsigned)(lo & 0xffffffffl); val[1] = (unsigned)((unsigned long)lo >> 32);
+          val[2] = (unsigned)(hi & 0xffffffffl); val[3] = (unsigned)((unsigned long)hi >> 32);
+        }
+        *reinterpret_cast<u32x4v*>(&V8[c][tk][16 * piece]) = val;
+      }
+    }
+  }
+
+  stamp(4);
+  // ---- S = Q K^T on the fp8 matrix pipe (the keys are loaded and quantised here)
   for (int tt = wave; tt * 32 < LP; tt += 4) {
     const int tok = tt * 32 + r;
     const float* kp = a.k + ((size_t)u * a.L + (tok < a.L ? tok : 0)) * AC + 8 * h;
@@ -480,9 +564,13 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
       S[m][tok] = tok < a.L ? lg * a.scale : -INFINITY;
     }
   }
-  __syncthreads();
+  __syncthreads();          // S and the value image are complete
+  stamp(5);
   {
     const int row = tid >> 3, sub = tid & 7;
+    // (rows of the tile that hold no query — 24 of 32 at B = 64 over 8 sets — are skipped: their logits are never read as results, and
+    //  the softmax is 3.7 of the kernel's 30 us there)
+    if (rows[row] >= 0) {
     float mx = -INFINITY;
     for (int l = sub; l < LP; l += 8) mx = fmaxf(mx, S[row][l]);
     mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
@@ -504,34 +592,16 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
       S[row][l] = p;
       if (gr >= 0 && l < a.L) a.attn[(size_t)gr * a.L + l] = p;
     }
+    }
   }
   __syncthreads();
+  stamp(6);
   f32x16 o[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int g = 0; g < 16; ++g) o[t][g] = 0.f;
-  const int nchunk = LP / 32;
-  auto stage = [&](int c, int buf) {      // tokens 32 c .. + 31 of set u, quantised -> V8[buf]: 512 pieces of 16 codes, two per thread
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int idx = tid + 256 * half;
-      const int tk = idx >> 4, piece = idx & 15;
-      const int l = 32 * c + tk;
-      u32x4v val = {0u, 0u, 0u, 0u};
-      if (l < a.L) {
-        const float* vp = a.v + ((size_t)u * a.L + l) * AC + 16 * piece;
-        const long lo = quant8(vp, iv), hi = quant8(vp + 8, iv);
-        val[0] = (unsigned)(lo & 0xffffffffl); val[1] = (unsigned)((unsigned long)lo >> 32);
-        val[2] = (unsigned)(hi & 0xffffffffl); val[3] = (unsigned)((unsigned long)hi >> 32);
-      }
-      *reinterpret_cast<u32x4v*>(&V8[buf][tk][16 * piece]) = val;
-    }
-  };
-  stage(0, 0);
-  __syncthreads();
   for (int c = 0; c < nchunk; ++c) {
-    if (c + 1 < nchunk) stage(c + 1, (c + 1) & 1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ks = 2 * c + kk;
@@ -548,12 +618,11 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
         const int ch = 64 * wave + 32 * t + r;
         bf16x8 vb;
 #pragma unroll
-        for (int s_ = 0; s_ < 8; ++s_) vb[s_] = (short)f2bf(e4m3_to_f32(V8[c & 1][16 * kk + 8 * h + s_][ch]));
+        for (int s_ = 0; s_ < 8; ++s_) vb[s_] = (short)f2bf(e4m3_to_f32(V8[c][16 * kk + 8 * h + s_][ch]));
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(phi, vb, o[t], 0, 0, 0);
         o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(plo, vb, o[t], 0, 0, 0);
       }
     }
-    __syncthreads();
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -563,6 +632,7 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
       const int gr = rows[m];
       if (gr >= 0) a.out[(size_t)gr * AC + 64 * wave + 32 * t + r] = o[t][g] * sv;
     }
+  stamp(7);
 }
 
 }  // namespace
@@ -628,7 +698,24 @@ extern "C" int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, con
   a.scale = scale; a.B = B; a.U = U; a.L = L; a.tiles = tiles; a.nmain = (int)nmain;
   a.ws = workspace; a.target = arrivals_before + (unsigned)(nmain + nhelp); a.parity = epoch & 1; a.need_amax = need;
   a.scales_out = scales_out; a.out = out; a.attn = attn;
-  hipLaunchKernelGGL(attn_fp8_mfma_fused_kernel, dim3((unsigned)(nmain + nhelp)), dim3(256), 0, wsmg_s(stream), a);
+  static float* trace_dev = nullptr;
+  const bool tracing = WSMG_TUNE("WSMG_FP8_TRACE", 0) != 0;
+  if (tracing && !trace_dev && hipMalloc((void**)&trace_dev, 16 * sizeof(float)) != hipSuccess) trace_dev = nullptr;
+  a.trace = tracing ? trace_dev : nullptr;
+  constexpr int FUSED_LDS = 32 * (LMAX + 4) * 4 + NCHMAX * 32 * (AC + 16);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_mfma_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS);
+    if (e0 != hipSuccess) return (int)e0;
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_fp8_mfma_fused_kernel, dim3((unsigned)(nmain + nhelp)), dim3(256), FUSED_LDS, wsmg_s(stream), a);
+  if (a.trace) {      // diagnostic only: synchronises
+    float h[8];
+    if (hipStreamSynchronize(wsmg_s(stream)) == hipSuccess && hipMemcpy(h, a.trace, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "fp8 fused trace (us since workgroup 0 started): rows %.2f, loads issued %.2f, arrived %.2f, barrier passed %.2f, quantised %.2f, "
+                      "S done %.2f, softmax done %.2f, end %.2f\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
