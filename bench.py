@@ -628,9 +628,11 @@ def main():
             # tools/pmc_traffic.py / tools/pmc_mfma.py; tools/refresh_profiles.sh): PMC collection cannot run inside a timed
             # bench, so the figures are read from profiles/ (newest round), not measured live
             fams = {"wsmg_conv2d_bwd_weight_bf16": ["conv_wgrad_bf16_kernel", "conv_win_wgrad_kernel", "conv_win3_wgrad_kernel", "conv_s2_wgrad_kernel"],
-                    "wsmg_conv2d_fwd_bf16": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel"],
-                    "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel"],
-                    "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>", "conv_win3_kernel"]}.get(r.get("entry"), [fam.replace("<*>", "")])
+                    # (conv_win3_kernel / conv_win3_mixed_kernel serve forward AND backward-data: the counter fold cannot tell the two
+                    #  directions of one kernel symbol apart, so both families' folds include all of its launches)
+                    "wsmg_conv2d_fwd_bf16": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel", "conv_win3_mixed_kernel"],
+                    "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel", "conv_win3_mixed_kernel"],
+                    "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>", "conv_win3_kernel", "conv_win3_mixed_kernel"]}.get(r.get("entry"), [fam.replace("<*>", "")])
             o["kernels_of_family"] = fams
             if args.dtype == "bf16" and tfiles:
                 tk = json.load(open(tfiles[-1])).get("kernels", {})
