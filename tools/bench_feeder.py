@@ -125,6 +125,10 @@ def feeder_rate(workers, batches_per_worker=6, transport="ring", raw_records=Fal
             steps += prev.shape[0]
         n += 1
     dt = time.time() - t_first
+    ct = getattr(fd, "consumer_times", None)
+    if ct and ct.get("n"):
+        feeder_rate.last_consumer = "consumer per batch: worker wait %.1f ms, launch %.1f ms, device wait %.1f ms" % (
+            ct["get"] / ct["n"] * 1e3, ct["launch"] / ct["n"] * 1e3, ct["sync"] / ct["n"] * 1e3)
     return steps / dt, n, fd.pinned_ring
 
 
@@ -163,6 +167,7 @@ if __name__ == "__main__" and os.environ.get("WSMG_FEEDER_E2E", "1") != "0":
             except RuntimeError as e:
                 print(f"  raw ring, {w:2d} workers, sparse={sp}: not run — {str(e).splitlines()[-1][:300]}")
                 continue
-            print(f"  raw ring, {w:2d} worker processes, ego map {'sparse' if sp else 'dense '} -> NHWC bf16: {r:8.0f} steps/s  ({n} batches)")
+            print(f"  raw ring, {w:2d} worker processes, ego map {'sparse' if sp else 'dense '} -> NHWC bf16: {r:8.0f} steps/s  ({n} batches; "
+                  f"{getattr(feeder_rate, 'last_consumer', '')})")
     r, n, _ = feeder_rate(8, transport="dataloader")
     print(f"  torch DataLoader transport, 8 workers (batches pickled through a pipe): {r:8.0f} steps/s")

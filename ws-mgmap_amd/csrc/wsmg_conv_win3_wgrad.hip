@@ -52,7 +52,6 @@ struct W3wArgs {
   unsigned x_bytes, dy_bytes;
 };
 
-constexpr int NSTG = 3;
 constexpr int RED_BYTES = 4 * 9 * 16 * 64 * 4;   // the closing reduction of a pixel-split tile: four waves' nine accumulator tiles (144 KB)
 constexpr int OOB = (int)0x80000000;
 
@@ -77,9 +76,10 @@ __device__ __forceinline__ int quarter_xor(int row) {
 // slices between them (small-channel layers, round 4: with Cout x Cin = 32 x 32 there is ONE tile pair — eight waves take one
 // eighth of the entries each and their accumulators meet in LDS when the workgroup is done); SL: slices per wave and k-step;
 // XCAP: window rows (KS + 2 (W + 3) <= XCAP); NLW: waves that issue the DMA pieces (8: all; 4: waves 0-3, one per SIMD)
-template <int WCO, int WCI, int WK, int SL, int XCAP, int NLW>
+template <int WCO, int WCI, int WK, int SL, int XCAP, int NLW, int NSTG = 3>
 __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
   static_assert(WCO * WCI * WK == 8, "8 waves");
+  static_assert(NSTG >= 3 && NSTG <= 6, "stages: the DMA of k-step s + NSTG - 1 is issued at the top of step s");
   constexpr int KS = 16 * WK * SL;                          // entries per k-step
   constexpr int NPAIR = WCO * WCI;
   constexpr int DP = 64 * WCO, XP = 64 * WCI;               // row pitches (bytes)
@@ -196,12 +196,12 @@ __global__ __launch_bounds__(512) void conv_win3_wgrad_kernel(W3wArgs a) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[tap][g] = 0.f;
 
-  dma_step(0);
-  dma_step(1);
+#pragma unroll
+  for (int st = 0; st < NSTG - 1; ++st) dma_step(st);
   for (int s = 0; s < steps; ++s) {
-    if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT) : "memory");   // this wave's pieces of step s (those of step s + 1 may be in flight)
-    __builtin_amdgcn_s_barrier();                      // everybody's; and stage (s + 2) % 3 = (s - 1) % 3 is no longer read
-    dma_step((s + 2) % NSTG);
+    if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * NSLOT) : "memory");   // this wave's pieces of step s (those of the next NSTG - 2 steps may be in flight)
+    __builtin_amdgcn_s_barrier();                      // everybody's; and stage (s + NSTG - 1) % NSTG = (s - 1) % NSTG is no longer read
+    dma_step((s + NSTG - 1) % NSTG);
     const unsigned char* const sb = smem + (s % NSTG) * STAGE;
     // 27 MFMAs per wave and step, each with its own B fragment (2 transposing reads): read -> use back to back leaves the
     // LDS round trip exposed 27 times per step, so the fragments run PD MFMAs ahead in a small register ring, and the
@@ -342,21 +342,21 @@ void plan_w3w(W3wArgs& a, W3wVariant v) {
   a.gz = (a.B + a.imgs - 1) / a.imgs;
 }
 
-template <int WCO, int WCI, int WK, int SL, int XCAP, int NLW>
+template <int WCO, int WCI, int WK, int SL, int XCAP, int NLW, int NSTG = 3>
 int launch_w3w(W3wArgs& a, W3wVariant v, hipStream_t s) {
   constexpr int STAGES = NSTG * (16 * WK * SL * 64 * WCO + XCAP * 64 * WCI) + 1024;
   constexpr int LDS = (WK > 1 && RED_BYTES > STAGES) ? RED_BYTES : STAGES;
   static_assert(LDS <= 160 * 1024, "LDS of one CU");
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_wgrad_kernel<WCO, WCI, WK, SL, XCAP, NLW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_wgrad_kernel<WCO, WCI, WK, SL, XCAP, NLW, NSTG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
   plan_w3w(a, v);
   const int ntile = a.gco * a.gci;
-  hipLaunchKernelGGL((conv_win3_wgrad_kernel<WCO, WCI, WK, SL, XCAP, NLW>), dim3((unsigned)(ntile * a.gz)), dim3(512), LDS, s, a);
+  hipLaunchKernelGGL((conv_win3_wgrad_kernel<WCO, WCI, WK, SL, XCAP, NLW, NSTG>), dim3((unsigned)(ntile * a.gz)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -387,7 +387,14 @@ int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, lon
   // 0.216 / 0.216 with all eight loading, and 0.421 / 0.247 / 0.225 for the generic kernel); WSMG_WIN3W_LOADERS=8: all eight (A/B).
   const int nlw = WSMG_TUNE("WSMG_WIN3W_LOADERS", 4);
   switch (v) {
-    case V421: return nlw == 8 ? launch_w3w<4, 2, 1, 3, 104, 8>(a, v, s) : launch_w3w<4, 2, 1, 3, 104, 4>(a, v, s);
+    case V421:
+      if (nlw == 8) return launch_w3w<4, 2, 1, 3, 104, 8>(a, v, s);
+      switch (WSMG_TUNE("WSMG_WIN3W_STAGES", 4)) {
+        case 3: return launch_w3w<4, 2, 1, 3, 104, 4, 3>(a, v, s);
+        case 5: return launch_w3w<4, 2, 1, 3, 104, 4, 5>(a, v, s);
+        case 6: return launch_w3w<4, 2, 1, 3, 104, 4, 6>(a, v, s);
+        default: return launch_w3w<4, 2, 1, 3, 104, 4, 4>(a, v, s);
+      }
     case V222: return launch_w3w<2, 2, 2, 2, 120, 8>(a, v, s);
     case V412: return launch_w3w<4, 1, 2, 2, 128, 8>(a, v, s);
     case V118: return launch_w3w<1, 1, 8, 2, 368, 8>(a, v, s);

@@ -258,6 +258,8 @@ class DeviceFeeder:
         coll = DeviceCollator(self.device, self.ego_map_nhwc_bf16)
         pending = collections.deque()          # (out, event, worker, slot)
         live = [True] * W
+        import time as _time
+        tacc = dict(get=0.0, launch=0.0, sync=0.0, n=0)       # where the consumer's time goes (reported under WSMG_FEEDER_TRACE)
         try:
             k = 0
             while any(live):
@@ -266,6 +268,7 @@ class DeviceFeeder:
                 if not live[w]:
                     continue
                 item, waited = None, 0.0
+                _t0 = _time.perf_counter()
                 while item is None:
                     try:
                         item = ready_qs[w].get(timeout=2.0)
@@ -276,6 +279,7 @@ class DeviceFeeder:
                                                f"shared-memory ring ({len(slots)} slots of {nbytes >> 20} MiB) does not fit in /dev/shm")
                         if waited >= 900.0:
                             raise RuntimeError(f"feeder worker {w} produced nothing for 15 minutes")
+                tacc["get"] += _time.perf_counter() - _t0
                 if item == _STOP:
                     live[w] = False
                     continue
@@ -295,13 +299,18 @@ class DeviceFeeder:
                 else:
                     sid, meta = item
                     self._trace("batch from worker %d in slot %d" % (w, sid))
+                    _t1 = _time.perf_counter()
                     out = coll.launch(meta, slots[sid], stream=side)
+                    tacc["launch"] += _time.perf_counter() - _t1
+                    tacc["n"] += 1
                     ev = torch.cuda.Event()
                     ev.record(side)
                     pending.append((out, ev, w, sid))
                 if len(pending) > self.prefetch:
                     out, ev, w0, s0 = pending.popleft()
+                    _t2 = _time.perf_counter()
                     ev.synchronize()                  # the copy out of the slot has finished: the worker may refill it
+                    tacc["sync"] += _time.perf_counter() - _t2
                     if s0 is not None:
                         free_qs[w0].put(s0)
                     yield self._hand_over(out, ev)
@@ -312,6 +321,10 @@ class DeviceFeeder:
                     free_qs[w0].put(s0)
                 yield self._hand_over(out, ev)
         finally:
+            if tacc["n"]:
+                self._trace("consumer per batch: waiting for the worker's batch %.1f ms, launch() %.1f ms, waiting for the device %.1f ms (%d batches)"
+                            % (tacc["get"] / tacc["n"] * 1e3, tacc["launch"] / tacc["n"] * 1e3, tacc["sync"] / tacc["n"] * 1e3, tacc["n"]))
+            self.consumer_times = dict(tacc)
             for q in free_qs:
                 q.put(None)
             for p in procs:
