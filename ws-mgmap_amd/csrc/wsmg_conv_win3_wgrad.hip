@@ -24,7 +24,10 @@
 // row & 3; 128-B rows: quarter ^= (row >> 1) & 1 — applied on the source side of the DMA and in the read address (a
 // constant per lane and tap: the slice and half offsets are multiples of 4 rows).
 //
-// Pipeline: 3 stages, the DMA of k-step s + 2 is issued at the top of step s after a counted `vmcnt` + one barrier.  The 25
+// Pipeline: NSTG stages, the DMA of k-step s + NSTG - 1 is issued at the top of step s after a counted `vmcnt` + one barrier.
+// NSTG = 4 since round 5 (V421: 103 KB, ONE workgroup per CU where three stages let two share it; measured per layer at B = 512,
+// interleaved: 0.190-0.197 -> 0.182-0.184 ms (256 <-> 128), 0.358 -> 0.344 (256 -> 256); 5 and 6 stages 0.188-0.194 / 0.356-0.369;
+// V222 0.112 -> 0.106 and 0.097 -> 0.093, V412 0.0425 -> 0.042; V118 unchanged at 0.047 and left at three).  The 25
 // pieces of a step are issued by waves 0-3 ONLY (one per SIMD, 8 slots each, spare slots to a dummy area): 25 KB per step
 // is ≈1 000 cycles of the CU's L2 -> LDS path, and a wave's DMA instructions stall in issue until the path takes them —
 // with every wave issuing its share at the top of the step, all eight stood there 1 400-1 700 cycles (s_memtime) while the
@@ -395,9 +398,9 @@ int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, lon
         case 6: return launch_w3w<4, 2, 1, 3, 104, 4, 6>(a, v, s);
         default: return launch_w3w<4, 2, 1, 3, 104, 4, 4>(a, v, s);
       }
-    case V222: return launch_w3w<2, 2, 2, 2, 120, 8>(a, v, s);
-    case V412: return launch_w3w<4, 1, 2, 2, 128, 8>(a, v, s);
-    case V118: return launch_w3w<1, 1, 8, 2, 368, 8>(a, v, s);
+    case V222: return WSMG_TUNE("WSMG_WIN3W_STAGES_222", 4) == 4 ? launch_w3w<2, 2, 2, 2, 120, 8, 4>(a, v, s) : launch_w3w<2, 2, 2, 2, 120, 8>(a, v, s);
+    case V412: return WSMG_TUNE("WSMG_WIN3W_STAGES_412", 4) == 4 ? launch_w3w<4, 1, 2, 2, 128, 8, 4>(a, v, s) : launch_w3w<4, 1, 2, 2, 128, 8>(a, v, s);
+    case V118: return WSMG_TUNE("WSMG_WIN3W_STAGES_118", 3) == 4 ? launch_w3w<1, 1, 8, 2, 368, 8, 4>(a, v, s) : launch_w3w<1, 1, 8, 2, 368, 8>(a, v, s);
     default: return WSMG_EINVAL;
   }
 }
