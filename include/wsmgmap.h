@@ -84,6 +84,12 @@ int wsmg_map_retrieve(const float* global_map, const float* gps, const float* co
  * instead of the crop going through `scratch`; bit-identical to wsmg_map_retrieve. */
 int wsmg_map_retrieve_fused(const float* global_map, const float* gps, const float* compass, int B, int C, int E, int G,
                             float resolution, float* out, wsmg_stream_t stream);
+/* The same in one launch through LDS (round 5): a workgroup stages the box of global-map pixels its 8 x 8 output tile can touch
+ * (<= 14 x 14 pixels x a slice of <= 40 channels) and takes the 16 taps of every element from there, the tap geometry computed once
+ * per (pixel, rotation tap); bit-identical to wsmg_map_retrieve.  Any C % 4 == 0.  WSMG_RETRIEVE_TRACE=1 (diagnostic) prints
+ * the phase boundaries of sampled workgroups in cycles and synchronises. */
+int wsmg_map_retrieve_tiled(const float* global_map, const float* gps, const float* compass, int B, int C, int E, int G,
+                            float resolution, float* out, wsmg_stream_t stream);
 
 /* ============================ operator 2: map conv / UNet decoder engine ============================ */
 /* cuDNN conv2d forward / backward at map_encoder.py:19-29,94-112, mg_map_policy.py:78-100,127,130.

@@ -753,9 +753,12 @@ def test_bev_scatter_rotate_and_plane_fuse_equal_the_separate_launches(B, E, C, 
         ops.map_fuse(rot, gm_a, gps, masks, 0.12)
         ops.map_fuse(rotp, gm_b, gps, masks, 0.12, planes=True)
         assert torch.equal(gm_a, gm_b), f"step {step}: global map differs in {int((gm_a != gm_b).sum())} elements"
-        one = ops.map_retrieve(gm_a, gps, compass, E, 0.12, fused=True)       # crop + rotation in one launch
+        one = ops.map_retrieve(gm_a, gps, compass, E, 0.12, fused=True)       # crop + rotation in one launch (registers)
         two = ops.map_retrieve(gm_a, gps, compass, E, 0.12, fused=False)
         assert torch.equal(one, two), f"step {step}: retrieved map differs in {int((one != two).sum())} elements"
+        lds = ops.map_retrieve(gm_a, gps, compass, E, 0.12, fused="tiled")    # round 5: one launch through LDS (the default)
+        assert torch.equal(lds, two), f"step {step}: LDS-tiled retrieved map differs in {int((lds != two).sum())} elements"
+        assert torch.equal(ops.map_retrieve(gm_a, gps, compass, E, 0.12), two)
     assert float(gm_a.abs().max()) > 0
 
 

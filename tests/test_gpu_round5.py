@@ -1,6 +1,7 @@
 """GPU tests, round 5 (VERDICT r04 "Next round" + ADVICE r04): the recurrent core's dense layers as one launch each, the persistent
 kernels beside pinned compute units, the gradient exchange on a policy stream, the race-free early dense inputs, the mixed-tile
 window convolution."""
+import math
 import os
 import sys
 
@@ -466,3 +467,34 @@ def test_sparse_ego_map_collates_bit_identically_to_the_dense_record():
     assert ego.dtype == torch.bfloat16 and ego.permute(0, 2, 3, 1).is_contiguous() and ego.shape[0] == 200 * 3
     with pytest.raises(_abi.WsmgError):
         DeviceCollator("cuda")(sparse)
+
+
+# ----------------------------------------------------------------------------- map retrieval: one launch through LDS
+@pytest.mark.parametrize("B,E,C,G", [(4, 100, 64, 240), (3, 200, 40, 480), (5, 33, 8, 64), (2, 50, 128, 120), (2, 24, 168, 24)],
+                         ids=["e100_c64", "e200_c40", "e33_c8", "e50_c128", "e24_c168_g_eq_e"])
+def test_map_retrieve_lds_tiles_equal_crop_then_rotate(B, E, C, G):
+    """wsmg_map_retrieve_tiled (round 5: ops.map_retrieve's default) against wsmg_map_retrieve — map_crop_kernel then
+    rotate_nhwc_kernel, the launches the oracle tests pin (rgb_mapping.py:57-70) — bit for bit on a DENSE global map (every tap
+    carries weight): headings on and between the axes (0, +-pi/4, +-pi/2, pi, random), agents in the centre, at and beyond the map
+    border (taps outside the global map), ego sizes that are not multiples of the 8-pixel tile, G == E; one map holds an infinity
+    and a NaN (a tap with weight 0 still propagates them the same way), one trial has an infinite gps (the tile geometry does not fit
+    the box: the kernel's register route).  Wide maps go as channel slices of <= 40 (C = 64: 2 x 32, 128: 4 x 32, 168: 6 x 28)."""
+    from wsmgmap import ops
+    g = torch.Generator(device="cuda").manual_seed(17)
+    gm = torch.randn(B, G, G, C, device="cuda", generator=g)
+    gm[0, G // 2, G // 2, 0] = float("inf")
+    gm[0, G // 2 + 3, G // 2 - 2, C - 1] = float("nan")
+    half = G * 0.12 / 2
+    fixed = [0.0, math.pi / 4, -math.pi / 4, math.pi / 2, -math.pi / 2, math.pi, 3.0, -1.3]
+    for trial in range(6):
+        compass = torch.tensor([fixed[(trial * B + b) % len(fixed)] for b in range(B)], device="cuda") if trial < 3 else \
+            torch.rand(B, device="cuda", generator=g) * 6.28 - 3.14
+        reach = [0.0, 0.5, 1.0, 1.4, 0.97, 1.0][trial]
+        gps = (torch.rand(B, 2, device="cuda", generator=g) * 2 - 1) * half * reach
+        if trial == 5:
+            gps[B - 1, 0] = float("inf")
+        two = ops.map_retrieve(gm, gps, compass, E, 0.12, fused=False)
+        lds = ops.map_retrieve(gm, gps, compass, E, 0.12, fused="tiled")
+        same = (lds == two) | (lds.isnan() & two.isnan())
+        assert bool(same.all()), f"trial {trial}: {int((~same).sum())} of {same.numel()} elements differ"
+        assert torch.equal(lds.view(torch.int32)[~two.isnan()], two.view(torch.int32)[~two.isnan()])   # signed zeros included

@@ -56,8 +56,7 @@ for name, B, Hf, E, C, G in [("cfg1 B=1 256^2 E100 C64", 1, 256, 100, 64, 240), 
             ("index",) + by["index"],
             ("scatter+rotate", lambda: ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E), by["scatter_max"][1]),
             ("fuse (planes)", lambda: ops.map_fuse(rotp, gm, gps, masks, 0.12, planes=True), by["fuse"][1]),
-            ("retrieve (1 launch)", lambda: ops.map_retrieve(gm, gps, compass, E, 0.12, fused=True), by["retrieve"][1] - B * 2 * C * E * E * 4)
-            if B * E * E * (C // 4) <= 500_000 else ("retrieve",) + by["retrieve"],      # ops.map_retrieve's own choice
+            ("retrieve (LDS tiles)", lambda: ops.map_retrieve(gm, gps, compass, E, 0.12), B * 2 * C * E * E * 4),   # ops.map_retrieve's own choice
         ]
         f_us = 0.0
         for k, fn, nbytes in frows:
@@ -65,6 +64,9 @@ for name, B, Hf, E, C, G in [("cfg1 B=1 256^2 E100 C64", 1, 256, 100, 64, 240), 
             f_us += us
             if k != "index":
                 print(f"{name:26s} {k:19s} {us:9.1f} {nbytes / 1e6:9.2f} {nbytes / us / 1e3:9.1f} {nbytes / us / 1e3 / 8000 * 100:10.1f}%")
+        us = timeit(lambda: ops.map_retrieve(gm, gps, compass, E, 0.12, fused=True))
+        nbytes = B * 2 * C * E * E * 4
+        print(f"{name:26s} {'retrieve (registers)':19s} {us:9.1f} {nbytes / 1e6:9.2f} {nbytes / us / 1e3:9.1f} {nbytes / us / 1e3 / 8000 * 100:10.1f}%   (not in the sum)")
         fb = sum(nb for _, _, nb in frows)
         print(f"{name:26s} {'ALL fused, own B':19s} {f_us:9.1f} {fb / 1e6:9.2f} {fb / f_us / 1e3:9.1f} {fb / f_us / 1e3 / 8000 * 100:10.1f}%")
         print(f"{name:26s} {'ALL fused, 5-stage B':19s} {f_us:9.1f} {tot_b / 1e6:9.2f} {tot_b / f_us / 1e3:9.1f} {tot_b / f_us / 1e3 / 8000 * 100:10.1f}%")

@@ -121,14 +121,21 @@ def feeder_rate(workers, batches_per_worker=6, transport="ring", raw_records=Fal
         torch.cuda.current_stream().synchronize()
         if n == nw - 1 or (workers == 0 and n == 0):     # every worker has delivered once: its store is built, the pipeline is full
             t_first, steps = time.time(), 0
+            for key in getattr(fd, "consumer_times", None) or {}:
+                fd.consumer_times[key] = 0
         elif t_first is not None:
             steps += prev.shape[0]
+        t_last = time.time()
         n += 1
-    dt = time.time() - t_first
+    # (up to the last batch: leaving the loop also tears the ring down — joins the workers, unpins 2 slots per worker of one batch
+    # each, seconds for a 16-worker ring — which is per epoch, not per batch; reported separately)
+    dt = t_last - t_first
+    feeder_rate.last_teardown = time.time() - t_last
     ct = getattr(fd, "consumer_times", None)
     if ct and ct.get("n"):
-        feeder_rate.last_consumer = "consumer per batch: worker wait %.1f ms, launch %.1f ms, device wait %.1f ms" % (
-            ct["get"] / ct["n"] * 1e3, ct["launch"] / ct["n"] * 1e3, ct["sync"] / ct["n"] * 1e3)
+        feeder_rate.last_consumer = ("consumer per batch: worker wait %.1f ms, launch %.1f ms, device wait %.1f ms; a worker per batch: records "
+                                     "%.1f ms, plan %.1f ms, slot wait %.1f ms, pack %.1f ms; ring teardown after the epoch %.1f s") % (tuple(
+            ct[k] / ct["n"] * 1e3 for k in ("get", "launch", "sync", "w_read", "w_plan", "w_slot", "w_pack")) + (feeder_rate.last_teardown,))
     return steps / dt, n, fd.pinned_ring
 
 

@@ -549,6 +549,77 @@ __global__ __launch_bounds__(256) void map_crop_kernel(const float* __restrict__
 // 16 bytes, all independent, neighbours' loads hitting the same lines in L1 / L2) instead of the crop going to memory (205 MB out,
 // 205 MB back at cfg4) between two launches.  Same arithmetic per value as the two kernels: crop = sum over k of q_k w_k, output =
 // sum over the rotation taps (nw, ne, sw, se) of crop w.
+__device__ __forceinline__ f32x4 retrieve_item_regs(const f32x4* __restrict__ gb, const MapArgs& a, float tx, float ty, Rot r,
+                                                    int x, int y, int c) {
+  const int C4 = a.C >> 2, E = a.E;
+  const Taps rt = rot_taps(x, y, E, r);
+  f32x4 q[4][4];
+  float w[4][4];
+  bool rok[4], cok[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {          // rotation tap k = crop pixel (cy, cx)
+    const int cy = rt.y0 + (k >> 1), cx = rt.x0 + (k & 1);
+    rok[k] = cy >= 0 && cy < E && cx >= 0 && cx < E;
+    float gx = base_coord(a.lo + (rok[k] ? cx : 0), a.G) + tx;
+    float gy = base_coord(a.lo + (rok[k] ? cy : 0), a.G) + ty;
+    const Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int yy = tp.y0 + (m >> 1), xx = tp.x0 + (m & 1);
+      w[k][m] = m == 0 ? tp.w00 : m == 1 ? tp.w01 : m == 2 ? tp.w10 : tp.w11;
+      cok[k][m] = rok[k] && yy >= 0 && yy < a.G && xx >= 0 && xx < a.G;
+      if (cok[k][m]) q[k][m] = gb[((size_t)yy * a.G + xx) * C4 + c];
+    }
+  }
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!rok[k]) continue;
+    f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (cok[k][m]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j] += q[k][m][j] * w[k][m];
+      }
+    const float wr = k == 0 ? rt.w00 : k == 1 ? rt.w01 : k == 2 ? rt.w10 : rt.w11;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += cv[j] * wr;
+  }
+  return v;
+}
+
+// the same value, one rotation tap at a time (4 loads in flight instead of 16: the tiled kernel's rare route, few registers)
+__device__ __noinline__ f32x4 retrieve_item_seq(const f32x4* __restrict__ gb, const MapArgs& a, float tx, float ty, Rot r, int x, int y,
+                                                int c) {
+  const int C4 = a.C >> 2, E = a.E;
+  const Taps rt = rot_taps(x, y, E, r);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const int cy = rt.y0 + (k >> 1), cx = rt.x0 + (k & 1);
+    if (!(cy >= 0 && cy < E && cx >= 0 && cx < E)) continue;
+    const float gx = base_coord(a.lo + cx, a.G) + tx;
+    const float gy = base_coord(a.lo + cy, a.G) + ty;
+    const Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+    f32x4 cv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int yy = tp.y0 + (m >> 1), xx = tp.x0 + (m & 1);
+      const float w = m == 0 ? tp.w00 : m == 1 ? tp.w01 : m == 2 ? tp.w10 : tp.w11;
+      if (yy >= 0 && yy < a.G && xx >= 0 && xx < a.G) {
+        const f32x4 q = gb[((size_t)yy * a.G + xx) * C4 + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cv[j] += q[j] * w;
+      }
+    }
+    const float wr = k == 0 ? rt.w00 : k == 1 ? rt.w01 : k == 2 ? rt.w10 : rt.w11;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] += cv[j] * wr;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void map_retrieve_fused_kernel(const float* __restrict__ gm, const float* __restrict__ gps,
                                                                  const float* __restrict__ heading, MapArgs a,
                                                                  float* __restrict__ out) {
@@ -565,42 +636,192 @@ __global__ __launch_bounds__(256) void map_retrieve_fused_kernel(const float* __
     const int c = (int)(i % C4);
     const int p = (int)(i / C4);
     const int y = p / E, x = p - y * E;
-    const Taps rt = rot_taps(x, y, E, r);
-    f32x4 q[4][4];
-    float w[4][4];
-    bool rok[4], cok[4][4];
+    ob[i] = retrieve_item_regs(gb, a, tx, ty, r, x, y, c);
+  }
+}
+
+// map_crop_kernel + rotate_nhwc_kernel in one pass through LDS (round 5).  The register form above pays 16 gathers of 16 bytes per
+// item through the texture path (cfg4: 311 us against 219 for the two launches, which is why it only ran at small batches); here a
+// workgroup owns an 8 x 8 tile of output pixels (and a slice of <= 40 channels), works out which global-map pixels the crop pixels
+// under its rotation taps touch (<= 14 x 14: 7 sqrt 2 + 2 crop pixels, one more for their own taps, one for a floor that slips),
+// stages that box once — rows of the box, pixels outside the map as zeros — and takes all 16 taps of an item from LDS.  The
+// tap geometry is computed once per (pixel, rotation tap) — 256 records, one per thread: box offset, four crop weights, rotation
+// weight — instead of once per (pixel, 4 channels) item (base_coord's IEEE divisions were the VALU time of the gather kernels),
+// from the same expressions, and each value keeps the two kernels' summation order: bit-identical.  Where the two kernels SKIP a
+// tap (outside the map, outside the crop) the record points at zeros with zero weights: an accumulator that starts at +0 is never
+// -0, so adding +-0 leaves it unchanged.  A tile whose geometry does not fit the box (cannot happen for finite inputs: the spans
+// above are bounds; an infinite gps does it) runs the register form instead.
+// Latency: a tile is little work behind a chain of dependent steps (pose -> taps -> box extents -> box -> taps from LDS), and LDS
+// holds few tiles per CU, so the chain is kept short: every thread derives its record from the pose alone (no tables, no LDS
+// round trips), the extents meet through one wave reduction (DPP) and 16 words of LDS — LDS atomics from 64 lanes on one word
+// took 20 000 of a workgroup's 32 000 cycles — and the box's loads are all in flight before the first LDS store.
+constexpr int RT = 8, RBOX = 14, RBIG = 0x10000000;
+struct Axis { int p0; float a, b; };  // floor(i), (floor(i) + 1) - i, i - floor(i): one axis of make_taps
+__device__ __forceinline__ Axis crop_axis(int j, float t, const MapArgs& a) {
+  const float i = unnorm(base_coord(a.lo + j, a.G) + t, a.G);
+  const float f0 = floorf(i);
+  Axis r;
+  r.p0 = (int)f0;
+  r.a = (f0 + 1.0f) - i;
+  r.b = i - f0;
+  return r;
+}
+// min / max over the lane's row of 16 (DPP: no LDS crossbar), in every lane of the row
+template <bool MAX>
+__device__ __forceinline__ int row_ext(int v) {
+#define WSMG_EXT_STEP(ctrl)                                                      \
+  {                                                                              \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, 0xf, 0xf, false);      \
+    v = MAX ? (o > v ? o : v) : (o < v ? o : v);                                 \
+  }
+  WSMG_EXT_STEP(0xB1)    // quad_perm [1, 0, 3, 2]
+  WSMG_EXT_STEP(0x4E)    // quad_perm [2, 3, 0, 1]
+  WSMG_EXT_STEP(0x141)   // row_half_mirror
+  WSMG_EXT_STEP(0x140)   // row_mirror
+#undef WSMG_EXT_STEP
+  return v;
+}
+// lane K of the caller's quad, in every lane of the quad
+template <int K>
+__device__ __forceinline__ int quad_get(int v) { return __builtin_amdgcn_update_dpp(v, v, K * 0x55, 0xf, 0xf, false); }
+template <int K>
+__device__ __forceinline__ float quad_getf(float v) { return __int_as_float(quad_get<K>(__float_as_int(v))); }
+
+__global__ __launch_bounds__(256, 4) void map_retrieve_tiled_kernel(const float* __restrict__ gm, const float* __restrict__ gps,
+                                                                 const float* __restrict__ heading, MapArgs a, int tiles_x,
+                                                                 int nsplit, int S4, unsigned magicS4, float* __restrict__ out,
+                                                                 unsigned* __restrict__ trace) {
+  extern __shared__ float boxf[];  // [bh][bw][4 S4] floats: the box; then bw + 2 pixels of zeros
+  __shared__ int s_ext[16][4];
+  // WSMG_RETRIEVE_TRACE=1 (diagnostic): cycles of every 64th workgroup at its phase boundaries
+  const bool tr = trace && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 64;
+  unsigned* const trw = trace + (blockIdx.x >> 6) * 8;
+  const unsigned long long t00 = tr ? __builtin_readcyclecounter() : 0;
+#define RTRACE(i) if (tr) trw[i] = (unsigned)(__builtin_readcyclecounter() - t00)
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int blk = bev_block();
+  const int tile = blk / nsplit, cs0 = (blk - tile * nsplit) * S4;   // first f32x4 of this workgroup's channel slice
+  const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  Pose ps = grid_cell(gps, b, a.G, a.cmax, a.cmin, a.gsz);
+  const float tx = (ps.gy - a.halfG) / a.halfG;
+  const float ty = (ps.gx - a.halfG) / a.halfG;
+  const int C4 = a.C >> 2, E = a.E, G = a.G;
+  const f32x4* gb = reinterpret_cast<const f32x4*>(gm + (size_t)b * G * G * a.C);
+  f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * E * E * a.C);
+  f32x4* box = reinterpret_cast<f32x4*>(boxf);
+  const float th = heading[b];
+  const Rot r{cosf(th), sinf(th)};
+
+  // ---- this thread's record: pixel tid / 4 of the tile, rotation tap tid % 4 = crop pixel (cy, cx)
+  const int pl_r = tid >> 2, k_r = tid & 3;
+  const int ry = tyi * RT + (pl_r >> 3), rx = txi * RT + (pl_r & 7);
+  const bool live = ry < E && rx < E;
+  const Taps rt = rot_taps(live ? rx : 0, live ? ry : 0, E, r);
+  const int cy = rt.y0 + (k_r >> 1), cx = rt.x0 + (k_r & 1);
+  const bool rok = live && cy >= 0 && cy < E && cx >= 0 && cx < E;
+  const Axis ax = crop_axis(rok ? cx : 0, tx, a), ay = crop_axis(rok ? cy : 0, ty, a);
+  // a coordinate that is not finite and small (an infinite / NaN gps): the floors saturate and the weights are NaN while the two
+  // kernels skip the taps — not this route's case
+  const bool sane = fabsf(ax.a) <= 2.0f && fabsf(ax.b) <= 2.0f && fabsf(ay.a) <= 2.0f && fabsf(ay.b) <= 2.0f && ax.p0 > -RBIG &&
+                    ax.p0 < RBIG && ay.p0 > -RBIG && ay.p0 < RBIG;
+  const bool use = rok && sane;
+  {  // (a record that is not sane stretches the box beyond RBOX: the tile takes the register form)
+    const int xlo = row_ext<false>(use ? ax.p0 : (rok ? -2 * RBIG : RBIG)), xhi = row_ext<true>(use ? ax.p0 + 1 : -RBIG);
+    const int ylo = row_ext<false>(use ? ay.p0 : RBIG), yhi = row_ext<true>(use ? ay.p0 + 1 : -RBIG);
+    if ((tid & 15) == 0) {
+      int* e = s_ext[tid >> 4];
+      e[0] = xlo; e[1] = xhi; e[2] = ylo; e[3] = yhi;
+    }
+  }
+  RTRACE(0);
+  __syncthreads();
+  RTRACE(1);
+  int gx_lo = RBIG, gx_hi = -RBIG, gy_lo = RBIG, gy_hi = -RBIG;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {          // rotation tap k = crop pixel (cy, cx)
-      const int cy = rt.y0 + (k >> 1), cx = rt.x0 + (k & 1);
-      rok[k] = cy >= 0 && cy < E && cx >= 0 && cx < E;
-      float gx = base_coord(a.lo + (rok[k] ? cx : 0), a.G) + tx;
-      float gy = base_coord(a.lo + (rok[k] ? cy : 0), a.G) + ty;
-      const Taps tp = make_taps(unnorm(gx, a.G), unnorm(gy, a.G));
+  for (int w = 0; w < 16; ++w) {
+    gx_lo = s_ext[w][0] < gx_lo ? s_ext[w][0] : gx_lo; gx_hi = s_ext[w][1] > gx_hi ? s_ext[w][1] : gx_hi;
+    gy_lo = s_ext[w][2] < gy_lo ? s_ext[w][2] : gy_lo; gy_hi = s_ext[w][3] > gy_hi ? s_ext[w][3] : gy_hi;
+  }
+  int bw = 2, bh = 0;                         // no tap of the tile lands in the crop: zeros only
+  bool slow = false;                          // uniform
+  if (gx_lo != RBIG) {
+    slow = gx_lo < -RBIG || gx_hi - gx_lo + 1 > RBOX || gy_hi - gy_lo + 1 > RBOX;
+    bw = gx_hi - gx_lo + 1; bh = gy_hi - gy_lo + 1;
+  } else {
+    gx_lo = gy_lo = 0;
+  }
+  if (slow) {  // the register form for this tile
+    for (int i = tid; i < RT * RT * S4; i += 256) {
+      const int pl = (int)__umulhi((unsigned)i, magicS4), c = cs0 + i - pl * S4;
+      const int qy = tyi * RT + (pl >> 3), qx = txi * RT + (pl & 7);
+      if (qy < E && qx < E) ob[((size_t)qy * E + qx) * C4 + c] = retrieve_item_seq(gb, a, tx, ty, r, qx, qy, c);
+    }
+    return;
+  }
+  // the record stays in registers: the four records of a pixel sit in one quad
+  int off = bh * bw;
+  f32x4 w = {0.f, 0.f, 0.f, 0.f};
+  float wr = 0.f;
+  if (use) {
+    off = (ay.p0 - gy_lo) * bw + (ax.p0 - gx_lo);
+    w[0] = ax.a * ay.a; w[1] = ax.b * ay.a; w[2] = ax.a * ay.b; w[3] = ax.b * ay.b;
+    wr = k_r == 0 ? rt.w00 : k_r == 1 ? rt.w01 : k_r == 2 ? rt.w10 : rt.w11;
+  }
+  // ---- stage the box: rows of the box (this slice's channels of each pixel), out-of-map pixels and the tail as zeros; a batch's
+  // loads all before its LDS stores (one load, one store per trip paid the memory latency per trip), branch-free
+  {
+    const unsigned rowq = (unsigned)(bw * S4), mrow = 0xFFFFFFFFu / rowq + 1u;
+    const unsigned nbox = (unsigned)bh * rowq, nq = nbox + (unsigned)(bw + 2) * S4;
+    constexpr int UB = 9;   // (14 x 14 + 16) pixels x 10 / 256 = 8.3: one batch
+    for (unsigned i0 = tid; i0 < nq; i0 += 256 * UB) {
+      f32x4 q[UB];
+      bool ok[UB];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int yy = tp.y0 + (m >> 1), xx = tp.x0 + (m & 1);
-        w[k][m] = m == 0 ? tp.w00 : m == 1 ? tp.w01 : m == 2 ? tp.w10 : tp.w11;
-        cok[k][m] = rok[k] && yy >= 0 && yy < a.G && xx >= 0 && xx < a.G;
-        if (cok[k][m]) q[k][m] = gb[((size_t)yy * a.G + xx) * C4 + c];
+      for (int u = 0; u < UB; ++u) {
+        const unsigned i = i0 + 256 * u;
+        const unsigned row = __umulhi(i, mrow), rem = i - row * rowq;
+        const unsigned px = __umulhi(rem, magicS4), c = rem - px * S4;
+        const int yy = gy_lo + (int)row, xx = gx_lo + (int)px;
+        ok[u] = i < nbox && yy >= 0 && yy < G && xx >= 0 && xx < G;
+        q[u] = gb[ok[u] ? ((size_t)yy * G + xx) * C4 + cs0 + c : (size_t)0];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (i0 + 256 * u < nq) box[i0 + 256 * u] = ok[u] ? q[u] : z;
       }
     }
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (!rok[k]) continue;
-      f32x4 cv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        if (cok[k][m]) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) cv[j] += q[k][m][j] * w[k][m];
-        }
-      const float wr = k == 0 ? rt.w00 : k == 1 ? rt.w01 : k == 2 ? rt.w10 : rt.w11;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] += cv[j] * wr;
-    }
-    ob[i] = v;
   }
+  RTRACE(2);
+  __syncthreads();
+  RTRACE(3);
+  // ---- thread = (its record's pixel, channel groups tid % 4, + 4, ...): the pixel's four records come from the quad (DPP, as
+  // they are used: held for the whole loop they cost 24 registers and the kernel its fourth workgroup per CU)
+  const int dn = bw * S4;
+  const int offS = off * S4;
+  for (int c = k_r; c < S4 + k_r; c += 4) {   // (uniform trip count: the quad broadcasts need the whole quad)
+    const bool on = live && c < S4;
+    const int cc = c < S4 ? c : 0;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#define WSMG_TAP(K)                                                                                                        \
+    {                                                                                                                        \
+      const f32x4* p = box + quad_get<K>(offS) + cc;                                                                         \
+      const f32x4 q0 = p[0], q1 = p[S4], q2 = p[dn], q3 = p[dn + S4];                                                        \
+      const float w0 = quad_getf<K>(w[0]), w1 = quad_getf<K>(w[1]), w2 = quad_getf<K>(w[2]), w3 = quad_getf<K>(w[3]);        \
+      const float wk = quad_getf<K>(wr);                                                                                     \
+      f32x4 cv = {0.f, 0.f, 0.f, 0.f};                                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) cv[j] += q0[j] * w0;                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) cv[j] += q1[j] * w1;                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) cv[j] += q2[j] * w2;                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) cv[j] += q3[j] * w3;                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) v[j] += cv[j] * wk;                                                      \
+    }
+    WSMG_TAP(0) WSMG_TAP(1) WSMG_TAP(2) WSMG_TAP(3)
+#undef WSMG_TAP
+    if (on) ob[((size_t)ry * E + rx) * C4 + cs0 + c] = v;
+  }
+  RTRACE(4);
+#undef RTRACE
 }
 
 MapArgs map_args(int B, int C, int E, int G, float resolution) {
@@ -748,6 +969,47 @@ extern "C" int wsmg_map_retrieve_fused(const float* global_map, const float* gps
   MapArgs a = map_args(B, C, E, G, resolution);
   int64_t n = (int64_t)E * E * (C / 4);
   hipLaunchKernelGGL(map_retrieve_fused_kernel, dim3(sgrid(n), B), dim3(256), 0, wsmg_s(stream), global_map, gps, compass, a, out);
+  WSMG_RETURN_LAUNCH();
+}
+
+// channel slices of wsmg_map_retrieve_tiled: the fewest that keep a slice at <= 40 channels and divide C / 4 (a box of 14 x 14 + 16
+// pixels x 40 channels and the records are 40 KB: four workgroups per CU); 0: none does with a box that fits LDS
+static int retrieve_slices(int C) {
+  const int C4 = C / 4;
+  for (int n = 1; n <= C4; ++n)
+    if (C4 % n == 0 && C4 / n <= 10) return n;
+  return 0;
+}
+
+extern "C" int wsmg_map_retrieve_tiled(const float* global_map, const float* gps, const float* compass, int B, int C, int E, int G,
+                                       float resolution, float* out, wsmg_stream_t stream) {
+  if (B <= 0 || C <= 0 || C % 4 || E <= 1 || G < E || B > 65535) return WSMG_EINVAL;
+  const int nsplit = retrieve_slices(C);
+  if (nsplit <= 0) return WSMG_EINVAL;
+  const int S4 = C / 4 / nsplit;
+  const size_t lds = (size_t)(RBOX * RBOX + RBOX + 2) * S4 * 16;
+  MapArgs a = map_args(B, C, E, G, resolution);
+  const int tiles = (E + RT - 1) / RT;
+  if ((int64_t)tiles * tiles * nsplit > 0x7fffffff) return WSMG_EINVAL;
+  // i / S4 as a multiply-high: exact while i * S4 < 2^32 (i < 16 * 14 * S4)
+  const unsigned magic = 0xFFFFFFFFu / (unsigned)S4 + 1u;
+  static unsigned* trace_dev = nullptr;
+  const bool tracing = WSMG_TUNE("WSMG_RETRIEVE_TRACE", 0) != 0;
+  if (tracing && !trace_dev && hipMalloc((void**)&trace_dev, 64 * 8 * sizeof(unsigned)) != hipSuccess) trace_dev = nullptr;
+  const int nblk = tiles * tiles * nsplit;
+  hipLaunchKernelGGL(map_retrieve_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), lds, wsmg_s(stream),
+                     global_map, gps, compass, a, tiles, nsplit, S4, magic, out, tracing ? trace_dev : nullptr);
+  if (tracing && trace_dev) {  // diagnostic only: synchronises
+    unsigned h[64 * 8];
+    const int n = nblk / 64 < 64 ? nblk / 64 : 64;
+    if (n > 0 && hipStreamSynchronize(wsmg_s(stream)) == hipSuccess && hipMemcpy(h, trace_dev, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      double m[5] = {0, 0, 0, 0, 0};
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < 5; ++j) m[j] += h[i * 8 + j] / (double)n;
+      fprintf(stderr, "map_retrieve_tiled trace (cycles since the workgroup started, mean of %d): records %.0f, extents met %.0f, box "
+                      "issued %.0f, box in LDS %.0f, end %.0f\n", n, m[0], m[1], m[2], m[3], m[4]);
+    }
+  }
   WSMG_RETURN_LAUNCH();
 }
 

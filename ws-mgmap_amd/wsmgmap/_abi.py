@@ -41,6 +41,7 @@ _SIG = {
     "wsmg_map_fuse": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "wsmg_map_retrieve": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p],
     "wsmg_map_retrieve_fused": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
+    "wsmg_map_retrieve_tiled": [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p],
     "wsmg_bev_scatter_rotate": [c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p],
     "wsmg_map_fuse_planes": [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p],
     "wsmg_conv2d_fwd": [c_p, c_p, c_p, c_p] + [c_i] * 11 + [c_p],

@@ -81,8 +81,10 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
                 if tok != "ack":
                     spare.append(tok)
 
+        import time
         while True:
             batch = []
+            t0 = time.perf_counter()
             try:
                 while len(batch) < batch_size:
                     batch.append(next(it))
@@ -90,7 +92,9 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
                 pass
             if len(batch) < batch_size:          # drop_last=True, as the reference's loader (dagger_trainer.py:585-594)
                 break
+            t1 = time.perf_counter()
             plan, meta = plan_batch(batch)
+            t2 = time.perf_counter()
             if meta["total"] > slots[0].numel():
                 big = torch.empty(meta["total"], dtype=torch.uint8).share_memory_()
                 pack_batch(plan, meta, big.numpy())
@@ -101,7 +105,10 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
             sid = take(False)
             if sid is None:
                 return
+            t3 = time.perf_counter()
             pack_batch(plan, meta, slots[sid].numpy())
+            # where this worker's time went, in seconds: reading / decoding the records, planning, waiting for a slot, packing
+            meta["worker_times"] = (t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3)
             ready_q.put((sid, meta))
         ready_q.put(_STOP)
     except Exception as e:  # pragma: no cover - reported to the consumer
@@ -259,7 +266,9 @@ class DeviceFeeder:
         pending = collections.deque()          # (out, event, worker, slot)
         live = [True] * W
         import time as _time
-        tacc = dict(get=0.0, launch=0.0, sync=0.0, n=0)       # where the consumer's time goes (reported under WSMG_FEEDER_TRACE)
+        # where the consumer's and the workers' time goes, per batch (reported under WSMG_FEEDER_TRACE; live: a caller may zero it
+        # once the pipeline is full)
+        tacc = self.consumer_times = dict(get=0.0, launch=0.0, sync=0.0, n=0, w_read=0.0, w_plan=0.0, w_slot=0.0, w_pack=0.0)
         try:
             k = 0
             while any(live):
@@ -303,6 +312,8 @@ class DeviceFeeder:
                     out = coll.launch(meta, slots[sid], stream=side)
                     tacc["launch"] += _time.perf_counter() - _t1
                     tacc["n"] += 1
+                    for key, v in zip(("w_read", "w_plan", "w_slot", "w_pack"), meta.get("worker_times", ())):
+                        tacc[key] += v
                     ev = torch.cuda.Event()
                     ev.record(side)
                     pending.append((out, ev, w, sid))
@@ -322,9 +333,10 @@ class DeviceFeeder:
                 yield self._hand_over(out, ev)
         finally:
             if tacc["n"]:
-                self._trace("consumer per batch: waiting for the worker's batch %.1f ms, launch() %.1f ms, waiting for the device %.1f ms (%d batches)"
-                            % (tacc["get"] / tacc["n"] * 1e3, tacc["launch"] / tacc["n"] * 1e3, tacc["sync"] / tacc["n"] * 1e3, tacc["n"]))
-            self.consumer_times = dict(tacc)
+                self._trace("consumer per batch: waiting for the worker's batch %.1f ms, launch() %.1f ms, waiting for the device %.1f ms; "
+                            "a worker per batch: records %.1f ms, plan %.1f ms, waiting for a slot %.1f ms, pack %.1f ms (%d batches)"
+                            % tuple([tacc[k] / tacc["n"] * 1e3 for k in ("get", "launch", "sync", "w_read", "w_plan", "w_slot", "w_pack")]
+                                    + [tacc["n"]]))
             for q in free_qs:
                 q.put(None)
             for p in procs:

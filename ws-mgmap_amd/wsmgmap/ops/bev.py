@@ -90,9 +90,9 @@ def map_fuse(ego_rot, global_map, gps, masks, resolution=0.12, planes=False):
 
 @torch.no_grad()
 def map_retrieve(global_map, gps, compass, E, resolution=0.12, fused=None):
-    """fused: crop + rotation in one launch, bit-identical to the two.  Default: for small batches only (B E^2 C / 4 <= 500 000
-    work items: 11 vs 16 us at B = 1; at B = 8 the 16 gathers per item already cost more than the crop's round trip through memory —
-    35 vs 26 us, 311 vs 219 us at cfg4); `fused` = True / False forces either."""
+    """fused: crop + rotation in one launch, bit-identical to the two.  "tiled" (the default): the LDS-staged launch
+    (wsmg_map_retrieve_tiled); True: the register form (16 gathers per item — 11 us at B = 1 but 311 vs 219 us at cfg4);
+    False: crop and rotation as two launches through a scratch map."""
     _req(global_map, gps, compass)
     B = gps.shape[0]
     _check_global_map(global_map, B, global_map.shape[3] if global_map.dim() == 4 else -1, gps, compass)
@@ -101,7 +101,10 @@ def map_retrieve(global_map, gps, compass, E, resolution=0.12, fused=None):
     G, C = global_map.shape[1], global_map.shape[3]
     out = torch.empty(B, E, E, C, device=gps.device, dtype=torch.float32)
     if fused is None:
-        fused = B * E * E * (C // 4) <= 500_000
+        fused = "tiled"
+    if fused == "tiled":
+        _abi.call("wsmg_map_retrieve_tiled", _p(global_map), _p(gps), _p(compass), B, C, E, G, float(resolution), _p(out), _stream())
+        return out
     if fused:
         _abi.call("wsmg_map_retrieve_fused", _p(global_map), _p(gps), _p(compass), B, C, E, G, float(resolution), _p(out), _stream())
         return out
