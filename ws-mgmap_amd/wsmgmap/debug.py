@@ -20,6 +20,7 @@ _TABLE = [
     ("decoder_streams", "WSMG_DECODER_STREAMS", 1, int, "0: map decoder on one stream; 1: side stream unless ranks share a GPU; 2: always"),
     ("early_dedup", "WSMG_EARLY_DEDUP", True, bool, "instruction dedup on its own stream when the producer marked the tokens ready (ops.mark_inputs_ready)"),
     ("early_dedup_dp", "WSMG_EARLY_DEDUP_DP", False, bool, "the early dedup also under a process group (needs the exchange on a policy stream: GradAllReducer(exchange_stream=...))"),
+    ("prelayout_first", "WSMG_PRELAYOUT_FIRST", True, bool, "update path: the map stack's weight layout is the first thing on the instruction stream (not behind the cached features' dense layers)"),
     ("enc_proj_side", "WSMG_ENC_PROJ_SIDE", True, bool, "map_encoded_linear on the decoder's side stream (its backward beside the resnet branch's small kernels)"),
     ("rollout_fold", "WSMG_ROLLOUT_FOLD", True, bool, "rollout map stack with BatchNorm-folded cached operands"),
     ("depth_engine", "WSMG_DEPTH_ENGINE", False, bool, "frozen depth ResNet50 on the bf16 NHWC engine (5 % error: opt-in)"),

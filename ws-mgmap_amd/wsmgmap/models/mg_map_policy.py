@@ -210,8 +210,9 @@ class MGMapNet(nn.Module):
         if (not train and not torch.is_grad_enabled() and ego_map.is_cuda and self.compute_dtype == torch.bfloat16
                 and debug.sw.rollout_fold):
             return self._map_stack_rollout(ego_map)
-        laid = None
-        if ego_map.is_cuda:
+        laid = getattr(self, "_laid_event", None)             # forward() already queued the layout (update path)
+        self._laid_event = None
+        if ego_map.is_cuda and laid is None:
             # operands of all the map stack's convolutions in one launch — on the instruction branch's stream, beside the ego
             # map's NCHW -> NHWC conversion (0.37 ms of pure HBM traffic) instead of in front of it (0.06 ms)
             entry = getattr(self, "_entry_event", None)
@@ -358,6 +359,20 @@ class MGMapNet(nn.Module):
         entry.record(torch.cuda.current_stream())
         self._entry_event = entry
         ops.mark("entry")
+        # Update path: the map stack's weight operands are laid out FIRST on the instruction branch's stream.  Queued from
+        # _map_stack they sat behind the cached features' dense layers (queued below, on the same stream, and stretched to 0.37 ms by
+        # the ego map's layout conversion they run beside): the stem's convolution started 0.15 ms after its input was ready.
+        self._laid_event = None
+        ego = observations.get("rgb_ego_map")
+        if (torch.is_grad_enabled() and torch.is_tensor(ego) and ego.is_cuda and self.recurrent_chunks > 0 and debug.sw.prelayout_first
+                and not torch.cuda.is_current_stream_capturing()):
+            if self._side_stream is None:
+                self._side_stream = ops.helper_stream("instruction")
+            self._side_stream.wait_event(entry)              # the optimizer's writes to the parameters are complete there
+            with torch.cuda.stream(self._side_stream):
+                ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
+            self._laid_event = torch.cuda.Event()
+            self._laid_event.record(self._side_stream)
         # Rollout (no autograd, RGB encoded from pixels): the instruction branch is queued FIRST and runs beside the frozen
         # RGB encoder — in a captured step (graph.GraphedAct) it otherwise lands behind the map decoder's side branch and the
         # main stream idles through the whole 0.45 ms LSTM (B = 1).  Training keeps the order described in _encode_instruction.
