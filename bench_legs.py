@@ -166,6 +166,11 @@ def cfg4_bev_mapenc(dev, reps=10):
     out["stage_bytes"] = int(stage_bytes)
     out["stage_gbps"] = round(stage_bytes / t_map / 1e3, 1)
     out["stage_frac_of_8TBs"] = round(stage_bytes / t_map / 1e3 / HBM_PEAK_GBS, 4)
+    # the accounting of rounds 3-4 (tools/bench_bev.py "5-stage B"): the bytes the five SEPARATE launches move — the unrotated planes
+    # written and read back (2 C E^2 4 per sample) and the crop's round trip (another 2 C E^2 4), which the fused launches never move
+    five = stage_bytes + B * 4 * C * E * E * 4
+    out["five_launch_bytes"] = int(five)
+    out["five_launch_frac_of_8TBs"] = round(five / t_map / 1e3 / HBM_PEAK_GBS, 4)
     out["stages"] = {k: _bw(us, nb) for k, (us, nb) in stages.items()}
     # MapEncoder at this geometry: [32, 40 -> 64 (zero-padded), 200, 200] -> [32, 256, 49, 49]
     enc = MapEncoder(E, C, 256).to(dev).train()

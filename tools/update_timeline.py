@@ -12,8 +12,12 @@ adam = [i for i, e in enumerate(ev) if "adam_multi_kernel" in e[2]]
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 5]
 one = ev[ends[-2] + 1:ends[-1] + 1]
 t0, busy_end = one[0][0], one[0][0]
+qend = {}      # per queue: end of its previous launch ("own": how long this queue sat idle before the launch — waiting for another
+               # queue's event, or for the host)
 for s, e, n, q in one:
     gap = max(0, s - busy_end)
-    print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f}  gap {gap / 1e3:6.1f}  q{q}  {short(n)}")
+    own = (s - qend[q]) / 1e3 if q in qend else 0.0
+    print(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f}  gap {gap / 1e3:6.1f}  own {own:7.1f}  q{q}  {short(n)}")
     busy_end = max(busy_end, e)
+    qend[q] = e
 print(f"{len(one)} launches, span {(busy_end - t0) / 1e3:.0f} us")
