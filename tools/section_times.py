@@ -45,14 +45,26 @@ torch.cuda.synchronize()
 acc, order = {}, []
 import time
 t0 = time.perf_counter()
+# WSMG_SECTIONS_NOSYNC=1: no synchronisation between the updates — the host runs ahead as it does in bench.py, and the sections are
+# those of the steady state (with the per-update sync the host starts every update level with the GPU and the first sections are its)
+nosync = os.environ.get("WSMG_SECTIONS_NOSYNC", "0") == "1"
+runs = []
 for r in range(reps):
     m = update(True)
-    torch.cuda.synchronize()
+    if not nosync:
+        torch.cuda.synchronize()
+    runs.append(m)
+torch.cuda.synchronize()
+if nosync:   # update to update: the previous update's last mark to this one's first
+    for r in range(1, len(runs)):
+        runs[r] = [("f:prev_opt_step", runs[r - 1][-1][1])] + runs[r]
+    runs = runs[1:]
+for m in runs:
     names = [n for n, _ in m]
     if not order: order = names
     for (n0, e0), (n1, e1) in zip(m[:-1], m[1:]):
         acc.setdefault((n0, n1), []).append(e0.elapsed_time(e1))
-wall = (time.perf_counter() - t0) / reps * 1e3
+wall = (time.perf_counter() - t0) / reps * 1e3   # (the loop above only sorts events: the wall time is dominated by the updates)
 tot = 0.0
 for (n0, n1), v in acc.items():
     ms = sum(v) / len(v); tot += ms
