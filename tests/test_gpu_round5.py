@@ -498,3 +498,54 @@ def test_map_retrieve_lds_tiles_equal_crop_then_rotate(B, E, C, G):
         same = (lds == two) | (lds.isnan() & two.isnan())
         assert bool(same.all()), f"trial {trial}: {int((~same).sum())} of {same.numel()} elements differ"
         assert torch.equal(lds.view(torch.int32)[~two.isnan()], two.view(torch.int32)[~two.isnan()])   # signed zeros included
+
+
+# ----------------------------------------------------------------------------- feeder: a ring that outlives the epoch
+class _BlobStore:
+    def __init__(self, blobs):
+        self.blobs = blobs
+
+    def __call__(self, i):
+        return self.blobs[i]
+
+
+def test_persistent_feeder_ring_serves_epoch_after_epoch_from_the_same_processes():
+    """DeviceFeeder(persistent=True): the worker processes, the shared slots and their page-locking are built once; every epoch
+    delivers exactly what a fresh feeder with the same seed delivers (order and values: common_trainer / dagger_trainer.py:585-594's
+    loader re-seeds per epoch, so does this); an epoch abandoned half way takes the ring down and the next one rebuilds it;
+    close() is idempotent."""
+    from oracle import data_cases as dc
+    from wsmgmap.data import TrajectoryDataset, DeviceFeeder, pack_record
+    lengths = (dc.DATASET_LENGTHS * 3)[:48]
+    store = _BlobStore([pack_record(*dc.episode(2000 + i, n)) for i, n in enumerate(lengths)])
+    mk = lambda: TrajectoryDataset(store, len(store.blobs), batch_size=2, rank=0, world_size=1)  # noqa: E731
+
+    def epoch(fd, stop_after=None):
+        seen = []
+        for n, (ob, prev, masks, corr, wts) in enumerate(fd):
+            seen.append((prev.view(-1, 2, 2)[0, :, 0].cpu().tolist(), float(ob["progress"].sum()), float(ob["rgb_ego_map"].float().abs().sum())))
+            if stop_after is not None and n + 1 >= stop_after:
+                break
+        return seen
+
+    fresh = DeviceFeeder(mk(), 2, "cuda", num_workers=2, prefetch=2, seed=9)
+    want = [epoch(fresh) for _ in range(3)]
+    assert fresh.ring_opens == 3 and fresh._ring is None
+    fd = DeviceFeeder(mk(), 2, "cuda", num_workers=2, prefetch=2, seed=9, persistent=True)
+    got = [epoch(fd)]
+    pids = [p.pid for p in fd._ring["procs"]]
+    got += [epoch(fd), epoch(fd)]
+    assert got == want
+    assert fd.ring_opens == 1 and [p.pid for p in fd._ring["procs"]] == pids and all(p.is_alive() for p in fd._ring["procs"])
+    procs = fd._ring["procs"]
+    part = epoch(fd, stop_after=2)                      # abandoned: the generator is closed with batches in flight
+    assert len(part) == 2 and fd._ring is None
+    for p in procs:
+        p.join(timeout=10)
+        assert not p.is_alive()
+    again = epoch(fd)                                   # epoch counter went on: this is epoch 4 of seed 9
+    flat = lambda ep: sorted(x for a in ep for x in a[0])  # noqa: E731  (the episodes of an epoch, however they were paired into batches)
+    assert fd.ring_opens == 2 and len(again) == len(want[0]) and flat(again) == flat(want[0])
+    fd.close()
+    fd.close()
+    assert fd._ring is None

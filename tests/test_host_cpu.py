@@ -520,6 +520,51 @@ def test_feeder_worker_sends_an_oversize_batch_outside_the_ring_and_waits_for_th
     assert not th.is_alive() and big >= 1 and len(got) == len(sizes) and sorted(got) == sorted(sizes)
 
 
+def test_feeder_worker_runs_epoch_after_epoch_when_the_ring_is_persistent():
+    """Round 5: a persistent ring's decode worker does not end with its epoch — after its _STOP it waits for ("epoch", seed) on the
+    queue its slots come back on (keeping the slot ids that arrive meanwhile), runs the next epoch with that seed exactly as a fresh
+    worker started with it would, and ends on None."""
+    import queue
+    import threading
+    from wsmgmap.data import feeder
+
+    def run(seeds, persistent):
+        slots = [torch.empty(1 << 20, dtype=torch.uint8) for _ in range(2)]
+        free_q, ready_q = queue.Queue(), queue.Queue()
+        free_q.put(0)
+        free_q.put(1)
+        th = threading.Thread(target=feeder._ring_worker, args=(_tiny_dataset(3), 2, 0, 1, slots, free_q, ready_q, seeds[0], persistent),
+                              daemon=True)
+        th.start()
+        epochs = []
+        for e, _ in enumerate(seeds):
+            got = []
+            while True:
+                item = ready_q.get(timeout=60)
+                if item == feeder._STOP:
+                    break
+                assert item[0] not in ("__error__", "__big__"), item
+                sid, meta = item
+                got.append((meta["total"], bytes(slots[sid][:64].numpy())))
+                free_q.put(sid)
+            epochs.append(got)
+            if e + 1 < len(seeds):
+                free_q.put(("epoch", seeds[e + 1]))
+        free_q.put(None)
+        th.join(timeout=10)
+        assert not th.is_alive()
+        return epochs
+
+    nthreads = torch.get_num_threads()
+    try:
+        three = run([5, 11, 5], True)
+        assert len(three) == 3 and all(len(e) > 0 for e in three)
+        assert three[0] == three[2], "the same seed must give the same epoch"
+        assert three[1] == run([11], False)[0], "an epoch of the standing worker differs from a fresh worker's with the same seed"
+    finally:
+        torch.set_num_threads(nthreads)
+
+
 def test_recoded_raw_records_decode_to_the_same_arrays_and_collate_identically():
     """`tools/recode_cache.py` rewrites the reference's zlib(msgpack_numpy) values (dagger_trainer.py:336-343)
     once into an uncompressed layout; a recoded record must give the same arrays (dtype, shape, bytes) and the same batch from

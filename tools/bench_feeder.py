@@ -176,5 +176,25 @@ if __name__ == "__main__" and os.environ.get("WSMG_FEEDER_E2E", "1") != "0":
                 continue
             print(f"  raw ring, {w:2d} worker processes, ego map {'sparse' if sp else 'dense '} -> NHWC bf16: {r:8.0f} steps/s  ({n} batches; "
                   f"{getattr(feeder_rate, 'last_consumer', '')})")
+    # epoch to epoch: from the last batch of one epoch to the first batch of the next, with the ring rebuilt (the default: what the
+    # reference's DataLoader does with its workers too) and with a ring that outlives the epoch (DeviceFeeder(persistent=True))
+    from wsmgmap.data import TrajectoryDataset, DeviceFeeder
+    for persistent in (False, True):
+        w = 8
+        ds = TrajectoryDataset(SynthStore(N * 4 * w, raw_records=True, sparse_ego=True), N * 4 * w, batch_size=N)
+        fd = DeviceFeeder(ds, N, "cuda", num_workers=w, prefetch=2, slot_bytes=int(raw * 1.05) + (1 << 20), ego_map_nhwc_bf16=True,
+                          persistent=persistent)
+        gaps, t_end = [], None
+        for ep in range(3):
+            for k, batch in enumerate(fd):
+                torch.cuda.current_stream().synchronize()
+                if k == 0 and t_end is not None:
+                    gaps.append(time.time() - t_end)
+                t_last = time.time()
+            t_end = t_last
+        t0 = time.time()
+        fd.close()
+        print(f"  epoch -> epoch, {w} workers, sparse ego map, persistent={persistent}: last batch of an epoch to the first of the next "
+              f"{' / '.join('%.2f' % g for g in gaps)} s (rings built: {fd.ring_opens}; close() {time.time() - t0:.2f} s)")
     r, n, _ = feeder_rate(8, transport="dataloader")
     print(f"  torch DataLoader transport, 8 workers (batches pickled through a pipe): {r:8.0f} steps/s")

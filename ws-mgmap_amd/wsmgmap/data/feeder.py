@@ -56,20 +56,20 @@ def _host_memory_available():
     return min(vals) if vals else None
 
 
-def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, seed):
+def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, seed, persistent=False):
     """Decode worker: its shard of the dataset, whole batches, packed into the shared slots it is handed.  A batch larger than a
     slot (the slots are sized from a probe batch; episodes vary in length) does NOT fail the epoch: it travels once as its own
-    shared-memory block ("__big__") and the worker waits for the consumer's acknowledgement before it goes on."""
+    shared-memory block ("__big__") and the worker waits for the consumer's acknowledgement before it goes on.
+    persistent: after an epoch's _STOP the worker waits for ("epoch", seed) on its free queue and runs the next one (round 5: a ring
+    that outlives the epoch — no process spawn, no re-pinning of the slots); None ends it."""
     import random
+    import time
 
     import numpy as np
     try:
         torch.set_num_threads(1)
-        random.seed(seed + wid)        # DataLoader seeds every worker with base_seed + worker_id
-        np.random.seed((seed + wid) % (1 << 32))
         dataset._worker_override = (nworkers, wid)
-        it = iter(dataset)
-        spare = []                     # slot ids that came back while this worker was waiting for an acknowledgement
+        spare = []                     # slot ids that came back while this worker was waiting for something else
 
         def take(want_ack):
             while True:
@@ -81,36 +81,54 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
                 if tok != "ack":
                     spare.append(tok)
 
-        import time
+        def next_epoch():
+            while True:
+                tok = free_q.get()
+                if tok is None:
+                    return None
+                if isinstance(tok, tuple) and tok[0] == "epoch":
+                    return tok[1]
+                if tok != "ack":
+                    spare.append(tok)
+
         while True:
-            batch = []
-            t0 = time.perf_counter()
-            try:
-                while len(batch) < batch_size:
-                    batch.append(next(it))
-            except StopIteration:
-                pass
-            if len(batch) < batch_size:          # drop_last=True, as the reference's loader (dagger_trainer.py:585-594)
-                break
-            t1 = time.perf_counter()
-            plan, meta = plan_batch(batch)
-            t2 = time.perf_counter()
-            if meta["total"] > slots[0].numel():
-                big = torch.empty(meta["total"], dtype=torch.uint8).share_memory_()
-                pack_batch(plan, meta, big.numpy())
-                ready_q.put(("__big__", meta, big))
-                if take(True) is None:
+            random.seed(seed + wid)        # DataLoader seeds every worker with base_seed + worker_id
+            np.random.seed((seed + wid) % (1 << 32))
+            it = iter(dataset)
+            while True:
+                batch = []
+                t0 = time.perf_counter()
+                try:
+                    while len(batch) < batch_size:
+                        batch.append(next(it))
+                except StopIteration:
+                    pass
+                if len(batch) < batch_size:          # drop_last=True, as the reference's loader (dagger_trainer.py:585-594)
+                    break
+                t1 = time.perf_counter()
+                plan, meta = plan_batch(batch)
+                t2 = time.perf_counter()
+                if meta["total"] > slots[0].numel():
+                    big = torch.empty(meta["total"], dtype=torch.uint8).share_memory_()
+                    pack_batch(plan, meta, big.numpy())
+                    ready_q.put(("__big__", meta, big))
+                    if take(True) is None:
+                        return
+                    continue
+                sid = take(False)
+                if sid is None:
                     return
-                continue
-            sid = take(False)
-            if sid is None:
+                t3 = time.perf_counter()
+                pack_batch(plan, meta, slots[sid].numpy())
+                # where this worker's time went, in seconds: reading / decoding the records, planning, waiting for a slot, packing
+                meta["worker_times"] = (t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3)
+                ready_q.put((sid, meta))
+            ready_q.put(_STOP)
+            if not persistent:
                 return
-            t3 = time.perf_counter()
-            pack_batch(plan, meta, slots[sid].numpy())
-            # where this worker's time went, in seconds: reading / decoding the records, planning, waiting for a slot, packing
-            meta["worker_times"] = (t1 - t0, t2 - t1, t3 - t2, time.perf_counter() - t3)
-            ready_q.put((sid, meta))
-        ready_q.put(_STOP)
+            seed = next_epoch()
+            if seed is None:
+                return
     except Exception as e:  # pragma: no cover - reported to the consumer
         import traceback
         ready_q.put(("__error__", traceback.format_exc() + repr(e)))
@@ -118,13 +136,17 @@ def _ring_worker(dataset, batch_size, wid, nworkers, slots, free_q, ready_q, see
 
 class DeviceFeeder:
     def __init__(self, dataset, batch_size, device="cuda", num_workers=0, prefetch=2, workers="ring", slot_bytes=None,
-                 slots_per_worker=2, seed=None, ego_map_nhwc_bf16=False):
+                 slots_per_worker=2, seed=None, ego_map_nhwc_bf16=False, persistent=False):
         """slot_bytes: capacity of one ring slot (default: sized from one batch this process plans itself — it decodes one batch
         of the first shard for that — with 50 % headroom, capped at the true upper bound batch_size x 200 steps; a larger batch
         travels outside the ring, counted in `oversize_batches`).
         seed: None (default) draws a fresh base seed from torch's generator for every epoch (= every `iter()`), which is what
         DataLoader does for its workers (dagger_trainer.py:116-119,585-594: the shuffle order changes each epoch); an integer is
-        a reproducibility override: epoch e seeds worker w with seed + e * num_workers + w."""
+        a reproducibility override: epoch e seeds worker w with seed + e * num_workers + w.
+        persistent (ring transport): the ring — worker processes, shared slots, their page-locking — outlives the epoch: an epoch that
+        ran to its end leaves it standing and the next `iter()` re-arms the workers with the new seed (the analogue of DataLoader's
+        persistent_workers; without it every epoch pays 2-5 s of process start + pinning and 0.6-4.8 s of teardown).  `close()`
+        (or garbage collection) takes it down; an epoch that is abandoned half way or fails takes it down too."""
         self.dataset, self.batch_size, self.device = dataset, batch_size, torch.device(device)
         self.num_workers, self.prefetch = int(num_workers), max(1, prefetch)
         self.workers = workers if self.num_workers > 0 else "none"
@@ -136,6 +158,9 @@ class DeviceFeeder:
         self.epoch = 0                # iterators created so far (ring transport)
         self.oversize_batches = 0     # batches that did not fit a ring slot and travelled as their own shared-memory block
         self.pinned_ring = None       # True / False once a ring exists: could the shared slots be registered as pinned memory
+        self.persistent = bool(persistent)
+        self.ring_opens = 0           # rings built so far (persistent: 1 however many epochs)
+        self._ring = None             # the standing ring of a persistent feeder between epochs
 
     def _trace(self, msg):
         from ..debug import sw
@@ -207,7 +232,8 @@ class DeviceFeeder:
         bound = (per_step * LIMITED_LEN_BY_GPU + 16 * len(plan)) * self.batch_size + 4096
         return min(bound, int(meta["total"] * 1.5) + 4096)
 
-    def _iter_ring(self):
+    def _ring_open(self, base_seed):
+        """Build the ring: shared slots (page-locked when the runtime allows), two queues and one decode process per worker."""
         W = self.num_workers
         # a worker's slot comes back when its batch leaves the prefetch queue: with `prefetch` batches queued (taken from the workers
         # in turn) a worker needs ceil(prefetch / W) slots there, one being handed over and one to fill meanwhile — fewer deadlocks
@@ -232,13 +258,6 @@ class DeviceFeeder:
             raise RuntimeError(f"the feeder's shared-memory ring needs {need >> 20} MiB ({W} workers x {self.slots_per_worker} slots x "
                                f"{nbytes >> 20} MiB), more than 40 % of the {avail >> 20} MiB of host memory this process may use: "
                                "fewer workers or slots_per_worker")
-        # DataLoader draws a fresh base seed per iterator from torch's default generator (worker w gets base_seed + w): the block
-        # shuffle and the tie-breaks of equal-length episodes differ from epoch to epoch.  An explicit seed stays reproducible.
-        if self.seed is None:
-            base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
-        else:
-            base_seed = self.seed + self.epoch * W
-        self.epoch += 1
         ctx = mp.get_context("spawn")
         slots = [torch.empty(nbytes, dtype=torch.uint8).share_memory_() for _ in range(W * self.slots_per_worker)]
         rt = torch.cuda.cudart()
@@ -256,11 +275,62 @@ class DeviceFeeder:
         for w in range(W):
             for k in range(self.slots_per_worker):
                 free_qs[w].put(w * self.slots_per_worker + k)
-            p = ctx.Process(target=_ring_worker, args=(self.dataset, self.batch_size, w, W, slots, free_qs[w], ready_qs[w], base_seed),
-                            daemon=True)
+            p = ctx.Process(target=_ring_worker, args=(self.dataset, self.batch_size, w, W, slots, free_qs[w], ready_qs[w], base_seed,
+                                                       self.persistent), daemon=True)
             p.start()
             procs.append(p)
         self._trace("%d workers started" % W)
+        self.ring_opens += 1
+        return dict(slots=slots, nbytes=nbytes, free_qs=free_qs, ready_qs=ready_qs, procs=procs, pinned=self.pinned_ring)
+
+    def _ring_close(self, ring):
+        if ring is None:
+            return
+        for q in ring["free_qs"]:
+            q.put(None)
+        for p in ring["procs"]:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        if ring["pinned"]:
+            rt = torch.cuda.cudart()
+            for t in ring["slots"]:
+                rt.cudaHostUnregister(t.data_ptr())
+        for q in ring["free_qs"] + ring["ready_qs"]:      # the queues' feeder threads and semaphores go with the ring, not with the interpreter
+            q.close()
+            q.cancel_join_thread()
+
+    def close(self):
+        """Take a persistent feeder's standing ring down (worker processes, page-locked slots).  Idempotent."""
+        ring, self._ring = self._ring, None
+        self._ring_close(ring)
+
+    def __del__(self):  # pragma: no cover - best effort at interpreter exit
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _iter_ring(self):
+        W = self.num_workers
+        # DataLoader draws a fresh base seed per iterator from torch's default generator (worker w gets base_seed + w): the block
+        # shuffle and the tie-breaks of equal-length episodes differ from epoch to epoch.  An explicit seed stays reproducible.
+        if self.seed is None:
+            base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        else:
+            base_seed = self.seed + self.epoch * W
+        self.epoch += 1
+        ring, self._ring = self._ring, None
+        if ring is not None and not all(p.is_alive() for p in ring["procs"]):
+            self._ring_close(ring)
+            ring = None
+        if ring is None:
+            ring = self._ring_open(base_seed)
+        else:               # a standing ring: every slot is back with its worker; re-arm the workers
+            self.pinned_ring = ring["pinned"]
+            for q in ring["free_qs"]:
+                q.put(("epoch", base_seed))
+        slots, nbytes, free_qs, ready_qs, procs = ring["slots"], ring["nbytes"], ring["free_qs"], ring["ready_qs"], ring["procs"]
         side = torch.cuda.Stream(self.device)
         coll = DeviceCollator(self.device, self.ego_map_nhwc_bf16)
         pending = collections.deque()          # (out, event, worker, slot)
@@ -269,6 +339,7 @@ class DeviceFeeder:
         # where the consumer's and the workers' time goes, per batch (reported under WSMG_FEEDER_TRACE; live: a caller may zero it
         # once the pipeline is full)
         tacc = self.consumer_times = dict(get=0.0, launch=0.0, sync=0.0, n=0, w_read=0.0, w_plan=0.0, w_slot=0.0, w_pack=0.0)
+        done = False
         try:
             k = 0
             while any(live):
@@ -331,21 +402,14 @@ class DeviceFeeder:
                 if s0 is not None:
                     free_qs[w0].put(s0)
                 yield self._hand_over(out, ev)
+            done = True
         finally:
             if tacc["n"]:
                 self._trace("consumer per batch: waiting for the worker's batch %.1f ms, launch() %.1f ms, waiting for the device %.1f ms; "
                             "a worker per batch: records %.1f ms, plan %.1f ms, waiting for a slot %.1f ms, pack %.1f ms (%d batches)"
                             % tuple([tacc[k] / tacc["n"] * 1e3 for k in ("get", "launch", "sync", "w_read", "w_plan", "w_slot", "w_pack")]
                                     + [tacc["n"]]))
-            for q in free_qs:
-                q.put(None)
-            for p in procs:
-                p.join(timeout=5)
-                if p.is_alive():
-                    p.terminate()
-            if self.pinned_ring:
-                for t in slots:
-                    rt.cudaHostUnregister(t.data_ptr())
-            for q in free_qs + ready_qs:      # the queues' feeder threads and semaphores go with the ring, not with the interpreter
-                q.close()
-                q.cancel_join_thread()
+            if done and self.persistent:
+                self._ring = ring        # every worker has sent its _STOP and has every slot back: the ring stands for the next epoch
+            else:
+                self._ring_close(ring)
