@@ -358,6 +358,10 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # round 5: BOTH named families are in every line, whichever of them the warm-up found larger — the larger
     # one timed on every update, the other on every 4th; a third family, should it ever lead, is timed on every update beside them
     both = sorted({dom_entry, WG, FW}) if dom_entry else None
+    # round 5, end: the largest family on every update still cost the line 0.12 ms per update (10.42 against 10.30 ms without any
+    # event, one box, interleaved: profiles/r05_bench_line_cost.txt) — BOTH families are now timed on every 4th update of the timed
+    # region only (10.38); WSMG_BENCH_PROF_EVERY=1 restores the largest family on every update
+    prof_every = int(os.environ.get("WSMG_BENCH_PROF_EVERY", "4"))
     if os.environ.get("WSMG_BENCH_NOPROF") != "1":
         ops.profile_begin(only=[dom_entry] if dom_entry else None)
     # an event every WIN updates (no synchronisation): `sustained` for --steps >= 200 (50-update windows), and `windows` for every
@@ -383,7 +387,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
             ev.record()
             marks.append(ev)
         if dom_entry:
-            ops.profile_set_only(both if i % 4 == 0 else [dom_entry])
+            ops.profile_set_only(both if i % 4 == 0 else ([dom_entry] if prof_every == 1 else ["-"]))
         h0 = time.perf_counter()
         loss = update()
         host += time.perf_counter() - h0
@@ -424,7 +428,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     prof = ops.profile_end()
     if dom_entry:
         for r in prof.values():       # the sampled families: their totals are over every 4th update
-            if r.get("entry") in (WG, FW) and r.get("entry") != dom_entry:
+            if r.get("entry") in (WG, FW) and (r.get("entry") != dom_entry or prof_every != 1):
                 r["per_steps"] = (steps + 3) // 4
                 r["phase"] = "timed region"
                 r["sampled"] = "every 4th update of the timed region"
