@@ -39,6 +39,7 @@ struct RowsGemmArgs {
   unsigned* signal_cnt;
   unsigned* status;      // process-wide status word (a wait that times out sets bit `fail_bit` and the tile becomes NaN)
   unsigned fail_bit;
+  const unsigned* gate;  // or null: a word the gate launch in front of this one (chain_gate_kernel) left non-zero when ITS wait timed out
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -75,6 +76,8 @@ __global__ __launch_bounds__(64 * WAVES) void rows_gemm_f32_kernel(RowsGemmArgs 
       if (bad && a.status) __hip_atomic_fetch_or(a.status, a.fail_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     timed_out = __syncthreads_or(bad) != 0;
+  } else if (a.gate) {
+    timed_out = __syncthreads_or(tid == 0 && __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) != 0;
   }
   const float* const p0 = a.a[0] + (size_t)row * a.lda[0];
   const float* const p1 = a.a[1] + (size_t)row * a.lda[1] - s1;      // (never dereferenced below s1: pointer arithmetic only)
@@ -134,6 +137,25 @@ __global__ __launch_bounds__(64 * WAVES) void rows_gemm_f32_kernel(RowsGemmArgs 
   }
 }
 
+// The wait of a chained product as its OWN one-workgroup launch in front of it (round 5, end).  With the wait inside the product every
+// workgroup of it spins while resident — the backward pass's first product of a chunk is 768 workgroups of 16 waves: two per CU, the
+// whole chip's wave slots — and the persistent recurrence it waits for needs all 32 of ITS workgroups resident to take a step: which
+// of the two reaches the CUs first is decided by a few microseconds of stream timing (removing one redundant event record in
+// wsmgmap/recurrent.py was enough to turn it: the recurrences timed out in 4 of 5 runs).  One spinning wave cannot starve anything.
+__global__ __launch_bounds__(64) void chain_gate_kernel(const unsigned* cnt, unsigned target, unsigned* status, unsigned fail_bit,
+                                                        unsigned* gate) {
+  if (threadIdx.x != 0) return;
+  unsigned n = 0;
+  int bad = 0;
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++n >= (1u << 21)) { bad = 1; break; }        // (seconds)
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (bad && status) __hip_atomic_fetch_or(status, fail_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(gate, bad ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int WAVES, int U>
 void launch_rows(const RowsGemmArgs& g, dim3 grid, hipStream_t s) {
   if (g.nn) hipLaunchKernelGGL((rows_gemm_f32_kernel<WAVES, U, true>), grid, dim3(64 * WAVES), 0, s, g);
@@ -182,6 +204,18 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
   g.M = M; g.N = N; g.K = K; g.relu = relu; g.nn = w_is_kn;
   g.wait_cnt = wait_count; g.wait_target = wait_target; g.signal_cnt = signal_count;
   g.status = wait_count ? wsmgi_rnn_status_dev() : nullptr; g.fail_bit = (unsigned)fail_bit;
+  g.gate = nullptr;
+  if (wait_count && WSMG_TUNE("WSMG_CHAIN_GATE", 1) != 0) {     // (0: the wait inside the product, as before — A/B)
+    static unsigned* gates = nullptr;      // one word per fail bit: launches that share one are ordered on one stream
+    if (!gates) {
+      if (hipMalloc((void**)&gates, 32 * sizeof(unsigned)) != hipSuccess) return WSMG_ENOMEM;
+      if (hipMemset(gates, 0, 32 * sizeof(unsigned)) != hipSuccess) return WSMG_ENOMEM;
+    }
+    unsigned* gate = gates + (__builtin_ctz((unsigned)fail_bit | 0x80000000u) & 31);
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(64), 0, wsmg_s(stream), wait_count, wait_target, g.status, g.fail_bit, gate);
+    g.wait_cnt = nullptr;
+    g.gate = gate;
+  }
   const dim3 grid((unsigned)(N / 16), (unsigned)wsmg_cdiv(M, 16));
   // (waves, chunks per wave) with waves x 16 x chunks == K: K = 256: 16 x 1, 512: 16 x 2, 1024: 16 x 4, 1536: 16 x 6 — every product of
   // the recurrent core is one round of loads; other multiples of 64: 4 waves; WSMG_ROWS_GEMM_WAVES caps the waves (A/B)

@@ -96,6 +96,15 @@ def _rg(a_segs, w, w_is_kn, out_segs, r0, M, bias=None, cin_segs=None, mask=None
               None if signal is None else ctypes.c_void_p(signal), int(fail_bit), _stream())
 
 
+def _fork(main, *streams):
+    """Every stream of `streams` waits for what `main` has queued so far — ONE event record on `main` (stream.wait_stream(main)
+    records one per call, and a record between two dependent kernels costs the recording stream ~3 us: tools/exp/event_cost.hip)."""
+    e = torch.cuda.Event()
+    e.record(main)
+    for st in streams:
+        st.wait_event(e)
+
+
 def rows_gemm_ok(H, C, in1):
     """Shapes wsmg_rows_gemm_f32 takes for the attention stage's five products (hidden size H, attention width C, GRU-2 input)."""
     return _sw.rows_gemm and H % 256 == 0 and C % 256 == 0 and in1 % 256 == 0
@@ -183,10 +192,10 @@ class _RecurrentBlock(torch.autograd.Function):
         tsfx = _sfx(text_k)
         ksfx = _sfx(tokens)
         nbytes = lib.wsmg_gru_workspace_bytes(Tc)
+        forked = False
         if sa is not main:
             # the buffers above come from the main stream's pool: whatever used their memory before is queued on main
-            sa.wait_stream(main)
-            sg.wait_stream(main)
+            # (forked below, once: the chained route after it has zeroed its counters on main)
             if text_ev is not None:
                 sa.wait_event(text_ev)
         elif text_ev is not None:
@@ -217,12 +226,14 @@ class _RecurrentBlock(torch.autograd.Function):
         if chain:
             cnt = torch.zeros(2 * K, device=dev, dtype=torch.int32)
             nwg = int(lib.wsmg_gru_chain_workgroups())
-            sa.wait_stream(main)         # (the counters are zeroed on main)
-            sg.wait_stream(main)
+            _fork(main, sa, sg)          # (the counters are zeroed on main)
+            forked = True
             _abi.call("wsmg_gru_fwd_chain", _p(gi1), _p(w_hh1), _p(b_hh1), _p(h01), _p(m), T, N, H, _p(y1), *[_p(s_) for s_ in sv1],
                       _p(_owned_ws(dev, "f1", lib.wsmg_gru_workspace_bytes(T))), Tc, None, 0, _p(cnt), _stream())
             _rnn_launched()
             _ops.mark("f.g1")
+        if multi and not forked:
+            _fork(main, sa, sg)
         # Enqueue order: stream by stream (all of GRU 1's chunks, then all attention chunks, then all of GRU 2's) — the dependencies are
         # events, so the GPU sees the same pipeline as with a chunk-by-chunk order, and the host changes its current stream twice
         # instead of eight times (the host has < 1.5 ms of lead over the GPU in this part of an update)
@@ -372,8 +383,6 @@ class _RecurrentBlock(torch.autograd.Function):
             keep = [dgi2, dgh2, dgi1, dgh1, dxc, dqf, dq2, dq1, dtext, dmap_all, dl, dstate, dtokens, dh02, dy2, datt, carry2, carry1,
                     list(ctx.saved_tensors)]
             torch.autograd.Variable._execution_engine.queue_callback(keep.clear)
-            sg.wait_stream(main)
-            sa.wait_stream(main)
         xcr = xc
         y1r = y1.view(B, H)
         dstate_r = dstate.view(B, H)
@@ -399,8 +408,8 @@ class _RecurrentBlock(torch.autograd.Function):
             cnt = torch.zeros(2 * K, device=dev, dtype=torch.int32)
             keep.append(cnt)
             nwg = int(lib.wsmg_gru_chain_workgroups())
-            sg.wait_stream(main)
-            sa.wait_stream(main)
+        if multi:
+            _fork(main, sg, sa)      # once, behind everything the pass has queued on main so far (buffers, the chain's counters)
         with torch.cuda.stream(sg):
             if chain:
                 _abi.call("wsmg_gru_bwd_chain", _p(dy2), None, _p(w_hh2), _p(h02), _p(m), _p(y2), _p(sr2), _p(sz2), _p(sn2), _p(sg2), T, N, H,
