@@ -664,10 +664,12 @@ int wsmg_instruction_dedup(const void* tokens, int is_f32, int B, int L, long lo
  * zero where mask[M][N] <= 0 (row stride ldmask, may be NULL: threshold_backward of the ReLU).
  * K % 64 == 0 (K / 16 a multiple of 16, or of 4, times 1-4, 6 or 8), ka_i % 16 == 0, nc_i % 16 == 0, strides % 4 == 0; WSMG_EINVAL
  * otherwise.  Deterministic (fixed reduction order).
- * Chaining to the whole-sequence GRU launches (wsmg_gru_fwd_chain / _bwd_chain): wait_count (may be NULL): every workgroup waits,
- * bounded, until *wait_count >= wait_target before it reads its operands (they are produced by a kernel still running on another
- * stream, enqueued earlier); a timeout sets bit `fail_bit` of the persistent kernels' status word (wsmg_rnn_status) and fills the
- * output with NaN.  signal_count (may be NULL): every workgroup adds one arrival when its tile is stored. */
+ * Chaining to the whole-sequence GRU launches (wsmg_gru_fwd_chain / _bwd_chain): wait_count (may be NULL): the product does not
+ * read its operands before *wait_count >= wait_target (they are produced by a kernel still running on another stream) — the wait,
+ * bounded, is a ONE-workgroup launch in front of the product on the same stream (a grid of spinning workgroups could keep that
+ * producer off the CUs; WSMG_CHAIN_GATE=0: the wait inside every workgroup of the product, round 5's first form); a timeout sets bit
+ * `fail_bit` of the persistent kernels' status word (wsmg_rnn_status) and fills the output with NaN.  signal_count (may be NULL):
+ * every workgroup adds one arrival when its tile is stored. */
 int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const float* a1, int lda1, int ka1, const float* a2, int lda2, int ka2,
                        const float* w, int ldw, int w_is_kn, const float* bias, const float* mask, int ldmask, int relu,
                        float* c0, int ldc0, int nc0, float* c1, int ldc1, int nc1, float* c2, int ldc2, int nc2,
