@@ -614,7 +614,10 @@ def test_frozen_encoders_on_the_bf16_engine_vs_oracle():
         f_ref = policy_ref.ddppo_resnet50(P, depth)
         f = pol.net.depth_encoder.visual_encoder({"depth": depth.cuda()})
     assert f.dtype == torch.float32 and tuple(f.shape) == (2, 128, 4, 4)
-    assert float((f.cpu() - f_ref).abs().max()) <= 1e-4
+    # (the bar of test_act_from_raw_depth_vs_oracle for this very tensor: 53 float32 conv + GroupNorm layers, MIOpen's algorithm
+    #  choice on one side and the host's thread split on the other — 6e-5 to 1.02e-4 over repeated runs, values reach 1.2.  This
+    #  line said 1e-4 and failed once in ~25 runs of the suite, on a box whose host was also slow enough to pace the DP bench)
+    assert float((f.cpu() - f_ref).abs().max()) <= 3e-4
 
 
 def test_depth_backbone_engine_path_opt_in():
