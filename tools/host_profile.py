@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU-box tool: where the HOST's time goes in one update (both threads: the caller's and autograd's), by torch.profiler's CPU
-activity — self CPU time per operator / Function over a few updates of the bench workload.   python tools/host_profile.py [updates]"""
+activity — self CPU time per operator / Function over a few updates of the bench workload.   python tools/host_profile.py [updates]
+WSMG_HOSTPROF_DP=1: with a one-rank RCCL process group and the gradient exchange bench.py --gpus N builds (what the exchange adds)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ws-mgmap_amd"))
@@ -24,6 +25,14 @@ class Box:
 pol = BasePolicy(None, Box(), default_model_config(num_proc=N, compute_dtype="bf16")).to(dev)
 pol.train(); pol.net.depth_encoder.eval(); pol.net.rgb_encoder.eval()
 opt = Adam(pol.parameters(), lr=2.5e-4)
+reducer = None
+if os.environ.get("WSMG_HOSTPROF_DP") == "1":
+    import torch.distributed as dist
+    from wsmgmap.parallel import GradAllReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev if dev.index is not None else torch.device("cuda:0"))
+    reducer = GradAllReducer(pol.parameters(), bucket_bytes=8 << 20, single_rank_exchange=True, exchange_stream="instruction")
+    reducer.broadcast_parameters(pol)
 obs, prev, masks, weights = bench.synth_batch(T, N, dev, 1000)
 ops.mark_inputs_ready(obs["instruction"])
 AuxLosses.activate()
@@ -37,6 +46,8 @@ def update():
     pred, aux = pol(o, h0, prev, masks, weights)
     loss = bench.dagger_loss(pred, aux, o["waypoint"], weights)
     loss.backward()
+    if reducer:
+        reducer.finish()
     opt.step()
 
 
