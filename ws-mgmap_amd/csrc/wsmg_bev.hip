@@ -263,13 +263,18 @@ __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* _
       const float gx = bx * r.c + by * r.s;
       const float gy = bx * (-r.s) + by * r.c;
       const Taps tp = make_taps(unnorm(gx, E), unnorm(gy, E));
-      bool x0ok = tp.x0 >= 0 && tp.x0 < E, x1ok = tp.x0 + 1 >= 0 && tp.x0 + 1 < E;
-      bool y0ok = tp.y0 >= 0 && tp.y0 < E, y1ok = tp.y0 + 1 >= 0 && tp.y0 + 1 < E;
-      float v = 0.f;
-      if (y0ok && x0ok) v += pb[tp.y0 * E + tp.x0] * tp.w00;
-      if (y0ok && x1ok) v += pb[tp.y0 * E + tp.x0 + 1] * tp.w01;
-      if (y1ok && x0ok) v += pb[(tp.y0 + 1) * E + tp.x0] * tp.w10;
-      if (y1ok && x1ok) v += pb[(tp.y0 + 1) * E + tp.x0 + 1] * tp.w11;
+      // branch-free (round 5, end): one unsigned compare per bound, every tap read from a clamped address, a tap outside the plane
+      // dropped by a select AFTER its product (what the four branches did, without four exec-mask round trips per pixel)
+      const bool x0ok = (unsigned)tp.x0 < (unsigned)E, x1ok = (unsigned)(tp.x0 + 1) < (unsigned)E;
+      const bool y0ok = (unsigned)tp.y0 < (unsigned)E, y1ok = (unsigned)(tp.y0 + 1) < (unsigned)E;
+      const int xa = x0ok ? tp.x0 : 0, xb = x1ok ? tp.x0 + 1 : 0;
+      const int ya = y0ok ? tp.y0 * E : 0, yb = y1ok ? (tp.y0 + 1) * E : 0;
+      const float q00 = pb[ya + xa], q01 = pb[ya + xb], q10 = pb[yb + xa], q11 = pb[yb + xb];
+      float v = 0.f, t;
+      t = v + q00 * tp.w00; v = (y0ok && x0ok) ? t : v;
+      t = v + q01 * tp.w01; v = (y0ok && x1ok) ? t : v;
+      t = v + q10 * tp.w10; v = (y1ok && x0ok) ? t : v;
+      t = v + q11 * tp.w11; v = (y1ok && x1ok) ? t : v;
       ob[p] = v;
     }
   }
