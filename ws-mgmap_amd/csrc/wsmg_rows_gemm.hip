@@ -206,7 +206,10 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
   g.status = wait_count ? wsmgi_rnn_status_dev() : nullptr; g.fail_bit = (unsigned)fail_bit;
   g.gate = nullptr;
   if (wait_count && WSMG_TUNE("WSMG_CHAIN_GATE", 1) != 0) {     // (0: the wait inside the product, as before — A/B)
-    static unsigned* gates = nullptr;      // one word per fail bit: launches that share one are ordered on one stream
+    static unsigned* gates_of[64] = {};    // per device: one word per fail bit (launches that share one are ordered on one stream)
+    int devi = 0;
+    if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= 64) return WSMG_EINVAL;
+    unsigned*& gates = gates_of[devi];
     if (!gates) {
       if (hipMalloc((void**)&gates, 32 * sizeof(unsigned)) != hipSuccess) return WSMG_ENOMEM;
       if (hipMemset(gates, 0, 32 * sizeof(unsigned)) != hipSuccess) return WSMG_ENOMEM;
