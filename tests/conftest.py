@@ -41,3 +41,18 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _no_stale_rnn_timeouts(request):
+    """GPU tests: a persistent-kernel timeout must not outlive the test that caused it — the status word is sticky until read, and a
+    bit left set would make the NEXT test's check raise for something it did not do (or hide that this test's kernels timed out).
+    A test that provokes a timeout on purpose reads the word itself (ops.check_rnn_status raises and clears)."""
+    yield
+    if "gpu" not in request.keywords or not _has_gpu():
+        return
+    import torch
+    from wsmgmap import _abi
+    torch.cuda.synchronize()
+    left = int(_abi.lib().wsmg_rnn_status(1))          # read AND clear, so that one offender does not fail every later test
+    assert left == 0, f"this test left persistent-kernel timeout bits {left:#x} set (a kernel of it timed out, unreported)"

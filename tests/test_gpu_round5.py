@@ -555,11 +555,13 @@ def test_persistent_feeder_ring_serves_epoch_after_epoch_from_the_same_processes
 def test_chained_product_waits_with_one_workgroup_not_with_its_whole_grid():
     """The first product of a chunk of the chained recurrent core waits, on the device, for a counter that a kernel on ANOTHER stream
     advances (wsmgmap/recurrent.py, csrc/wsmg_rnn.hip chain_signal).  That producer may need whole CUs — the persistent recurrences
-    need all 32 of their workgroups resident at once — so the wait must not hold the chip: here the product (768 workgroups of 16
-    waves: every wave slot of the GPU if they all spun) is enqueued FIRST, and the counter is only advanced behind a kernel of 256
-    whole-CU workgroups (wsmg_debug_occupy: 1 024 threads + 160 KB of LDS each) enqueued after it on a second stream.  With the
-    wait inside the product that kernel could not start until the product's spin timed out; with the one-workgroup gate launch in
-    front of the product (round 5) it runs, the counter moves, the product follows — no timeout, the same numbers as unchained."""
+    need all 32 of their workgroups resident at once — so the wait must not hold the chip.  Here the producer stream is enqueued
+    first, as the product code does (a waiter behind its producer in host order cannot deadlock even where two streams share a
+    hardware queue), but its work starts late: a 30 ms delay kernel, then 256 whole-CU workgroups (wsmg_debug_occupy: 1 024 threads
+    + 160 KB of LDS each), then the counter.  The waiting product — 768 workgroups of 16 waves: every wave slot of the GPU if they
+    all spun — is on the GPU long before that.  With the wait inside the product the whole-CU kernel could not start until the
+    product's spin timed out (WSMG_CHAIN_GATE=0: this test fails with a timeout); with the one-workgroup gate launch in front of the
+    product (round 5) it runs, the counter moves, the product follows — no timeout, the same numbers as unchained."""
     from wsmgmap import _abi, ops, recurrent
     g = torch.Generator(device="cuda").manual_seed(3)
     M, K, N = 128, 1536, 1536
@@ -577,12 +579,12 @@ def test_chained_product_waits_with_one_workgroup_not_with_its_whole_grid():
     torch.cuda.synchronize()
     import time
     t0 = time.time()
-    with torch.cuda.stream(s_wait):
-        recurrent._rg([a], w, True, [got], 0, M, mask=mask, wait=(cnt.data_ptr(), 1), fail_bit=2)
-    time.sleep(0.05)                       # the waiter is on the GPU, spinning, before its producer is even enqueued
     with torch.cuda.stream(s_prod):
+        torch.cuda._sleep(60_000_000)          # ~30 ms: the producer's kernels reach the GPU after the waiter has settled in
         _abi.call("wsmg_debug_occupy", 256, 160 * 1024, 20, ops._p(stop), ops._p(arrived), ops._stream())   # 256 whole CUs for 20 ms
         cnt.fill_(1)
+    with torch.cuda.stream(s_wait):
+        recurrent._rg([a], w, True, [got], 0, M, mask=mask, wait=(cnt.data_ptr(), 1), fail_bit=2)
     torch.cuda.synchronize()
     dt = time.time() - t0
     assert int(arrived) == 256, "the whole-CU workgroups did not all get a CU"
