@@ -192,12 +192,15 @@ struct HeadsBwd {
 
 // A workgroup owns 32 features (columns) for ALL rows: thread = (feature f, row group g of 8); row b belongs to group b % 8.
 // d x[b][f] = sum_o g_o[b] w_o[f] is written directly; d w_o[f] = sum_b g_o[b] x[b][f] is accumulated per thread over its rows
-// in row order and the 8 groups are added in group order — no atomics, the same bits every run.  g_o[b] (A + 1 numbers per row)
+// in row order and the 32 groups are added in group order — no atomics, the same bits every run.  g_o[b] (A + 1 numbers per row)
 // is recomputed by every workgroup: it is a handful of flops.
 __global__ __launch_bounds__(256) void update_heads_bwd_kernel(HeadsBwd a) {
-  __shared__ float part[8][MAXA + 1][32];
-  const int f = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + f;
+  // (round 5, end: 8 feature columns x 32 row groups per workgroup instead of 32 x 8 — 64 workgroups of 16-row loops instead of 16 of
+  //  64-row loops: the kernel sits alone between the recurrent core's forward and backward, 45 us of dependent loads)
+  constexpr int FC = 8, RG = 32;
+  __shared__ float part[RG][MAXA + 1][FC];
+  const int f = threadIdx.x & (FC - 1), g = threadIdx.x / FC;
+  const int col = blockIdx.x * FC + f;
   const bool live = col < a.K;
   float wv[MAXA + 1], acc[MAXA + 1], bacc[MAXA + 1];
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256) void update_heads_bwd_kernel(HeadsBwd a) {
     wv[MAXA] = a.wp[col];
   }
 #pragma unroll 4
-  for (int b = g; b < a.B; b += 8) {        // (independent rows: several in flight)
+  for (int b = g; b < a.B; b += RG) {       // (independent rows: several in flight)
     float go[MAXA + 1];
 #pragma unroll
     for (int o = 0; o < MAXA; ++o) go[o] = (o < a.A && a.dpred) ? a.dpred[(size_t)b * a.A + o] : 0.f;
@@ -238,12 +241,12 @@ __global__ __launch_bounds__(256) void update_heads_bwd_kernel(HeadsBwd a) {
     for (int o = 0; o <= MAXA; ++o) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += part[q][o][f];
+      for (int q = 0; q < RG; ++q) s += part[q][o][f];
       if (o < MAXA) { if (o < a.A) a.dwm[(size_t)o * a.K + col] = s; }
       else a.dwp[col] = s;
     }
   }
-  if (blockIdx.x == 0) {      // bias gradients: the 8 groups' row sums, in group order (every feature lane holds the same numbers)
+  if (blockIdx.x == 0) {      // bias gradients: the groups' row sums, in group order (every feature lane holds the same numbers)
     __syncthreads();
 #pragma unroll
     for (int o = 0; o <= MAXA; ++o) part[g][o][f] = bacc[o];
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void update_heads_bwd_kernel(HeadsBwd a) {
       const int o = threadIdx.x;
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += part[q][o][0];
+      for (int q = 0; q < RG; ++q) s += part[q][o][0];
       if (o < MAXA) { if (o < a.A) a.dbm[o] = s; }
       else a.dbp[0] = s;
     }
@@ -311,7 +314,7 @@ extern "C" int wsmg_update_heads_bwd(const float* x, const float* wm, const floa
   if (!x || !wm || !wp || !prog || !dx || !dwm || !dbm || !dwp || !dbp || B <= 0 || K <= 0 || A <= 0 || A > MAXA) return WSMG_EINVAL;
   if (dprog_rows && !progress) return WSMG_EINVAL;
   HeadsBwd a{x, wm, wp, prog, progress, dpred, dprog, dprog_rows, dx, dwm, dbm, dwp, dbp, B, K, A};
-  hipLaunchKernelGGL(update_heads_bwd_kernel, dim3((unsigned)wsmg_cdiv(K, 32)), dim3(256), 0, wsmg_s(stream), a);
+  hipLaunchKernelGGL(update_heads_bwd_kernel, dim3((unsigned)wsmg_cdiv(K, 8)), dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
 
