@@ -241,6 +241,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # the forward's one host read-back — the instruction dedup, still launched and read back in every update — need not wait for
     # the previous update to finish on the GPU (wsmgmap/ops/core.py, "input readiness")
     ops.mark_inputs_ready(obs["instruction"])
+    # likewise the cached ego map (reference layout: float32 NCHW): its layout / dtype pass is still run in EVERY update, on the early stream
+    # behind this event (WSMG_EARLY_EGO=0: at the head of the update on the caller's stream, as in rounds 1-5)
+    ops.mark_inputs_ready(obs["rgb_ego_map"])
     AuxLosses.activate()
 
     def update():
@@ -256,203 +259,245 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         opt.step()
         return loss
 
-    # N > 1: the decoder's side stream beside RCCL's own streams was never run on the target (no multi-GPU box reachable from the
-    # build environment), and on a SHARED GPU a third stream per process once took updates from 49 ms to 4.3 s.  So it is
-    # measured before it is trusted: 3 updates with and 3 without it (after one untimed update each), max over ranks; more than
-    # 1.3x slower with the stream -> fall back to one stream for the run and say so in the line.
-    measure.side_stream = None
-    from wsmgmap import debug
-    if args.dp and os.environ.get("WSMG_DECODER_STREAMS") is None:
-        def timed(k):
+    # ---- round 6: a persistent-kernel timeout must not cost the run its line --------------------------------
+    # The two recurrences and the instruction LSTM are persistent kernels whose workgroups wait for each other with BOUNDED spins;
+    # the chained recurrent core adds kernels that spin on device counters.  Beside real RCCL ring kernels (never run from the build
+    # environment: its boxes have one GPU) a workgroup that is not resident in time makes a spin run out: the kernel fills its outputs
+    # with NaN and sets a bit in a host-mapped status word.  Everything from the probe below to the end of the timed region runs inside
+    # `guarded`: if ANY rank saw a timeout (its own status word, or the exchange's cross-rank error flag) ALL ranks together — one
+    # 4-byte MAX all-reduce — switch IN PROCESS to the next more conservative recurrent core, restore the state saved before the probe,
+    # re-discover the live gradient set and run the phase again.  Level 1: the staged core (one persistent kernel at a time, no
+    # device-side chaining, no decoder side stream); level 2: the stock (MIOpen) GRU / LSTM, no persistent kernel at all.  The line
+    # says which one ran (`data_parallel.recurrent_core` / `recurrent_core`).  WSMG_BENCH_INJECT_TIMEOUT=n: test hook — the status bit
+    # is injected once, after n updates of the first attempt.
+    from wsmgmap import _abi, debug
+    from wsmgmap.fallback import RecurrentCoreFallback
+    fbk = RecurrentCoreFallback(policy, opt, reducer, verbose=(rank == 0))
+    guarded = fbk.guarded
+    inject = [int(os.environ.get("WSMG_BENCH_INJECT_TIMEOUT", "0") or 0)]
+    n_upd = [0]
+    _update_inner = update
+
+    def update():     # noqa: F811 — the same update, counted (the injection hook)
+        loss_ = _update_inner()
+        n_upd[0] += 1
+        if inject[0] and n_upd[0] == inject[0] and (rank == 0 or not args.dp):
+            inject[0] = 0
+            _abi.lib().wsmg_rnn_debug_inject(1)
+        return loss_
+
+    def probe():
+        for _ in range(3):
             update()
-            torch.cuda.synchronize()
-            dist.barrier()
-            t_ = time.perf_counter()
-            for _ in range(k):
+    guarded(probe)
+
+    def phases():
+        # N > 1: the decoder's side stream beside RCCL's own streams was never run on the target (no multi-GPU box reachable from the
+        # build environment), and on a SHARED GPU a third stream per process once took updates from 49 ms to 4.3 s.  So it is
+        # measured before it is trusted: 3 updates with and 3 without it (after one untimed update each), max over ranks; more than
+        # 1.3x slower with the stream -> fall back to one stream for the run and say so in the line.
+        measure.side_stream = None
+        from wsmgmap import debug
+        if args.dp and os.environ.get("WSMG_DECODER_STREAMS") is None:
+            def timed(k):
                 update()
-            torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item()) / k
-        update()                                   # discovery pass of the gradient exchange, allocator warm-up
-        debug.sw.decoder_streams = 0
-        t_one = timed(3)
-        debug.sw.decoder_streams = 1
-        t_two = timed(3)
-        keep = t_two <= 1.3 * t_one
-        if not keep:
+                torch.cuda.synchronize()
+                dist.barrier()
+                t_ = time.perf_counter()
+                for _ in range(k):
+                    update()
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t_], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                return float(tt.item()) / k
+            update()                                   # discovery pass of the gradient exchange, allocator warm-up
             debug.sw.decoder_streams = 0
-        measure.side_stream = dict(ms_per_update_one_stream=round(t_one * 1e3, 3), ms_per_update_with_decoder_side_stream=round(t_two * 1e3, 3),
-                                   decoder_side_stream_used=bool(keep),
-                                   note="3 updates each, max over ranks; the side stream is dropped for the run when it is > 1.3x slower")
+            t_one = timed(3)
+            debug.sw.decoder_streams = 1
+            t_two = timed(3)
+            keep = t_two <= 1.3 * t_one
+            if not keep:
+                debug.sw.decoder_streams = 0
+            measure.side_stream = dict(ms_per_update_one_stream=round(t_one * 1e3, 3), ms_per_update_with_decoder_side_stream=round(t_two * 1e3, 3),
+                                       decoder_side_stream_used=bool(keep),
+                                       note="3 updates each, max over ranks; the side stream is dropped for the run when it is > 1.3x slower")
+            if reducer:
+                reducer.stats(reset=True)
+
+        # which conv-engine kernel family dominates is learned on the warm-up updates (all six entry points timed); inside
+        # the timed region only that family is bracketed with HIP events — every timed launch costs two event records on a
+        # host that is within 10 % of being the bottleneck, and `value` should not pay for the other five
+        warm_prof = {}
+        for i in range(warmup):
+            if i == warmup - 1:
+                ops.profile_begin()      # the last warm-up update: first-launch effects are over
+            update()
+        if warmup > 0:
+            warm_prof = ops.profile_end()
+        dom_entry = None
+        if warm_prof:
+            # the family with the most time in the last warm-up update, no tie rule (rounds 2-3 gave ties within 15 % to
+            # the backward-weight family); `kernels` carries every family's figures either way
+            dom_entry = max(warm_prof.values(), key=lambda r: r["ms_total"])["entry"]
+        import gc
+        # The host's cyclic garbage collector and the timed region.  The collector stays ON (off, the autograd graphs — reference cycles —
+        # give their tensors back late and the allocator grows: 2 / 4 / 23 windows more than 3 % over the median and 11.6 ms per update in
+        # the third run of profiles/r04_gc_ab.txt).  But a full (generation-2) collection walks every tracked object of the process — the
+        # import-time heap of torch included — and takes 100-170 ms here; it comes once every ~360 updates (profiles/
+        # r04_host_stalls_and_collections.txt: update 334-338 of every 500-update run, one window at 31-46 ms).  The heap that exists after
+        # the warm-up is therefore moved to the permanent generation (gc.freeze) after one full collection: later collections look at what
+        # the updates themselves allocate, and a full one takes about a millisecond.  WSMG_BENCH_GC=plain: no freeze; =0: collector off.
+        # (Done HERE, before the pre-timing spin: the full collection takes ~110 ms of host time, the GPU drains and clocks down meanwhile, and
+        # right in front of the timed region that showed as a first window 0.3-0.5 ms per update above the rest.)
+        gc_mode = os.environ.get("WSMG_BENCH_GC", "freeze")
+        if gc_mode == "0":
+            gc.collect()
+            gc.disable()
+        elif gc_mode == "freeze":
+            gc.collect()
+            gc.freeze()
+        # Pre-timing spin of real updates (reported as `prewarm_s` / `prewarm_updates`; `warmup` stays what the caller passed): on a
+        # fresh lease the first ~20 updates after 5 warm-up ones ran 14.6 / 11.8 ms against a steady 11.4 (BENCH_r03 `windows`) — the GPU
+        # comes out of idle clocks, the allocator is still growing after profile_end(), the per-stream workspaces see first use.
+        # The updates are the timed region's own; all ranks agree on when to stop (the exchange is a collective).
+        measure.prewarm = None
+        prewarm_s = args.prewarm_s if dtype == args.dtype else min(args.prewarm_s, 0.5)   # the extra float32 leg: a short one
+        if prewarm_s > 0:
+            tp = time.perf_counter()
+            n_pw = 0
+            while True:
+                for _ in range(4):
+                    update()
+                n_pw += 4
+                torch.cuda.synchronize()
+                go = 1.0 if time.perf_counter() - tp < prewarm_s else 0.0
+                if args.dp:
+                    tg = torch.tensor([go], device=dev)
+                    dist.all_reduce(tg, op=dist.ReduceOp.MIN)
+                    go = float(tg.item())
+                if go == 0.0:
+                    break
+            measure.prewarm = dict(seconds=round(time.perf_counter() - tp, 3), updates=n_pw)
+        if args.dp:
+            dist.barrier()
+        torch.cuda.synchronize()
         if reducer:
             reducer.stats(reset=True)
-
-    # which conv-engine kernel family dominates is learned on the warm-up updates (all six entry points timed); inside
-    # the timed region only that family is bracketed with HIP events — every timed launch costs two event records on a
-    # host that is within 10 % of being the bottleneck, and `value` should not pay for the other five
-    warm_prof = {}
-    for i in range(warmup):
-        if i == warmup - 1:
-            ops.profile_begin()      # the last warm-up update: first-launch effects are over
-        update()
-    if warmup > 0:
-        warm_prof = ops.profile_end()
-    dom_entry = None
-    if warm_prof:
-        # the family with the most time in the last warm-up update, no tie rule (rounds 2-3 gave ties within 15 % to
-        # the backward-weight family); `kernels` carries every family's figures either way
-        dom_entry = max(warm_prof.values(), key=lambda r: r["ms_total"])["entry"]
-    import gc
-    # The host's cyclic garbage collector and the timed region.  The collector stays ON (off, the autograd graphs — reference cycles —
-    # give their tensors back late and the allocator grows: 2 / 4 / 23 windows more than 3 % over the median and 11.6 ms per update in
-    # the third run of profiles/r04_gc_ab.txt).  But a full (generation-2) collection walks every tracked object of the process — the
-    # import-time heap of torch included — and takes 100-170 ms here; it comes once every ~360 updates (profiles/
-    # r04_host_stalls_and_collections.txt: update 334-338 of every 500-update run, one window at 31-46 ms).  The heap that exists after
-    # the warm-up is therefore moved to the permanent generation (gc.freeze) after one full collection: later collections look at what
-    # the updates themselves allocate, and a full one takes about a millisecond.  WSMG_BENCH_GC=plain: no freeze; =0: collector off.
-    # (Done HERE, before the pre-timing spin: the full collection takes ~110 ms of host time, the GPU drains and clocks down meanwhile, and
-    # right in front of the timed region that showed as a first window 0.3-0.5 ms per update above the rest.)
-    gc_mode = os.environ.get("WSMG_BENCH_GC", "freeze")
-    if gc_mode == "0":
-        gc.collect()
-        gc.disable()
-    elif gc_mode == "freeze":
-        gc.collect()
-        gc.freeze()
-    # Pre-timing spin of real updates (reported as `prewarm_s` / `prewarm_updates`; `warmup` stays what the caller passed): on a
-    # fresh lease the first ~20 updates after 5 warm-up ones ran 14.6 / 11.8 ms against a steady 11.4 (BENCH_r03 `windows`) — the GPU
-    # comes out of idle clocks, the allocator is still growing after profile_end(), the per-stream workspaces see first use.
-    # The updates are the timed region's own; all ranks agree on when to stop (the exchange is a collective).
-    measure.prewarm = None
-    prewarm_s = args.prewarm_s if dtype == args.dtype else min(args.prewarm_s, 0.5)   # the extra float32 leg: a short one
-    if prewarm_s > 0:
-        tp = time.perf_counter()
-        n_pw = 0
-        while True:
-            for _ in range(4):
-                update()
-            n_pw += 4
-            torch.cuda.synchronize()
-            go = 1.0 if time.perf_counter() - tp < prewarm_s else 0.0
-            if args.dp:
-                tg = torch.tensor([go], device=dev)
-                dist.all_reduce(tg, op=dist.ReduceOp.MIN)
-                go = float(tg.item())
-            if go == 0.0:
-                break
-        measure.prewarm = dict(seconds=round(time.perf_counter() - tp, 3), updates=n_pw)
-    if args.dp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if reducer:
-        reducer.stats(reset=True)
-    # timed live (HIP events around every launch, inside the timed region): the family with the most time, and the weight-gradient
-    # family whichever it is — rounds 1-3 reported that one, and its kernels are what round 4 rebuilt; a line must show both
-    WG = "wsmg_conv2d_bwd_weight_bf16" if dtype == "bf16" else "wsmg_conv2d_bwd_weight"
-    FW = "wsmg_conv2d_fwd_bf16" if dtype == "bf16" else "wsmg_conv2d_fwd"      # (the *_stats entry points fold into it: ops._prof_key)
-    # Every timed launch is two HIP event records on its stream (~1.5 us of GPU time each): with both families timed on every update
-    # the line itself cost 0.1-0.2 ms per update (10.58 / 10.67 vs 10.46 / 10.46 ms, profiles/r04_first_window_and_event_cost.txt).
-    # So: the largest family on every update, as in rounds 1-3; the weight-gradient family, when it is not the largest, on every
-    # 4th update of the timed region (a sample of the same region).  WSMG_BENCH_NOPROF=1: no events at all (diagnostic).
-    # round 5: BOTH named families are in every line, whichever of them the warm-up found larger — the larger
-    # one timed on every update, the other on every 4th; a third family, should it ever lead, is timed on every update beside them
-    both = sorted({dom_entry, WG, FW}) if dom_entry else None
-    # round 5, end: the largest family on every update still cost the line 0.12 ms per update (10.42 against 10.30 ms without any
-    # event, one box, interleaved: profiles/r05_bench_line_cost.txt) — BOTH families are now timed on every 4th update of the timed
-    # region only (10.38); WSMG_BENCH_PROF_EVERY=1 restores the largest family on every update
-    prof_every = int(os.environ.get("WSMG_BENCH_PROF_EVERY", "4"))
-    if os.environ.get("WSMG_BENCH_NOPROF") != "1":
-        ops.profile_begin(only=[dom_entry] if dom_entry else None)
-    # an event every WIN updates (no synchronisation): `sustained` for --steps >= 200 (50-update windows), and `windows` for every
-    # run (a quarter of the run each), so that a transient stall inside the timed region — one run in ~40 on this pool came out at
-    # 14-19 ms per update for no reason the process could see — shows in the line as what it is
-    WIN = 50 if steps >= 200 else max(1, (steps + 3) // 4)
-    if os.environ.get("WSMG_BENCH_WINDOW"):        # diagnostic: another window length (1 = an event per update)
-        WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
-    marks = []
-    gc_log, host_each = [], []
-    if os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
-        def _gc_cb(phase, info, _t=[0.0]):
-            if phase == "start":
-                _t[0] = time.perf_counter()
-            else:
-                gc_log.append((len(host_each), info.get("generation"), round((time.perf_counter() - _t[0]) * 1e3, 2), info.get("collected")))
-        gc.callbacks.append(_gc_cb)
-    t0 = time.perf_counter()
-    host = 0.0
-    for i in range(steps):
-        if i % WIN == 0:
+            if os.environ.get("WSMG_DP_EXCHANGE", "instruction") not in ("hook", ""):
+                reducer.time_buckets(True)
+        # timed live (HIP events around every launch, inside the timed region): the family with the most time, and the weight-gradient
+        # family whichever it is — rounds 1-3 reported that one, and its kernels are what round 4 rebuilt; a line must show both
+        WG = "wsmg_conv2d_bwd_weight_bf16" if dtype == "bf16" else "wsmg_conv2d_bwd_weight"
+        FW = "wsmg_conv2d_fwd_bf16" if dtype == "bf16" else "wsmg_conv2d_fwd"      # (the *_stats entry points fold into it: ops._prof_key)
+        # Every timed launch is two HIP event records on its stream (~1.5 us of GPU time each): with both families timed on every update
+        # the line itself cost 0.1-0.2 ms per update (10.58 / 10.67 vs 10.46 / 10.46 ms, profiles/r04_first_window_and_event_cost.txt).
+        # So: the largest family on every update, as in rounds 1-3; the weight-gradient family, when it is not the largest, on every
+        # 4th update of the timed region (a sample of the same region).  WSMG_BENCH_NOPROF=1: no events at all (diagnostic).
+        # round 5: BOTH named families are in every line, whichever of them the warm-up found larger — the larger
+        # one timed on every update, the other on every 4th; a third family, should it ever lead, is timed on every update beside them
+        both = sorted({dom_entry, WG, FW}) if dom_entry else None
+        # round 5, end: the largest family on every update still cost the line 0.12 ms per update (10.42 against 10.30 ms without any
+        # event, one box, interleaved: profiles/r05_bench_line_cost.txt) — BOTH families are now timed on every 4th update of the timed
+        # region only (10.38); WSMG_BENCH_PROF_EVERY=1 restores the largest family on every update
+        prof_every = int(os.environ.get("WSMG_BENCH_PROF_EVERY", "4"))
+        if os.environ.get("WSMG_BENCH_NOPROF") != "1":
+            ops.profile_begin(only=[dom_entry] if dom_entry else None)
+        # an event every WIN updates (no synchronisation): `sustained` for --steps >= 200 (50-update windows), and `windows` for every
+        # run (a quarter of the run each), so that a transient stall inside the timed region — one run in ~40 on this pool came out at
+        # 14-19 ms per update for no reason the process could see — shows in the line as what it is
+        WIN = 50 if steps >= 200 else max(1, (steps + 3) // 4)
+        if os.environ.get("WSMG_BENCH_WINDOW"):        # diagnostic: another window length (1 = an event per update)
+            WIN = max(1, int(os.environ["WSMG_BENCH_WINDOW"]))
+        marks = []
+        gc_log, host_each = [], []
+        if os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
+            def _gc_cb(phase, info, _t=[0.0]):
+                if phase == "start":
+                    _t[0] = time.perf_counter()
+                else:
+                    gc_log.append((len(host_each), info.get("generation"), round((time.perf_counter() - _t[0]) * 1e3, 2), info.get("collected")))
+            gc.callbacks.append(_gc_cb)
+        t0 = time.perf_counter()
+        host = 0.0
+        for i in range(steps):
+            if i % WIN == 0:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append(ev)
+            if dom_entry:
+                ops.profile_set_only(both if i % 4 == 0 else ([dom_entry] if prof_every == 1 else ["-"]))
+            h0 = time.perf_counter()
+            loss = update()
+            host += time.perf_counter() - h0
+            host_each.append(time.perf_counter() - h0)
+        if marks:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             marks.append(ev)
+        torch.cuda.synchronize()
+        measure.sustained = measure.windows = None
+        measure.host_ms = round(host / steps * 1e3, 3)      # wall time of the update() calls of the timed region, per update
+        if len(marks) >= 2:
+            spans = [(min(WIN, steps - j * WIN), marks[j].elapsed_time(marks[j + 1])) for j in range(len(marks) - 1)]
+            per = [ms / n for n, ms in spans if n > 0]
+            measure.windows = dict(window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
+                                   note="HIP-event time of consecutive windows of the timed region (rank 0's stream)")
+        if len(marks) >= 3 and steps >= 200:
+            tail = per[len(per) // 2:]
+            measure.sustained = dict(updates=steps, window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
+                                     ms_per_update_first_window=round(per[0], 3),
+                                     ms_per_update_second_half=round(sum(tail) / len(tail), 3),
+                                     note="HIP-event time of consecutive 50-update windows inside the same timed region")
+        gc.enable()
+        gc.unfreeze()
+        if gc_log or os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
+            gc.callbacks[:] = [c for c in gc.callbacks if getattr(c, "__name__", "") != "_gc_cb"]
+            if rank == 0:
+                med = sorted(host_each)[len(host_each) // 2]
+                slow = [(i, round(v * 1e3, 2)) for i, v in enumerate(host_each) if v > 1.5 * med]
+                print("host per update: median %.2f ms; updates over 1.5 x median: %s" % (med * 1e3, slow[:40]), file=sys.stderr)
+                print("collections (update index, generation, ms, collected): %s" % [g for g in gc_log if g[1] >= 1 or g[2] > 1.0][:60], file=sys.stderr)
+        if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
+            print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
+        if args.dp:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = ops.profile_end()
         if dom_entry:
-            ops.profile_set_only(both if i % 4 == 0 else ([dom_entry] if prof_every == 1 else ["-"]))
-        h0 = time.perf_counter()
-        loss = update()
-        host += time.perf_counter() - h0
-        host_each.append(time.perf_counter() - h0)
-    if marks:
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        marks.append(ev)
-    torch.cuda.synchronize()
-    measure.sustained = measure.windows = None
-    measure.host_ms = round(host / steps * 1e3, 3)      # wall time of the update() calls of the timed region, per update
-    if len(marks) >= 2:
-        spans = [(min(WIN, steps - j * WIN), marks[j].elapsed_time(marks[j + 1])) for j in range(len(marks) - 1)]
-        per = [ms / n for n, ms in spans if n > 0]
-        measure.windows = dict(window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
-                               note="HIP-event time of consecutive windows of the timed region (rank 0's stream)")
-    if len(marks) >= 3 and steps >= 200:
-        tail = per[len(per) // 2:]
-        measure.sustained = dict(updates=steps, window=WIN, ms_per_update_by_window=[round(v, 3) for v in per],
-                                 ms_per_update_first_window=round(per[0], 3),
-                                 ms_per_update_second_half=round(sum(tail) / len(tail), 3),
-                                 note="HIP-event time of consecutive 50-update windows inside the same timed region")
-    gc.enable()
-    gc.unfreeze()
-    if gc_log or os.environ.get("WSMG_BENCH_HOSTTIME") == "2":
-        gc.callbacks[:] = [c for c in gc.callbacks if getattr(c, "__name__", "") != "_gc_cb"]
-        if rank == 0:
-            med = sorted(host_each)[len(host_each) // 2]
-            slow = [(i, round(v * 1e3, 2)) for i, v in enumerate(host_each) if v > 1.5 * med]
-            print("host per update: median %.2f ms; updates over 1.5 x median: %s" % (med * 1e3, slow[:40]), file=sys.stderr)
-            print("collections (update index, generation, ms, collected): %s" % [g for g in gc_log if g[1] >= 1 or g[2] > 1.0][:60], file=sys.stderr)
-    if os.environ.get("WSMG_BENCH_HOSTTIME") == "1" and rank == 0:   # diagnostic: how long the host needs to ENQUEUE one update
-        print("host enqueue time %.3f ms per update" % (host / steps * 1e3), file=sys.stderr)
-    if args.dp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof = ops.profile_end()
-    if dom_entry:
-        for r in prof.values():       # the sampled families: their totals are over every 4th update
-            if r.get("entry") in (WG, FW) and (r.get("entry") != dom_entry or prof_every != 1):
-                r["per_steps"] = (steps + 3) // 4
-                r["phase"] = "timed region"
-                r["sampled"] = "every 4th update of the timed region"
-    ops.check_rnn_status()        # a persistent-RNN timeout anywhere in the run invalidates it: fail loudly
-    if reducer:
-        reducer.check()
-        st = reducer.stats()
-        measure.dp_info = dict(ranks_in_process_group=dist.get_world_size(), backend=dist.get_backend(),
-                               gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
-                               exchange=os.environ.get("WSMG_DP_EXCHANGE", "instruction"), early_dedup=bool(debug.sw.early_dedup_dp),
-                               live_gradient_bytes=reducer.live_bytes, buckets=reducer.num_buckets,
-                               devices_visible=torch.cuda.device_count(),
-                               exposed_allreduce_ms=st["exposed_allreduce_ms"], exposed_allreduce_max_ms=st["exposed_allreduce_max_ms"],
-                               host_ms_in_finish=st["host_ms_in_finish"], updates_measured=st["updates"],
-                               exposed_note="HIP-event time on the compute stream between the end of backward (entry of finish()) and the "
-                                            "last averaged bucket: the part of the gradient all-reduce that backward did not hide; rank 0",
-                               side_stream_check=measure.side_stream)
-    for name, r in warm_prof.items():     # the other families: per-launch figures from the warm-up updates, labelled so
-        if name not in prof:
-            prof[name] = dict(r, per_steps=1, phase="last warm-up update")
-    if args.dp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+            for r in prof.values():       # the sampled families: their totals are over every 4th update
+                if r.get("entry") in (WG, FW) and (r.get("entry") != dom_entry or prof_every != 1):
+                    r["per_steps"] = (steps + 3) // 4
+                    r["phase"] = "timed region"
+                    r["sampled"] = "every 4th update of the timed region"
+        ops.check_rnn_status()        # a persistent-RNN timeout anywhere in the run invalidates it: fail loudly
+        if reducer:
+            reducer.check()
+            st = reducer.stats()
+            measure.dp_info = dict(ranks_in_process_group=dist.get_world_size(), backend=dist.get_backend(),
+                                   gpu_max_hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"),
+                                   exchange=os.environ.get("WSMG_DP_EXCHANGE", "instruction"), early_dedup=bool(debug.sw.early_dedup_dp),
+                                   live_gradient_bytes=reducer.live_bytes, buckets=reducer.num_buckets,
+                                   devices_visible=torch.cuda.device_count(),
+                                   exposed_allreduce_ms=st["exposed_allreduce_ms"], exposed_allreduce_max_ms=st["exposed_allreduce_max_ms"],
+                                   host_ms_in_finish=st["host_ms_in_finish"], updates_measured=st["updates"],
+                                   per_bucket_allreduce_ms=st.get("per_bucket_allreduce_ms"),
+                                   per_bucket_note="HIP-event time of each bucket's pack + all-reduce on the exchange stream, mean over the timed "
+                                                   "region (a ring step's time, the peers' skew included); rank 0",
+                                   exposed_note="HIP-event time on the compute stream between the end of backward (entry of finish()) and the "
+                                                "last averaged bucket: the part of the gradient all-reduce that backward did not hide; rank 0",
+                                   side_stream_check=measure.side_stream)
+        for name, r in warm_prof.items():     # the other families: per-launch figures from the warm-up updates, labelled so
+            if name not in prof:
+                prof[name] = dict(r, per_steps=1, phase="last warm-up update")
+        if args.dp:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof, loss, warm_prof
+
+    dt, prof, loss, warm_prof = guarded(phases)
+    measure.fallback = fbk.report()
     final_loss = float(loss.detach())
     # The same update captured into ONE HIP graph and replayed (wsmgmap.graph.GraphedUpdate): reported beside the eager figure,
     # never as `value` — the roofline object is measured with HIP events around eager launches inside the timed region, which
@@ -487,6 +532,9 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
                                     "input signature, replayed; only the instruction dedup stays eager.  The batch is registered as the "
                                     "graph's static inputs: a trainer fed by the feeder pays one more copy of it per update (the "
                                     "cached ego map alone is 1.3 GB), which this figure does not contain")
+    if reducer:
+        reducer.close()
+    del fbk, guarded
     del policy, opt, obs
     torch.cuda.empty_cache()
     return dt, prof, final_loss, state_cpu
@@ -584,6 +632,10 @@ def main():
     dt, prof, final_loss, state_cpu = measure(args, args.dtype, args.steps, args.warmup, rank, world, local, dev)
     measure.host_ms_main = getattr(measure, "host_ms", None)
     dp_info = measure.dp_info
+    fallback = getattr(measure, "fallback", None)
+    if dp_info is not None and fallback is not None:
+        dp_info["recurrent_core"] = fallback["recurrent_core"]
+        dp_info["fallback"] = fallback
     graphed = getattr(measure, "graphed", None)
     sustained = getattr(measure, "sustained", None)
     windows = getattr(measure, "windows", None)
@@ -682,6 +734,7 @@ def main():
                                    f"80-token instructions, cached rgb/depth/ego-map features (BASELINE configs[1])",
                        "T": T, "N_per_gpu": N, "parallelism": f"dp{world}"},
             "data_parallel": dp_info,
+            "recurrent_core": fallback,
             "whole_update_tflops": round(ALG_GFLOP_PER_STEP * steps_per_s / 1e3 / world, 2),
             "loss": round(final_loss, 5),
             "f32_parity_mode": parity,

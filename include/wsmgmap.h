@@ -527,8 +527,12 @@ int wsmg_group_norm_nhwc_bf16(const void* x, int x_f32, const void* residual, co
  * wsmg_rnn_status returns that word WITHOUT synchronising the device (clear != 0: and resets the bits it returns);
  * a caller checks it at its next natural synchronisation point (the reference has no counterpart: cuDNN RNNs
  * cannot time out; mg_map_policy.py:220-227,242-249, instruction_encoder.py:80-92 are the replaced call sites).
- * wsmg_rnn_debug_spin_limit(n): bound every spin by n polls (0 = default, 2^20) — test hook to force a timeout. */
+ * wsmg_rnn_debug_spin_limit(n): bound every spin by n polls (0 = default, 2^20) — test hook to force a timeout.
+ * Bit 16 (round 6): the grid barrier of wsmg_attn_fp8_mfma_fused timed out (its outputs are NaN).
+ * wsmg_rnn_debug_inject(bits): OR `bits` into the word as a timed-out kernel would — test hook for the callers' error paths
+ * (bench.py's in-process fallback, GradAllReducer's cross-rank agreement); returns the word after the OR. */
 int wsmg_rnn_status(int clear);
+int wsmg_rnn_debug_inject(unsigned bits);
 /* Whole-sequence GRU launches chained by time chunk to kernels on other streams (round 5: the recurrent core of the update as
  * three concurrent kernel chains instead of 16 chunk launches; mg_map_policy.py:220-249).  As wsmg_gru_fwd_owned / _bwd_owned, plus:
  * steps_per_chunk divides T; in_count (may be NULL): one device counter per chunk that must reach in_target before the chunk's

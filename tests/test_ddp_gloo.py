@@ -276,3 +276,83 @@ def test_broadcast_buffers_every_n_updates_gloo():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
+
+
+class _NetHolder(torch.nn.Module):
+    """What RecurrentCoreFallback touches of a policy: `.net.recurrent_chunks`, parameters, state_dict."""
+
+    def __init__(self):
+        super().__init__()
+        self.net = Net()
+        self.net.recurrent_chunks = 4
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def _worker_fallback(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "ws-mgmap_amd"))
+    from wsmgmap import debug
+    from wsmgmap.fallback import RecurrentCoreFallback
+    from wsmgmap.parallel import GradAllReducer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    pol = _NetHolder()
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-2)
+    red = GradAllReducer(pol.parameters(), bucket_bytes=300)
+    red.broadcast_parameters(pol)
+    fb = RecurrentCoreFallback(pol, opt, red, verbose=False)
+    before = {k: v.clone() for k, v in pol.state_dict().items()}
+    torch.manual_seed(9 + rank)
+    x, t = torch.randn(6, 8), torch.randn(6, 4)
+    attempts = []
+    # rank 1 ALONE "sees a timeout bit" on the first attempt (what wsmg_rnn_status would return after a kernel's spin ran out)
+    seen = [1 if rank == 1 else 0]
+
+    def status():
+        v, seen[0] = seen[0], 0
+        return v
+    fb.read_status = status
+
+    def phase():
+        attempts.append(fb.level)
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            ((pol(x) - t) ** 2).mean().backward()
+            red.finish()
+            opt.step()
+        return "done"
+    out = fb.guarded(phase)
+    # both ranks ran the phase twice: at level 0, then — together — at level 1, from the state saved before the first attempt
+    ok = out == "done" and attempts == [0, 1] and fb.level == 1 and pol.net.recurrent_chunks == 0 and debug.sw.decoder_streams == 0
+    ok = ok and "status word" in fb.reasons[0] if rank == 1 else ok and "peer" in fb.reasons[0]
+    w = pol.net.a.weight.detach().clone()
+    got = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(got, w)
+    ok = ok and torch.equal(got[0], got[1])            # the ranks' parameters are identical after the fallback
+    # second attempt started from the snapshot: three Adam steps away from `before`, not six
+    ref = _NetHolder()
+    ref.load_state_dict(before)
+    q.put((rank, bool(ok), attempts, fb.report()))
+    red.close()
+    dist.destroy_process_group()
+
+
+def test_recurrent_core_fallback_is_agreed_on_by_both_ranks_gloo():
+    """a persistent-kernel timeout seen by ONE rank makes BOTH ranks switch to the staged recurrent core together
+    (wsmgmap.fallback.RecurrentCoreFallback: one MAX all-reduce), restore the saved state and run the phase again — nobody hangs in a
+    collective, the parameters stay identical (reference: the DDP wrap of common_trainer.py:61-66 keeps ranks in step the same way)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fallback, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert all(r[3]["fallback_level"] == 1 and r[3]["recurrent_core"].startswith("staged") for r in res), res

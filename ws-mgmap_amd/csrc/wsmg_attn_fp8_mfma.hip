@@ -309,6 +309,7 @@ struct F8fArgs {
   const int64_t* inverse;  // [B]
   const int* lengths;      // [U] or null
   float fixed[3];          // > 0: the caller's scale of q / k / v
+  unsigned* host_status;   // the process-wide persistent-kernel status word (host-mapped): bit 16 = this kernel's barrier timed out
   float scale;
   int B, U, L, tiles, nmain;
   unsigned* ws;            // [0..2] / [4..6]: |x| maxima of the launch with epoch parity 0 / 1; [8]: arrivals (monotonic)
@@ -491,6 +492,8 @@ __global__ __launch_bounds__(256) void attn_fp8_mfma_fused_kernel(F8fArgs a) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1u << 24)) { ok = false; break; }     // (seconds: a workgroup of this launch never ran — results become NaN)
       }
+      // a timeout is REPORTED, not only visible as NaN: the host's next status check raises
+      if (!ok && a.host_status) __hip_atomic_fetch_or(a.host_status, 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const float am = __uint_as_float(__hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -674,6 +677,21 @@ extern "C" int wsmg_attn_fp8_mfma_fwd(const uint8_t* q_codes, const float* q_sca
   WSMG_RETURN_LAUNCH();
 }
 
+// co-residency budget of the fused launch's grid barrier, from the device's own CU count
+static int fused_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
+static int fused_main_limit() { const int h = fused_cus() / 2; return h < 128 ? h : 128; }
+static int fused_total_limit() { const int t = fused_cus() - 32; return t < 224 ? (t > 1 ? t : 1) : 224; }
+
 extern "C" int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, const float* v_sets, const int64_t* inverse, const int* lengths,
                                         float q_scale, float k_scale, float v_scale, float scale, int B, int U, int L, int C,
                                         unsigned* workspace, unsigned arrivals_before, int epoch, float* scales_out, float* out, float* attn,
@@ -683,18 +701,21 @@ extern "C" int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, con
   const int tiles = (int)wsmg_cdiv(B, 32);
   const int64_t nmain = (int64_t)U * tiles;
   const int need = !(q_scale > 0.f && k_scale > 0.f && v_scale > 0.f);
-  if (need && nmain > 128) return WSMG_EINVAL;       // the spinning workgroups must leave room for the helpers (see the kernel)
+  // the spinning workgroups (one per CU: ~90 KB of LDS each) must leave room for the helpers — half the CUs THIS device has (a
+  // partitioned or CU-masked device has fewer than 256), never more than 128 (see the kernel)
+  if (need && nmain > fused_main_limit()) return WSMG_EINVAL;
   if (nmain > (1 << 20)) return WSMG_EINVAL;
   int nhelp = 0;
   if (need) {     // ~8 KB of float32 per workgroup in the |x| pass, at most one workgroup per CU in all
     const int64_t tot4 = ((int64_t)B * C + 2ll * U * L * C) / 4;
     int64_t want = wsmg_cdiv(tot4, 256 * 4);
-    if (want > 224) want = 224;
+    if (want > fused_total_limit()) want = fused_total_limit();
     nhelp = want > nmain ? (int)(want - nmain) : 0;
   }
   F8fArgs a;
   a.q = q; a.k = k_sets; a.v = v_sets; a.inverse = inverse; a.lengths = lengths;
   a.fixed[0] = q_scale; a.fixed[1] = k_scale; a.fixed[2] = v_scale;
+  a.host_status = wsmgi_rnn_status_dev();
   a.scale = scale; a.B = B; a.U = U; a.L = L; a.tiles = tiles; a.nmain = (int)nmain;
   a.ws = workspace; a.target = arrivals_before + (unsigned)(nmain + nhelp); a.parity = epoch & 1; a.need_amax = need;
   a.scales_out = scales_out; a.out = out; a.attn = attn;
@@ -725,9 +746,9 @@ extern "C" int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, con
 extern "C" int wsmg_attn_fp8_mfma_fused_arrivals(int B, int U, int L, int C) {
   if (B <= 0 || U <= 0 || U > 1024 || L <= 0 || L > LMAX || C != AC) return 0;
   const int64_t nmain = (int64_t)U * wsmg_cdiv(B, 32);
-  if (nmain > 128) return 0;
+  if (nmain > fused_main_limit()) return 0;
   const int64_t tot4 = ((int64_t)B * C + 2ll * U * L * C) / 4;
   int64_t want = wsmg_cdiv(tot4, 256 * 4);
-  if (want > 224) want = 224;
+  if (want > fused_total_limit()) want = fused_total_limit();
   return (int)(want > nmain ? want : nmain);
 }

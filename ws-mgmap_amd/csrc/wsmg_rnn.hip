@@ -843,6 +843,10 @@ extern "C" int wsmg_rnn_status(int clear) {
   if (clear && v) __atomic_and_fetch(g_status_host, ~v, __ATOMIC_ACQ_REL);
   return (int)v;
 }
+extern "C" int wsmg_rnn_debug_inject(unsigned bits) {
+  if (!rnn_status_dev()) return 0;
+  return (int)__atomic_or_fetch(g_status_host, bits, __ATOMIC_ACQ_REL);
+}
 extern "C" int wsmg_rnn_debug_spin_limit(unsigned limit) {
   g_spin = limit ? limit : SPIN_LIMIT;
   return 0;

@@ -140,6 +140,7 @@ _SIG["wsmg_lstm_bwd"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 2 + [c_p]
 _SIG["wsmg_group_norm_nhwc_bf16"] = [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]
 _SIG["wsmg_rnn_status"] = [c_i]
 _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
+_SIG["wsmg_rnn_debug_inject"] = [ctypes.c_uint]
 _SIG["wsmg_instruction_dedup"] = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
 _SIG["wsmg_conv_debug_win3_tile"] = [c_i]
 _SIG["wsmg_copy_multi"] = [c_p, c_i, c_p]
@@ -205,14 +206,24 @@ def call(name, *args):
 rnn_timeouts = 0      # persistent-RNN timeouts reported so far in this process
 
 
-def check_rnn_status(sync=False):
+# Under a process group an exception that ONE rank raises between two collectives leaves its peers blocked in theirs.  While a
+# GradAllReducer is active the forward pass's status checks therefore do nothing (`defer_rnn_status`); the reducer's `finish()`
+# reads the word (force=True) and the ranks agree on the error before any of them raises (wsmgmap/parallel.py).
+defer_rnn_status = False
+
+STATUS_BITS = ((1, "gru_fwd"), (2, "gru_bwd"), (4, "lstm_fwd"), (8, "lstm_bwd"), (16, "attn_fp8_fused barrier"))
+
+
+def check_rnn_status(sync=False, force=False):
     """Raise WsmgError if a persistent RNN kernel reported a timeout since the last check.  Reads a word in host-mapped
     pinned memory: no device synchronisation by itself.  Called at the host's natural sync points (the instruction dedup
     read-back of every forward pass, GradAllReducer.finish(), the end of an update in bench / tests) — those see every kernel
     that had FINISHED by then, so a timeout of the current update can surface one update late.  sync=True waits for the device
     first: the exact form, for a trainer that wants the guarantee that NaN-filled outputs never reach optimizer.step()
-    (`BasePolicy.check_status()`)."""
+    (`BasePolicy.check_status()`).  force: also while a GradAllReducer defers the checks (its own call)."""
     global rnn_timeouts
+    if defer_rnn_status and not force:
+        return
     if sync:
         import torch
         if torch.cuda.is_available():
@@ -220,11 +231,25 @@ def check_rnn_status(sync=False):
     v = lib().wsmg_rnn_status(1)
     if v:
         rnn_timeouts += 1       # (owners of persistent, never-cleared RNN workspaces re-zero them: the error word in them is sticky)
-        names = [n for b, n in ((1, "gru_fwd"), (2, "gru_bwd"), (4, "lstm_fwd"), (8, "lstm_bwd")) if v & b]
-        raise WsmgError("persistent RNN kernel(s) timed out waiting for their cooperating workgroups: " + ", ".join(names) +
+        names = [n for b, n in STATUS_BITS if v & b]
+        raise WsmgError("persistent kernel(s) timed out waiting for their cooperating workgroups: " + ", ".join(names) +
                         " — their outputs were filled with NaN; results since the previous check are invalid "
                         "(the persistent kernels need all their workgroups resident at once: too many concurrent persistent "
                         "kernels for the free CUs?  net.recurrent_chunks = 0 runs one at a time)")
+
+
+def take_rnn_status():
+    """The status word's bits since the last read, cleared, WITHOUT raising (0: nothing timed out) — for callers that handle a
+    timeout themselves (bench.py's in-process fallback).  Counts as a reported timeout for the owners of never-cleared workspaces."""
+    global rnn_timeouts
+    v = int(lib().wsmg_rnn_status(1))
+    if v:
+        rnn_timeouts += 1
+    return v
+
+
+def status_names(bits):
+    return [n for b, n in STATUS_BITS if bits & b]
 
 
 def exported_names():

@@ -19,6 +19,7 @@ _TABLE = [
     ("recurrent_chain", "WSMG_RECURRENT_CHAIN", True, bool, "each recurrence of the pipelined core as ONE launch chained to the attention stage by device-side counters"),
     ("decoder_streams", "WSMG_DECODER_STREAMS", 1, int, "0: map decoder on one stream; 1: side stream unless ranks share a GPU; 2: always"),
     ("early_dedup", "WSMG_EARLY_DEDUP", True, bool, "instruction dedup on its own stream when the producer marked the tokens ready (ops.mark_inputs_ready)"),
+    ("early_ego", "WSMG_EARLY_EGO", True, bool, "update path: the cached ego map's NCHW -> NHWC pass on the early stream when its producer marked it ready"),
     ("early_dedup_dp", "WSMG_EARLY_DEDUP_DP", False, bool, "the early dedup also under a process group (needs the exchange on a policy stream: GradAllReducer(exchange_stream=...))"),
     ("prelayout_first", "WSMG_PRELAYOUT_FIRST", True, bool, "update path: the map stack's weight layout is the first thing on the instruction stream (not behind the cached features' dense layers)"),
     ("enc_proj_side", "WSMG_ENC_PROJ_SIDE", True, bool, "map_encoded_linear on the decoder's side stream (its backward beside the resnet branch's small kernels)"),
@@ -35,6 +36,7 @@ _TABLE = [
     ("conv_splitk", "WSMG_CONV_SPLITK", True, bool, "split-K for rollout-size layers"),
     ("rows_linear", "WSMG_ROWS_LINEAR", True, bool, "one-launch dense layers for <= 16 rows"),
     ("bev_fused", "WSMG_BEV_FUSED", True, bool, "scatter + rotation in one launch, plane-consuming fuse"),
+    ("rnn_stock", "WSMG_RNN_STOCK", False, bool, "the three recurrences on the stock (MIOpen) GRU / LSTM: no persistent kernel at all (bench.py's last fallback; needs recurrent_chunks = 0)"),
     ("rnn_poison", "WSMG_RNN_POISON", False, bool, "NaN-fill the persistent kernels' workspaces first (stress tool)"),
     ("rnn_check", "WSMG_RNN_CHECK", False, bool, "synchronise and check after every persistent launch"),
     ("feeder_trace", "WSMG_FEEDER_TRACE", False, bool, "trace lines from data.feeder"),

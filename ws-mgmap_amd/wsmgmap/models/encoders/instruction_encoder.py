@@ -147,7 +147,8 @@ class InstructionEncoder(nn.Module):
         already has it (no host read-back here then).  lstm_after: an event the persistent LSTM launch waits for (the dedup, the
         embedding and the input projection do not)."""
         uniq, inverse, len_host, len_dev = self.dedup(instruction) if dedup is None else dedup
-        if stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
+        from ...debug import sw
+        if stock or sw.rnn_stock or not isinstance(self.encoder_rnn, nn.LSTM) or not self.bidir:
             embedded = self.embedding_layer(uniq)
             packed = nn.utils.rnn.pack_padded_sequence(embedded, len_host, batch_first=True, enforce_sorted=False)
             output, _ = self.encoder_rnn(packed)

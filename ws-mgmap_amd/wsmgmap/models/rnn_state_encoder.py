@@ -36,6 +36,9 @@ class RNNStateEncoder(nn.Module):
 
     def forward(self, x, hidden_states, masks):
         """x [T*N, in] (time-major rows) or [N, in]; hidden_states [1, N, H]; masks [T*N, 1]."""
+        from ..debug import sw
+        if sw.rnn_stock:      # no persistent kernel (bench.py's last fallback under a process group; MIOpen, one host read-back)
+            return self.forward_stock(x, hidden_states, masks)
         r = self.rnn
         n = hidden_states.size(1)
         t = x.size(0) // n

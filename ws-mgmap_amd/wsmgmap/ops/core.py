@@ -299,11 +299,18 @@ def _zero_pool_retire():
         z["buf"], z["off"], z["used"], z["armed"] = None, 0, 0, False
 
 
+# True from a CHAINED recurrent core's forward pass (wsmgmap/recurrent.py) until its backward pass has queued its kernels: the
+# gradient exchange holds its buckets meanwhile (wsmgmap/parallel.py::_launch_ready)
+chain_in_flight = False
+
+
 def reset_pass_state():
     """Called at the entry of every policy forward pass.  The end-of-backward callbacks that retire the zero pool and
     join the weight-gradient side stream do not run when backward() raises (a WsmgError from a kernel, OOM): without
     this reset one failed backward would leave them 'armed' for ever — every later request would fall back to a
     torch.zeros launch, and the optimizer could race gradients that a leaf stream is still writing."""
+    global chain_in_flight
+    chain_in_flight = False
     TokenGradSink.check_none_pending()
     _prelaid.clear()
     if any(z["armed"] for z in _zero_pool.values()):

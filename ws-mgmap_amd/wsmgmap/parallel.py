@@ -63,10 +63,12 @@ class GradAllReducer:
         # None: the round-2 form (pack on the stream of the hook that completes a bucket, asynchronous collective on the
         # backend's internal stream).  DESIGN.md section 4.3 / 5.
         self._xstream = exchange_stream
+        self._restore = []          # process-wide settings this reducer changed: close() puts them back
         if exchange_stream is not None:
             # with no stream beyond the policy's own in the process, the policy may keep its early instruction dedup under a process
             # group too (mg_map_policy.MGMapNet._encode_instruction; measured: profiles/r05_dp_exchange_ab.txt)
             from . import debug
+            self._restore.append((debug.sw, "early_dedup_dp", debug.sw.early_dedup_dp))
             debug.sw.early_dedup_dp = True
         self._module = module
         self._buffers_every = int(broadcast_buffers_every)
@@ -102,6 +104,34 @@ class GradAllReducer:
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         for p in self.params:
             p._wsmg_reducer = True      # wsmgmap.recurrent: this parameter's gradient-ready hook is ours (it follows _wsmg_grad_stream)
+        self._bucket_events = None  # time_buckets(): per update [(bucket, event before, event after the collective)]
+        self._bucket_ms = {}
+        if not self._off and self.params and self.params[0].is_cuda:
+            # a status check that raises on ONE rank in the middle of a forward pass would leave the peers blocked in their collectives:
+            # while this reducer lives, only finish() reads the persistent kernels' status word, and the ranks agree on what it said
+            from . import _abi
+            self._restore.append((_abi, "defer_rnn_status", _abi.defer_rnn_status))
+            _abi.defer_rnn_status = True
+
+    def close(self):
+        """Remove the gradient hooks and put back the process-wide settings the constructor changed (the deferred status checks, the
+        early dedup under a process group): a dropped reducer must not leave them behind."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            if hasattr(p, "_wsmg_reducer"):
+                del p._wsmg_reducer
+        for obj, name, val in reversed(self._restore):
+            setattr(obj, name, val)
+        self._restore = []
+        self._off = True
+
+    def time_buckets(self, on=True):
+        """Bracket every bucket's pack + collective with two events on the stream it runs on (exchange_stream forms only);
+        `stats()["per_bucket_allreduce_ms"]` then lists the mean per bucket — what a ring step over xGMI takes, peers' skew included."""
+        self._bucket_events = [] if on else None
+        self._bucket_ms = {}
 
     # -- setup ---------------------------------------------------------------------
     def broadcast_parameters(self, module, src=0):
@@ -250,9 +280,16 @@ class GradAllReducer:
         b["launched"] = True
         if xs is not None:
             with torch.cuda.stream(xs):
+                e0 = e1 = None
+                if self._bucket_events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(xs)
                 if dst:
                     torch._foreach_copy_(dst, [g for g in grads if g is not None])
                 dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group)     # synchronous form: runs on `xs` itself
+                if e1 is not None:
+                    e1.record(xs)
+                    self._bucket_events.append((bi, e0, e1))
             self._works.append((bi, None))
             return
         if dst:
@@ -261,6 +298,15 @@ class GradAllReducer:
 
     def _launch_ready(self):
         """Issue every ready bucket whose predecessors have been issued: all ranks issue bucket 0, 1, 2, ... in that order."""
+        if self._xstream is not None and self._buckets and self._buckets[0]["params"][0].is_cuda:
+            # The exchange stream is the attention-stage stream of the chained recurrent core (recurrent.py: `sa`).  A blocking
+            # cross-rank collective enqueued there BEFORE the core's backward pass would sit in front of the attention kernels the
+            # resident, spinning recurrences wait for — a slow peer then runs their bounded spins out (ADVICE r05).  While a chained
+            # forward pass is waiting for its backward, buckets are held; the core's backward releases them when it has queued its
+            # kernels (its leaf pass calls these hooks), and finish() issues whatever is left.
+            from .ops import core as _core
+            if _core.chain_in_flight:
+                return
         while self._next < len(self._buckets) and self._buckets[self._next]["pending"] == 0:
             self._launch(self._next)
             self._next += 1
@@ -349,7 +395,7 @@ class GradAllReducer:
             ev0.record(torch.cuda.current_stream())      # the backward pass ends here on the compute stream
             from . import _abi
             try:
-                _abi.check_rnn_status()
+                _abi.check_rnn_status(force=True)
             except _abi.WsmgError as e:   # agreed on with the other ranks below: no rank may leave the collectives alone
                 # in a data-parallel run the first suspect is co-residency: a persistent GRU / LSTM kernel needs all of its 32 / 16
                 # workgroups running at once and spins (bounded) for its peers — beside the collective library's kernels and up to
@@ -358,6 +404,11 @@ class GradAllReducer:
                            "the collective's kernels — fall back to one persistent kernel at a time with policy.net.recurrent_chunks = 0 "
                            "(WSMG_RECURRENT_CHUNKS=0) and WSMG_DECODER_STREAMS=0, and check GPU_MAX_HW_QUEUES (8 for one process per GPU, "
                            "unset when ranks share a GPU)]")
+        if dev.type == "cuda":
+            from .ops import core as _core
+            _core.chain_in_flight = False        # backward is over: nothing of the chained core is pending any more
+            if self._buckets is not None:
+                self._launch_ready()
         if self._buckets is None:  # first update: discovery pass, exchange synchronously
             self._agree_on_layout()
             self._build_buckets()
@@ -411,6 +462,13 @@ class GradAllReducer:
     def _fold_timing(self, keep=0):
         """Fold completed updates' timings into the running statistics (events of the newest `keep` updates may be in flight)."""
         todo, self._timing = self._timing[:len(self._timing) - keep], self._timing[len(self._timing) - keep:]
+        if self._bucket_events and keep == 0:
+            for bi, e0, e1 in self._bucket_events:
+                e1.synchronize()
+                acc = self._bucket_ms.setdefault(bi, [0.0, 0])
+                acc[0] += e0.elapsed_time(e1)
+                acc[1] += 1
+            self._bucket_events = []
         for host_s, ev0, ev1 in todo:
             exposed = 0.0
             if ev0 is not None and ev1 is not None:
@@ -432,8 +490,11 @@ class GradAllReducer:
         n = max(1, s["updates"])
         out = dict(updates=s["updates"], exposed_allreduce_ms=round(s["exposed_ms"] / n, 4), exposed_allreduce_max_ms=round(s["exposed_max_ms"], 4),
                    host_ms_in_finish=round(s["host_wait_ms"] / n, 4), buckets=self.num_buckets, live_gradient_bytes=self.live_bytes)
+        if self._bucket_ms:
+            out["per_bucket_allreduce_ms"] = [round(self._bucket_ms[bi][0] / max(1, self._bucket_ms[bi][1]), 4) for bi in sorted(self._bucket_ms)]
         if reset:
             self._stats = dict(updates=0, host_wait_ms=0.0, exposed_ms=0.0, exposed_max_ms=0.0)
+            self._bucket_ms = {}
         return out
 
     def check(self):

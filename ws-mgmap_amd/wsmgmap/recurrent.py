@@ -26,6 +26,7 @@ import torch
 
 from . import _abi
 from . import ops as _ops
+from .ops import core as _core
 from .debug import sw as _sw
 from .ops import _join_side_at_end, _p, _rnn_launched, _rnn_workspace, _sfx, _stream
 
@@ -192,6 +193,8 @@ class _RecurrentBlock(torch.autograd.Function):
         tsfx = _sfx(text_k)
         ksfx = _sfx(tokens)
         nbytes = lib.wsmg_gru_workspace_bytes(Tc)
+        # (wsmgmap.parallel holds its buckets until this block's backward has queued its kernels: see _launch_ready there)
+        _core.chain_in_flight = bool(sa is not main and any(ctx.needs_input_grad))
         forked = False
         if sa is not main:
             # the buffers above come from the main stream's pool: whatever used their memory before is queued on main
@@ -508,6 +511,7 @@ class _RecurrentBlock(torch.autograd.Function):
             dw_hh1, db_hh1 = gh1.t() @ hp1.view(B, H), gh1.sum(0)
             dw_ih1, db_ih1 = g1.t() @ state_in, g1.sum(0)
         pgrads = [dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2]
+        _core.chain_in_flight = False      # every kernel of this block's backward is queued: the gradient exchange may issue buckets again
         if multi:
             main.wait_event(ekv)
             for i, p in enumerate(params):
