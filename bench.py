@@ -241,9 +241,6 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # the forward's one host read-back — the instruction dedup, still launched and read back in every update — need not wait for
     # the previous update to finish on the GPU (wsmgmap/ops/core.py, "input readiness")
     ops.mark_inputs_ready(obs["instruction"])
-    # likewise the cached ego map (reference layout: float32 NCHW): its layout / dtype pass is still run in EVERY update, on the early stream
-    # behind this event (WSMG_EARLY_EGO=0: at the head of the update on the caller's stream, as in rounds 1-5)
-    ops.mark_inputs_ready(obs["rgb_ego_map"])
     AuxLosses.activate()
 
     def update():

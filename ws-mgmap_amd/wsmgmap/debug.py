@@ -19,7 +19,6 @@ _TABLE = [
     ("recurrent_chain", "WSMG_RECURRENT_CHAIN", True, bool, "each recurrence of the pipelined core as ONE launch chained to the attention stage by device-side counters"),
     ("decoder_streams", "WSMG_DECODER_STREAMS", 1, int, "0: map decoder on one stream; 1: side stream unless ranks share a GPU; 2: always"),
     ("early_dedup", "WSMG_EARLY_DEDUP", True, bool, "instruction dedup on its own stream when the producer marked the tokens ready (ops.mark_inputs_ready)"),
-    ("early_ego", "WSMG_EARLY_EGO", True, bool, "update path: the cached ego map's NCHW -> NHWC pass on the early stream when its producer marked it ready"),
     ("early_dedup_dp", "WSMG_EARLY_DEDUP_DP", False, bool, "the early dedup also under a process group (needs the exchange on a policy stream: GradAllReducer(exchange_stream=...))"),
     ("prelayout_first", "WSMG_PRELAYOUT_FIRST", True, bool, "update path: the map stack's weight layout is the first thing on the instruction stream (not behind the cached features' dense layers)"),
     ("enc_proj_side", "WSMG_ENC_PROJ_SIDE", True, bool, "map_encoded_linear on the decoder's side stream (its backward beside the resnet branch's small kernels)"),

@@ -226,15 +226,7 @@ class MGMapNet(nn.Module):
                 laid.record(self._side_stream)
             else:
                 ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
-        early_x = getattr(self, "_ego_early", None)
-        self._ego_early = None
-        if early_x is not None and early_x[0] is ego_map:
-            # forward() queued the layout pass on the early stream, behind the producer's event alone (see there)
-            x = early_x[1]
-            torch.cuda.current_stream().wait_event(early_x[2])
-            x.record_stream(torch.cuda.current_stream())
-        else:
-            x = self._ego_to_nhwc(ego_map)
+        x = self._ego_to_nhwc(ego_map)
         if laid is not None:
             torch.cuda.current_stream().wait_event(laid)
         enc = self.map_encoder(x)
@@ -381,26 +373,6 @@ class MGMapNet(nn.Module):
                 ops.prelayout_conv_weights(self._map_stack_conv_weights(), self.compute_dtype)
             self._laid_event = torch.cuda.Event()
             self._laid_event.record(self._side_stream)
-        # Update path, cached ego map in the reference's layout (float32 NCHW): its layout / dtype pass (2 GB of HBM traffic, 0.36 ms
-        # alone at the head of every update) is parameter-free and depends on the input only.  When the producer said when the map was
-        # complete (ops.mark_inputs_ready) the pass is queued on the early stream behind THAT event: the host runs 2-3 ms ahead of the
-        # GPU, so it runs beside the previous update's last weight-gradient kernels (matrix-pipe-bound, HBM-light) instead of alone.
-        self._ego_early = None
-        if (self._laid_event is not None and debug.sw.early_ego and ego.dtype == torch.float32 and ego.is_contiguous()
-                and self.training and not (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                           and not debug.sw.early_dedup_dp)):
-            ready = ops.inputs_ready_event(ego)
-            if ready is not None:
-                if getattr(self, "_early_stream", None) is None:
-                    self._early_stream = ops.helper_stream("early", priority=-1)
-                early_s = self._early_stream
-                early_s.wait_event(ready)
-                with torch.cuda.stream(early_s):
-                    ego.record_stream(early_s)
-                    x_early = self._ego_to_nhwc(ego)
-                    done = torch.cuda.Event()
-                    done.record(early_s)
-                self._ego_early = (ego, x_early, done)
         # Rollout (no autograd, RGB encoded from pixels): the instruction branch is queued FIRST and runs beside the frozen
         # RGB encoder — in a captured step (graph.GraphedAct) it otherwise lands behind the map decoder's side branch and the
         # main stream idles through the whole 0.45 ms LSTM (B = 1).  Training keeps the order described in _encode_instruction.
