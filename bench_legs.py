@@ -145,12 +145,14 @@ def cfg4_bev_mapenc(dev, reps=10):
         compass = obs["compass"].reshape(B).contiguous()
         gps = obs["gps"].contiguous()
         gm = mapper.full_global_map
-        lin = ops.bev_index(depth, Hf, Hf, E)
-        rot = ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E)
+        compact_ok = ops.bev_compact_ok(Hf, Hf, E)
+        lin, comp = ops.bev_index_compact(depth, Hf, Hf, E) if compact_ok else (ops.bev_index(depth, Hf, Hf, E), None)
+        rot = ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E, compact=comp)
         m1 = masks.reshape(B).contiguous()
+        index_fn = (lambda: ops.bev_index_compact(depth, Hf, Hf, E)) if compact_ok else (lambda: ops.bev_index(depth, Hf, Hf, E))
         stages = {
-            "index": (_events_gpu(lambda: ops.bev_index(depth, Hf, Hf, E), reps), B * (256 * 256 * 4 + Hf * Hf * 4)),
-            "scatter_rotate": (_events_gpu(lambda: ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E), reps),
+            "index": (_events_gpu(index_fn, reps), B * (256 * 256 * 4 + Hf * Hf * 4)),
+            "scatter_rotate": (_events_gpu(lambda: ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E, compact=comp), reps),
                                B * (64 * Hf * Hf * 4 + Hf * Hf * 4 + C * E * E * 4)),
             "fuse": (_events_gpu(lambda: ops.map_fuse(rot, gm, gps, m1, 0.12, planes=True), reps), B * 3 * C * (E + 4) ** 2 * 4),
             "retrieve": (_events_gpu(lambda: ops.map_retrieve(gm, gps, compass, E, 0.12), reps), B * 2 * C * E * E * 4),
@@ -166,11 +168,9 @@ def cfg4_bev_mapenc(dev, reps=10):
     out["stage_bytes"] = int(stage_bytes)
     out["stage_gbps"] = round(stage_bytes / t_map / 1e3, 1)
     out["stage_frac_of_8TBs"] = round(stage_bytes / t_map / 1e3 / HBM_PEAK_GBS, 4)
-    # the accounting of rounds 3-4 (tools/bench_bev.py "5-stage B"): the bytes the five SEPARATE launches move — the unrotated planes
-    # written and read back (2 C E^2 4 per sample) and the crop's round trip (another 2 C E^2 4), which the fused launches never move
-    five = stage_bytes + B * 4 * C * E * E * 4
-    out["five_launch_bytes"] = int(five)
-    out["five_launch_frac_of_8TBs"] = round(five / t_map / 1e3 / HBM_PEAK_GBS, 4)
+    out["valid_source_fraction"] = round(float((lin >= 0).float().mean()), 4)
+    out["accounting"] = ("`frac_of_8TBs` is on SURVEY 8d's ALGORITHMIC bytes (23.4 + 25.6 MB per sample): the one headline; `stage_*` counts what "
+                         "each launch of the fused route must move (reported, not a headline; the five-launch figure of rounds 3-5 is gone)")
     out["stages"] = {k: _bw(us, nb) for k, (us, nb) in stages.items()}
     # MapEncoder at this geometry: [32, 40 -> 64 (zero-padded), 200, 200] -> [32, 256, 49, 49]
     enc = MapEncoder(E, C, 256).to(dev).train()
@@ -196,8 +196,11 @@ def cfg4_bev_mapenc(dev, reps=10):
 
 
 def cfg5_attn_fp8(dev, reps=50):
-    """configs[4]: B = 64 rows over U = 8 shared instruction sets of L = 160 tokens, e4m3 storage: the whole operator from float32
-    q / k / v (scales, codes, row grouping and the attention itself), and the single-query form (one key / value set per row)."""
+    """configs[4] as SURVEY 8d defines it: the text stage of `_attn` (mg_map_policy.py:173-178) at B = 64 rows, each over its OWN
+    160-token set (x = key input = values, ragged valid lengths), e4m3 token storage, float32 query / softmax: 82 KB per row.
+    Headline (round 6): ops.attn_fp8_fused — query fold + attention per row in ONE launch.  Secondary: the update path's form, B rows
+    over U = 8 SHARED instruction sets from float32 q / k / v (ops.attention_fp8_shared: scales + codes + row grouping + attention)."""
+    import importlib
     from wsmgmap import ops
     B, U, L, C = 64, 8, 160, 256
     gen = torch.Generator(device=dev)
@@ -207,36 +210,39 @@ def cfg5_attn_fp8(dev, reps=50):
     v = torch.randn(U, L, C, device=dev, generator=gen)
     inv = torch.arange(B, device=dev) % U
     lens = torch.randint(L // 2, L + 1, (U,), device=dev, generator=gen).to(torch.int32)
+    att = importlib.import_module("wsmgmap.ops.attention")
     with torch.no_grad():
-        t_shared_host = _events(lambda: ops.attention_fp8_shared(q, k, v, lens, inv, 1 / 16), reps)
-        t_shared = _events_gpu(lambda: ops.attention_fp8_shared(q, k, v, lens, inv, 1 / 16), reps)
-        # single-query form: per-row token sets (x is key input and value), key projection folded into the query
+        # per-row token sets (x is key input and value), key projection folded into the query inside the launch
         w = torch.randn(C, C, device=dev, generator=gen) / 16
         b = torch.randn(C, device=dev, generator=gen) * 0.1
         x = torch.randn(B, L, C, device=dev, generator=gen)
         xs = float(x.abs().max() / 448.0)
         codes = ops.quantize_e4m3(x, xs)
         xs_t = torch.full((1,), xs, device=dev)
-        lr = torch.full((B,), L, dtype=torch.int32, device=dev)
-        t_single = _events_gpu(lambda: ops.attn_fp8_fused(q, w, b, codes, xs_t, lr, 1 / 16), reps)
+        lr = torch.randint(L // 2, L + 1, (B,), device=dev, generator=gen).to(torch.int32)
+        t_row_host = _events(lambda: ops.attn_fp8_fused(q, w, b, codes, xs_t, lr, 1 / 16), reps)
+        t_row = _events_gpu(lambda: ops.attn_fp8_fused(q, w, b, codes, xs_t, lr, 1 / 16), reps)
+        row_launches = int(att.last_fp8_row_launches)
+        t_shared_host = _events(lambda: ops.attention_fp8_shared(q, k, v, lens, inv, 1 / 16), reps)
+        t_shared = _events_gpu(lambda: ops.attention_fp8_shared(q, k, v, lens, inv, 1 / 16), reps)
     alg_shared = 2 * U * L * C + B * (C + C * 4 + L * 4)             # key + value bytes of the U sets, B queries in, contexts + weights out
-    alg_single = B * (2 * C * L + C * 4)                              # 82 KB per row at L = 160
+    alg_row = B * (2 * C * L + C * 4)                                 # 82 KB per row at L = 160
     flops = 2.0 * B * L * C * 2
-    out = dict(workload="_attn text stage, B=64 rows over U=8 shared instruction sets, L=160, e4m3 storage, f32 softmax "
-                        "(ops.attention_fp8_shared from float32 q/k/v: scales + codes + row grouping + S=QK^T on the fp8 pipe + PV)")
-    out.update(_bw(t_shared, alg_shared))
-    out["ms"] = round(t_shared / 1e3, 5)
-    out["unit_rate"] = round(B * 1e6 / t_shared, 1)
+    out = dict(workload="_attn text stage, B=64 rows x their own 160-token set (SURVEY 8d: 82 KB per row), e4m3 token storage, float32 query "
+                        "and softmax, ragged lengths (ops.attn_fp8_fused: query fold + logits + softmax + context per row)")
+    out.update(_bw(t_row, alg_row))
+    out["ms"] = round(t_row / 1e3, 5)
+    out["unit_rate"] = round(B * 1e6 / t_row, 1)
     out["unit"] = "attention rows/s"
-    out["gflops"] = round(flops / t_shared / 1e3, 2)
-    out["us_host_paced_loop"] = round(t_shared_host, 2)
+    out["gflops"] = round((flops + 2.0 * B * C * C) / t_row / 1e3, 2)
+    out["launches"] = row_launches
+    out["us_host_paced_loop"] = round(t_row_host, 2)
     out["timing_note"] = ("`us`: HIP events around 50 calls enqueued while the stream was held busy, i.e. kernels back to back on the GPU; "
                           "`us_host_paced_loop`: the same 50 calls on an idle stream (the host's ~30 us per Python-level call paces them)")
-    import importlib
-    out["launches"] = int(importlib.import_module("wsmgmap.ops.attention").last_fp8_shared_launches)
-    out["single_query_form"] = dict(_bw(t_single, alg_single), note="ops.attn_fp8_fused: one token set per row (SURVEY 8d: 82 KB per row), "
-                                    "query fold on the f32 matrix pipe + split-row kernel: 2 launches")
-    out["note"] = "latency-bound at this size (5 MB, 21 MFLOP): the figure to watch is us, not the fraction"
+    out["shared_set_form"] = dict(_bw(t_shared, alg_shared), launches=int(att.last_fp8_shared_launches), us_host_paced_loop=round(t_shared_host, 2),
+                                  note="ops.attention_fp8_shared: B = 64 rows over U = 8 shared instruction sets (the update path's form) from "
+                                       "float32 q / k / v: scales, e4m3 codes, row grouping, S = QK^T on the fp8 matrix pipe, PV")
+    out["note"] = "latency-bound at this size (5.3 MB, 29 MFLOP with the fold): the figure to watch is us, not the fraction"
     return out
 
 

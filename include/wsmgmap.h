@@ -72,6 +72,15 @@ int wsmg_map_fuse(const float* ego_rot, float* global_map, const float* gps, con
  * global map stays [num_proc][G][G][C]).  C % 4 == 0, C <= 64, E*E*4 <= 160 KiB. */
 int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx, const float* heading, float sign, int B, int Cf, int Hf,
                             int Wf, int C, int E, float* out_planes, wsmg_stream_t stream);
+/* Round 6 — the index launch also compacts the valid sources (75-80 % of a frame's sources are invalid, SURVEY section 7, and every
+ * one of the C plane workgroups of a sample walked all Hf x Wf entries): clist [B][Hf*Wf] uint32 = (source << 16) | cell, the valid
+ * entries of each block of 8192 sources packed at the block's front, cnt [B][ceil(Hf*Wf / 8192)] their counts; lin_idx as
+ * wsmg_bev_index.  Needs Hf*Wf <= 65536 and E*E <= 65536.  wsmg_bev_scatter_rotate_compact: wsmg_bev_scatter_rotate from that list
+ * (the scatter is a max: order-independent, bit-identical planes; rgb_mapping.py:153-232). */
+int wsmg_bev_index_compact(const float* depth, int B, int Hd, int Wd, float depth_scale, int Hf, int Wf, int E, float local_scale,
+                           int32_t* lin_idx, uint32_t* clist, int32_t* cnt, wsmg_stream_t stream);
+int wsmg_bev_scatter_rotate_compact(const float* feat, const uint32_t* clist, const int32_t* cnt, const float* heading, float sign, int B,
+                                    int Cf, int Hf, int Wf, int C, int E, float* out_planes, wsmg_stream_t stream);
 int wsmg_map_fuse_planes(const float* ego_rot_planes, float* global_map, const float* gps, const float* masks, int B, int C,
                          int E, int G, float resolution, wsmg_stream_t stream);
 
@@ -223,6 +232,52 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
+/* ---- round 6: BatchNorm-backward sums and ReLU masks in the epilogue of the kernel that PRODUCES the gradient ---------------
+ * The 13 train-mode BatchNorms of the map stack (map_encoder.py:19-29,94-112, mg_map_policy.py:78-100; cuDNN's batch-norm backward
+ * in the reference) need sum g and sum g * xhat over the whole batch, g = dy masked by the ReLU that follows the BatchNorm.  The kernel
+ * that WRITES dy takes them: it reads the matching 16-byte piece of x (the BatchNorm's input) while it holds the gradient piece,
+ * stores the masked gradient, and every workgroup STORES its partial sums as block `blk` of `part` [blocks][2][C] float64 — the
+ * layout of the reduction pass it replaces (plain stores, each element written once: no atomics, bit-reproducible);
+ * wsmg_bn_act_bwd_bf16_parts adds the blocks in block order and applies.
+ *   mode 0: nothing.  1: out = g where z > 0 else 0 (z = the ReLU OUTPUT: the fused ReLU of a convolution without BatchNorm,
+ *   mg_map_policy.py:89-100; no sums).  2: BatchNorm + ReLU: keep = ((z - mean) invstd gamma + beta > 0) — bn_apply's own
+ *   expression —, out = g keep, sums of out and out * (z - mean) invstd.  3: BatchNorm without ReLU: the sums only.
+ *   Gradient channels [c0, c0 + C) correspond to z's channels [0, C); ld = z's pixel pitch in elements (z may be a channel slice);
+ *   C, c0, ld multiples of 8, z 16-byte aligned.  cap_blocks: blocks `part` can hold (ceil(pixels / 128) + 8 suffices for every
+ *   kernel here); the launcher writes the number of blocks its launch fills into `blocks` (host memory, at launch time). */
+typedef struct {
+  const void* z;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  double* part;
+  int mode, c0, C, ld, cap_blocks, blocks;
+} wsmg_bn_aux_t;
+/* wsmg_conv2d_bwd_data_bf16 with the hook on dx (aux may be NULL).  wsmg_conv2d_fwd_bf16_stats with the hook on y — the call that
+ * computes the input gradient of a ConvTranspose2d — and with y_ld (0 = Cout): the pixel pitch of y in elements, so that a
+ * convolution writes its output straight into its channel slice of the concatenation that follows (torch.cat at
+ * mg_map_policy.py:197; `y` then points at the slice's first channel).  dx2 / split_c (dx2 may be NULL): the input gradient of a
+ * convolution over a two-part concatenation leaves as its two parts — channels [0, split_c) to dx [pixels][split_c], the rest to dx2
+ * [pixels][Cin - split_c] (what torch.cat's backward hands to the two producers, contiguous); split_c a multiple of 8. */
+int wsmg_conv2d_bwd_data_bf16_ex(const void* dy, const void* w_ihwo, void* dx, wsmg_bn_aux_t* aux, void* dx2, int split_c, int B, int H,
+                                 int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, wsmg_stream_t stream);
+int wsmg_conv2d_fwd_bf16_ex(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, double* stats, int nslab,
+                            wsmg_bn_aux_t* aux, int y_ld, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                            int pad, int OH, int OW, wsmg_stream_t stream);
+/* The elementwise producers of a BatchNorm's incoming gradient with the same hook (modes 2 / 3, c0 = 0): y = a + b + c (the encoded
+ * map's three consumers, mg_map_policy.py:189-207; rows x aux->C channels) and the bilinear upsampling's backward
+ * (map_encoder.py:103,108; dy read with pixel pitch ld_dy). */
+int wsmg_add3_bf16_aux(const void* a, const void* b, const void* c, void* y, int64_t rows, wsmg_bn_aux_t* aux, wsmg_stream_t stream);
+int wsmg_upsample2x_bwd_ld_bf16_aux(const void* dy, int64_t ld_dy, void* dx, int B, int H, int W, int C, wsmg_bn_aux_t* aux,
+                                    wsmg_stream_t stream);
+/* Train-mode BatchNorm backward behind such a producer: dy is already masked, `part` [blocks][2][C] holds the producer's partial
+ * sums.  Two launches (rounds 1-5: three, the first of them a pass over dy and x): the blocks are added in block order (dgamma /
+ * dbeta), then dx = gamma invstd (g - dbeta / n - xhat dgamma / n).  No residual form (those gradients keep the reduction pass).
+ * scratch [scratch_blocks >= 64][2][C] float64 (may be NULL): a list of more than 1536 blocks is first folded to 64 (one more launch). */
+int wsmg_bn_act_bwd_bf16_parts(const void* dy, int64_t ld_dy, const void* x, const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_invstd, int relu, int64_t rows, int C, void* dx, float* dgamma, float* dbeta,
+                               const double* part, int blocks, double* scratch, int scratch_blocks, wsmg_stream_t stream);
 /* A list of device-to-device copies (non-overlapping) in one launch: the inputs of a captured rollout step handed into its
  * static tensors (wsmgmap.graph.GraphedAct).  Any alignment, any byte count. */
 typedef struct {
@@ -274,6 +329,9 @@ int wsmg_adam_step_multi_dev(const WsmgAdamDesc* descs, int n, float lr, float b
  * env WSMG_CONV_WIN3).
  * Returns the previous choice.  No reference counterpart (the reference calls torch.nn.Conv2d, map_encoder.py:29-112). */
 int wsmg_conv_debug_win3_tile(int mt);
+/* round 6 experiment (weights of the 3 x 3 window kernel from global memory into registers instead of through LDS): 1 on, 0 off, -1 by
+ * the environment (WSMG_WIN3_BREG); returns the previous setting.  Bit-identical results. */
+int wsmg_conv_debug_win3_breg(int on);
 int wsmg_bn_act_fwd_bf16_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, int64_t rows, int C, void* y,
                              float* save_mean, float* save_invstd, double* stats, int nslab, wsmg_stream_t stream);
@@ -336,6 +394,13 @@ int wsmg_attn_shared_bwd_bf16(const float* q, const void* k_sets, const void* v_
                               const float* dattn, const int64_t* row_index, float scale, int B, int I, int C, float* dq,
                               float* dlogits, wsmg_stream_t stream);
 
+/* BASELINE configs[4] as SURVEY 8d defines it — B rows, each over its OWN token set — in ONE launch (round 6): the query fold
+ * q_f = q W_k (w_k [256][256] = the Conv1d weight [C_out][C_in] of mg_map_policy.py:126-127; its bias cancels in the softmax) and
+ * the attention of wsmg_attn_fp8_fwd, one workgroup per row, no workspace.  q [B][256] float32, x_e4m3 [B][L][256], L <= 224;
+ * q_folded [B][256] (may be NULL) receives q_f for wsmg_attn_fp8_bwd.  Replaces wsmg_attn_fp8_fold + wsmg_attn_fp8_fwd
+ * (mg_map_policy.py:173-178,229-232). */
+int wsmg_attn_fp8_row_fwd(const float* q, const float* w_k, const uint8_t* x_e4m3, const float* x_scale, const int* lengths,
+                          float scale, int B, int L, int C, float* q_folded, float* out, float* attn, wsmg_stream_t stream);
 /* fp8 (OCP e4m3) text attention, BASELINE configs[4] (B=64, L=160), forward and backward (csrc/wsmg_attn_fp8.hip).  The k=1
  * Conv1d key projection of mg_map_policy.py:126-127 is folded into the single query — q.(W_k x_l + b_k) = (q W_k).x_l +
  * q.b_k, and the last term cancels in the softmax — so every token of x is read from HBM once, as bytes:

@@ -3,4 +3,43 @@
 case "$1" in
 1) python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/c1_tests.txt
    tools/ab.sh c1_early_ego 3 30 "X=1" "WSMG_EARLY_EGO=0" > gpurun_out/c1_early_ego.txt 2>&1 ;;
+2) python -m pytest tests/test_gpu_round6.py -x -q 2>&1 | tail -30 > gpurun_out/c2_r6.txt
+   python -m pytest tests/test_gpu_policy.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q 2>&1 | tail -15 > gpurun_out/c2_tests.txt
+   tools/ab.sh c2_bn 3 30 "X=1" "WSMG_BN_PRODUCER_SUMS=0" "WSMG_BN_PRODUCER_SUMS=0 WSMG_BN_BWD_SLABS=0" > gpurun_out/c2_bn.txt 2>&1 ;;
+3) python -m pytest tests/test_gpu_round6.py -x -q 2>&1 | tail -30 > gpurun_out/c3_r6.txt
+   python -m pytest tests/test_gpu_policy.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q 2>&1 | tail -15 > gpurun_out/c3_tests.txt
+   tools/ab.sh c3_bn 3 30 "X=1" "WSMG_BN_PRODUCER_SUMS=0" "WSMG_BN_PRODUCER_SUMS=0 WSMG_RELU_PRODUCER_MASK=0 WSMG_CONV_INTO_CAT=0" > gpurun_out/c3_bn.txt 2>&1 ;;
+4) python -m pytest tests/test_gpu_round6.py -q 2>&1 | tail -40 > gpurun_out/c4_r6.txt
+   python -m pytest tests/test_gpu_kernels.py tests/test_gpu_policy.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q 2>&1 | tail -15 > gpurun_out/c4_tests.txt
+   tools/ab.sh c4_bn 3 30 "X=1" "WSMG_BN_PRODUCER_SUMS=0" "WSMG_BN_PRODUCER_SUMS=0 WSMG_RELU_PRODUCER_MASK=0 WSMG_CONV_INTO_CAT=0" > gpurun_out/c4_bn.txt 2>&1
+   python - > gpurun_out/c4_legs.txt 2>&1 <<'PY'
+import json, sys, torch
+sys.path.insert(0, "ws-mgmap_amd")
+import bench_legs
+dev = torch.device("cuda")
+for name, fn in (("cfg4", bench_legs.cfg4_bev_mapenc), ("cfg5", bench_legs.cfg5_attn_fp8)):
+    r = fn(dev)
+    print(name, json.dumps(r)[:3000])
+PY
+   python tools/stock_ops.py 3 > gpurun_out/c4_stock_ops.txt 2>&1 ;;
+5) python -m pytest tests/test_gpu_round6.py -q 2>&1 | tail -12 > gpurun_out/c5_r6.txt
+   python tools/breg_ab.py 30 > gpurun_out/c5_breg.txt 2>&1
+   for arm in 1 0; do
+     WSMG_BEV_COMPACT=$arm python - > gpurun_out/c5_cfg4_compact$arm.txt 2>&1 <<'PY'
+import json, sys, torch
+sys.path.insert(0, "ws-mgmap_amd")
+import bench_legs
+r = bench_legs.cfg4_bev_mapenc(torch.device("cuda"))
+print(r["us"], {k: v["us"] for k, v in r["stages"].items()})
+PY
+   done
+   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   for arm in new old; do
+     if [ $arm = old ]; then export WSMG_BN_PRODUCER_SUMS=0; else unset WSMG_BN_PRODUCER_SUMS; fi
+     rm -rf gpurun_out/st_$arm
+     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st_$arm -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c5_st_$arm.log 2>&1
+     cp $(ls gpurun_out/st_$arm/*/*kernel_stats.csv | head -1) gpurun_out/c5_kernel_stats_$arm.csv
+     rm -rf gpurun_out/st_$arm
+   done
+   unset WSMG_BN_PRODUCER_SUMS ;;
 esac

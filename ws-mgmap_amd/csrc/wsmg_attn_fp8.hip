@@ -200,6 +200,124 @@ __global__ __launch_bounds__(256) void attn_fp8_fwd_kernel(Fp8FwdArgs a) {
   }
 }
 
+// ----------------------------------------------------------------------------- forward in ONE launch: fold + attention per row
+// BASELINE configs[4] as SURVEY 8d defines it (B = 64 rows, each with its OWN L = 160 token set: 82 KB per row): rounds 3-5 ran it as
+// the fold launch + the split forward launch (18.9 us).  Here one workgroup of 512 threads owns a row from the float32 query to the
+// context: (1) the row's token bytes are requested first and stay in flight in registers; (2) the query fold q_f = q W_k — a
+// [1,256] x [256,256] product per row, W_k (256 KB) read through L2 — as two float32 fmaf chains per output column (threads j and
+// 256 + j take the two halves of the reduction); (3) the tokens land in LDS, the logits, the softmax and the weighted sum are
+// attn_fp8_fwd_kernel's (whole row, ns = 1), with eight waves instead of four.  No second launch, no workspace, no ticket.
+constexpr int ROW_MAX_L = 224;        // 56 KB of dynamic LDS for the row's bytes
+struct Fp8RowArgs {
+  const float* q;         // [B][256]
+  const float* w;         // [256][256] Conv1d weight [C_out][C_in]: q_f[j] = sum_o q[o] w[o][j]
+  const uint8_t* x;       // [B][L][256] e4m3
+  const float* x_scale;
+  const int* lengths;     // [B] or null
+  float scale;
+  int L;
+  float* qf;              // [B][256] or null (the backward pass wants it)
+  float* out;             // [B][256]
+  float* attn;            // [B][L]
+};
+
+__global__ __launch_bounds__(512) void attn_fp8_row_kernel(Fp8RowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t xs[];   // L * 256 token bytes
+  __shared__ float lg[ROW_MAX_L];
+  __shared__ __attribute__((aligned(16))) float qs[AC];
+  __shared__ __attribute__((aligned(16))) float qfs[2][AC];
+  __shared__ __attribute__((aligned(16))) float psum[8][AC];
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, grp = lane >> 4;
+  const int L = a.L;
+  const int len = a.lengths ? a.lengths[b] : L;
+  // (1) the row's bytes: up to 7 x 16 bytes per thread, in flight while the fold runs
+  constexpr int TRIPS = ROW_MAX_L * (AC / 16) / 512;
+  const u32x4* src = reinterpret_cast<const u32x4*>(a.x + (size_t)b * L * AC);
+  const int npiece = L * (AC / 16);
+  u32x4 tok[TRIPS];
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int i = tid + 512 * t;
+    tok[t] = i < npiece ? src[i] : u32x4{0u, 0u, 0u, 0u};
+  }
+  if (tid < AC) qs[tid] = a.q[(size_t)b * AC + tid];
+  const float xsc = *a.x_scale;
+  __syncthreads();
+  // (2) fold: column j, reduction half `hf`
+  {
+    const int j = tid & (AC - 1), hf = tid >> 8;
+    const float* wp = a.w + (size_t)(hf * (AC / 2)) * AC + j;
+    float acc = 0.f;
+#pragma unroll 1
+    for (int o0 = 0; o0 < AC / 2; o0 += 16) {
+      float wv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) wv[u] = wp[(size_t)(o0 + u) * AC];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fmaf(qs[hf * (AC / 2) + o0 + u], wv[u], acc);
+    }
+    qfs[hf][j] = acc;
+  }
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int i = tid + 512 * t;
+    if (i < npiece) reinterpret_cast<u32x4*>(xs)[i] = tok[t];
+  }
+  __syncthreads();
+  if (tid < AC) {
+    const float v = qfs[0][tid] + qfs[1][tid];
+    qfs[0][tid] = v;
+    if (a.qf) a.qf[(size_t)b * AC + tid] = v;
+  }
+  __syncthreads();
+  float qv[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(&qfs[0][l16 * 16])[j];
+    qv[4 * j] = v[0]; qv[4 * j + 1] = v[1]; qv[4 * j + 2] = v[2]; qv[4 * j + 3] = v[3];
+  }
+  // (3) logits: 16 lanes per token, 32 tokens per trip of the workgroup
+  for (int i0 = 0; i0 < L; i0 += 32) {
+    const int i = i0 + wave * 4 + grp;
+    float d = dot16(xs + (size_t)(i < L ? i : L - 1) * AC, qv, l16);
+    if (i < L && l16 == 0) {
+      d = d * xsc;
+      if (i >= len) d = d - 1e8f;          // the reference's additive mask (mg_map_policy.py:175)
+      lg[i] = d * a.scale;
+    }
+  }
+  __syncthreads();
+  const float v = tid < L ? lg[tid] : -INFINITY;
+  float mx = wave_max(v);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+  const float e = tid < L ? expf(v - mx) : 0.f;
+  float sm = wave_sum(e);
+  if (lane == 0) red[8 + wave] = sm;
+  if (tid < L) lg[tid] = e;
+  __syncthreads();
+  sm = ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+  f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < L; i += 8) {
+    const float w = lg[i];
+    const f32x4 xv = cvt4_e4m3(reinterpret_cast<const unsigned*>(xs + (size_t)i * AC)[lane]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc4[j] = fmaf(w, xv[j], acc4[j]);
+  }
+  reinterpret_cast<f32x4*>(&psum[wave][0])[lane] = acc4;
+  __syncthreads();
+  const float inv1 = 1.f / sm;
+  if (tid < AC) {
+    const float mine = ((psum[0][tid] + psum[1][tid]) + (psum[2][tid] + psum[3][tid])) + ((psum[4][tid] + psum[5][tid]) + (psum[6][tid] + psum[7][tid]));
+    a.out[(size_t)b * AC + tid] = mine * inv1 * xsc;
+  }
+  if (tid < L) a.attn[(size_t)b * L + tid] = lg[tid] * inv1;
+}
+
 // ----------------------------------------------------------------------------- backward (one workgroup per row)
 constexpr int F8_MAX_L = 224;   // 56 KB of LDS for the row's bytes
 struct Fp8BwdArgs {
@@ -322,6 +440,21 @@ extern "C" int wsmg_attn_fp8_fwd(const float* q_folded, const uint8_t* x_e4m3, c
     attr = true;
   }
   hipLaunchKernelGGL(attn_fp8_fwd_kernel, dim3((unsigned)a.ns, (unsigned)B), dim3(256), (size_t)chunk * AC, wsmg_s(stream), a);
+  WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_attn_fp8_row_fwd(const float* q, const float* w_k, const uint8_t* x_e4m3, const float* x_scale, const int* lengths,
+                                     float scale, int B, int L, int C, float* q_folded, float* out, float* attn, wsmg_stream_t stream) {
+  if (C != AC || B <= 0 || L <= 0 || L > ROW_MAX_L || !q || !w_k || !x_e4m3 || !x_scale || !out || !attn) return WSMG_EINVAL;
+  Fp8RowArgs a{q, w_k, x_e4m3, x_scale, lengths, scale, L, q_folded, out, attn};
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fp8_row_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       ROW_MAX_L * AC);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_fp8_row_kernel, dim3((unsigned)B), dim3(512), (size_t)L * AC, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
 

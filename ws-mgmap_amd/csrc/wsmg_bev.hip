@@ -54,6 +54,61 @@ __global__ __launch_bounds__(256) void bev_index_kernel(IndexArgs a) {
   }
 }
 
+// Round 6 — the index launch also COMPACTS the valid sources.  75-80 % of the sources of a frame are invalid (no depth, above the
+// horizon, outside the map: SURVEY section 7), and every (sample, channel) plane workgroup of the scatter walked all Hf x Wf index
+// entries to find the rest — 40 times per sample at cfg4, eight dependent trips of index -> feature -> LDS atomic each.  Here a
+// workgroup owns a block of CB = 8192 consecutive sources, writes their index entries as before, and packs the valid ones —
+// (source << 16) | cell, both < 65 536 — to the front of ITS block of `clist`, count in cnt[sample][block]: no global atomics,
+// nothing to zero, any order inside a block (the scatter is a max: order-independent, bit-exact).  The scatter then walks
+// sum(cnt) entries instead of Hf x Wf.
+constexpr int CB = 8192;
+__device__ __forceinline__ int index_of(const IndexArgs& a, int b, unsigned p) {
+  const unsigned hfu = p / (unsigned)a.Wf;
+  const int hf = (int)hfu, wf = (int)(p - hfu * (unsigned)a.Wf);
+  int ih = (int)((float)hf * a.K);
+  int iw = (int)((float)wf * a.K);
+  float z = a.depth[((size_t)b * a.Hd + ih) * a.Wd + iw] * a.depth_scale;
+  float xx = ((float)iw - a.cx) / a.fx;
+  float yy = ((float)(a.Hd - ih) - a.cy) / a.fy;
+  float X = xx * z;
+  float Y = yy * z;
+  bool valid = (z != 0.f) && (Y > -1.5f) && (Y < 0.1f);
+  float xg = rintf(X / a.local_scale + a.half);
+  float yg = rintf(-(z / a.local_scale) + a.half);
+  float Ef = (float)a.E;
+  bool inr = (yg < Ef) && (yg >= 0.f) && (xg < Ef) && (xg >= 0.f);
+  return (valid && inr) ? (int)yg * a.E + (int)xg : -1;
+}
+__global__ __launch_bounds__(1024) void bev_index_compact_kernel(IndexArgs a, unsigned* __restrict__ clist, int* __restrict__ cnt) {
+  __shared__ int lcount;
+  const unsigned per = (unsigned)(a.Hf * a.Wf);
+  const int b = blockIdx.y, k = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  unsigned* const mine = clist + (size_t)b * per + (size_t)k * CB;
+#pragma unroll 1
+  for (int u = 0; u < CB / 1024; ++u) {
+    const unsigned p = (unsigned)k * CB + threadIdx.x + 1024u * u;
+    int v = -1;
+    if (p < per) {
+      v = index_of(a, b, p);
+      a.lin[(size_t)b * per + p] = v;
+    }
+    const bool ok = v >= 0;
+    const unsigned long long m = __ballot(ok);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&lcount, __popcll(m));
+      base = __shfl(base, leader, 64);
+      if (ok) mine[base + __popcll(m & ((1ull << lane) - 1ull))] = (p << 16) | (unsigned)v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[b * (int)gridDim.x + k] = lcount;
+}
+
 // ----------------------------------------------------------------------------- scatter-max
 __device__ __forceinline__ unsigned f2key(float v) {
   unsigned u = __float_as_uint(v);
@@ -144,6 +199,63 @@ __device__ __forceinline__ void scatter_plane(const float* __restrict__ feat, co
   }
 }
 
+// The same scatter from the compacted source list of bev_index_compact_kernel: `nblk` blocks of CB entries, cnt[k] valid at the
+// front of block k.  The flat entry index i in [0, sum cnt) is mapped to (block, offset) against the prefix sums in registers.
+template <int WU>
+__device__ __forceinline__ void scatter_plane_compact(const float* __restrict__ feat, const unsigned* __restrict__ cl, const int* __restrict__ cnt,
+                                                      int nblk, int b, int c, int Cf, int HW, int C, unsigned* tg, int tid) {
+  const int ws = (int)(((int64_t)c * Cf) / C);
+  const int we = (int)((((int64_t)(c + 1)) * Cf + C - 1) / C);
+  const float* fb = feat + ((size_t)b * Cf + ws) * HW;
+  const int nwin = we - ws;
+  // (the list is short — ~16 k entries per sample at cfg4, 16 per thread — and every entry is a dependent chain entry -> feature ->
+  //  LDS atomic: eight of them in flight per thread — 16 spilled at WU = 2 and cost the E = 100 geometry its second workgroup per CU)
+  constexpr int U = 8;
+  int off[9];            // prefix sums of the (up to 8) block counts
+  off[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) off[k + 1] = off[k] + (k < nblk ? cnt[k] : 0);
+  const int N = off[8];
+  auto entry = [&](int i) -> unsigned {
+    if (i >= N) return 0xffffffffu;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) k += (i >= off[j]) ? 1 : 0;
+    return cl[(size_t)k * CB + (i - off[k])];
+  };
+  unsigned nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) nxt[u] = entry(tid + 1024 * u);
+  for (int i0 = tid; i0 < N; i0 += 1024 * U) {
+    unsigned e[U];
+    float f[U][WU];
+#pragma unroll
+    for (int u = 0; u < U; ++u) e[u] = nxt[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int w = 0; w < WU; ++w) f[u][w] = (e[u] != 0xffffffffu && w < nwin) ? fb[(size_t)w * HW + (e[u] >> 16)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) nxt[u] = entry(i0 + 1024 * (U + u));
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u] = f[u][0];
+#pragma unroll
+      for (int w = 1; w < WU; ++w)
+        if (w < nwin) v[u] = fmaxf(v[u], f[u][w]);
+    }
+    for (int w = WU; w < nwin; ++w) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e[u] != 0xffffffffu) v[u] = fmaxf(v[u], fb[(size_t)w * HW + (e[u] >> 16)]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (e[u] != 0xffffffffu) atomicMax(&tg[e[u] & 0xffffu], f2key(v[u]));
+  }
+}
+
 // one workgroup = (sample, CG consecutive map channels); the CG E*E planes live in LDS
 template <int WU>
 __global__ __launch_bounds__(1024) void bev_scatter_kernel(const float* __restrict__ feat,
@@ -227,7 +339,8 @@ template <int WU>
 __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* __restrict__ feat, const int32_t* __restrict__ lin,
                                                                   const float* __restrict__ heading, float sign, int Cf, int HW,
                                                                   int C, int E, int CG, unsigned magicE, int table,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, const unsigned* __restrict__ clist,
+                                                                  const int* __restrict__ cnt, int nblk) {
   extern __shared__ unsigned tile[];
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * CG;
@@ -242,7 +355,8 @@ __global__ __launch_bounds__(1024) void bev_scatter_rotate_kernel(const float* _
   for (int g = 0; g < CG; ++g) {
     int c = c0 + g;
     if (c >= C) break;
-    scatter_plane<WU>(feat, lb, b, c, Cf, HW, C, tile + (size_t)g * E2, tid);
+    if (clist) scatter_plane_compact<WU>(feat, clist + (size_t)b * HW, cnt + (size_t)b * nblk, nblk, b, c, Cf, HW, C, tile + (size_t)g * E2, tid);
+    else scatter_plane<WU>(feat, lb, b, c, Cf, HW, C, tile + (size_t)g * E2, tid);
   }
   __syncthreads();
   for (int i = tid; i < CG * E2; i += 1024) {   // keys -> the values bev_scatter_kernel writes, in place
@@ -882,6 +996,27 @@ extern "C" int wsmg_bev_index(const float* depth, int B, int Hd, int Wd, float d
   WSMG_RETURN_LAUNCH();
 }
 
+// wsmg_bev_index + the compacted list of valid sources (round 6): clist [B][Hf*Wf] uint32, cnt [B][ceil(Hf*Wf / 8192)] int32, both
+// written in full by this launch (nothing to zero); needs Hf*Wf <= 65536 and E*E <= 65536.
+extern "C" int wsmg_bev_index_compact(const float* depth, int B, int Hd, int Wd, float depth_scale, int Hf, int Wf, int E,
+                                      float local_scale, int32_t* lin_idx, uint32_t* clist, int32_t* cnt, wsmg_stream_t stream) {
+  if (B <= 0 || Hd <= 0 || Wd <= 0 || Hf <= 0 || Wf <= 0 || E <= 0 || Hf > Hd || Wf > Wd || B > 65535) return WSMG_EINVAL;
+  if ((int64_t)Hf * Wf > 65536 || (int64_t)E * E > 65536 || !clist || !cnt || !lin_idx) return WSMG_EINVAL;
+  IndexArgs a;
+  a.depth = depth; a.lin = lin_idx;
+  a.B = B; a.Hd = Hd; a.Wd = Wd; a.Hf = Hf; a.Wf = Wf; a.E = E;
+  a.depth_scale = depth_scale;
+  a.local_scale = local_scale;
+  a.half = (float)((E - 1) / 2.0);
+  const double tn = tan(45.0 * 3.14159265358979323846 / 180.0);
+  a.cx = (float)(Hd / 2.0); a.cy = (float)(Wd / 2.0);
+  a.fx = (float)((Hd / 2.0) / tn); a.fy = (float)((Wd / 2.0) / tn);
+  a.K = (float)((double)Wd / (double)Wf);
+  hipLaunchKernelGGL(bev_index_compact_kernel, dim3((unsigned)wsmg_cdiv((int64_t)Hf * Wf, CB), (unsigned)B), dim3(1024), 0, wsmg_s(stream), a,
+                     clist, cnt);
+  WSMG_RETURN_LAUNCH();
+}
+
 extern "C" int wsmg_bev_scatter_max(const float* feat, const int32_t* lin_idx, int B, int Cf, int Hf, int Wf, int C,
                                     int E, float* out, wsmg_stream_t stream) {
   if (B <= 0 || Cf <= 0 || C <= 0 || C > Cf || E <= 0 || B > 65535) return WSMG_EINVAL;
@@ -929,9 +1064,11 @@ extern "C" int wsmg_map_fuse(const float* ego_rot, float* global_map, const floa
   WSMG_RETURN_LAUNCH();
 }
 
-extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx, const float* heading, float sign, int B, int Cf,
-                                       int Hf, int Wf, int C, int E, float* out_planes, wsmg_stream_t stream) {
+static int bev_scatter_rotate_impl(const float* feat, const int32_t* lin_idx, const uint32_t* clist, const int32_t* cnt, const float* heading,
+                                   float sign, int B, int Cf, int Hf, int Wf, int C, int E, float* out_planes, wsmg_stream_t stream) {
   if (B <= 0 || Cf <= 0 || C <= 0 || C > Cf || E <= 1 || B > 65535) return WSMG_EINVAL;
+  if (clist && (!cnt || (int64_t)Hf * Wf > 65536 || (int64_t)E * E > 65536)) return WSMG_EINVAL;
+  const int nblk = (int)wsmg_cdiv((int64_t)Hf * Wf, CB);
   const int E2 = E * E;
   const size_t plane = (size_t)E2 * sizeof(unsigned);
   if (plane > 160 * 1024) return WSMG_EINVAL;
@@ -952,11 +1089,22 @@ extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx
       attr_set = true;                                                                                                             \
     }                                                                                                                              \
     hipLaunchKernelGGL(bev_scatter_rotate_kernel<WU_>, grid, dim3(1024), lds, wsmg_s(stream), feat, lin_idx, heading, sign,        \
-                       Cf, Hf * Wf, C, E, CG, magicE, table, out_planes);                                                          \
+                       Cf, Hf * Wf, C, E, CG, magicE, table, out_planes, clist, cnt, nblk);                                        \
   }
   if (wu == 1) WSMG_SCATTER(1) else if (wu == 2) WSMG_SCATTER(2) else if (wu == 3) WSMG_SCATTER(3) else WSMG_SCATTER(4)
 #undef WSMG_SCATTER
   WSMG_RETURN_LAUNCH();
+}
+
+extern "C" int wsmg_bev_scatter_rotate(const float* feat, const int32_t* lin_idx, const float* heading, float sign, int B, int Cf,
+                                       int Hf, int Wf, int C, int E, float* out_planes, wsmg_stream_t stream) {
+  return bev_scatter_rotate_impl(feat, lin_idx, nullptr, nullptr, heading, sign, B, Cf, Hf, Wf, C, E, out_planes, stream);
+}
+// the same from wsmg_bev_index_compact's list of valid sources (bit-identical planes)
+extern "C" int wsmg_bev_scatter_rotate_compact(const float* feat, const uint32_t* clist, const int32_t* cnt, const float* heading, float sign,
+                                               int B, int Cf, int Hf, int Wf, int C, int E, float* out_planes, wsmg_stream_t stream) {
+  if (!clist || !cnt) return WSMG_EINVAL;
+  return bev_scatter_rotate_impl(feat, nullptr, clist, cnt, heading, sign, B, Cf, Hf, Wf, C, E, out_planes, stream);
 }
 
 extern "C" int wsmg_map_fuse_planes(const float* ego_rot_planes, float* global_map, const float* gps, const float* masks, int B,

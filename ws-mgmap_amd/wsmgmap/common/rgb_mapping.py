@@ -54,12 +54,17 @@ class Mapping(nn.Module):
         if not gm.is_contiguous():
             raise ops._abi.WsmgError("full_global_map must be a contiguous [num_proc,G,G,C] tensor")
         local_scale = float(self.global_map_size * self.resolution) / float(self.global_map_size)
-        lin = ops.bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
+        fused = ops.bev_planes_ok(C, E) and debug.sw.bev_fused
+        compact = None
+        if fused and ops.bev_compact_ok(Hf, Wf, E):      # round 6: the index launch also packs the valid sources (20-25 % of a frame)
+            lin, compact = ops.bev_index_compact(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
+        else:
+            lin = ops.bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
         compass = observations["compass"].reshape(bs).float().contiguous()
         gps = observations["gps"].reshape(bs, 2).float().contiguous()
-        if ops.bev_planes_ok(C, E) and debug.sw.bev_fused:
+        if fused:
             # scatter-max + rotation in one launch (the channel plane is rotated out of LDS); the fuse reads the rotated planes
-            rotated = ops.bev_scatter_rotate(features.float().contiguous(), lin, compass, -1.0, C, E)
+            rotated = ops.bev_scatter_rotate(features.float().contiguous(), lin, compass, -1.0, C, E, compact=compact)
             ops.map_fuse(rotated, gm, gps, masks.reshape(bs).float().contiguous(), self.resolution, planes=True)
         else:
             planes = ops.bev_scatter_max(features.float().contiguous(), lin, C, E)

@@ -230,6 +230,9 @@ class MGMapNet(nn.Module):
         if laid is not None:
             torch.cuda.current_stream().wait_event(laid)
         enc = self.map_encoder(x)
+        # (the encoded map has three consumers below: the BatchNorm sink its tensor carries goes to the fan-out, whose backward — the one
+        #  pass that adds the three gradients — takes that BatchNorm's sums; no single consumer may find it on the tensor)
+        enc_sink = ops.take_sink(enc)
         # the stem's forward is a PERSISTENT kernel, one workgroup per CU: the instruction branch's persistent LSTM (16 workgroups
         # that claim their CUs) must not start beside it, or 16 of the stem's workgroups wait for the LSTM to finish and then
         # do their whole share alone (_encode_instruction waits for this event before the LSTM launch)
@@ -239,20 +242,33 @@ class MGMapNet(nn.Module):
             self._encoder_done.record(torch.cuda.current_stream())
         conv = lambda t, seq, pad: ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad, relu=True)  # noqa: E731
         # the encoded map has three consumers: their gradients meet in one launch (ops.fanout3) instead of two autograd adds
-        e_tok, e_full, e_stem = ops.fanout3(enc) if (train and enc.dtype == torch.bfloat16) else (enc, enc, enc)
+        e_tok, e_full, e_stem = ops.fanout3(enc, enc_sink) if (train and enc.dtype == torch.bfloat16) else (enc, enc, enc)
         # map_encoded_linear (0.17 ms forward, 0.38 ms backward of full-chip kernels) depends on the encoded map only and is consumed
         # after the decoder: it goes on the decoder's side stream, in front of the full-resolution branch (round 4).  Forward it
         # then runs beside the stem's convolution; backward — autograd replays a node on its forward stream — its two kernels run
         # beside the resnet branch's ~45 launch-latency-bound kernels instead of alone on the main stream after them.
         side = self.map_decoder.side_stream(enc) if (debug.sw.enc_proj_side and enc.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
+        # round 6: the two projections write straight into their channel slices of the tensor map_cated_linear reads (torch.cat at
+        # mg_map_policy.py:197 of the reference: no concatenation pass), and map_cated_linear's input-gradient kernel applies their
+        # fused ReLUs' masks and hands each its own contiguous part (ops.conv2d_over_written_parts)
+        cat_base = rs_e = rs_c = None
+        co_e, co_c = self.map_encoded_linear[0].out_channels, self.map_classified_linear[0].out_channels
+        if (train and enc.dtype == torch.bfloat16 and debug.sw.conv_into_cat and torch.is_grad_enabled() and co_e % 8 == 0 and co_c % 8 == 0
+                and self.map_cated_linear[0].kernel_size == (3, 3)):
+            cat_base = torch.empty(enc.shape[0], enc.shape[1], enc.shape[2], co_e + co_c, device=enc.device, dtype=enc.dtype)
+            rs_e, rs_c = ops.ReluSink(), ops.ReluSink()
+        conv_e = lambda t: ops.conv2d(t, self.map_encoded_linear[0].weight, self.map_encoded_linear[0].bias, 1, 1, relu=True,  # noqa: E731
+                                      relu_sink=rs_e, into=None if cat_base is None else (cat_base, 0))
         if side is not None:
             main_s = torch.cuda.current_stream()
             side.wait_stream(main_s)
             e_tok.record_stream(side)
+            if cat_base is not None:
+                cat_base.record_stream(side)
             with torch.cuda.stream(side):
-                enc_proj = conv(e_tok, self.map_encoded_linear, 1)
+                enc_proj = conv_e(e_tok)
         else:
-            enc_proj = conv(e_tok, self.map_encoded_linear, 1)
+            enc_proj = conv_e(e_tok)
         dec = self.map_decoder((e_full, e_stem))      # (joins the side stream into the main one before its last convolution)
         if side is not None:
             enc_proj.record_stream(main_s)
@@ -262,7 +278,8 @@ class MGMapNet(nn.Module):
         st1 = ops.bn_stats_slabs(id(c[1]), 32, dec.device) if fused else None
         y = ops.conv_transpose2d(dec, c[0].weight, 2, 1, st1)
         bump(c[1], train)
-        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps, st1)
+        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps, st1,
+                       sole_consumer=True)
         st4 = ops.bn_stats_slabs(id(c[4]), 32, dec.device) if fused else None
         y = ops.conv2d(y, c[3].weight, None, 1, 1, stats=st4)
         bump(c[4], train)
@@ -288,9 +305,14 @@ class MGMapNet(nn.Module):
         self.sem_logits_nhwc = sem
         pred_sem_map = None if self.skip_pred_map_nchw else ops.to_nchw(sem, SEM_CLASSES)
         # (27 -> 32 input channels: ops.conv2d zero-pads the weight to the activation's channel count)
-        cls_proj = ops.conv2d(pooled, self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True)
-        emb = ops.conv2d_cat([enc_proj, cls_proj], self.map_cated_linear[0].weight, self.map_cated_linear[0].bias, 1, 1, relu=True,
-                             relu_sink=self._token_sink)
+        cls_proj = ops.conv2d(pooled, self.map_classified_linear[0].weight, self.map_classified_linear[0].bias, 1, 1, relu=True,
+                              relu_sink=rs_c, into=None if cat_base is None else (cat_base, co_e))
+        if cat_base is not None:
+            emb = ops.conv2d_over_written_parts(enc_proj, cls_proj, cat_base, self.map_cated_linear[0].weight, self.map_cated_linear[0].bias,
+                                                relu=True, relu_sink=self._token_sink, mask_sinks=[rs_e, rs_c])
+        else:
+            emb = ops.conv2d_cat([enc_proj, cls_proj], self.map_cated_linear[0].weight, self.map_cated_linear[0].bias, 1, 1, relu=True,
+                                 relu_sink=self._token_sink)
         b, s1, s2, ch = emb.shape
         return emb.view(b, s1 * s2, ch), pred_sem_map
 

@@ -180,8 +180,22 @@ def _fp8_fold(x, w, transpose):
     return out
 
 
+last_fp8_row_launches = 0       # launches the last single-query fp8 forward took (1: wsmg_attn_fp8_row_fwd)
+
+
 def _fp8_forward(q, w2d, x_q, xs_t, lengths, scale):
+    global last_fp8_row_launches
     B, L, C = x_q.shape
+    if sw.fp8_row_fused and L <= 224 and C == 256:
+        # round 6: fold + attention of a row in ONE launch, one workgroup per row (SURVEY 8d's configs[4]: every row its own tokens)
+        qf = torch.empty(B, C, device=q.device, dtype=torch.float32)
+        out = torch.empty(B, C, device=q.device, dtype=torch.float32)
+        attn = torch.empty(B, L, device=q.device, dtype=torch.float32)
+        _abi.call("wsmg_attn_fp8_row_fwd", _p(q), _p(w2d), _p(x_q), _p(xs_t), _p(lengths), float(scale), B, L, C, _p(qf), _p(out), _p(attn),
+                  _stream())
+        last_fp8_row_launches = 1
+        return qf, out, attn
+    last_fp8_row_launches = 2
     qf = _fp8_fold(q, w2d, False)                       # q W_k on the matrix cores (float32 MFMA)
     out = torch.empty(B, C, device=q.device, dtype=torch.float32)
     attn = torch.empty(B, L, device=q.device, dtype=torch.float32)

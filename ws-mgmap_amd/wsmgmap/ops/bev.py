@@ -22,6 +22,26 @@ def bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=0.12):
     return lin
 
 
+def bev_compact_ok(Hf, Wf, E):
+    """Shapes the compacted-source route takes (source and cell ids are packed into 16 bits each)."""
+    return Hf * Wf <= 65536 and E * E <= 65536 and sw.bev_compact
+
+
+@torch.no_grad()
+def bev_index_compact(depth, Hf, Wf, E, depth_scale=10.0, local_scale=0.12):
+    """bev_index + the list of valid sources: -> (lin_idx int32 [B,Hf*Wf], (clist uint32-as-int32 [B,Hf*Wf], cnt int32 [B,nblk]))."""
+    _req(depth)
+    _f32(depth)
+    B, Hd, Wd = depth.shape
+    per = Hf * Wf
+    lin = torch.empty(B, per, device=depth.device, dtype=torch.int32)
+    clist = torch.empty(B, per, device=depth.device, dtype=torch.int32)
+    cnt = torch.empty(B, (per + 8191) // 8192, device=depth.device, dtype=torch.int32)
+    _abi.call("wsmg_bev_index_compact", _p(depth), B, Hd, Wd, float(depth_scale), Hf, Wf, E, float(local_scale), _p(lin), _p(clist), _p(cnt),
+              _stream())
+    return lin, (clist, cnt)
+
+
 @torch.no_grad()
 def bev_scatter_max(feat, lin, C, E):
     """feat [B,Cf,Hf,Wf] NCHW -> [B,C,E,E] NCHW planes."""
@@ -44,12 +64,17 @@ def bev_rotate(planes, heading, sign):
 
 
 @torch.no_grad()
-def bev_scatter_rotate(feat, lin, heading, sign, C, E):
-    """bev_scatter_max + bev_rotate in one launch; the rotated map stays in NCHW planes [B,C,E,E] (for map_fuse(..., planes=True))."""
+def bev_scatter_rotate(feat, lin, heading, sign, C, E, compact=None):
+    """bev_scatter_max + bev_rotate in one launch; the rotated map stays in NCHW planes [B,C,E,E] (for map_fuse(..., planes=True)).
+    compact: bev_index_compact's (clist, cnt) — the scatter then walks the valid sources only (same planes bit for bit)."""
     _req(feat, lin, heading)
     _f32(feat, heading)
     B, Cf, Hf, Wf = feat.shape
     out = torch.empty(B, C, E, E, device=feat.device, dtype=torch.float32)
+    if compact is not None:
+        _abi.call("wsmg_bev_scatter_rotate_compact", _p(feat), _p(compact[0]), _p(compact[1]), _p(heading), float(sign), B, Cf, Hf, Wf, C, E,
+                  _p(out), _stream())
+        return out
     _abi.call("wsmg_bev_scatter_rotate", _p(feat), _p(lin), _p(heading), float(sign), B, Cf, Hf, Wf, C, E, _p(out), _stream())
     return out
 

@@ -101,7 +101,7 @@ _prof = None
 def _prof_key(name):
     """The entry points of one kernel family share a key: *_stats launch the same kernels with the statistics epilogue, *_slabs
     the same weight-gradient kernels with stores into slabs instead of atomics."""
-    return name.replace("_stats", "").replace("_slabs", "")
+    return name.replace("_stats", "").replace("_slabs", "").replace("_ex", "")
 
 
 KERNEL_OF = {  # C-ABI entry -> device kernel symbol (as rocprofv3 --kernel-trace names it)
