@@ -232,52 +232,30 @@ int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* b
 int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, int B,
                                     int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                     wsmg_stream_t stream);
-/* ---- round 6: BatchNorm-backward sums and ReLU masks in the epilogue of the kernel that PRODUCES the gradient ---------------
- * The 13 train-mode BatchNorms of the map stack (map_encoder.py:19-29,94-112, mg_map_policy.py:78-100; cuDNN's batch-norm backward
- * in the reference) need sum g and sum g * xhat over the whole batch, g = dy masked by the ReLU that follows the BatchNorm.  The kernel
- * that WRITES dy takes them: it reads the matching 16-byte piece of x (the BatchNorm's input) while it holds the gradient piece,
- * stores the masked gradient, and every workgroup STORES its partial sums as block `blk` of `part` [blocks][2][C] float64 — the
- * layout of the reduction pass it replaces (plain stores, each element written once: no atomics, bit-reproducible);
- * wsmg_bn_act_bwd_bf16_parts adds the blocks in block order and applies.
- *   mode 0: nothing.  1: out = g where z > 0 else 0 (z = the ReLU OUTPUT: the fused ReLU of a convolution without BatchNorm,
- *   mg_map_policy.py:89-100; no sums).  2: BatchNorm + ReLU: keep = ((z - mean) invstd gamma + beta > 0) — bn_apply's own
- *   expression —, out = g keep, sums of out and out * (z - mean) invstd.  3: BatchNorm without ReLU: the sums only.
- *   Gradient channels [c0, c0 + C) correspond to z's channels [0, C); ld = z's pixel pitch in elements (z may be a channel slice);
- *   C, c0, ld multiples of 8, z 16-byte aligned.  cap_blocks: blocks `part` can hold (ceil(pixels / 128) + 8 suffices for every
- *   kernel here); the launcher writes the number of blocks its launch fills into `blocks` (host memory, at launch time). */
-typedef struct {
-  const void* z;
-  const float* mean;
-  const float* invstd;
-  const float* gamma;
-  const float* beta;
-  double* part;
-  int mode, c0, C, ld, cap_blocks, blocks;
-} wsmg_bn_aux_t;
-/* wsmg_conv2d_bwd_data_bf16 with the hook on dx (aux may be NULL).  wsmg_conv2d_fwd_bf16_stats with the hook on y — the call that
- * computes the input gradient of a ConvTranspose2d — and with y_ld (0 = Cout): the pixel pitch of y in elements, so that a
- * convolution writes its output straight into its channel slice of the concatenation that follows (torch.cat at
- * mg_map_policy.py:197; `y` then points at the slice's first channel).  dx2 / split_c (dx2 may be NULL): the input gradient of a
- * convolution over a two-part concatenation leaves as its two parts — channels [0, split_c) to dx [pixels][split_c], the rest to dx2
- * [pixels][Cin - split_c] (what torch.cat's backward hands to the two producers, contiguous); split_c a multiple of 8. */
-int wsmg_conv2d_bwd_data_bf16_ex(const void* dy, const void* w_ihwo, void* dx, wsmg_bn_aux_t* aux, void* dx2, int split_c, int B, int H,
+/* ---- round 6: the concatenation in front of map_cated_linear without a copy in either direction ------------------------------
+ * (mg_map_policy.py:89-100,197,207 of the reference: torch.cat of two Conv2d + ReLU outputs, then Conv2d + ReLU.)
+ * wsmg_conv2d_fwd_bf16_ex = wsmg_conv2d_fwd_bf16_stats with y_ld (0 = Cout): the pixel pitch of y in elements, so that a convolution
+ * writes its output straight into its channel slice of the tensor the next convolution reads (`y` points at the slice's first
+ * channel); bf16 output, Cout and y_ld multiples of 8.
+ * wsmg_conv2d_bwd_data_bf16_ex = wsmg_conv2d_bwd_data_bf16 with (a) relu_y [B][H][W][Cin] bf16 or NULL: dx is masked with it before it
+ * is stored (dx = g where relu_y > 0, else 0 — the fused ReLUs of the layers that PRODUCED this convolution's input, whose separate
+ * mask passes then do not run); (b) dx2 / split_c (dx2 may be NULL): the input gradient leaves as its two parts — channels
+ * [0, split_c) to dx [pixels][split_c], the rest to dx2 [pixels][Cin - split_c] — what torch.cat's backward hands to the two producers,
+ * contiguous; split_c a multiple of 8. */
+int wsmg_conv2d_bwd_data_bf16_ex(const void* dy, const void* w_ihwo, void* dx, const void* relu_y, void* dx2, int split_c, int B, int H,
                                  int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW, wsmg_stream_t stream);
-int wsmg_conv2d_fwd_bf16_ex(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, double* stats, int nslab,
-                            wsmg_bn_aux_t* aux, int y_ld, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                            int pad, int OH, int OW, wsmg_stream_t stream);
-/* The elementwise producers of a BatchNorm's incoming gradient with the same hook (modes 2 / 3, c0 = 0): y = a + b + c (the encoded
- * map's three consumers, mg_map_policy.py:189-207; rows x aux->C channels) and the bilinear upsampling's backward
- * (map_encoder.py:103,108; dy read with pixel pitch ld_dy). */
-int wsmg_add3_bf16_aux(const void* a, const void* b, const void* c, void* y, int64_t rows, wsmg_bn_aux_t* aux, wsmg_stream_t stream);
-int wsmg_upsample2x_bwd_ld_bf16_aux(const void* dy, int64_t ld_dy, void* dx, int B, int H, int W, int C, wsmg_bn_aux_t* aux,
-                                    wsmg_stream_t stream);
-/* Train-mode BatchNorm backward behind such a producer: dy is already masked, `part` [blocks][2][C] holds the producer's partial
- * sums.  Two launches (rounds 1-5: three, the first of them a pass over dy and x): the blocks are added in block order (dgamma /
- * dbeta), then dx = gamma invstd (g - dbeta / n - xhat dgamma / n).  No residual form (those gradients keep the reduction pass).
- * scratch [scratch_blocks >= 64][2][C] float64 (may be NULL): a list of more than 1536 blocks is first folded to 64 (one more launch). */
-int wsmg_bn_act_bwd_bf16_parts(const void* dy, int64_t ld_dy, const void* x, const float* gamma, const float* beta, const float* save_mean,
-                               const float* save_invstd, int relu, int64_t rows, int C, void* dx, float* dgamma, float* dbeta,
-                               const double* part, int blocks, double* scratch, int scratch_blocks, wsmg_stream_t stream);
+int wsmg_conv2d_fwd_bf16_ex(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, double* stats, int nslab, int y_ld,
+                            int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
+                            wsmg_stream_t stream);
+/* Column sums of up to 16 float32 matrices in one launch (round 6): out[c] = sum_r x[r][c] — the bias gradients of the recurrent
+ * core's dense layers (mg_map_policy.py:118-132,147-152; torch: a reduction kernel + a memset per tensor).  descs is a HOST array.
+ * Fixed summation order: bit-reproducible. */
+typedef struct {
+  const float* x;
+  float* out;
+  int rows, cols;
+} WsmgColsumDesc;
+int wsmg_colsum_multi(const WsmgColsumDesc* descs, int n, wsmg_stream_t stream);
 /* A list of device-to-device copies (non-overlapping) in one launch: the inputs of a captured rollout step handed into its
  * static tensors (wsmgmap.graph.GraphedAct).  Any alignment, any byte count. */
 typedef struct {
@@ -329,9 +307,6 @@ int wsmg_adam_step_multi_dev(const WsmgAdamDesc* descs, int n, float lr, float b
  * env WSMG_CONV_WIN3).
  * Returns the previous choice.  No reference counterpart (the reference calls torch.nn.Conv2d, map_encoder.py:29-112). */
 int wsmg_conv_debug_win3_tile(int mt);
-/* round 6 experiment (weights of the 3 x 3 window kernel from global memory into registers instead of through LDS): 1 on, 0 off, -1 by
- * the environment (WSMG_WIN3_BREG); returns the previous setting.  Bit-identical results. */
-int wsmg_conv_debug_win3_breg(int on);
 int wsmg_bn_act_fwd_bf16_pre(const void* x, const void* residual, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, int64_t rows, int C, void* y,
                              float* save_mean, float* save_invstd, double* stats, int nslab, wsmg_stream_t stream);

@@ -1,6 +1,6 @@
 """GPU tests, round 6 (VERDICT r05 "Next round" + ADVICE r05): the in-process recurrent-core fallback of bench.py, the gradient
 exchange's bucket hold beside the chained core, the fused fp8 attention's CU-derived barrier bound and reported timeout, the
-BatchNorm sums / finalize folded into their neighbours, the new window-kernel shapes."""
+concatenation written in place with its ReLU masks in the gradient kernel, the one-launch fp8 row attention, the compacted BEV sources."""
 import json
 import os
 import subprocess
@@ -61,7 +61,7 @@ def test_bench_line_names_the_default_core_without_a_timeout():
     assert line["recurrent_core"]["fallback_level"] == 0 and line["recurrent_core"]["recurrent_core"].startswith("chained"), line["recurrent_core"]
 
 
-# ----------------------------------------------------------------------------- BatchNorm sums / finalize folded into their neighbours
+# ----------------------------------------------------------------------------- the concatenation in front of map_cated_linear, in place
 def _update_grads(monkeypatch, T, N, seed=91, **switches):
     import bench
     import test_gpu_round2 as r2
@@ -72,56 +72,32 @@ def _update_grads(monkeypatch, T, N, seed=91, **switches):
     torch.manual_seed(3)
     pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
     obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), seed)
-    outs = [r4._one_update(pol, obs, prev, masks, weights, N, 4) for _ in range(2)]      # (two passes: both parities of the slab pairs)
+    outs = [r4._one_update(pol, obs, prev, masks, weights, N, 4) for _ in range(2)]
     ops.check_rnn_status()
     stats = {k: v.detach().clone() for k, v in pol.state_dict().items() if "running_" in k}
     return outs, stats
 
 
 @pytest.mark.parametrize("T,N", [(64, 8), (4, 2)])
-def test_batchnorm_sums_in_producer_epilogues_match_the_reduction_pass(monkeypatch, T, N):
-    """VERDICT r05 item 1 (map_encoder.py:19-29,94-112, mg_map_policy.py:78-100 of the reference: 13 train-mode BatchNorms).  The
-    update with the BatchNorm-backward sums taken in the epilogue of the kernel that produces the gradient (backward-data convolutions
-    of all tile shapes incl. the stride-2 parity classes and channel slices, the ConvTranspose's input gradient, the three-way add, the
-    upsampling's backward), the two projections writing into the concatenation in place and map_cated_linear's input-gradient kernel
-    applying their ReLU masks — against the round-5 route (reduction passes, concatenation and mask passes) on the bench workload and
-    a small one: logits, loss, BatchNorm running statistics and every gradient.  The two routes compute the same sums from the same
-    bf16 values; only the float64 summation order differs, which can flip a last float32 bit of dgamma / dbeta and with it isolated
-    bf16 roundings downstream (the first layer of each backward chain, whose bf16 dy has crossed the most roundings, moves most: 1e-2 of
-    its largest element, cosine 0.99997): bars 1e-5 / 0.9999999 for the BatchNorm affine gradients (they ARE the sums), 2e-2 / 0.9999 for
-    everything behind them; forward results identical."""
+def test_concatenation_written_in_place_and_masks_in_the_gradient_kernel_change_no_bit(monkeypatch, T, N):
+    """VERDICT r05 item 1(c) (mg_map_policy.py:89-100,197,207 of the reference: cat of two Conv2d + ReLU outputs, then Conv2d + ReLU).
+    map_encoded_linear / map_classified_linear writing straight into their channel slices of the tensor map_cated_linear reads
+    (no concatenation pass), and map_cated_linear's backward-data kernel applying their fused ReLUs' masks and storing the gradient as
+    its two contiguous parts (no mask passes): logits, loss, BatchNorm statistics and EVERY gradient bit-identical to the route with
+    the three passes, on the bench workload (window kernels, mixed tiles) and a small one (implicit-GEMM kernels); and each switch
+    alone."""
     new, st_new = _update_grads(monkeypatch, T, N)
-    old, st_old = _update_grads(monkeypatch, T, N, bn_producer_sums=False, relu_producer_mask=False, conv_into_cat=False)
-    for k in st_new:
-        assert torch.equal(st_new[k], st_old[k]), k
-    for a, b in zip(new, old):
-        assert torch.equal(a[0], b[0]) and a[1] == b[1], "the forward pass must not change"
-        bad = []
-        for k, g in a[4].items():
-            h = b[4][k]
-            assert (g is None) == (h is None), k
-            if g is None:
-                continue
-            assert torch.isfinite(g).all(), k
-            scale = float(h.abs().max())
-            d = float((g - h).abs().max()) / max(scale, 1e-20)
-            cos = float(torch.nn.functional.cosine_similarity(g.flatten().double(), h.flatten().double(), dim=0)) if scale > 1e-12 else 1.0
-            # BatchNorm affine gradients ARE the sums: they may differ in the last float32 bits only; everything behind them in bf16 steps
-            tight = k.endswith(("1.weight", "1.bias", "4.weight", "4.bias", "bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias")) and g.dim() == 1
-            if d > (1e-5 if tight else 2e-2) or cos < (0.9999999 if tight else 0.9999):
-                bad.append((k, d, cos))
-        assert not bad, sorted(bad, key=lambda t: -t[1])[:12]
-    # bit-reproducible run to run (plain stores of per-workgroup partials, added in block order: no atomics anywhere)
-    again, _ = _update_grads(monkeypatch, T, N)
-    for a, b in zip(new, again):
-        for k, g in a[4].items():
-            assert g is None or torch.equal(g, b[4][k]), k
+    for sw_off in (dict(relu_producer_mask=False, conv_into_cat=False), dict(relu_producer_mask=False), dict(conv_into_cat=False)):
+        old, st_old = _update_grads(monkeypatch, T, N, **{"relu_producer_mask": True, "conv_into_cat": True, **sw_off})
+        for k in st_new:
+            assert torch.equal(st_new[k], st_old[k]), k
+        for a, b in zip(new, old):
+            assert torch.equal(a[0], b[0]) and a[1] == b[1]
+            for k, g in a[4].items():
+                assert (g is None) == (b[4][k] is None) and (g is None or torch.equal(g, b[4][k])), (sw_off, k)
 
 
-def test_update_launch_counts_after_the_batchnorm_folding(monkeypatch):
-    """Done-criterion of VERDICT r05 item 1: per update at most 3 reduction passes over a BatchNorm's gradient (the three BatchNorms whose
-    output has more than one consumer or a residual); the other 12 take their sums from the producer's partials; no concatenation
-    pass and no ReLU-mask pass around map_cated_linear."""
+def test_update_has_no_concatenation_or_mask_pass_around_map_cated_linear(monkeypatch):
     import bench
     import test_gpu_round2 as r2
     import test_gpu_round4 as r4
@@ -138,10 +114,10 @@ def test_update_launch_counts_after_the_batchnorm_folding(monkeypatch):
     monkeypatch.setattr(_abi, "call", counting)
     r4._one_update(pol, obs, prev, masks, weights, 4, 4)
     monkeypatch.setattr(_abi, "call", real)
-    assert counts.get("wsmg_bn_act_bwd_bf16_parts", 0) == 12, counts
-    assert counts.get("wsmg_bn_act_bwd_bf16", 0) + counts.get("wsmg_bn_act_bwd_ld_bf16", 0) == 3, counts
-    for gone in ("wsmg_cat_channels", "wsmg_relu_bwd_rows_bf16", "wsmg_relu_bwd_bf16", "wsmg_add3_bf16"):
+    for gone in ("wsmg_cat_channels", "wsmg_relu_bwd_rows_bf16", "wsmg_relu_bwd_bf16"):
         assert counts.get(gone, 0) == 0, (gone, counts)
+    assert counts.get("wsmg_conv2d_bwd_data_bf16_ex", 0) == 1 and counts.get("wsmg_conv2d_fwd_bf16_ex", 0) == 2, counts
+    assert counts.get("wsmg_colsum_multi", 0) == 1, counts
 
 
 # ----------------------------------------------------------------------------- configs[4] per row, one launch
@@ -221,3 +197,18 @@ def test_bev_compacted_sources_give_the_same_planes_bit_for_bit(name):
         l1, comp = ops.bev_index_compact(d2, Hf, Hf, E)
         assert torch.equal(l0, l1) and int(comp[1].sum()) == int((l0 >= 0).sum())
         assert torch.equal(ops.bev_scatter_rotate(feat, l0, heading, -1.0, C, E), ops.bev_scatter_rotate(feat, l1, heading, -1.0, C, E, compact=comp))
+
+
+def test_colsum_multi_matches_float64():
+    """The recurrent core's seven bias gradients in one launch (mg_map_policy.py:118-132,147-152: Linear / GRU biases) against
+    float64 column sums: 1e-6 of the largest sum; more than 16 tensors, ragged widths; bit-identical twice."""
+    from wsmgmap import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    mats = [torch.randn(r, c, device="cuda", generator=g) for r, c in
+            [(512, 1536), (512, 1536), (512, 512), (512, 256), (37, 256), (512, 1), (3, 70), (1, 64)] + [(64, 8 * k + 1) for k in range(1, 12)]]
+    a = ops.colsum_multi(mats)
+    b = ops.colsum_multi(mats)
+    for m, x, y in zip(mats, a, b):
+        want = m.double().sum(0)
+        assert float((x.double() - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())) * max(1, m.shape[0] // 64)
+        assert torch.equal(x, y)

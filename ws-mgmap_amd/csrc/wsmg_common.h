@@ -89,10 +89,10 @@ int wsmg_conv_s2_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long 
 int wsmg_conv_s2_wgrad_splits(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW);
 // wsmg_conv_win3.hip: 3 x 3 / stride 1 / pad 1 out of a zero-padded LDS pixel window (forward / backward-data), N % 128 == 0,
 // Kc % 32 == 0, mt = 512 or 256 pixels per workgroup, mixed != 0: the last partial round as half-size tiles; WSMG_EINVAL otherwise
-// (round 6) aux: the gradient hook of wsmg_bn_aux.h on the output, or null; dst_ld: pixel pitch of dst in elements (0 = N); dst2 /
-// split_c: output channels >= split_c go to the second tensor (null: none)
+// (round 6) relu_z [pixels][N] or null: ReLU outputs the output tile is masked with (wsmg_relu_mask.h); dst_ld: pixel pitch of dst in
+// elements (0 = N); dst2 / split_c: output channels >= split_c go to the second tensor (null: none)
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
-                        int B, int H, int W, int Kc, int N, int mt, int mixed, wsmg_bn_aux_t* aux, int dst_ld, void* dst2, int split_c,
+                        int B, int H, int W, int Kc, int N, int mt, int mixed, const void* relu_z, int dst_ld, void* dst2, int split_c,
                         hipStream_t s);
 // wsmg_conv_win3_wgrad.hip: weight gradient of a 3 x 3 / stride 1 / pad 1 layer out of a zero-padded LDS window (W <= 24, channel
 // multiples of 64 / 128); WSMG_EINVAL otherwise

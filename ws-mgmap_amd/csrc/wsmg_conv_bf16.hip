@@ -14,7 +14,7 @@
 #include <stdlib.h>
 
 #include "wsmg_common.h"
-#include "wsmg_bn_aux.h"
+#include "wsmg_relu_mask.h"
 
 namespace {
 
@@ -58,9 +58,9 @@ struct ConvArgsB {
   int ksplit;
   float* part;      // [ksplit][pixels][N] float32 partial sums; splitk_finish_kernel adds them and runs the epilogue
   // round 6 (bf16 16-byte-store epilogue only): pixel pitch of dst in elements (0 = N: > N writes a channel slice of a wider tensor —
-  // the concatenation that follows — in place) and the gradient hook of wsmg_bn_aux.h
+  // the concatenation that follows — in place) and the ReLU outputs [pixels][N] the gradient tile is masked with (wsmg_relu_mask.h)
   int dst_ld;
-  BnAux aux;
+  const bf16_t* relu_z;
   void* dst2;       // output channels >= split_c go here ([pixels][N - split_c]) and the others to dst ([pixels][split_c]); null: one tensor
   int split_c;
 };
@@ -107,18 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
     KHc = (a.KH - cy + 1) >> 1; KWc = (a.KW - cx + 1) >> 1;
   }
   const int Mc = a.B * THc * TWc;
-  if (m0 >= Mc) {
-    // (a class with fewer tiles than the grid's: its block of the BatchNorm partials is still read by the finalize — zeros)
-    if (a.aux.mode >= 2 && tid < BN) {
-      const int n = n0 + tid;
-      if (n >= a.aux.c0 && n < a.aux.c0 + a.aux.C && n < a.N) {
-        double* const st = a.aux.part + (size_t)((int)blockIdx.y * a.mtiles + logical / a.ntiles) * 2 * a.aux.C + (n - a.aux.c0);
-        st[0] = 0.0;
-        st[a.aux.C] = 0.0;
-      }
-    }
-    return;
-  }
+  if (m0 >= Mc) return;
 
   // Address generation is kept off the critical path (the kernel is instruction-issue bound once the
   // MFMAs are bf16): per staged row ONE 32-bit base offset and two validity bitmasks (bit t = class tap
@@ -320,18 +309,17 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
       __syncthreads();
       constexpr int CPR = BN / 8;   // 16-byte pieces per row
       const int ldd = a.dst_ld ? a.dst_ld : a.N;
-      // (a thread's pieces all belong to ONE 8-channel group: 256 % CPR == 0)
-      BnAuxAccF ax;
-      bn_aux_begin(a.aux, n0 + (tid % CPR) * 8, ax);
-      if (n0 + (tid % CPR) * 8 >= a.N) ax.on = false;
-      // (the hook's pieces of z are requested together, ahead of the store loop: see conv_win3's epilogue)
+      // (the pieces of relu_z are requested together, ahead of the store loop: see conv_win3's epilogue)
       constexpr int ROWS = BM * CPR / 256;
       u32x4 zr[ROWS];
-      if (ax.on) {
+      if (a.relu_z) {
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-          const int dp = dpix[(tid + 256 * j) / CPR];
-          zr[j] = bn_aux_load(a.aux, ax, (size_t)(dp < 0 ? 0 : dp));
+          const int c = tid + 256 * j;
+          const int row = c / CPR, ch = c - row * CPR;
+          const int dp = dpix[row];
+          const int n = n0 + ch * 8;
+          zr[j] = (dp >= 0 && n < a.N) ? *reinterpret_cast<const u32x4*>(a.relu_z + (size_t)dp * a.N + n) : u32x4{0u, 0u, 0u, 0u};
         }
       }
 #pragma unroll
@@ -348,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
                                          ((size_t)dp * (hi ? a.N - a.split_c : a.split_c) + (hi ? n - a.split_c : n)) * 2);
         }
         u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * OP + ch * 16);
-        if (ax.on) v = bn_aux_apply(a.aux, ax, v, zr[j]);
+        if (a.relu_z) v = relu_mask8(v, zr[j]);
         if (a.out_f32 & 4) {
           const u32x4 old = *out;
 #pragma unroll
@@ -360,10 +348,6 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
           }
         }
         *out = v;
-      }
-      if (a.aux.mode >= 2) {
-        __syncthreads();
-        bn_aux_store_block<4>(a.aux, ax, CPR, reinterpret_cast<double*>(smem), (int)blockIdx.y * a.mtiles + logical / a.ntiles);
       }
       return;
     }
@@ -663,13 +647,12 @@ void launch_igemm_pf(ConvArgsB& a, dim3 grid, bool bk64, bool bn128, hipStream_t
 }
 
 template <bool BWD>
-int launch_igemm(ConvArgsB& a, int64_t mrows, int classes, hipStream_t s, wsmg_bn_aux_t* aux = nullptr) {
+int launch_igemm(ConvArgsB& a, int64_t mrows, int classes, hipStream_t s) {
   const bool bk64 = (a.Kc % 64) == 0;
   const bool bn128 = a.N >= 128;
   const int bn = bn128 ? 128 : 64;
   a.mtiles = (int)wsmg_cdiv(mrows, BM);
   a.ntiles = (int)wsmg_cdiv(a.N, bn);
-  if (int e = bn_aux_blocks(aux, (int64_t)a.mtiles * classes)) return e;
   dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)classes);
   switch (conv_prefetch(1)) {
     case 1: launch_igemm_pf<BWD, 1>(a, grid, bk64, bn128, s); break;
@@ -788,16 +771,14 @@ extern "C" int wsmg_conv2d_fwd_bf16_splitk(const void* x, const void* w_ohwi, co
 }
 
 namespace {
-// aux (may be null): the gradient hook of wsmg_bn_aux.h applied to the OUTPUT (this entry point is the backward-data of a
-// ConvTranspose2d); y_ld (0 = Cout): pixel pitch of y in elements — y may be a channel slice of a wider tensor
-int conv_fwd_bf16_impl(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, double* stats, int nslab,
-                       wsmg_bn_aux_t* aux, int y_ld, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+// y_ld (0 = Cout): pixel pitch of y in elements — y may be a channel slice of a wider tensor
+int conv_fwd_bf16_impl(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32, double* stats, int nslab, int y_ld, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                        int OH, int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
   if (stats && (nslab <= 0 || (out_f32 & 5) != 0 || (Cout & 7) != 0)) return WSMG_EINVAL;   // statistics: bf16 output, no accumulate
-  const bool ex = (aux && aux->mode) || (y_ld && y_ld != Cout);
+  const bool ex = y_ld && y_ld != Cout;
   if (ex) {
-    if ((out_f32 & 5) != 0 || (Cout & 7) != 0 || bn_aux_bad(aux, Cout)) return WSMG_EINVAL;
+    if ((out_f32 & 5) != 0 || (Cout & 7) != 0) return WSMG_EINVAL;
     if (y_ld && (y_ld < Cout || (y_ld & 7) || ((uintptr_t)y & 15))) return WSMG_EINVAL;
     if ((int64_t)B * OH * OW * (y_ld ? y_ld : Cout) * 2 >= (1ll << 31)) return WSMG_EINVAL;
   }
@@ -811,15 +792,14 @@ int conv_fwd_bf16_impl(const void* x, const void* w_ohwi, const float* bias, voi
   }
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 5) == 0) {
     if (const int mt = win3_choice((int64_t)B * OH * OW, Cin, Cout)) {
-      int rc = wsmg_conv_win3_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, mt, win3_tile() == 1, aux, y_ld, nullptr, 0, wsmg_s(stream));
+      int rc = wsmg_conv_win3_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, mt, win3_tile() == 1, nullptr, y_ld, nullptr, 0, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
     }
   }
   ConvArgsB a{(const bf16_t*)x, (const bf16_t*)w_ohwi, bias, y, B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, 0, 0, out_f32,
               (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
   a.dst_ld = y_ld;
-  a.aux = bn_aux_host(aux);
-  if (int e = launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream), aux)) return e;
+  if (int e = launch_igemm<false>(a, (int64_t)B * OH * OW, 1, wsmg_s(stream))) return e;
   WSMG_RETURN_LAUNCH();
 }
 }  // namespace
@@ -827,13 +807,13 @@ int conv_fwd_bf16_impl(const void* x, const void* w_ohwi, const float* bias, voi
 extern "C" int wsmg_conv2d_fwd_bf16_stats(const void* x, const void* w_ohwi, const float* bias, void* y, int out_f32,
                                           double* stats, int nslab, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                                           int stride, int pad, int OH, int OW, wsmg_stream_t stream) {
-  return conv_fwd_bf16_impl(x, w_ohwi, bias, y, out_f32, stats, nslab, nullptr, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
+  return conv_fwd_bf16_impl(x, w_ohwi, bias, y, out_f32, stats, nslab, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
 }
 
 extern "C" int wsmg_conv2d_fwd_bf16_ex(const void* x, const void* w_ohwi, const float* bias, void* y, int flags, double* stats, int nslab,
-                                       wsmg_bn_aux_t* aux, int y_ld, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                                       int y_ld, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                                        int stride, int pad, int OH, int OW, wsmg_stream_t stream) {
-  return conv_fwd_bf16_impl(x, w_ohwi, bias, y, flags, stats, nslab, aux, y_ld, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
+  return conv_fwd_bf16_impl(x, w_ohwi, bias, y, flags, stats, nslab, y_ld, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
 }
 
 // tests / tools: choose the window kernel's tile (0 = off, 1 = by shape, 256, 512) for the calls that follow; returns the previous choice
@@ -850,22 +830,22 @@ extern "C" int wsmg_conv2d_fwd_bf16(const void* x, const void* w_ohwi, const flo
 }
 
 namespace {
-int conv_bwd_data_bf16_impl(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, wsmg_bn_aux_t* aux,
+int conv_bwd_data_bf16_impl(const void* dy, const void* w_ihwo, void* dx, int out_f32, double* stats, int nslab, const void* relu_y,
                             void* dx2, int split_c, int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH,
                             int OW, wsmg_stream_t stream) {
   if (int e = check_conv(B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW)) return e;
   if (stats && (nslab <= 0 || (out_f32 & 5) != 0 || (Cin & 7) != 0)) return WSMG_EINVAL;
-  if (aux && aux->mode && ((out_f32 & 5) != 0 || (Cin & 7) != 0 || bn_aux_bad(aux, Cin))) return WSMG_EINVAL;
+  if (relu_y && ((out_f32 & 5) != 0 || (Cin & 7) != 0 || ((uintptr_t)relu_y & 15))) return WSMG_EINVAL;
   if (dx2 && ((out_f32 & 5) != 0 || (Cin & 7) != 0 || split_c <= 0 || split_c >= Cin || (split_c & 7) || ((uintptr_t)dx2 & 15))) return WSMG_EINVAL;
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 7) == 0) {
     if (const int mt = win3_choice((int64_t)B * H * W, Cout, Cin)) {
-      int rc = wsmg_conv_win3_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cout, Cin, mt, win3_tile() == 1, aux, 0, dx2, split_c, wsmg_s(stream));
+      int rc = wsmg_conv_win3_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cout, Cin, mt, win3_tile() == 1, relu_y, 0, dx2, split_c, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
     }
   }
   ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32,
               (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
-  a.aux = bn_aux_host(aux);
+  a.relu_z = (const bf16_t*)relu_y;
   a.dst2 = dx2;
   a.split_c = split_c;
   int classes = 1;
@@ -874,7 +854,7 @@ int conv_bwd_data_bf16_impl(const void* dy, const void* w_ihwo, void* dx, int ou
     classes = 4;
     mmax = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
   }
-  if (int e = launch_igemm<true>(a, mmax, classes, wsmg_s(stream), aux)) return e;
+  if (int e = launch_igemm<true>(a, mmax, classes, wsmg_s(stream))) return e;
   WSMG_RETURN_LAUNCH();
 }
 }  // namespace
@@ -885,10 +865,10 @@ extern "C" int wsmg_conv2d_bwd_data_bf16_stats(const void* dy, const void* w_ihw
   return conv_bwd_data_bf16_impl(dy, w_ihwo, dx, out_f32, stats, nslab, nullptr, nullptr, 0, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
 }
 
-extern "C" int wsmg_conv2d_bwd_data_bf16_ex(const void* dy, const void* w_ihwo, void* dx, wsmg_bn_aux_t* aux, void* dx2, int split_c,
+extern "C" int wsmg_conv2d_bwd_data_bf16_ex(const void* dy, const void* w_ihwo, void* dx, const void* relu_y, void* dx2, int split_c,
                                             int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW,
                                             wsmg_stream_t stream) {
-  return conv_bwd_data_bf16_impl(dy, w_ihwo, dx, 0, nullptr, 0, aux, dx2, split_c, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
+  return conv_bwd_data_bf16_impl(dy, w_ihwo, dx, 0, nullptr, 0, relu_y, dx2, split_c, B, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW, stream);
 }
 
 // ConvTranspose2d forward of the rollout route (the semantic classifier's first layer, mg_map_policy.py:59-61): the

@@ -43,7 +43,7 @@
 #include <type_traits>
 
 #include "wsmg_common.h"
-#include "wsmg_bn_aux.h"
+#include "wsmg_relu_mask.h"
 
 namespace {
 
@@ -64,10 +64,9 @@ struct Win3Args {
   // round 5 — two tile sizes in ONE launch: blocks [0, nbig) take MT-pixel tiles from pixel 0, blocks [nbig, nbig + nsmall) take
   // MT/2-pixel tiles from pixel m_split (0 / 0 / 0: every block is a big tile)
   int nbig, nsmall, m_split;
-  // round 6: pixel pitch of dst in elements (0 = N: larger writes a channel slice of a wider tensor in place) and the gradient hook
-  // of wsmg_bn_aux.h (BatchNorm-backward sums / ReLU mask on the tile about to be stored)
+  // round 6: pixel pitch of dst in elements (0 = N: larger writes a channel slice of a wider tensor in place)
   int dst_ld;
-  BnAux aux;
+  const bf16_t* relu_z;   // [pixels][N] or null: the ReLU outputs the gradient tile is masked with before it is stored (wsmg_relu_mask.h)
   // output channels >= split_c (a multiple of the channel tile) go to dst2 [pixels][N - split_c] instead, channels below it to dst
   // [pixels][split_c]: the gradient of a two-part concatenation leaves as its two parts (dst2 null: one tensor)
   bf16_t* dst2;
@@ -95,14 +94,9 @@ constexpr int n_issue(int tap, int npw) { return ((tap % 9 + 9) % 9) < npw ? 2 :
 // NT: output channels per workgroup — 128 (8 waves as 4 along the pixels x 2 along the channels) or, round 3, 64 for the
 // 64-channel layers (8 x 1: every wave takes MT / 8 pixels x all 64 channels; waves 4-7 have no weight rows to fetch and issue
 // their weight DMA as a zero-fill into a dummy KB, so that every wave's `vmcnt` counts the same instructions)
-// AUX: 0 = no gradient hook compiled in (the forward passes, plain gradients: the round-5 kernel, register for register); 1 = the
-// ReLU mask only (wsmg_bn_aux_t mode 1: no per-channel constants, no sums); 2 = BatchNorm sums (modes 2 / 3).  The 512 x 128 tile has
-// no AUX = 2 form (its 232 registers leave no room for the hook's 48: the launcher takes 256-pixel tiles for such a launch).
-// BREG (round 6 experiment): the B (weight) fragments never touch LDS — every wave loads its own 16-byte pieces
-// straight from the OHWI / IHWO weight (L2-resident: <= 1.2 MB per layer) into a three-step register ring, three k-steps ahead;
-// LDS carries the activation window only, the per-k-step barrier becomes two barriers per 32-channel chunk (the window buffers'
-// hand-over), and a wave issues no weight DMA.
-template <int MT, int NPW, int NT, int AUX, bool BREG = false>
+// AUX: 0 = the plain store loop (the forward passes, plain gradients: the round-5 kernel, register for register); 1 = the gradient
+// tile is masked with relu_z and / or stored as two tensors (dst2 / split_c).
+template <int MT, int NPW, int NT, int AUX>
 __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid, const int nblocks, const int m_base, const int blk_base) {
   constexpr int WN = NT >= 128 ? 2 : 1, WM = 8 / WN;   // waves along the channels / along the pixels
   constexpr int NU = NT >= 64 ? 2 : 1;         // 32-column accumulator tiles per wave (NT = 32: one)
@@ -183,34 +177,12 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
     for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-  // BREG: this lane's 16-byte piece of weight row n (k = 8 h .. 8 h + 7 of a 16-deep slice), and the ring of three k-steps
-  u32x4 bq[BREG ? 3 : 1][NU][2];
-  int bvo[NU];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) bvo[u] = ((n0 + wn + 32 * u + r) * 9 * a.Kc + 8 * h) * 2;
-  auto b_load = [&](auto slotc, int chunk, int tap) {
-    constexpr int slot = decltype(slotc)::value;
-    const int so = (tap * a.Kc + chunk * DK) * 2;
-    const bool live = chunk < nchunks;
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        bq[slot][u][ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_wt, live ? bvo[u] + so + 32 * ks : (int)0x80000000, 0, 0);
-  };
-
   // ---- prologue: the whole window of chunk 0, then the weights of k-steps 0, 1, 2
 #pragma unroll
   for (int j = 0; j < NPW; ++j) dma_window_piece(j, 0);
-  if constexpr (BREG) {
-    b_load(std::integral_constant<int, 0>{}, 0, 0);
-    b_load(std::integral_constant<int, 1>{}, 0, 1);
-    b_load(std::integral_constant<int, 2>{}, 0, 2);
-  } else {
-    dma_weights(0, 0);
-    dma_weights(0, 1);
-    dma_weights(0, 2);
-  }
+  dma_weights(0, 0);
+  dma_weights(0, 1);
+  dma_weights(0, 2);
 
   const int sgn = a.bwd ? -1 : 1;
   // Fragments of a k-step's first 16-deep slice are read one step EARLY (during the previous step's MFMAs), so the MFMAs
@@ -236,39 +208,6 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
     asm volatile("" : "+s"(shift));   // keep the 9 taps' fragment addresses from being hoisted out of the chunk loop (they spill)
     return shift;
   };
-  auto read_a = [&](bf16x8 (&af)[TT], const unsigned char* win, int shift, int ks) {
-#pragma unroll
-    for (int t = 0; t < TT; ++t) {
-      const int e = ecen[t] + shift;
-      af[t] = *reinterpret_cast<const bf16x8*>(win + e * ROWB + (((2 * ks + h) ^ ((e >> 2) & 3)) << 4));
-    }
-  };
-  auto kstep_breg = [&](auto tapc, int chunk) {
-    constexpr int tap = decltype(tapc)::value;
-    constexpr int ntap = (tap + 1) % 9;
-    constexpr int slot = tap % 3;                      // (9 % 3 == 0: the ring slot of a step is a compile-time constant)
-    const unsigned char* const win = smem + (chunk & 1) * WINB;
-    const unsigned char* const nwinp = smem + ((tap == 8 ? chunk + 1 : chunk) & 1) * WINB;
-    // B of this step (requested at the END of step - 3) has landed when at most the requests of the two steps since are in flight:
-    // 2 x 2 NU fragment loads + the window pieces those steps carried.  At tap 8 that also covers every piece of the next window.
-    constexpr int younger = 2 * 2 * NU + (((tap + 8) % 9) < NPW ? 1 : 0) + (((tap + 7) % 9) < NPW ? 1 : 0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
-    // two barriers per chunk: at tap 8 the next window becomes readable (its slice-0 fragments are read early, below); at tap 0
-    // nobody reads the buffer any more that the next-but-one window is about to be written into
-    if constexpr (tap == 0 || tap == 8) __builtin_amdgcn_s_barrier();
-    if constexpr (tap < NPW) dma_window_piece(tap, chunk + 1);
-    bf16x8 af1[TT], bw0[NU], bw1[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      bw0[u] = __builtin_bit_cast(bf16x8, bq[slot][u][0]);
-      bw1[u] = __builtin_bit_cast(bf16x8, bq[slot][u][1]);
-    }
-    read_a(af1, win, tap_shift(tap), 1);
-    mfma_slice(af0, bw0);
-    read_a(af0, nwinp, tap_shift(ntap), 0);
-    mfma_slice(af1, bw1);
-    b_load(std::integral_constant<int, slot>{}, chunk + (tap + 3) / 9, (tap + 3) % 9);     // into the slot just consumed
-  };
   auto kstep = [&](auto tapc, int chunk) {
     constexpr int tap = decltype(tapc)::value;
     constexpr int ntap = (tap + 1) % 9;
@@ -289,22 +228,6 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
     read_slice(af0, bf0, nwinp, smem + OFF_B + ((step + 1) % NST) * BSTAGE, tap_shift(ntap), 0);
     mfma_slice(af1, bf1);
   };
-  if constexpr (BREG) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * NU) : "memory");   // the window of chunk 0 and B of step 0 (steps 1, 2 may be in flight)
-    __syncthreads();
-    read_a(af0, smem, tap_shift(0), 0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-      kstep_breg(std::integral_constant<int, 0>{}, chunk);
-      kstep_breg(std::integral_constant<int, 1>{}, chunk);
-      kstep_breg(std::integral_constant<int, 2>{}, chunk);
-      kstep_breg(std::integral_constant<int, 3>{}, chunk);
-      kstep_breg(std::integral_constant<int, 4>{}, chunk);
-      kstep_breg(std::integral_constant<int, 5>{}, chunk);
-      kstep_breg(std::integral_constant<int, 6>{}, chunk);
-      kstep_breg(std::integral_constant<int, 7>{}, chunk);
-      kstep_breg(std::integral_constant<int, 8>{}, chunk);
-    }
-  } else {
   asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the window of chunk 0 and the weights of step 0 (steps 1, 2 may be in flight)
   __syncthreads();
   read_slice(af0, bf0, smem, smem + OFF_B, tap_shift(0), 0);
@@ -318,7 +241,6 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
     kstep(std::integral_constant<int, 6>{}, chunk);
     kstep(std::integral_constant<int, 7>{}, chunk);
     kstep(std::integral_constant<int, 8>{}, chunk);
-  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs past the last k-step must not land in the staging below
   __syncthreads();
@@ -368,25 +290,20 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
       }
       __syncthreads();
     } else {
-      // (a thread's pieces of this pass all belong to ONE 8-channel group: 512 % PCS == 0)
-      BnAuxAccF ax;
-      {
-        const int ch = tid % PCS;
-        bn_aux_begin(a.aux, n0 + (ch >> 2) * 64 + 32 * u + (ch & 3) * 8, ax);
-      }
-      // the hook's pieces of z are requested in groups of (up to) four rows, ahead of those rows' stores: inside a plain store loop
-      // every load would wait behind the previous row's store (the compiler cannot prove z and dst apart) — one exposed memory round
-      // trip per row instead of one per group
+      // the pieces of relu_z are requested in groups of (up to) four rows, ahead of those rows' stores: inside a plain store loop every
+      // load would wait behind the previous row's store (the compiler cannot prove z and dst apart)
       constexpr int ROWS = MT * PCS / 512;
       constexpr int GR = ROWS < 4 ? ROWS : 4;
 #pragma unroll
       for (int j0 = 0; j0 < ROWS; j0 += GR) {
         u32x4 zr[GR];
-        if (ax.on) {
+        if (a.relu_z) {
 #pragma unroll
           for (int jj = 0; jj < GR; ++jj) {
-            const int row = (tid + 512 * (j0 + jj)) / PCS;
-            zr[jj] = bn_aux_load(a.aux, ax, (size_t)(m0 + row < Mtot ? m0 + row : m0));
+            const int c = tid + 512 * (j0 + jj);
+            const int row = c / PCS, ch = c % PCS;
+            const int n = n0 + (ch >> 2) * 64 + 32 * u + (ch & 3) * 8;
+            zr[jj] = *reinterpret_cast<const u32x4*>(a.relu_z + (size_t)(m0 + row < Mtot ? m0 + row : m0) * a.N + n);
           }
         }
 #pragma unroll
@@ -396,7 +313,7 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
           const int n = n0 + (ch >> 2) * 64 + 32 * u + (ch & 3) * 8;
           if (m0 + row >= Mtot) continue;
           u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * OPITCH + ch * 16);
-          if (ax.on) v = bn_aux_apply(a.aux, ax, v, zr[jj]);
+          if (a.relu_z) v = relu_mask8(v, zr[jj]);
           if (a.dst2) {
             const bool hi = n >= a.split_c;
             unsigned char* const base = reinterpret_cast<unsigned char*>(hi ? a.dst2 : a.dst);
@@ -407,8 +324,6 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
         }
       }
       __syncthreads();
-      // (the staged tile is dead: its memory carries the cross-wave sum of this pass's BatchNorm partials)
-      if constexpr (AUX == 2) bn_aux_store_block<8>(a.aux, ax, PCS, reinterpret_cast<double*>(smem), blk_base + logical / a.ntiles);
     }
   }
 }
@@ -429,29 +344,8 @@ __global__ __launch_bounds__(512) void conv_win3_mixed_kernel(Win3Args a) {
   else win3_tile_body<MT / 2, NPW_S, NT, AUX>(a, (int)blockIdx.x - a.nbig, a.nsmall, a.m_split, a.nbig / a.ntiles);
 }
 
-template <int MT, int NPW, int NT>
-__global__ __launch_bounds__(512) void conv_win3_breg_kernel(Win3Args a) {
-  win3_tile_body<MT, NPW, NT, 0, true>(a, blockIdx.x, gridDim.x, 0, 0);
-}
-template <int MT, int NPW, int NT>
-int launch_win3_breg(Win3Args& a, hipStream_t s) {
-  constexpr int LDS = 2 * 128 * NPW * ROWB + NST * NT * ROWB + 1024;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_breg_kernel<MT, NPW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  const int64_t M = (int64_t)a.B * a.H * a.W;
-  a.mtiles = (int)wsmg_cdiv(M, MT);
-  a.ntiles = a.N / NT;
-  hipLaunchKernelGGL((conv_win3_breg_kernel<MT, NPW, NT>), dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS, s, a);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
-}
-
 template <int MT, int NPW, int NT, int AUX>
-int launch_win3_aux(Win3Args& a, wsmg_bn_aux_t* aux, hipStream_t s) {
+int launch_win3_aux(Win3Args& a, hipStream_t s) {
   constexpr int LDS = 2 * 128 * NPW * ROWB + NST * NT * ROWB + 1024;
   static bool attr = false;
   if (!attr) {
@@ -462,20 +356,15 @@ int launch_win3_aux(Win3Args& a, wsmg_bn_aux_t* aux, hipStream_t s) {
   const int64_t M = (int64_t)a.B * a.H * a.W;
   a.mtiles = (int)wsmg_cdiv(M, MT);
   a.ntiles = a.N / NT;
-  if (int e = bn_aux_blocks(aux, a.mtiles)) return e;
   hipLaunchKernelGGL((conv_win3_kernel<MT, NPW, NT, AUX>), dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
-// which hook form a launch needs: 0 none, 1 mask / split output, 2 sums
-inline int aux_form(const Win3Args& a) { return a.aux.mode >= 2 ? 2 : ((a.aux.mode == 1 || a.dst2) ? 1 : 0); }
-template <int MT, int NPW, int NT, bool HAS2 = true>
-int launch_win3(Win3Args& a, wsmg_bn_aux_t* aux, hipStream_t s) {
-  const int f = aux_form(a);
-  if (f == 0) return launch_win3_aux<MT, NPW, NT, 0>(a, aux, s);
-  if (f == 1) return launch_win3_aux<MT, NPW, NT, 1>(a, aux, s);
-  if constexpr (HAS2) return launch_win3_aux<MT, NPW, NT, 2>(a, aux, s);
-  return WSMG_EINVAL;
+// which store loop a launch needs: 1 = mask / split output
+inline int aux_form(const Win3Args& a) { return (a.relu_z || a.dst2) ? 1 : 0; }
+template <int MT, int NPW, int NT>
+int launch_win3(Win3Args& a, hipStream_t s) {
+  return aux_form(a) ? launch_win3_aux<MT, NPW, NT, 1>(a, s) : launch_win3_aux<MT, NPW, NT, 0>(a, s);
 }
 
 int g_cus3 = 0;
@@ -508,7 +397,7 @@ bool mixed_plan(Win3Args& a, int64_t M, int MT, int NT) {
 }
 
 template <int MT, int NPW, int NPW_S, int NT, int AUX>
-int launch_win3_mixed_aux(Win3Args& a, wsmg_bn_aux_t* aux, hipStream_t s) {
+int launch_win3_mixed_aux(Win3Args& a, hipStream_t s) {
   constexpr int LDS = 2 * 128 * NPW * ROWB + NST * NT * ROWB + 1024;
   static bool attr = false;
   if (!attr) {
@@ -518,21 +407,14 @@ int launch_win3_mixed_aux(Win3Args& a, wsmg_bn_aux_t* aux, hipStream_t s) {
   }
   a.ntiles = a.N / NT;
   a.mtiles = 0;
-  if (int e = bn_aux_blocks(aux, (a.nbig + a.nsmall) / a.ntiles)) return e;
   hipLaunchKernelGGL((conv_win3_mixed_kernel<MT, NPW, NPW_S, NT, AUX>), dim3((unsigned)(a.nbig + a.nsmall)), dim3(512), LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
-template <int MT, int NPW, int NPW_S, int NT, bool HAS2 = true>
-int launch_win3_mixed(Win3Args& a, wsmg_bn_aux_t* aux, hipStream_t s) {
-  const int f = aux_form(a);
-  if (f == 0) return launch_win3_mixed_aux<MT, NPW, NPW_S, NT, 0>(a, aux, s);
-  if (f == 1) return launch_win3_mixed_aux<MT, NPW, NPW_S, NT, 1>(a, aux, s);
-  if constexpr (HAS2) return launch_win3_mixed_aux<MT, NPW, NPW_S, NT, 2>(a, aux, s);
-  return WSMG_EINVAL;
+template <int MT, int NPW, int NPW_S, int NT>
+int launch_win3_mixed(Win3Args& a, hipStream_t s) {
+  return aux_form(a) ? launch_win3_mixed_aux<MT, NPW, NPW_S, NT, 1>(a, s) : launch_win3_mixed_aux<MT, NPW, NPW_S, NT, 0>(a, s);
 }
-
-int g_win3_breg = -1;     // wsmg_conv_debug_win3_breg: -1 = the environment's WSMG_WIN3_BREG
 
 // window entries a tile of mt consecutive pixels can need: the pixels, 2 pads per image row crossed, the pad rows between
 // images, and one padded row + 1 entry of halo on either side
@@ -547,52 +429,38 @@ int window_bound(int mt, int H, int W) {
 // 3 x 3 / stride 1 / pad 1, bf16 in / bf16 out, N % 64 == 0 (128-channel tiles when N % 128 == 0), Kc % 32 == 0; WSMG_EINVAL otherwise (the caller then uses the
 // implicit-GEMM kernel).  bwd = 0: forward (src = x, wt = OHWI); 1: backward-data (src = dy, wt = IHWO).
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
-                        int B, int H, int W, int Kc, int N, int mt, int mixed, wsmg_bn_aux_t* aux, int dst_ld, void* dst2, int split_c,
+                        int B, int H, int W, int Kc, int N, int mt, int mixed, const void* relu_z, int dst_ld, void* dst2, int split_c,
                         hipStream_t s) {
   if (N <= 0 || N % 32 || Kc % DK || B <= 0) return WSMG_EINVAL;
   if (dst2 && (dst_ld || split_c <= 0 || split_c >= N || (split_c & 7) || ((uintptr_t)dst2 & 15))) return WSMG_EINVAL;
   if ((int64_t)B * (H + 2) * (W + 2) * 1 > (1 << 30) || (int64_t)B * H * W * (Kc > N ? Kc : N) * 2 >= (1ll << 31)) return WSMG_EINVAL;
-  if (bn_aux_bad(aux, N) || (dst_ld && (dst_ld < N || (dst_ld & 7)))) return WSMG_EINVAL;
+  if ((dst_ld && (dst_ld < N || (dst_ld & 7))) || ((uintptr_t)relu_z & 15)) return WSMG_EINVAL;
   Win3Args a{(const bf16_t*)src, (const bf16_t*)wt, bias, (bf16_t*)dst, B, H, W, Kc, N, 0, 0, relu, bwd,
-             (unsigned)((size_t)B * H * W * Kc * 2), (unsigned)((size_t)N * 9 * Kc * 2), stats, nslab, 0, 0, 0, dst_ld, bn_aux_host(aux), (bf16_t*)dst2, split_c};
+             (unsigned)((size_t)B * H * W * Kc * 2), (unsigned)((size_t)N * 9 * Kc * 2), stats, nslab, 0, 0, 0, dst_ld, (const bf16_t*)relu_z, (bf16_t*)dst2, split_c};
   const int64_t M = (int64_t)B * H * W;
   // mixed == 0 (a tile size forced through wsmg_conv_debug_win3_tile) or WSMG_CONV_WIN3_MIXED=0: one tile size per launch (rounds 2-4; A/B)
   const bool mix = mixed && WSMG_TUNE("WSMG_CONV_WIN3_MIXED", 1) != 0;
   if (N % 128 == 0) {
-    if (mt == 512 && aux_form(a) == 2) mt = 256;      // (the 512 x 128 tile has no register room for the sums hook)
-    // WSMG_WIN3_BREG=1 (experiment): weights from global memory into registers, plain launches without a hook
-    if (aux_form(a) == 0 && !dst_ld && (g_win3_breg < 0 ? WSMG_TUNE("WSMG_WIN3_BREG", 0) : g_win3_breg)) {
-      if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3_breg<512, 6, 128>(a, s);
-      if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3_breg<256, 4, 128>(a, s);
-    }
     if (mt == 512 && window_bound(512, H, W) <= 128 * 6) {
-      if (mix && window_bound(256, H, W) <= 128 * 4 && mixed_plan(a, M, 512, 128)) return launch_win3_mixed<512, 6, 4, 128, false>(a, aux, s);
-      return launch_win3<512, 6, 128, false>(a, aux, s);
+      if (mix && window_bound(256, H, W) <= 128 * 4 && mixed_plan(a, M, 512, 128)) return launch_win3_mixed<512, 6, 4, 128>(a, s);
+      return launch_win3<512, 6, 128>(a, s);
     }
     if (mt == 256 && window_bound(256, H, W) <= 128 * 4) {
-      if (mix && window_bound(128, H, W) <= 128 * 2 && mixed_plan(a, M, 256, 128)) return launch_win3_mixed<256, 4, 2, 128>(a, aux, s);
-      return launch_win3<256, 4, 128>(a, aux, s);
+      if (mix && window_bound(128, H, W) <= 128 * 2 && mixed_plan(a, M, 256, 128)) return launch_win3_mixed<256, 4, 2, 128>(a, s);
+      return launch_win3<256, 4, 128>(a, s);
     }
     return WSMG_EINVAL;
   }
   if (N % 64 == 0) {   // 64-channel tiles (N = 64, 192, ...)
     if (mt == 512 && window_bound(512, H, W) <= 128 * 6) {
-      if (mix && window_bound(256, H, W) <= 128 * 4 && mixed_plan(a, M, 512, 64)) return launch_win3_mixed<512, 6, 4, 64>(a, aux, s);
-      return launch_win3<512, 6, 64>(a, aux, s);
+      if (mix && window_bound(256, H, W) <= 128 * 4 && mixed_plan(a, M, 512, 64)) return launch_win3_mixed<512, 6, 4, 64>(a, s);
+      return launch_win3<512, 6, 64>(a, s);
     }
-    if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 64>(a, aux, s);
+    if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 64>(a, s);
     return WSMG_EINVAL;
   }
   // 32-channel tiles (N = 32, 96, ...)
-  if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 32>(a, aux, s);
-  if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 32>(a, aux, s);
+  if (mt == 512 && window_bound(512, H, W) <= 128 * 6) return launch_win3<512, 6, 32>(a, s);
+  if (mt == 256 && window_bound(256, H, W) <= 128 * 4) return launch_win3<256, 4, 32>(a, s);
   return WSMG_EINVAL;
-}
-
-// tests / tools: the BREG form (weights from global memory into registers) for the launches that follow: 1 on, 0 off, -1 = by the
-// environment (WSMG_WIN3_BREG); returns the previous setting
-extern "C" int wsmg_conv_debug_win3_breg(int on) {
-  const int old = g_win3_breg;
-  g_win3_breg = on;
-  return old;
 }

@@ -562,51 +562,6 @@ extern "C" int wsmg_bn_act_bwd_ld_bf16(const void* dy, int64_t ld_dy, const void
                               rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream, ld_dy);
 }
 
-// First level of a long block list (round 6: a stride-2 backward-data convolution leaves 10 000 blocks, one per 128-pixel tile):
-// `chunks` workgroups per 64-channel group each add a contiguous run of blocks, lanes = channels (whole 512-byte rows), the four waves
-// interleaved over the run and combined in wave order -> out[chunk][2][C]; the one-wave-per-channel finalize then adds `chunks` blocks.
-__global__ __launch_bounds__(256) void part_reduce_kernel(const double* __restrict__ part, int blocks, int C, int chunks, double* __restrict__ out) {
-  __shared__ double sh[4][2][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.y * 64 + lane, chunk = blockIdx.x;
-  const int per = (blocks + chunks - 1) / chunks;
-  const int b0 = chunk * per, b1 = b0 + per < blocks ? b0 + per : blocks;
-  double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int b = b0 + wave; b < b1; b += 4) { s += part[((size_t)b * 2 + 0) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
-  sh[wave][0][lane] = s;
-  sh[wave][1][lane] = q;
-  __syncthreads();
-  if (wave == 0 && c < C) {
-    out[((size_t)chunk * 2 + 0) * C + c] = (sh[0][0][lane] + sh[1][0][lane]) + (sh[2][0][lane] + sh[3][0][lane]);
-    out[((size_t)chunk * 2 + 1) * C + c] = (sh[0][1][lane] + sh[1][1][lane]) + (sh[2][1][lane] + sh[3][1][lane]);
-  }
-}
-
-// Round 6 (include/wsmgmap.h): BatchNorm backward behind a producer that left the partial sums of the (already masked) gradient in
-// `part` [blocks][2][C] (csrc/wsmg_bn_aux.h) — the reduction pass over dy and x is gone, the blocks are added in block order by the
-// finalize kernel the reduction pass fed.
-extern "C" int wsmg_bn_act_bwd_bf16_parts(const void* dy, int64_t ld_dy, const void* x, const float* gamma, const float* beta,
-                                          const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, void* dx,
-                                          float* dgamma, float* dbeta, const double* part, int blocks, double* scratch, int scratch_blocks,
-                                          wsmg_stream_t stream) {
-  if (!chan_ok(C) || (C & 7) || rows <= 0 || !part || blocks <= 0 || !dgamma || !dbeta || !dy || !x || !dx) return WSMG_EINVAL;
-  if (ld_dy == 0) ld_dy = C;
-  if (ld_dy < C || (ld_dy & 7) || ((uintptr_t)dy & 15)) return WSMG_EINVAL;
-  if (relu && !beta) return WSMG_EINVAL;
-  hipStream_t s = wsmg_s(stream);
-  if (blocks > 1536 && scratch && scratch_blocks >= 64) {
-    hipLaunchKernelGGL(part_reduce_kernel, dim3(64, (unsigned)wsmg_cdiv(C, 64)), dim3(256), 0, s, part, blocks, C, 64, scratch);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)scratch, 64, C, dgamma, dbeta);
-  } else {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, part, blocks, C, dgamma, dbeta);
-  }
-  hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)nullptr, gamma, beta, save_mean, save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C,
-                     (bf16_t*)dx, (bf16_t*)nullptr, ld_dy);
-  WSMG_RETURN_LAUNCH();
-}
-
 // ----------------------------------------------------------------------------- GroupNorm (frozen DD-PPO depth ResNet50)
 // nn.GroupNorm over NHWC bf16 activations, inference only: statistics per (sample, group) over H x W x C/G elements
 // (biased variance, eps under the root), then gamma / beta per channel, optional residual add, optional ReLU.

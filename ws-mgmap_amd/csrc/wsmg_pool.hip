@@ -6,7 +6,6 @@
 #include <type_traits>
 
 #include "wsmg_common.h"
-#include "wsmg_bn_aux.h"
 
 namespace {
 
@@ -581,78 +580,6 @@ __global__ void add3_bf16_kernel(const u32x4_t* __restrict__ a, const u32x4_t* _
     y[i] = o;
   }
 }
-// ---- round 6: the two elementwise producers of a BatchNorm's incoming gradient with the hook of wsmg_bn_aux.h ----------------
-// A thread keeps ONE 8-channel group for the whole launch (the grid stride is a multiple of C / 8); a workgroup's sums are block
-// blockIdx of the partials (bn_aux_store_block).
-__global__ __launch_bounds__(256) void add3_bf16_aux_kernel(const u32x4_t* __restrict__ a, const u32x4_t* __restrict__ b,
-                                                            const u32x4_t* __restrict__ c, u32x4_t* __restrict__ y, int64_t n8, int C8,
-                                                            BnAux aux) {
-  BnAuxAcc ax;
-  bn_aux_begin(aux, (int)(threadIdx.x % C8) * 8, ax);
-  GRID_STRIDE(i, n8) {
-    const u32x4_t u = a[i], v = b[i], w = c[i];
-    u32x4_t o = {add3_2(u[0], v[0], w[0]), add3_2(u[1], v[1], w[1]), add3_2(u[2], v[2], w[2]), add3_2(u[3], v[3], w[3])};
-    if (ax.on) o = bn_aux_apply(aux, ax, o, bn_aux_load(aux, ax, (size_t)(i / C8)));
-    y[i] = o;
-  }
-  __shared__ double red[4 * 16 * 64];
-  bn_aux_store_block<4>(aux, ax, C8 < 64 ? C8 : 64, red, (int)blockIdx.x);
-}
-
-// upsample_bwd_kernel<bf16_t> on 8 channels per thread (the same taps in the same order per channel: bit-identical values), + the hook
-__global__ __launch_bounds__(256) void upsample_bwd8_aux_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int H, int W,
-                                                                int C, int64_t ld_dy, BnAux aux) {
-  const int OH = 2 * H, OW = 2 * W, C8 = C / 8;
-  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
-  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-  const int64_t n = (int64_t)B * H * W * C8;
-  BnAuxAcc ax;
-  bn_aux_begin(aux, (int)(threadIdx.x % C8) * 8, ax);
-  GRID_STRIDE(i, n) {
-    const int c = (int)(i % C8) * 8;
-    int64_t p = i / C8;
-    const int ix = (int)(p % W); p /= W;
-    const int iy = (int)(p % H);
-    const int b = (int)(p / H);
-    float g[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = 0.f;
-    const int oy_lo = 2 * iy - 2 < 0 ? 0 : 2 * iy - 2, oy_hi = 2 * iy + 3 > OH - 1 ? OH - 1 : 2 * iy + 3;
-    const int ox_lo = 2 * ix - 2 < 0 ? 0 : 2 * ix - 2, ox_hi = 2 * ix + 3 > OW - 1 ? OW - 1 : 2 * ix + 3;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      int y0, y1;
-      float hy0, hy1;
-      up_src(oy, H, sh, y0, y1, hy0, hy1);
-      const float wy = (y0 == iy ? hy0 : 0.f) + (y1 == iy ? hy1 : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        int x0, x1;
-        float wx0, wx1;
-        up_src(ox, W, sw, x0, x1, wx0, wx1);
-        const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
-        if (wx == 0.f) continue;
-        const u32x4_t d = *reinterpret_cast<const u32x4_t*>(dy + (((size_t)b * OH + oy) * OW + ox) * ld_dy + c);
-        const float wgt = wy * wx;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          g[2 * q] += wgt * __uint_as_float(d[q] << 16);
-          g[2 * q + 1] += wgt * __uint_as_float(d[q] & 0xffff0000u);
-        }
-      }
-    }
-    u32x4_t o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bf16_t l = (bf16_t)g[2 * q], h = (bf16_t)g[2 * q + 1];
-      o[q] = (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
-    }
-    if (ax.on) o = bn_aux_apply(aux, ax, o, bn_aux_load(aux, ax, (size_t)(i / C8)));
-    *reinterpret_cast<u32x4_t*>(dx + i * 8) = o;
-  }
-  __shared__ double red[4 * 16 * 64];
-  bn_aux_store_block<4>(aux, ax, C8 < 64 ? C8 : 64, red, (int)blockIdx.x);
-}
-
 __global__ void relu_fwd8_kernel(const u32x4_t* __restrict__ x, u32x4_t* __restrict__ y, int64_t n8) {
   GRID_STRIDE(i, n8) {
     const u32x4_t v = x[i];
@@ -818,33 +745,6 @@ extern "C" int wsmg_add3_bf16(const void* a, const void* b, const void* c, void*
   if (!a || !b || !c || !y || n <= 0 || (n & 7) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)y) & 15)) return WSMG_EINVAL;
   hipLaunchKernelGGL(add3_bf16_kernel, dim3(sgrid(n / 8)), dim3(256), 0, wsmg_s(s), (const u32x4_t*)a, (const u32x4_t*)b, (const u32x4_t*)c,
                      (u32x4_t*)y, n / 8);
-  WSMG_RETURN_LAUNCH();
-}
-static int aux_grid(int64_t n) {     // (a workgroup = one block of the partials: a bounded number of them)
-  int64_t g = wsmg_cdiv(n, 256 * 4);
-  if (g > 1024) g = 1024;
-  if (g < 1) g = 1;
-  return (int)g;
-}
-extern "C" int wsmg_add3_bf16_aux(const void* a, const void* b, const void* c, void* y, int64_t rows, wsmg_bn_aux_t* aux, wsmg_stream_t s) {
-  if (!aux || aux->mode < 2 || aux->c0 != 0 || bn_aux_bad(aux, aux->C)) return WSMG_EINVAL;
-  const int C8 = aux->C / 8;
-  if (!a || !b || !c || !y || rows <= 0 || (256 % C8) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)y) & 15)) return WSMG_EINVAL;
-  const int64_t n8 = rows * C8;
-  if (int e = bn_aux_blocks(aux, aux_grid(n8))) return e;
-  hipLaunchKernelGGL(add3_bf16_aux_kernel, dim3(aux_grid(n8)), dim3(256), 0, wsmg_s(s), (const u32x4_t*)a, (const u32x4_t*)b, (const u32x4_t*)c,
-                     (u32x4_t*)y, n8, C8, bn_aux_host(aux));
-  WSMG_RETURN_LAUNCH();
-}
-extern "C" int wsmg_upsample2x_bwd_ld_bf16_aux(const void* dy, int64_t ld_dy, void* dx, int B, int H, int W, int C, wsmg_bn_aux_t* aux,
-                                               wsmg_stream_t s) {
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || (256 % (C / 8))) return WSMG_EINVAL;
-  if (!aux || aux->mode < 2 || aux->c0 != 0 || aux->C != C || bn_aux_bad(aux, C)) return WSMG_EINVAL;
-  if (ld_dy == 0) ld_dy = C;
-  if (ld_dy < C || (ld_dy & 7) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return WSMG_EINVAL;
-  if (int e = bn_aux_blocks(aux, aux_grid((int64_t)B * H * W * C / 8))) return e;
-  hipLaunchKernelGGL(upsample_bwd8_aux_kernel, dim3(aux_grid((int64_t)B * H * W * C / 8)), dim3(256), 0, wsmg_s(s), CB16(dy), B16(dx), B, H, W,
-                     C, ld_dy, bn_aux_host(aux));
   WSMG_RETURN_LAUNCH();
 }
 extern "C" int wsmg_relu_fwd(const float* x, float* y, int64_t n, wsmg_stream_t s) { return relu_fwd_t<float>(x, y, n, s); }

@@ -189,3 +189,49 @@ extern "C" int wsmg_act_heads(const float* feat, int B, int K, const float* w_pr
   hipLaunchKernelGGL(act_heads_kernel, dim3((unsigned)B), dim3(256), 0, wsmg_s(stream), a);
   WSMG_RETURN_LAUNCH();
 }
+
+// ---- round 6: the bias gradients of the recurrent core's dense layers in ONE launch -------------------------------------------
+// d bias = sum over rows of a [rows][cols] float32 matrix (mg_map_policy.py:118-123,126-132,147-152: the Linear / GRU biases; torch
+// runs a reduction kernel + a memset per tensor: 14 launches for the seven of them in the core's leaf pass).  A workgroup = one
+// 64-column block of one tensor: lane = column (coalesced 256-byte rows), the four waves take rows w, w + 4, ..., float32 sums in
+// row order per wave, waves combined in wave order — bit-reproducible.
+namespace {
+struct ColsumBatch {
+  WsmgColsumDesc d[16];
+  int first_block[17];    // prefix sum of ceil(cols / 64)
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumBatch b) {
+  __shared__ float sh[4][64];
+  int t = 0;
+  while (t + 1 < b.n && (int)blockIdx.x >= b.first_block[t + 1]) ++t;
+  const WsmgColsumDesc d = b.d[t];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = ((int)blockIdx.x - b.first_block[t]) * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < d.cols) {
+    int r = wave;
+    for (; r + 4 < d.rows; r += 8) { s0 += d.x[(size_t)r * d.cols + c]; s1 += d.x[(size_t)(r + 4) * d.cols + c]; }
+    if (r < d.rows) s0 += d.x[(size_t)r * d.cols + c];
+  }
+  sh[wave][lane] = s0 + s1;
+  __syncthreads();
+  if (wave == 0 && c < d.cols) d.out[c] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+}  // namespace
+
+extern "C" int wsmg_colsum_multi(const WsmgColsumDesc* descs, int n, wsmg_stream_t stream) {
+  if (!descs || n <= 0 || n > 16) return WSMG_EINVAL;
+  ColsumBatch b;
+  b.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!descs[i].x || !descs[i].out || descs[i].rows <= 0 || descs[i].cols <= 0) return WSMG_EINVAL;
+    b.d[i] = descs[i];
+    b.first_block[i] = blocks;
+    blocks += (descs[i].cols + 63) / 64;
+  }
+  b.first_block[n] = blocks;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, wsmg_s(stream), b);
+  WSMG_RETURN_LAUNCH();
+}

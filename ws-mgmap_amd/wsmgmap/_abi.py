@@ -31,14 +31,8 @@ class RelayoutDesc(ctypes.Structure):     # WsmgRelayoutDesc of include/wsmgmap.
                 ("I_pad", c_i), ("reserved", c_i)]
 
 
-class BnAux(ctypes.Structure):            # wsmg_bn_aux_t of include/wsmgmap.h (round 6)
-    _fields_ = [("z", c_p), ("mean", c_p), ("invstd", c_p), ("gamma", c_p), ("beta", c_p), ("part", c_p),
-                ("mode", c_i), ("c0", c_i), ("C", c_i), ("ld", c_i), ("cap_blocks", c_i), ("blocks", c_i)]
-
-
-def aux_ptr(a):
-    """ctypes argument for a `const wsmg_bn_aux_t*` parameter (None -> NULL)."""
-    return None if a is None else ctypes.cast(ctypes.byref(a), c_p)
+class ColsumDesc(ctypes.Structure):       # WsmgColsumDesc of include/wsmgmap.h (round 6)
+    _fields_ = [("x", c_p), ("out", c_p), ("rows", c_i), ("cols", c_i)]
 
 
 # name -> argtypes (all return int unless listed in _RESTYPE)
@@ -153,7 +147,6 @@ _SIG["wsmg_rnn_debug_spin_limit"] = [ctypes.c_uint]
 _SIG["wsmg_rnn_debug_inject"] = [ctypes.c_uint]
 _SIG["wsmg_instruction_dedup"] = [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p]
 _SIG["wsmg_conv_debug_win3_tile"] = [c_i]
-_SIG["wsmg_conv_debug_win3_breg"] = [c_i]
 _SIG["wsmg_copy_multi"] = [c_p, c_i, c_p]
 _SIG["wsmg_linear_rows"] = [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]
 _SIG["wsmg_act_heads"] = [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]
@@ -172,13 +165,11 @@ _SIG["wsmg_attn_fp8_mfma_fused_arrivals"] = [c_i] * 4
 _SIG["wsmg_collate_ego_sparse_nhwc_bf16"] = [c_p] * 5 + [c_i] * 4 + [c_f, c_p, c_p]
 _SIG["wsmg_debug_occupy"] = [c_i, c_i, c_i, c_p, c_p, c_p]
 _SIG["wsmg_conv2d_bwd_data_bf16_ex"] = [c_p] * 5 + [c_i] * 12 + [c_p]
-_SIG["wsmg_conv2d_fwd_bf16_ex"] = [c_p] * 4 + [c_i, c_p, c_i, c_p, c_i] + [c_i] * 11 + [c_p]
+_SIG["wsmg_conv2d_fwd_bf16_ex"] = [c_p] * 4 + [c_i, c_p, c_i, c_i] + [c_i] * 11 + [c_p]
 _SIG["wsmg_bev_index_compact"] = [c_p, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p]
 _SIG["wsmg_bev_scatter_rotate_compact"] = [c_p, c_p, c_p, c_p, c_f] + [c_i] * 6 + [c_p, c_p]
+_SIG["wsmg_colsum_multi"] = [c_p, c_i, c_p]
 _SIG["wsmg_attn_fp8_row_fwd"] = [c_p] * 5 + [c_f, c_i, c_i, c_i] + [c_p] * 4
-_SIG["wsmg_add3_bf16_aux"] = [c_p] * 4 + [c_l, c_p, c_p]
-_SIG["wsmg_upsample2x_bwd_ld_bf16_aux"] = [c_p, c_l, c_p] + [c_i] * 4 + [c_p, c_p]
-_SIG["wsmg_bn_act_bwd_bf16_parts"] = [c_p, c_l] + [c_p] * 5 + [c_i, c_l, c_i] + [c_p] * 4 + [c_i, c_p, c_i, c_p]
 _RESTYPE = {"wsmg_cls_tail_workspace_floats": c_l, "wsmg_attn_fp8_workspace_bytes": c_l, "wsmg_lstm_workspace_bytes": c_l, "wsmg_build_info": ctypes.c_char_p, "wsmg_channel_reduce_workspace_bytes": c_l, "wsmg_gru_workspace_bytes": c_l}
 
 _lib = None

@@ -31,7 +31,6 @@ _TABLE = [
     ("fused_ce", "WSMG_FUSED_CE", True, bool, "prediction monitor's cross-entropy from the NHWC logits"),
     ("fused_cls_tail", "WSMG_FUSED_CLS_TAIL", True, bool, "classifier tail (BN + ReLU + 1x1 + CE + pool) in one pass per direction"),
     ("bn_fused_stats", "WSMG_BN_FUSED_STATS", True, bool, "BatchNorm sums in the producing convolution's epilogue"),
-    ("bn_producer_sums", "WSMG_BN_PRODUCER_SUMS", True, bool, "BatchNorm-backward sums in the epilogue of the kernel that produces the gradient (round 6)"),
     ("relu_producer_mask", "WSMG_RELU_PRODUCER_MASK", True, bool, "fused-ReLU masks of map_encoded / map_classified_linear in map_cated_linear's backward-data epilogue (round 6)"),
     ("conv_into_cat", "WSMG_CONV_INTO_CAT", True, bool, "map_encoded / map_classified_linear write straight into their slices of the concatenation (round 6)"),
     ("strided_grads", "WSMG_STRIDED_GRADS", True, bool, "channel slices of a concatenation's gradient read in place"),

@@ -45,10 +45,8 @@ class batched_bumps:
         return False
 
 
-def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None, sole=False):
-    """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC.
-    sole: the caller promises that the result is read by exactly ONE differentiable operator (ops.bn_act(sole_consumer=...): that
-    operator's gradient kernel then takes this BatchNorm's backward sums in its epilogue)."""
+def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
+    """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
     # (if x carries zero-padded channels, ops.conv2d pads the weight's input channels to match)
     if isinstance(x, (list, tuple)):   # convolution over a channel concatenation: one vectorised concatenation, then the conv
         # (running it part by part over the weight's input-channel slices was measured and dropped: DESIGN.md section 7)
@@ -59,8 +57,7 @@ def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True,
         stats = ops.bn_stats_slabs(id(bn), conv.out_channels, x.device)
     y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train, stats=stats)
     bump(bn, train)
-    out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps, stats,
-                     sole_consumer=sole)
+    out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps, stats)
     if stats is not None:
         ops.bn_stats_done(id(bn), conv.out_channels, x.device)
     return out
@@ -198,9 +195,7 @@ class MapEncoder(nn.Module):
             if fold is not None:
                 x_nhwc = conv_infer(x_nhwc, fold, self.cnn[i], self.cnn[i + 1])
             else:
-                # (every layer's output has one consumer inside this module; the last one's consumers are the caller's business:
-                #  MGMapNet._map_stack takes its sink off the tensor — ops.take_sink — and gives it to the fan-out)
-                x_nhwc = conv_bn_relu(x_nhwc, self.cnn[i], self.cnn[i + 1], train, sole=True)
+                x_nhwc = conv_bn_relu(x_nhwc, self.cnn[i], self.cnn[i + 1], train)
         return x_nhwc
 
 
@@ -228,7 +223,7 @@ class MapDecoder(nn.Module):
     def _block(self, x, blk, train, fold=None):
         if fold is not None:
             return conv_infer(conv_infer(x, fold, blk.conv1, blk.bn1), fold, blk.conv2, blk.bn2, residual=x)
-        y = conv_bn_relu(x, blk.conv1, blk.bn1, train, sole=True)
+        y = conv_bn_relu(x, blk.conv1, blk.bn1, train)
         return conv_bn_relu(y, blk.conv2, blk.bn2, train, relu=True, residual=x)
 
     def side_stream(self, x):
@@ -252,9 +247,9 @@ class MapDecoder(nn.Module):
         x_full, x = x if isinstance(x, (tuple, list)) else (x, x)
         train = self.training
         if fold is not None:
-            cr = lambda t, seq, sole=False: conv_infer(t, fold, seq[0], seq[1])  # noqa: E731
+            cr = lambda t, seq: conv_infer(t, fold, seq[0], seq[1])  # noqa: E731
         else:
-            cr = lambda t, seq, sole=False: conv_bn_relu(t, seq[0], seq[1], train, sole=sole)  # noqa: E731
+            cr = lambda t, seq: conv_bn_relu(t, seq[0], seq[1], train)  # noqa: E731
         # The full-resolution branch (two 3x3 convs) is independent of the resnet branch until the last concatenation, and
         # the resnet branch is mostly launch-latency-bound (6x6 and 12x12 maps: ~15 us kernels that leave the chip idle):
         # the full-resolution branch runs on a side stream beside it — in backward too, where autograd replays every node
@@ -265,9 +260,9 @@ class MapDecoder(nn.Module):
             side.wait_stream(main)
             x_full.record_stream(side)   # saved for the side-stream backward of these layers: no reuse of its memory before that ran
             with torch.cuda.stream(side):
-                x_original = cr(cr(x_full, self.conv_original_size0, True), self.conv_original_size1, True)
+                x_original = cr(cr(x_full, self.conv_original_size0), self.conv_original_size1)
         else:
-            x_original = cr(cr(x_full, self.conv_original_size0, True), self.conv_original_size1, True)
+            x_original = cr(cr(x_full, self.conv_original_size0), self.conv_original_size1)
         stem = self.base_model
         layer0 = cr(x, (stem.conv1, stem.bn1))
         layer1 = ops.maxpool3x3s2(layer0)
@@ -281,14 +276,11 @@ class MapDecoder(nn.Module):
             return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2)
         if x.dtype == torch.bfloat16:
             # upsample + torch.cat(dim=1) of the reference in one launch, under autograd too (ops._Up2Cat)
-            # (sole consumers: each of these BatchNorm outputs is read by one operator — the sinks ride on the tensors; `layer0`,
-            #  read by the max-pool and by layer0_1x1, and the residual blocks' outputs are not)
-            up = cr(ops.upsample2x_cat(cr(layer1, self.layer1_1x1, True), cr(layer0, self.layer0_1x1, True)), self.conv_up0, True)
+            up = cr(ops.upsample2x_cat(cr(layer1, self.layer1_1x1), cr(layer0, self.layer0_1x1)), self.conv_up0)
             if side is not None:
                 main.wait_stream(side)
                 x_original.record_stream(main)
-            return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2, True)
-        ops.take_sink(x_original)      # (float32 route: the concatenations below are copies; nobody may use the sink)
+            return cr(ops.upsample2x_cat(up, x_original), self.conv_original_size2)
         up = ops.upsample2x(cr(layer1, self.layer1_1x1))
         up = cr([up, cr(layer0, self.layer0_1x1)], self.conv_up0)        # torch.cat(dim=1) of the reference, folded into the conv
         up = ops.upsample2x(up)

@@ -230,9 +230,6 @@ class MGMapNet(nn.Module):
         if laid is not None:
             torch.cuda.current_stream().wait_event(laid)
         enc = self.map_encoder(x)
-        # (the encoded map has three consumers below: the BatchNorm sink its tensor carries goes to the fan-out, whose backward — the one
-        #  pass that adds the three gradients — takes that BatchNorm's sums; no single consumer may find it on the tensor)
-        enc_sink = ops.take_sink(enc)
         # the stem's forward is a PERSISTENT kernel, one workgroup per CU: the instruction branch's persistent LSTM (16 workgroups
         # that claim their CUs) must not start beside it, or 16 of the stem's workgroups wait for the LSTM to finish and then
         # do their whole share alone (_encode_instruction waits for this event before the LSTM launch)
@@ -242,7 +239,7 @@ class MGMapNet(nn.Module):
             self._encoder_done.record(torch.cuda.current_stream())
         conv = lambda t, seq, pad: ops.conv2d(t, seq[0].weight, seq[0].bias, 1, pad, relu=True)  # noqa: E731
         # the encoded map has three consumers: their gradients meet in one launch (ops.fanout3) instead of two autograd adds
-        e_tok, e_full, e_stem = ops.fanout3(enc, enc_sink) if (train and enc.dtype == torch.bfloat16) else (enc, enc, enc)
+        e_tok, e_full, e_stem = ops.fanout3(enc) if (train and enc.dtype == torch.bfloat16) else (enc, enc, enc)
         # map_encoded_linear (0.17 ms forward, 0.38 ms backward of full-chip kernels) depends on the encoded map only and is consumed
         # after the decoder: it goes on the decoder's side stream, in front of the full-resolution branch (round 4).  Forward it
         # then runs beside the stem's convolution; backward — autograd replays a node on its forward stream — its two kernels run
@@ -278,8 +275,7 @@ class MGMapNet(nn.Module):
         st1 = ops.bn_stats_slabs(id(c[1]), 32, dec.device) if fused else None
         y = ops.conv_transpose2d(dec, c[0].weight, 2, 1, st1)
         bump(c[1], train)
-        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps, st1,
-                       sole_consumer=True)
+        y = ops.bn_act(y, c[1].weight, c[1].bias, c[1].running_mean, c[1].running_var, train, True, None, c[1].momentum, c[1].eps, st1)
         st4 = ops.bn_stats_slabs(id(c[4]), 32, dec.device) if fused else None
         y = ops.conv2d(y, c[3].weight, None, 1, 1, stats=st4)
         bump(c[4], train)

@@ -9,7 +9,7 @@ from .. import _abi
 from ..debug import sw
 from .core import _p, _raw_stream, _stream, _req, _f32, _sfx, _workspace, _rows_of, _conv_out, _launch, _zeros_f32, _prelaid, _join_side_at_end, TokenGradSink
 from .nhwc import cat_channels
-from .norm import channel_sum, take_sink
+from .norm import channel_sum
 
 # ----------------------------------------------------------------------------- convolution
 
@@ -103,7 +103,7 @@ def _weight_grad(sfx, x, dy, dims, fl, Cin_w):
 class ReluSink:
     """Links a convolution whose ReLU was fused into its forward epilogue (no BatchNorm: map_encoded_linear, map_classified_linear,
     mg_map_policy.py:89-96) to the operator that consumes its output: when that operator's gradient kernel masks the gradient with
-    the ReLU itself (wsmg_bn_aux_t mode 1) it sets `masked`, and this convolution's backward skips its own masking pass.
+    the ReLU itself (wsmg_conv2d_bwd_data_bf16_ex's relu_y) it sets `masked`, and this convolution's backward skips its own masking pass.
     (ops.TokenGradSink plays the same role for map_cated_linear.)"""
 
     def __init__(self):
@@ -111,33 +111,14 @@ class ReluSink:
         self.masked = False
 
 
-def _in_sinks(x):
-    """[(first channel, BnGradSink)] of the BatchNorm outputs this tensor is (or, for a concatenation, contains) — taken off the
-    tensor: only ONE consumer may use them."""
-    s = take_sink(x)
-    if s is not None:
-        return [(0, s)]
-    lst = getattr(x, "_bn_sinks", None)
-    if lst:
-        del x._bn_sinks
-        return [(c0, t) for c0, t in lst if t is not None]
-    return []
-
-
-def _grad_aux(in_sinks, mask_z=None, mask_sinks=None, pixels=0):
-    """The one wsmg_bn_aux_t a gradient kernel can carry: the ReLU mask of the consumed tensor (mode 1) or the first usable
-    BatchNorm sink.  -> (aux or None, what to mark afterwards)."""
-    if mask_z is not None and mask_sinks and sw.relu_producer_mask and all(m.relu for m in mask_sinks):
-        C = mask_z.shape[-1]
-        a = _abi.BnAux(mask_z.data_ptr(), None, None, None, None, None, 1, 0, C, C, 0, 0)
-        for m in mask_sinks:
-            m.masked = True
-        return a
-    for c0, sk in in_sinks or ():
-        a = sk.aux(c0, pixels)
-        if a is not None:
-            return a
-    return None
+def _mask_of(mask_z, mask_sinks):
+    """The tensor a gradient kernel masks its output with: `mask_z` (the consumed tensor = the producers' ReLU outputs) when every
+    producer's ReLU is fused and the switch is on; marks the producers so that their own mask passes do not run."""
+    if mask_z is None or not mask_sinks or not sw.relu_producer_mask or not all(m.relu for m in mask_sinks):
+        return None
+    for m in mask_sinks:
+        m.masked = True
+    return mask_z
 
 
 class _Conv2d(torch.autograd.Function):
@@ -146,8 +127,7 @@ class _Conv2d(torch.autograd.Function):
     channels than w (the engine pads activations to multiples of 32) the weight is zero-padded to match."""
 
     @staticmethod
-    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, in_sinks=None,
-                mask_sinks=None, into=None):
+    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, into=None):
         _req(x, w_oihw, bias)
         _f32(w_oihw, bias)
         sfx = _sfx(x)
@@ -163,7 +143,7 @@ class _Conv2d(torch.autograd.Function):
             base, c_off = into
             y = base[..., c_off:c_off + Cout]
             _launch("wsmg_conv2d_fwd_bf16_ex", fl, _p(x), _p(w), _p(bias), ctypes.c_void_p(base.data_ptr() + c_off * 2), 2 if relu else 0,
-                    None, 0, None, base.shape[-1], *dims, _stream())
+                    None, 0, base.shape[-1], *dims, _stream())
         else:
             y = torch.empty(B, OH, OW, Cout, device=x.device, dtype=x.dtype)
             if sfx and stats is not None:   # + the output's BatchNorm sums in the epilogue (see bn_stats_slabs)
@@ -181,8 +161,6 @@ class _Conv2d(torch.autograd.Function):
         ctx.relu_sink = relu_sink if relu else None
         if ctx.relu_sink is not None:
             relu_sink.relu = True
-        ctx.in_sinks = in_sinks if sfx else None
-        ctx.mask_sinks = mask_sinks if sfx else None
         return y
 
     @staticmethod
@@ -209,12 +187,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if sfx:
-                # the hook on dx (round 6): BatchNorm-backward sums of the layer that produced x, or the fused ReLU's mask of x
-                aux = _grad_aux(ctx.in_sinks, x if ctx.mask_sinks else None, ctx.mask_sinks, B * H * W)
-                if aux is not None:
-                    _launch("wsmg_conv2d_bwd_data_bf16_ex", fl, _p(dy), _p(w_ihwo), _p(dx), _abi.aux_ptr(aux), None, 0, *dims, _stream())
-                else:
-                    _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
+                _launch("wsmg_conv2d_bwd_data_bf16", fl, _p(dy), _p(w_ihwo), _p(dx), 0, *dims, _stream())
             else:
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
@@ -223,7 +196,7 @@ class _Conv2d(torch.autograd.Function):
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
             db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class _ConvT2d(torch.autograd.Function):
@@ -231,7 +204,7 @@ class _ConvT2d(torch.autograd.Function):
     parameter [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW weight (O = Cin_t channels on the small grid)."""
 
     @staticmethod
-    def forward(ctx, x, w_iohw, stride, pad, stats=None, in_sinks=None):
+    def forward(ctx, x, w_iohw, stride, pad, stats=None):
         _req(x, w_iohw)
         _f32(w_iohw)
         sfx = _sfx(x)
@@ -251,7 +224,6 @@ class _ConvT2d(torch.autograd.Function):
             _launch("wsmg_conv2d_bwd_data", fl, _p(x), _p(w_ihwo), _p(y), *dims, _stream())
         ctx.save_for_backward(x, w)
         ctx.cfg = dims + (sfx,)
-        ctx.in_sinks = in_sinks if sfx else None
         return y
 
     @staticmethod
@@ -264,34 +236,28 @@ class _ConvT2d(torch.autograd.Function):
         fl = 2.0 * B * Hs * Ws * O * I * KH * KW
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            aux = _grad_aux(ctx.in_sinks, pixels=B * Hs * Ws) if sfx else None
-            if aux is not None:      # the input is a BatchNorm's output: its backward sums in this kernel's epilogue
-                _launch("wsmg_conv2d_fwd_bf16_ex", fl, _p(dy), _p(w), None, _p(dx), 0, None, 0, _abi.aux_ptr(aux), 0, *dims, _stream())
-            elif sfx:
+            if sfx:
                 _launch("wsmg_conv2d_fwd_bf16", fl, _p(dy), _p(w), None, _p(dx), 0, *dims, _stream())
             else:
                 _launch("wsmg_conv2d_fwd", fl, _p(dy), _p(w), None, _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(sfx, dy, x, tuple(dims), fl, I)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None
 
 
-def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, mask_sinks=None, into=None):
+def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, into=None):
     """x NHWC; weight = the reference's OIHW parameter (laid out for the engine in one launch inside the autograd
     node, so the parameter's .grad comes back OIHW float32).  bias_grad_zero: the output feeds a train-mode
     BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros.  relu: y = relu(conv + bias), fused into
-    the conv epilogue in bf16 mode.  relu_sink: see ReluSink / TokenGradSink.  mask_sinks: the ReluSinks of the fused-ReLU
-    convolutions whose outputs make up x — this convolution's backward-data kernel then applies their masks.  into = (base, c):
-    write the output into channels [c, c + Cout) of the bf16 tensor `base` [B,OH,OW,Ctot] (the concatenation that follows) and
-    return that slice.  A BatchNorm sink carried by x (ops.bn_act(sole_consumer=True)) is taken and used."""
-    in_sinks = _in_sinks(x) if (x.is_cuda and torch.is_grad_enabled()) else None
-    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats, relu_sink, in_sinks, mask_sinks, into)
+    the conv epilogue in bf16 mode.  relu_sink: see ReluSink / TokenGradSink.  into = (base, c): write the output into channels
+    [c, c + Cout) of the bf16 tensor `base` [B,OH,OW,Ctot] (the concatenation that follows) and return that slice."""
+    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats, relu_sink, into)
 
 
 class _Conv2dCat2(torch.autograd.Function):
     """relu(conv2d(cat([a, b], channels), w) + bias), bf16, where a and b ARE the two channel slices of `base` — written in place
     by their producers (conv2d(into=(base, .))) — so that no concatenation pass runs in either direction: forward reads `base`;
-    backward's input-gradient kernel masks the gradient with the producers' fused ReLUs (wsmg_bn_aux_t mode 1 on base) and stores
+    backward's input-gradient kernel masks the gradient with the producers' fused ReLUs (relu_y = base) and stores
     it as its two contiguous parts (dx2 / split_c), which go to the producers as they are.  mg_map_policy.py:89-100,197,207."""
 
     @staticmethod
@@ -331,8 +297,7 @@ class _Conv2dCat2(torch.autograd.Function):
         fl = 2.0 * B * H * W * Cout * Cin * 9
         da = torch.empty(B, H, W, ca, device=dy.device, dtype=dy.dtype)
         db = torch.empty(B, H, W, Cin - ca, device=dy.device, dtype=dy.dtype)
-        aux = _grad_aux(None, base, ctx.mask_sinks)
-        _launch("wsmg_conv2d_bwd_data_bf16_ex", fl, _p(dy), _p(w_ihwo), _p(da), _abi.aux_ptr(aux), _p(db), ca, *dims, _stream())
+        _launch("wsmg_conv2d_bwd_data_bf16_ex", fl, _p(dy), _p(w_ihwo), _p(da), _p(_mask_of(base, ctx.mask_sinks)), _p(db), ca, *dims, _stream())
         dw = _weight_grad("_bf16", base, dy, tuple(dims), fl, Cin) if ctx.needs_input_grad[3] else None
         dbias = channel_sum(dy.view(-1, Cout)) if (has_bias and ctx.needs_input_grad[4]) else None
         return da, db, None, dw, dbias, None, None, None
@@ -444,5 +409,4 @@ def conv_transpose2d_infer_bf16(x, w_ihwo_bf16, bias, stride, pad, relu):
 
 def conv_transpose2d(x, weight_iohw, stride=2, pad=1, stats=None):
     """nn.ConvTranspose2d weight is [Cin_t, Cout_t, KH, KW] = the adjoint conv's OIHW."""
-    in_sinks = _in_sinks(x) if (x.is_cuda and torch.is_grad_enabled()) else None
-    return _ConvT2d.apply(x, weight_iohw, stride, pad, stats, in_sinks)
+    return _ConvT2d.apply(x, weight_iohw, stride, pad, stats)

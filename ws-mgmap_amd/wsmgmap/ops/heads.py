@@ -313,3 +313,20 @@ def act_heads(features, prog_pred, fc_mean, logstd, critic_fc, noise=None):
     _abi.call("wsmg_act_heads", _p(features), B, K, _p(prog_pred.weight), _p(prog_pred.bias), _p(fc_mean.weight), _p(fc_mean.bias),
               _p(ls), A, _p(critic_fc.weight), _p(critic_fc.bias), _p(noise), _p(prog), _p(value), _p(action), _p(logp), _stream())
     return prog, value, action, logp
+
+
+@torch.no_grad()
+def colsum_multi(mats):
+    """[x.sum(0) for x in mats] for up to 16 contiguous float32 [rows, cols] GPU matrices in ONE launch (wsmg_colsum_multi): the bias
+    gradients of the recurrent core's dense layers.  Fixed summation order (bit-reproducible)."""
+    import ctypes
+    _req(*mats)
+    _f32(*mats)
+    outs = [torch.empty(m.shape[1], device=m.device, dtype=torch.float32) for m in mats]
+    for i in range(0, len(mats), 16):
+        grp = list(zip(mats[i:i + 16], outs[i:i + 16]))
+        arr = (_abi.ColsumDesc * len(grp))()
+        for j, (m, o) in enumerate(grp):
+            arr[j].x, arr[j].out, arr[j].rows, arr[j].cols = m.data_ptr(), o.data_ptr(), m.shape[0], m.shape[1]
+        _abi.call("wsmg_colsum_multi", ctypes.cast(arr, ctypes.c_void_p), len(grp), _stream())
+    return outs

@@ -188,8 +188,7 @@ class _Fanout3(torch.autograd.Function):
     float32 sums, one rounding) where autograd's own accumulation is two add launches over the tensor."""
 
     @staticmethod
-    def forward(ctx, x, sink=None):
-        ctx.sink = sink
+    def forward(ctx, x):
         return x.view_as(x), x.view_as(x), x.view_as(x)
 
     @staticmethod
@@ -200,29 +199,21 @@ class _Fanout3(torch.autograd.Function):
             gs = [g.contiguous() for g in gs]
             if all(g.data_ptr() % 16 == 0 for g in gs):
                 out = torch.empty_like(gs[0])
-                C = out.shape[-1]
-                # x is a BatchNorm's output with these three consumers: the sum IS that BatchNorm's incoming gradient, and the
-                # pass that forms it takes the backward sums (round 6: no reduction pass over it afterwards)
-                aux = ctx.sink.aux(0, out.numel() // C) if (ctx.sink is not None and 256 % max(C // 8, 1) == 0 and C % 8 == 0) else None
-                if aux is not None:
-                    _abi.call("wsmg_add3_bf16_aux", _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(out), out.numel() // C, _abi.aux_ptr(aux), _stream())
-                    return out, None
                 _abi.call("wsmg_add3_bf16", _p(gs[0]), _p(gs[1]), _p(gs[2]), _p(out), out.numel(), _stream())
-                return out, None
+                return out
         if not gs:
-            return None, None
+            return None
         out = gs[0]
         for g in gs[1:]:
             out = out + g
-        return out, None
+        return out
 
 
-def fanout3(x, sink=None):
-    """(x, x, x) for an activation with three consumers, whose gradients then meet in one launch (see _Fanout3).  sink: the
-    BnGradSink of the BatchNorm that produced x (ops.take_sink) — the three consumers are its whole fan-out."""
+def fanout3(x):
+    """(x, x, x) for an activation with three consumers, whose gradients then meet in one launch (see _Fanout3)."""
     if not (x.requires_grad and torch.is_grad_enabled()):
         return x, x, x
-    return _Fanout3.apply(x, sink)
+    return _Fanout3.apply(x)
 
 
 class _Up2Cat(torch.autograd.Function):
@@ -230,13 +221,12 @@ class _Up2Cat(torch.autograd.Function):
     channel slice (read in place: wsmg_upsample2x_bwd_ld) and dy's second slice as a view, as `_Up2` + `_CatChannels` return them."""
 
     @staticmethod
-    def forward(ctx, a, b, sink_a=None):
+    def forward(ctx, a, b):
         B, H, W, Ca = a.shape
         Cb = b.shape[-1]
         y = torch.empty(B, 2 * H, 2 * W, Ca + Cb, device=a.device, dtype=torch.bfloat16)
         _abi.call("wsmg_upsample2x_cat_bf16", _p(a), _p(b), _p(y), B, H, W, Ca, Cb, _stream())
         ctx.shape = (B, H, W, Ca)
-        ctx.sink_a = sink_a
         return y
 
     @staticmethod
@@ -246,15 +236,11 @@ class _Up2Cat(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             part, ld = _rows_of(dy[..., :Ca], Ca)
             da = torch.empty(B, H, W, Ca, device=dy.device, dtype=dy.dtype)
-            # `a` is a BatchNorm's output and this its only consumer: the upsampling's backward takes that BatchNorm's sums (round 6)
-            aux = ctx.sink_a.aux(0, B * H * W) if (ctx.sink_a is not None and Ca % 8 == 0 and 256 % (Ca // 8) == 0) else None
-            if aux is not None:
-                _abi.call("wsmg_upsample2x_bwd_ld_bf16_aux", _p(part), ld, _p(da), B, H, W, Ca, _abi.aux_ptr(aux), _stream())
-            elif ld != Ca:
+            if ld != Ca:
                 _abi.call("wsmg_upsample2x_bwd_ld_bf16", _p(part), ld, _p(da), B, H, W, Ca, _stream())
             else:
                 _abi.call("wsmg_upsample2x_bwd_bf16", _p(part), _p(da), B, H, W, Ca, _stream())
-        return da, (dy[..., Ca:] if ctx.needs_input_grad[1] else None), None
+        return da, (dy[..., Ca:] if ctx.needs_input_grad[1] else None)
 
 
 def upsample2x_cat(a, b):
@@ -266,14 +252,7 @@ def upsample2x_cat(a, b):
     B, H, W, Ca = a.shape
     if b.shape[:3] != (B, 2 * H, 2 * W):
         raise _abi.WsmgError(f"upsample2x_cat: {tuple(b.shape)} is not twice the size of {tuple(a.shape)}")
-    from .norm import take_sink
-    grad = torch.is_grad_enabled()
-    sink_a = take_sink(a) if grad else None
-    sink_b = take_sink(b) if grad else None
-    y = _Up2Cat.apply(a.contiguous(), b.contiguous(), sink_a)
-    if sink_b is not None:
-        y._bn_sinks = [(Ca, sink_b)]      # channels [Ca, Ca + Cb) of y's gradient are b's BatchNorm's (ops.conv._in_sinks)
-    return y
+    return _Up2Cat.apply(a.contiguous(), b.contiguous())
 
 
 def cat_channels(a, b):

@@ -20,45 +20,9 @@ def channel_sum(x2d):
 
 
 # ----------------------------------------------------------------------------- batch norm (+res)(+relu)
-class BnGradSink:
-    """Links a train-mode BatchNorm (+ ReLU) to the ONE operator that consumes its output (round 6).  That operator's backward
-    produces the BatchNorm's incoming gradient; handed this object (`out._bn_sink`, read by ops.conv2d / conv_transpose2d /
-    upsample2x_cat / fanout3), it passes `aux()` to its gradient kernel, whose epilogue then masks the gradient with the ReLU and
-    stores every workgroup's partial sums (sum g, sum g xhat) as a block of `part` (csrc/wsmg_bn_aux.h); the BatchNorm's backward
-    then skips its reduction pass over dy and x (wsmg_bn_act_bwd_bf16_parts).  A tensor with several consumers must NOT carry a
-    sink (each consumer's gradient is only a part of the sum)."""
-
-    def __init__(self):
-        self.x = self.mean = self.invstd = self.gamma = self.beta = None
-        self.relu = False
-        self.part = None       # float64 [cap_blocks, 2, C], filled by the producer's launch
-        self._aux = None
-
-    def ready(self):
-        return self.x is not None
-
-    @property
-    def blocks(self):
-        return 0 if self._aux is None else int(self._aux.blocks)
-
-    def aux(self, c0, pixels):
-        """The wsmg_bn_aux_t for a gradient of `pixels` pixels whose channels [c0, c0 + C) are this BatchNorm's (None if the sink
-        cannot be used, or was used already)."""
-        if not self.ready() or self._aux is not None:
-            return None
-        C = self.x.shape[-1]
-        if self.x.numel() // C != pixels:
-            return None
-        cap = max((int(pixels) + 127) // 128 + 8, 1032)     # (convolution tiles of >= 128 pixels; the elementwise producers' <= 1024 workgroups)
-        self.part = torch.empty(cap, 2, C, device=self.x.device, dtype=torch.float64)
-        self._aux = _abi.BnAux(self.x.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr(),
-                               self.part.data_ptr(), 2 if self.relu else 3, int(c0), C, C, cap, 0)
-        return self._aux
-
-
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats=None, sink=None):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats=None):
         _req(x, residual, gamma, beta, running_mean, running_var)
         _f32(gamma, beta, running_mean, running_var)
         sfx = _sfx(x)
@@ -86,10 +50,6 @@ class _BnAct(torch.autograd.Function):
         keep_y = relu and residual is not None
         ctx.save_for_backward(x, y if keep_y else None, gamma, beta, mean, invstd)
         ctx.cfg = (rows, C, int(relu), residual is not None, bool(train), sfx)
-        ctx.sink = None
-        if sink is not None and train and sfx and residual is None and C % 8 == 0 and sw.bn_producer_sums:
-            sink.x, sink.mean, sink.invstd, sink.gamma, sink.beta, sink.relu = x, mean, invstd, gamma, beta, bool(relu)
-            ctx.sink = sink
         return y
 
     @staticmethod
@@ -103,14 +63,6 @@ class _BnAct(torch.autograd.Function):
         dres = torch.empty_like(x) if has_res else None
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
-        sink = ctx.sink
-        if sink is not None and sink.blocks > 0:
-            # the kernel that produced dy masked it and left its partial sums (BnGradSink): no reduction pass over dy and x
-            scratch = torch.empty(64, 2, C, device=x.device, dtype=torch.float64) if sink.blocks > 1536 else None
-            _abi.call("wsmg_bn_act_bwd_bf16_parts", _p(dy), ld, _p(x), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
-                      _p(dx), _p(dgamma), _p(dbeta), _p(sink.part), sink.blocks, _p(scratch), 64, _stream())
-            sink.part = None
-            return dx, None, dgamma, dbeta, None, None, None, None, None, None, None, None
         ws = _workspace(x.device)
         if ld != C:     # a channel slice of a concatenation's gradient, read in place
             _abi.call("wsmg_bn_act_bwd_ld" + sfx, _p(dy), ld, _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
@@ -118,26 +70,11 @@ class _BnAct(torch.autograd.Function):
         else:
             _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
                       _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5, stats=None, sole_consumer=False):
-    """sole_consumer: the caller promises that the returned tensor is read by exactly ONE differentiable operator — that operator may
-    then take the BatchNorm-backward sums in its gradient kernel's epilogue (BnGradSink; the tensor carries the sink as `_bn_sink`)."""
-    sink = BnGradSink() if (sole_consumer and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
-                            and not torch.cuda.is_current_stream_capturing()) else None
-    out = _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats, sink)
-    if sink is not None and sink.ready():
-        out._bn_sink = sink
-    return out
-
-
-def take_sink(t):
-    """The BnGradSink a tensor carries (and may hand on ONCE: the attribute is removed, a second consumer gets None)."""
-    s = getattr(t, "_bn_sink", None)
-    if s is not None:
-        del t._bn_sink
-    return s
+def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5, stats=None):
+    return _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats)
 
 
 BN_SLABS = 64

@@ -493,23 +493,25 @@ class _RecurrentBlock(torch.autograd.Function):
         # parameter gradients: full-batch GEMMs and column sums, off the chain
         with torch.cuda.stream(sl):
             g2 = dgi2r
-            dw_ih2, db_ih2 = g2.t() @ xc, g2.sum(0)
-            hp2 = torch.cat([h02.unsqueeze(0), y2[:-1]], dim=0) * m.unsqueeze(-1)
             gh2 = dgh2.view(B, 3 * H)
-            dw_hh2, db_hh2 = gh2.t() @ hp2.view(B, H), gh2.sum(0)
+            g1 = dgi1.view(B, 3 * H)
+            gh1 = dgh1.view(B, 3 * H)
+            # the seven bias gradients (column sums) in one launch (round 6; torch: a reduction kernel + a memset each)
+            db_ih2, db_hh2, dbc, dbq2, dbq1, db_hh1, db_ih1 = _ops.colsum_multi([g2, gh2, dxc, dq2, dq1, gh1, g1])
+            dw_ih2 = g2.t() @ xc
+            hp2 = torch.cat([h02.unsqueeze(0), y2[:-1]], dim=0) * m.unsqueeze(-1)
+            dw_hh2 = gh2.t() @ hp2.view(B, H)
             if rg:
                 x = torch.cat([y1r, text_emb, x], dim=1)          # (x held map_emb)
-            dwc, dbc = dxc.t() @ x, dxc.sum(0)
+            dwc = dxc.t() @ x
             dwk = (q2.t() @ dqf).reshape(wk_shape)
             # (the key projection's bias adds the same number to every token's logit: it cancels in the softmax, gradient exactly 0)
             dbk = torch.zeros(wk_shape[0], **f32) if params[9] is not None else None
-            dwq2, dbq2 = dq2.t() @ text_emb, dq2.sum(0)
-            dwq1, dbq1 = dq1.t() @ y1r, dq1.sum(0)
-            g1 = dgi1.view(B, 3 * H)
+            dwq2 = dq2.t() @ text_emb
+            dwq1 = dq1.t() @ y1r
             hp1 = torch.cat([h01.unsqueeze(0), y1[:-1]], dim=0) * m.unsqueeze(-1)
-            gh1 = dgh1.view(B, 3 * H)
-            dw_hh1, db_hh1 = gh1.t() @ hp1.view(B, H), gh1.sum(0)
-            dw_ih1, db_ih1 = g1.t() @ state_in, g1.sum(0)
+            dw_hh1 = gh1.t() @ hp1.view(B, H)
+            dw_ih1 = g1.t() @ state_in
         pgrads = [dw_ih1, db_ih1, dw_hh1, db_hh1, dwq1, dbq1, dwq2, dbq2, dwk, dbk, dwc, dbc, dw_ih2, db_ih2, dw_hh2, db_hh2]
         _core.chain_in_flight = False      # every kernel of this block's backward is queued: the gradient exchange may issue buckets again
         if multi:
