@@ -42,4 +42,7 @@ PY
      rm -rf gpurun_out/st_$arm
    done
    unset WSMG_BN_PRODUCER_SUMS ;;
+6) python -m pytest tests/test_gpu_round6.py -q 2>&1 | tail -12 > gpurun_out/c6_r6.txt
+   python tools/igemm_tile_ab.py 30 > gpurun_out/c6_igemm.txt 2>&1
+   tools/ab.sh c6_bm 3 30 "X=1" "WSMG_IGEMM_BM256=0" > gpurun_out/c6_bm.txt 2>&1 ;;
 esac
