@@ -711,15 +711,16 @@ int wsmg_instruction_dedup(const void* tokens, int is_f32, int B, int L, long lo
  * Chaining to the whole-sequence GRU launches (wsmg_gru_fwd_chain / _bwd_chain): wait_count (may be NULL): the product does not
  * read its operands before *wait_count >= wait_target (they are produced by a kernel still running on another stream) — the wait,
  * bounded, is a ONE-workgroup launch in front of the product on the same stream (a grid of spinning workgroups could keep that
- * producer off the CUs; WSMG_CHAIN_GATE=0: the wait inside every workgroup of the product, round 5's first form); a timeout sets bit
- * `fail_bit` of the persistent kernels' status word (wsmg_rnn_status) and fills the output with NaN.  signal_count (may be NULL):
- * every workgroup adds one arrival when its tile is stored. */
+ * producer off the CUs); its verdict travels through `gate_word` (one device word of the caller's, required with wait_count, written
+ * by every call: nothing to initialise; one word per concurrent pass and chunk); a timeout sets bit `fail_bit` of the persistent
+ * kernels' status word (wsmg_rnn_status) and fills the output with NaN.  signal_count (may be NULL): every workgroup adds one
+ * arrival when its tile is stored. */
 int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const float* a1, int lda1, int ka1, const float* a2, int lda2, int ka2,
                        const float* w, int ldw, int w_is_kn, const float* bias, const float* mask, int ldmask, int relu,
                        float* c0, int ldc0, int nc0, float* c1, int ldc1, int nc1, float* c2, int ldc2, int nc2,
                        const float* cin0, int ldcin0, const float* cin1, int ldcin1, const float* cin2, int ldcin2,
                        int M, const unsigned* wait_count, unsigned wait_target, unsigned* signal_count, int fail_bit,
-                       wsmg_stream_t stream);
+                       unsigned* gate_word, wsmg_stream_t stream);
 /* workgroups one wsmg_rows_gemm_f32 launch of M rows x N columns runs (= the arrivals it adds to signal_count) */
 int wsmg_rows_gemm_workgroups(int M, int N);
 

@@ -1151,7 +1151,7 @@ extern "C" int wsmg_map_retrieve_tiled(const float* global_map, const float* gps
   // i / S4 as a multiply-high: exact while i * S4 < 2^32 (i < 16 * 14 * S4)
   const unsigned magic = 0xFFFFFFFFu / (unsigned)S4 + 1u;
   static unsigned* trace_dev = nullptr;
-  const bool tracing = WSMG_TUNE("WSMG_RETRIEVE_TRACE", 0) != 0;
+  const bool tracing = (0) != 0;
   if (tracing && !trace_dev && hipMalloc((void**)&trace_dev, 64 * 8 * sizeof(unsigned)) != hipSuccess) trace_dev = nullptr;
   const int nblk = tiles * tiles * nsplit;
   hipLaunchKernelGGL(map_retrieve_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), lds, wsmg_s(stream),

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // pipeline variant: WSMG_CONV_DB=0/1 (tuning knob; default set from measurements)
-bool conv_double_buffer() { return WSMG_TUNE("WSMG_CONV_DB", 0) != 0; }
+bool conv_double_buffer() { return (0) != 0; }
 
 int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, int OH, int OW) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0) return WSMG_EINVAL;

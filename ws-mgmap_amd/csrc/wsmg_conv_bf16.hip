@@ -593,10 +593,7 @@ int check_conv(int B, int H, int W, int Cin, int Cout, int KH, int KW, int strid
 
 // register prefetch depth (k-steps in flight).  Measured on MI355X (tools/bench_conv.py): the igemm
 // kernels are fastest at 1 (deeper costs occupancy, which hides more latency than the prefetch does).
-int conv_prefetch(int dflt) {
-  const int v = WSMG_TUNE("WSMG_CONV_PF", -1);
-  return (v >= 1 && v <= 3) ? v : dflt;
-}
+int conv_prefetch(int dflt) { return dflt; }
 
 int g_win3_tile = -1;
 int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 256 = that many pixels per workgroup
@@ -670,9 +667,7 @@ int splitk_plan(int64_t M, int Kc, int N, int KH, int KW) {
   const int bk = (Kc % 64) == 0 ? 64 : 32;
   const int steps = KH * KW * (Kc / bk);
   const int tiles = (int)(wsmg_cdiv(M, BM) * wsmg_cdiv(N, 64));
-  const int target = WSMG_TUNE("WSMG_SPLITK_TARGET", 256) > 0 ? WSMG_TUNE("WSMG_SPLITK_TARGET", 256) : 256;
-  const int minsteps = WSMG_TUNE("WSMG_SPLITK_MINSTEPS", 4) > 0 ? WSMG_TUNE("WSMG_SPLITK_MINSTEPS", 4) : 4;
-  const int maxtiles = WSMG_TUNE("WSMG_SPLITK_MAXTILES", 128) > 0 ? WSMG_TUNE("WSMG_SPLITK_MAXTILES", 128) : 128;
+  const int target = 256, minsteps = 4, maxtiles = 128;
   if (tiles >= maxtiles || steps < 4 * minsteps || (N & 7)) return 1;
   int ks = (int)wsmg_cdiv(target, tiles);
   if (ks > steps / minsteps) ks = steps / minsteps;
@@ -928,10 +923,6 @@ WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW
   // (the 64-channel k8 stem, 128 units of 64 input channels: 64 co x 8 units measured 0.94 vs 0.99 ms; every other
   // 64-wide layer is faster with 4 units)
   int tc = (Cout % 128 == 0 && units >= 48) ? 4 : 2, tu = (tc == 4 || (Cin == 64 && units >= 128)) ? 2 : 1;
-  {   // tuning: WSMG_WGRAD_TILE = 42, 21 or 22
-    const int v = WSMG_TUNE("WSMG_WGRAD_TILE", 0);
-    if (v == 42 || v == 21 || v == 22) { tc = v / 10; tu = v % 10; }
-  }
   const int gx = (int)wsmg_cdiv(units, 4 * tu), gy = (int)wsmg_cdiv(Cout, 32 * tc);
   // workgroups over the pixel reduction (the k8 stem's 64 x 8 tile: 0.90 ms at 2048, 0.96 at 1024).  Every workgroup ends
   // with its tile going to memory — float atomics, 40-50 % of the launch for the small layers, or (slab form) plain stores
@@ -939,7 +930,6 @@ WgradPlan wgrad_plan_bf16(int B, int H, int W, int Cin, int Cout, int KH, int KW
   // layers of the update; tools sweep, WSMG_WGRAD_WANT)
   const double gflop = 2.0 * (double)npix * Cout * Cin * KH * KW * 1e-9;
   int64_t target = tc == 4 ? 1024 : (gflop < 40.0 ? 768 : 2048);
-  if (const int v = WSMG_TUNE("WSMG_WGRAD_WANT", 0); v > 0) target = v;
   int64_t want = wsmg_cdiv(target, (int64_t)gx * gy);
   int64_t maxz = wsmg_cdiv(npix, WKP * 8);
   int64_t gz = want < 1 ? 1 : (want > maxz ? maxz : want);

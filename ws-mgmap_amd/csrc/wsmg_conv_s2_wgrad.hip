@@ -227,7 +227,6 @@ const S2wShape* s2w_shape(int B, int H, int W, int Cin, int Cout, int KH, int KW
 int s2w_groups(const S2wShape* s, int B, int OH) {
   const int ntiles = B * ((OH + s->TH - 1) / s->TH);
   int groups = s->groups;
-  if (const int g = WSMG_TUNE("WSMG_S2WIN_GROUPS", 0); g > 0) groups = g;
   if (groups > ntiles) groups = ntiles;
   return (groups + 7) / 8 * 8;   // whole XCD rounds (groups beyond the tile count find no tile and flush zeros)
 }

@@ -270,7 +270,6 @@ int wsmg_conv_win_fwd_bf16(const void* x, const void* w_ohwi, const float* bias,
     attr = true;
   }
   int ntiles = B * a.tiles_y * a.tiles_x, grid = ntiles < 256 ? ntiles : 256;
-  if (const int g = WSMG_TUNE("WSMG_WIN_GRID", 0); g > 0) grid = g < ntiles ? g : ntiles;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, s, a);
   WSMG_RETURN_LAUNCH();
 }

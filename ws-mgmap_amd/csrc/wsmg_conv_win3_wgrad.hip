@@ -324,11 +324,9 @@ W3wVariant w3w_variant(int B, int H, int W, int Cin, int Cout) {
   if (nmax * PW >= (1ull << 32)) return V_NONE;
   auto fits = [&](W3wVariant v) { return kShape[v].ks + 2 * (W + 3) <= kShape[v].xcap; };
   if (Cout % 128 == 0 && Cin % 64 == 0) return fits(V421) ? V421 : V_NONE;
-  // WSMG_WIN3W_SMALL: bit 0 = V222, bit 1 = V412, bit 2 = V118 (A/B: 0 keeps the generic kernel for the small-channel layers)
-  const int small = WSMG_TUNE("WSMG_WIN3W_SMALL", 7);
-  if (Cout % 64 == 0 && Cin % 64 == 0) return ((small & 1) && fits(V222)) ? V222 : V_NONE;
-  if (Cout % 128 == 0 && Cin % 32 == 0) return ((small & 2) && fits(V412)) ? V412 : V_NONE;
-  if (Cout % 32 == 0 && Cin % 32 == 0) return ((small & 4) && fits(V118)) ? V118 : V_NONE;
+  if (Cout % 64 == 0 && Cin % 64 == 0) return fits(V222) ? V222 : V_NONE;
+  if (Cout % 128 == 0 && Cin % 32 == 0) return fits(V412) ? V412 : V_NONE;
+  if (Cout % 32 == 0 && Cin % 32 == 0) return fits(V118) ? V118 : V_NONE;
   return V_NONE;
 }
 
@@ -338,7 +336,6 @@ void plan_w3w(W3wArgs& a, W3wVariant v) {
   a.gci = a.Cin / (32 * kShape[v].wci);
   const int ntile = a.gco * a.gci;
   int gz = w3w_cus() / ntile;
-  if (const int t = WSMG_TUNE("WSMG_WIN3W_SPLITS", 0); t > 0) gz = t;
   if (gz < 1) gz = 1;
   if (gz > a.B) gz = a.B;
   a.imgs = (a.B + gz - 1) / gz;
@@ -387,20 +384,13 @@ int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, lon
   W3wArgs a{(const bf16_t*)x, (const bf16_t*)dy, dw_ohwi, (int64_t)slab_floats, B, H, W, Cin, Cout, 0, 0, 0, 0, (unsigned)((1ull << 32) / PW + 1),
             (unsigned)((size_t)B * H * W * Cin * 2), (unsigned)((size_t)B * H * W * Cout * 2)};
   // V421: waves 0-3 load (measured at B = 512: 0.373 / 0.205 / 0.206 ms on the 256->256, 128->256 and 256->128 layers against 0.404 /
-  // 0.216 / 0.216 with all eight loading, and 0.421 / 0.247 / 0.225 for the generic kernel); WSMG_WIN3W_LOADERS=8: all eight (A/B).
-  const int nlw = WSMG_TUNE("WSMG_WIN3W_LOADERS", 4);
+  // 0.216 / 0.216 with all eight loading, and 0.421 / 0.247 / 0.225 for the generic kernel); four LDS stages except for the 32 x 32
+  // tiling (three: profiles/r05_win3w_stages_ab.txt — five and six lost, eight loaders lost; those forms are gone)
   switch (v) {
-    case V421:
-      if (nlw == 8) return launch_w3w<4, 2, 1, 3, 104, 8>(a, v, s);
-      switch (WSMG_TUNE("WSMG_WIN3W_STAGES", 4)) {
-        case 3: return launch_w3w<4, 2, 1, 3, 104, 4, 3>(a, v, s);
-        case 5: return launch_w3w<4, 2, 1, 3, 104, 4, 5>(a, v, s);
-        case 6: return launch_w3w<4, 2, 1, 3, 104, 4, 6>(a, v, s);
-        default: return launch_w3w<4, 2, 1, 3, 104, 4, 4>(a, v, s);
-      }
-    case V222: return WSMG_TUNE("WSMG_WIN3W_STAGES_222", 4) == 4 ? launch_w3w<2, 2, 2, 2, 120, 8, 4>(a, v, s) : launch_w3w<2, 2, 2, 2, 120, 8>(a, v, s);
-    case V412: return WSMG_TUNE("WSMG_WIN3W_STAGES_412", 4) == 4 ? launch_w3w<4, 1, 2, 2, 128, 8, 4>(a, v, s) : launch_w3w<4, 1, 2, 2, 128, 8>(a, v, s);
-    case V118: return WSMG_TUNE("WSMG_WIN3W_STAGES_118", 3) == 4 ? launch_w3w<1, 1, 8, 2, 368, 8, 4>(a, v, s) : launch_w3w<1, 1, 8, 2, 368, 8>(a, v, s);
+    case V421: return launch_w3w<4, 2, 1, 3, 104, 4, 4>(a, v, s);
+    case V222: return launch_w3w<2, 2, 2, 2, 120, 8, 4>(a, v, s);
+    case V412: return launch_w3w<4, 1, 2, 2, 128, 8, 4>(a, v, s);
+    case V118: return launch_w3w<1, 1, 8, 2, 368, 8>(a, v, s);
     default: return WSMG_EINVAL;
   }
 }

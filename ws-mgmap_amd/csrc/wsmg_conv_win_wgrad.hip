@@ -241,7 +241,6 @@ static bool winw_fits(int B, int H, int W, int Cin, int Cout, int KH, int KW, in
 static int winw_groups(int B, int OH, int OW) {
   const int ntiles = B * ((OH + TH - 1) / TH) * ((OW + TW - 1) / TW);
   int groups = 64;   // 8 roles x 64 groups = 512 workgroups = 2 per CU (78 KB of LDS each)
-  if (const int g = WSMG_TUNE("WSMG_WIN_WGRAD_GROUPS", 0); g > 0) groups = g;
   if (groups > ntiles) groups = ntiles;
   return (groups + 7) / 8 * 8;   // whole XCD rounds (groups beyond the tile count find no tile and only flush zeros)
 }

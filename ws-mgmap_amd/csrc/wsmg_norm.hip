@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
 
 // WSMG_BN_VEC8=0: the 4-channel kernels for bf16 as well (A/B)
 bool bn_vec8() {
-  return WSMG_TUNE("WSMG_BN_VEC8", 1) != 0;
+  return (1) != 0;
 }
 
 int stream_grid8(int64_t rows, int C) {

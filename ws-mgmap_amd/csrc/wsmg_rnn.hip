@@ -226,118 +226,8 @@ __device__ __forceinline__ void halve_row(float (&v)[NV], int lane) {
   }
 }
 
-// Work split: wave = 4 hidden units; 16-lane row g of the wave owns unit u0+g (its r, z, n rows of W_hh in
-// registers); the 16 lanes of a row split K = 512 (32 k each, as 8 interleaved float4s), so the reduction
-// is a 4-stage butterfly inside a row (31 lane exchanges per step, 23 of them DPP) instead of a 7-stage
-// one across the wave (127 ds_bpermute, which measured 3.7 us of a 9.9 us step).
-__global__ __launch_bounds__(256) void gru_fwd_kernel(GruFwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float hs[2][NB][H];   // h_{t-1}, double-buffered by step parity
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = lane >> 4, kl = lane & 15;
-  const int my_unit = blockIdx.x * UNITS_WG + wave * UNITS_WAVE + grp;
-  // W_hh rows (r, z, n) of my_unit: k = 64 j + 4 kl + e
-  float w[3][32];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(a.whh + (size_t)(g * H + my_unit) * H + 64 * j + 4 * kl);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[g][4 * j + e] = v[e];
-    }
-  // after the butterfly lane kl of a row holds acc index 2 kl + {0,1} with index = 4 b + gate: even lanes
-  // (r, z) of batch kl/2, odd lanes (n, -).  Even lanes do the gate math for (my_unit, my_b).
-  const int my_b = kl >> 1;
-  const bool worker = ((kl & 1) == 0) && (my_b < a.N);
-  const float br = a.bhh[my_unit], bz = a.bhh[H + my_unit], bn = a.bhh[2 * H + my_unit];
-
-  // staging role of this thread: the 16 units of producer workgroup sw for batch sb
-  const int sw = tid >> 3, sb = tid & 7;
-  const int xw = (blockIdx.x * NB + my_b) * UNITS_WG + wave * UNITS_WAVE + grp;   // this lane's slot in a step image
-  for (int t = 0; t < a.T; ++t) {
-    float (*hcur)[H] = hs[t & 1];
-    // inputs of this step's gate math do not depend on the recurrence: fetch them before waiting
-    float gr = 0.f, gz = 0.f, gn = 0.f, mk = 0.f;
-    const size_t orow = (size_t)t * a.N + my_b;
-    if (worker) {
-      const float* g = a.gi + orow * 3 * H;
-      gr = g[my_unit]; gz = g[H + my_unit]; gn = g[2 * H + my_unit];
-      mk = a.masks[t * a.N + my_b];
-    }
-    {
-      float row[16];
-      bool good = true;
-      if (sb >= a.N) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) row[i] = 0.f;
-      } else if (t == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(a.h0 + (size_t)sb * H + sw * UNITS_WG + 4 * i);
-          row[4 * i] = v[0]; row[4 * i + 1] = v[1]; row[4 * i + 2] = v[2]; row[4 * i + 3] = v[3];
-        }
-      } else {
-        const unsigned long long* src = a.xh + ((size_t)(t - 1) * NWG + sw) * NB * UNITS_WG + sb * UNITS_WG;
-        good = poll_row16(src, a.tagbase | (unsigned)t, a.sync, row, a.spin);
-      }
-      // the mask of this step is applied once, here (h_{t-1} * mask_t is what every consumer needs)
-      const float sm = sb < a.N ? a.masks[t * a.N + sb] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v = {row[4 * i] * sm, row[4 * i + 1] * sm, row[4 * i + 2] * sm, row[4 * i + 3] * sm};
-        *reinterpret_cast<f32x4*>(&hcur[sb][sw * UNITS_WG + 4 * i]) = v;
-      }
-      // one workgroup barrier per step; it also orders the re-use of hs[t & 1] two steps later
-      if (__syncthreads_or(good ? 0 : 1)) {   // timeout or error elsewhere: every thread leaves
-        rnn_fail(a.status, 1u);
-        rnn_poison(a.y, (size_t)a.T * a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
-        return;
-      }
-    }
-    float acc[32];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-      if (b < a.N) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(&hcur[b][64 * j + 4 * kl]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s0 = fmaf(w[0][4 * j + e], hv[e], s0);
-            s1 = fmaf(w[1][4 * j + e], hv[e], s1);
-            s2 = fmaf(w[2][4 * j + e], hv[e], s2);
-          }
-        }
-      }
-      acc[4 * b] = s0; acc[4 * b + 1] = s1; acc[4 * b + 2] = s2; acc[4 * b + 3] = 0.f;
-    }
-    halve_row<32, 8>(acc, lane);
-    halve_row<16, 4>(acc, lane);
-    halve_row<8, 2>(acc, lane);
-    halve_row<4, 1>(acc, lane);
-    const float nsum = row_xor<1>(acc[0]);   // odd lane's acc[0] = n gate of the same batch
-    if (worker) {
-      const float ghr = acc[0] + br, ghz = acc[1] + bz, ghn = nsum + bn;
-      const float r = sigmoidf_(gr + ghr);
-      const float z = sigmoidf_(gz + ghz);
-      const float nn = tanhf(gn + r * ghn);
-      const float hprev = hcur[my_b][my_unit];   // already masked
-      const float h = (1.0f - z) * nn + z * hprev;
-      // publish first: the other workgroups are waiting for exactly this word
-      if (t + 1 < a.T)
-        __hip_atomic_store(a.xh + (size_t)t * NWG * NB * UNITS_WG + xw,
-                           ((unsigned long long)(a.tagbase | (unsigned)(t + 1)) << 32) | __float_as_uint(h),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a.y[orow * H + my_unit] = h;
-      a.sr[orow * H + my_unit] = r;
-      a.sz[orow * H + my_unit] = z;
-      a.sn[orow * H + my_unit] = nn;
-      a.sghn[orow * H + my_unit] = ghn;
-    }
-    (void)mk;
-  }
-}
+// (The four-wave forms of the two GRU kernels — rounds 1-2, then the WSMG_GRU_WAVES=4 arm of an A/B — are gone: the chained core has
+//  only ever run the eight-wave forms below.)
 
 // ---- 8-wave form of the forward kernel (round 3).  One wave per SIMD issues a vector instruction every 4 cycles, two every 2:
 // the 768 FMAs per lane of the 4-wave form are the longest phase of its step (1.8 us of 5.5).  Here waves w and w + 4 share the
@@ -519,137 +409,6 @@ constexpr int BWD_RING = 4;
 constexpr size_t XP_CONSUMER = (size_t)NWG * NB * UNITS_WG;   // words one consumer polls per step (4096)
 constexpr size_t XP_SLOT = (size_t)NWG * XP_CONSUMER;         // words per ring slot (1 MB)
 
-__global__ __launch_bounds__(256) void gru_bwd_kernel(GruBwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float part[NWG][NB][UNITS_WG];   // the 32 producers' partial sums for my units
-  __shared__ __attribute__((aligned(16))) float dgs[3 * UNITS_WG][NB];     // my gate gradients of this step: rows r, z, n
-  const int tid = threadIdx.x;
-  // gate rows (g, u) of my 16 units, columns k = 2 tid, 2 tid + 1
-  f32x2 w[3 * UNITS_WG];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int u = 0; u < UNITS_WG; ++u)
-      w[g * UNITS_WG + u] = *reinterpret_cast<const f32x2*>(a.whh + (size_t)(g * H + blockIdx.x * UNITS_WG + u) * H + 2 * tid);
-  // element-wise role (threads 0..127): unit wu of this workgroup, batch slot wb
-  const int wu = tid & 15, wb = tid >> 4;
-  const bool worker = tid < 128 && wb < a.N;
-  const int my_unit = blockIdx.x * UNITS_WG + wu;
-  // polling role: the 16 units of producer pq for batch slot pb
-  const int pq = tid >> 3, pb = tid & 7;
-  // publishing role: columns 2 tid, 2 tid + 1 belong to consumer workgroup tid / 8, its units (2 tid) % 16 and + 1
-  const size_t pub = ((size_t)(tid >> 3) * NWG + blockIdx.x) * NB * UNITS_WG + ((2 * tid) & 15);
-
-  float direct = 0.f, mk_next = 0.f;   // dh_{t+1} * z_{t+1} and mask_{t+1}: the non-recurrent part of dh_t
-  for (int t = a.T - 1; t >= -1; --t) {
-    // this step's element-wise inputs do not depend on the recurrence: fetch them before waiting
-    float dyv = 0.f, r = 0.f, z = 0.f, nn = 0.f, ghn = 0.f, hprev = 0.f, mk = 0.f;
-    size_t row = 0;
-    if (worker && t >= 0) {
-      row = (size_t)t * a.N + wb;
-      const size_t o = row * H + my_unit;
-      mk = a.masks[t * a.N + wb];
-      const float* hsrc = (t == 0) ? a.h0 : a.y + (size_t)(t - 1) * a.N * H;
-      hprev = hsrc[(size_t)wb * H + my_unit] * mk;
-      dyv = a.dy[o];
-      r = a.sr[o]; z = a.sz[o]; nn = a.sn[o]; ghn = a.sghn[o];
-    }
-    // gradient flowing into h_t from step t+1: mask_{t+1} * (dh_{t+1} z_{t+1} + sum_rows W_hh[row][u] dgate_{t+1}[row])
-    float carry = 0.f;
-    if (t == a.T - 1) {
-      if (worker && a.dhT) carry = a.dhT[(size_t)wb * H + my_unit];
-    } else {
-      bool good = true;
-      if (pb < a.N) {
-        float rowv[16];
-        const unsigned long long* src = a.xp + (size_t)((t + 1) % BWD_RING) * XP_SLOT + (size_t)blockIdx.x * XP_CONSUMER +
-                                        ((size_t)pq * NB + pb) * UNITS_WG;
-        good = poll_row16(src, a.tagbase | (unsigned)(t + 2), a.sync, rowv, a.spin);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 v = {rowv[4 * i], rowv[4 * i + 1], rowv[4 * i + 2], rowv[4 * i + 3]};
-          *reinterpret_cast<f32x4*>(&part[pq][pb][4 * i]) = v;
-        }
-      }
-      if (__syncthreads_or(good ? 0 : 1)) {   // timeout or error elsewhere: every thread leaves
-        rnn_fail(a.status, 2u);
-        for (int g = 0; g < 3; ++g) {
-          rnn_poison(a.dgi, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
-          rnn_poison(a.dgh, (size_t)a.T * a.N, 3 * H, g * H + blockIdx.x * UNITS_WG, UNITS_WG);
-        }
-        rnn_poison(a.dh0, (size_t)a.N, H, blockIdx.x * UNITS_WG, UNITS_WG);
-        return;
-      }
-      if (worker) {
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int q = 0; q < NWG; q += 2) { s0 += part[q][wb][wu]; s1 += part[q + 1][wb][wu]; }
-        carry = (direct + (s0 + s1)) * mk_next;
-      }
-    }
-    if (t < 0) {
-      if (worker) a.dh0[(size_t)wb * H + my_unit] = carry;
-      break;
-    }
-    if (tid < 128) {
-      float dr_pre = 0.f, dz_pre = 0.f, dnr = 0.f;
-      if (worker) {
-        const float dh = dyv + carry;
-        const float dn_pre = dh * (1.0f - z) * (1.0f - nn * nn);
-        dz_pre = dh * (hprev - nn) * z * (1.0f - z);
-        dr_pre = dn_pre * ghn * r * (1.0f - r);
-        dnr = dn_pre * r;
-        float* gi = a.dgi + row * 3 * H;
-        float* gh = a.dgh + row * 3 * H;
-        gi[my_unit] = dr_pre; gi[H + my_unit] = dz_pre; gi[2 * H + my_unit] = dn_pre;
-        gh[my_unit] = dr_pre; gh[H + my_unit] = dz_pre; gh[2 * H + my_unit] = dnr;
-        direct = dh * z;
-        mk_next = mk;
-      }
-      dgs[wu][wb] = dr_pre; dgs[UNITS_WG + wu][wb] = dz_pre; dgs[2 * UNITS_WG + wu][wb] = dnr;   // zeros for unused batch slots
-    }
-    __syncthreads();   // dgs complete; also: every read of part[] is done before the next step overwrites it
-    // my two columns of W_hh^T dgate for all batch slots
-    float acc0[NB], acc1[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) { acc0[b] = 0.f; acc1[b] = 0.f; }
-    // Groups of 8 rows, LDS reads in inline asm, each group's reads ordered behind the previous group's FMAs.  Left to
-    // itself the compiler issues all 96 reads first (384 live registers on top of the 96 weights): the weights end up
-    // in AGPRs / scratch and every FMA pays a v_accvgpr_read.  (v_pk_fma_f32 was tried: hipcc materialises the {w, w}
-    // broadcast pairs instead of using op_sel, 418 registers and 240 extra moves.)
-    const unsigned dgs_addr = (unsigned)(size_t)&dgs[0][0];
-#pragma unroll
-    for (int c8 = 0; c8 < 3 * UNITS_WG; c8 += 8) {
-      f32x4 d[16];
-      // asm volatile statements keep their order, and this one consumes every accumulator
-      asm volatile("" :: "v"(acc0[0]), "v"(acc0[1]), "v"(acc0[2]), "v"(acc0[3]), "v"(acc0[4]), "v"(acc0[5]), "v"(acc0[6]), "v"(acc0[7]),
-                         "v"(acc1[0]), "v"(acc1[1]), "v"(acc1[2]), "v"(acc1[3]), "v"(acc1[4]), "v"(acc1[5]), "v"(acc1[6]), "v"(acc1[7]));
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d[i]) : "v"(dgs_addr), "n"((c8 * NB + 4 * i) * 4) : "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
-                     "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rw = c8 + i;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          acc0[b] = fmaf(w[rw][0], d[2 * i][b], acc0[b]);             acc1[b] = fmaf(w[rw][1], d[2 * i][b], acc1[b]);
-          acc0[4 + b] = fmaf(w[rw][0], d[2 * i + 1][b], acc0[4 + b]); acc1[4 + b] = fmaf(w[rw][1], d[2 * i + 1][b], acc1[4 + b]);
-        }
-      }
-    }
-    unsigned long long* dst = a.xp + (size_t)(t % BWD_RING) * XP_SLOT + pub;
-    const unsigned long long tag = (unsigned long long)(a.tagbase | (unsigned)(t + 1)) << 32;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b < a.N) {
-        __hip_atomic_store(dst + b * UNITS_WG, tag | __float_as_uint(acc0[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + b * UNITS_WG + 1, tag | __float_as_uint(acc1[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
 
 // ---- 8-wave form of the backward kernel (round 3; see gru_fwd8_kernel).  Thread pair (tid, tid + 256) owns the same two columns
 // k = 2 c, 2 c + 1 (c = tid & 255) and splits the 48 gate ROWS: half q multiplies rows 24 q .. 24 q + 23 (24 weight pairs per lane
@@ -876,11 +635,7 @@ static int gru_fwd_launch(const float* gi, const float* w_hh, const float* b_hh,
   if (clear && (e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)T * NWG * NB * UNITS_WG * 8, s)) != hipSuccess) return (int)e;
   GruFwdArgs a{gi, w_hh, b_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin, Tc, in_cnt, in_target, out_cnt};
-  if (Tc > 0 || WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave forward kernel (A/B; not chained)
-    hipLaunchKernelGGL(gru_fwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
-    WSMG_RETURN_LAUNCH();
-  }
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gru_fwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 
@@ -912,11 +667,7 @@ static int gru_bwd_launch(const float* dy, const float* dhT, const float* w_hh, 
   if (clear && (e = hipMemsetAsync(sync_ws, 0, 256 + (size_t)BWD_RING * XP_SLOT * 8, s)) != hipSuccess) return (int)e;
   GruBwdArgs a{dy, dhT, w_hh, h0, masks, y, save_r, save_z, save_n, save_ghn, dgi, dgh, dh0, (unsigned*)sync_ws,
                (unsigned long long*)((char*)sync_ws + 256), T, N, next_tagbase(), rnn_status_dev(), g_spin, Tc, in_cnt, in_target, out_cnt};
-  if (Tc > 0 || WSMG_TUNE("WSMG_GRU_WAVES", 8) == 8) {       // WSMG_GRU_WAVES=4: the 4-wave backward kernel (A/B; not chained)
-    hipLaunchKernelGGL(gru_bwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
-    WSMG_RETURN_LAUNCH();
-  }
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(NWG), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gru_bwd8_kernel, dim3(NWG), dim3(512), 0, s, a);
   WSMG_RETURN_LAUNCH();
 }
 

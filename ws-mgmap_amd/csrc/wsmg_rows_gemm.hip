@@ -181,7 +181,8 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
                                   float* c0, int ldc0, int nc0, float* c1, int ldc1, int nc1, float* c2, int ldc2, int nc2,
                                   const float* cin0, int ldcin0, const float* cin1, int ldcin1, const float* cin2, int ldcin2,
                                   int M, const unsigned* wait_count, unsigned wait_target, unsigned* signal_count, int fail_bit,
-                                  wsmg_stream_t stream) {
+                                  unsigned* gate_word, wsmg_stream_t stream) {
+  if (wait_count && !gate_word) return WSMG_EINVAL;
   if (!a0 || !w || !c0 || M <= 0 || ka0 <= 0 || nc0 <= 0) return WSMG_EINVAL;
   if ((ka1 > 0 && !a1) || (ka2 > 0 && !a2) || (nc1 > 0 && !c1) || (nc2 > 0 && !c2) || ka1 < 0 || ka2 < 0 || nc1 < 0 || nc2 < 0) return WSMG_EINVAL;
   if (ka2 > 0 && ka1 <= 0) return WSMG_EINVAL;
@@ -205,24 +206,18 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
   g.wait_cnt = wait_count; g.wait_target = wait_target; g.signal_cnt = signal_count;
   g.status = wait_count ? wsmgi_rnn_status_dev() : nullptr; g.fail_bit = (unsigned)fail_bit;
   g.gate = nullptr;
-  if (wait_count && WSMG_TUNE("WSMG_CHAIN_GATE", 1) != 0) {     // (0: the wait inside the product, as before — A/B)
-    static unsigned* gates_of[64] = {};    // per device: one word per fail bit (launches that share one are ordered on one stream)
-    int devi = 0;
-    if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= 64) return WSMG_EINVAL;
-    unsigned*& gates = gates_of[devi];
-    if (!gates) {
-      if (hipMalloc((void**)&gates, 32 * sizeof(unsigned)) != hipSuccess) return WSMG_ENOMEM;
-      if (hipMemset(gates, 0, 32 * sizeof(unsigned)) != hipSuccess) return WSMG_ENOMEM;
-    }
-    unsigned* gate = gates + (__builtin_ctz((unsigned)fail_bit | 0x80000000u) & 31);
-    hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(64), 0, wsmg_s(stream), wait_count, wait_target, g.status, g.fail_bit, gate);
+  if (wait_count) {
+    // the wait is a ONE-workgroup launch in front of the product (a grid of spinning workgroups can keep the producer it waits for off
+    // the CUs: DESIGN.md section 5); its verdict goes through the CALLER's word (round 6, ADVICE r05: a process-wide word per fail
+    // bit let a second stream's gate overwrite a timeout before this product had read it)
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(1), dim3(64), 0, wsmg_s(stream), wait_count, wait_target, g.status, g.fail_bit, gate_word);
     g.wait_cnt = nullptr;
-    g.gate = gate;
+    g.gate = gate_word;
   }
   const dim3 grid((unsigned)(N / 16), (unsigned)wsmg_cdiv(M, 16));
   // (waves, chunks per wave) with waves x 16 x chunks == K: K = 256: 16 x 1, 512: 16 x 2, 1024: 16 x 4, 1536: 16 x 6 — every product of
-  // the recurrent core is one round of loads; other multiples of 64: 4 waves; WSMG_ROWS_GEMM_WAVES caps the waves (A/B)
-  const int cap = WSMG_TUNE("WSMG_ROWS_GEMM_WAVES", 16);
+  // the recurrent core is one round of loads; other multiples of 64: 4 waves
+  const int cap = 16;
   hipStream_t st = wsmg_s(stream);
   const int c16 = K / 16;                           // 16-deep chunks in all
   if (cap >= 16 && c16 % 16 == 0 && c16 / 16 <= 8) {

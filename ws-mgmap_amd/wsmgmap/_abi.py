@@ -155,7 +155,7 @@ _SIG["wsmg_path_kl_bwd"] = [c_p, c_p, c_p, c_i, c_i, c_p, c_p]
 _SIG["wsmg_adam_step_multi"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, ctypes.c_double, ctypes.c_double, c_p]
 _SIG["wsmg_adam_step_multi_dev"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
 _SIG["wsmg_rows_gemm_f32"] = ([c_p, c_i, c_i] * 3 + [c_p, c_i, c_i, c_p, c_p, c_i, c_i] + [c_p, c_i, c_i] * 3 + [c_p, c_i] * 3
-                              + [c_i, c_p, ctypes.c_uint, c_p, c_i, c_p])
+                              + [c_i, c_p, ctypes.c_uint, c_p, c_i, c_p, c_p])
 _SIG["wsmg_rows_gemm_workgroups"] = [c_i, c_i]
 _SIG["wsmg_gru_fwd_chain"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_i, c_p, ctypes.c_uint, c_p, c_p]
 _SIG["wsmg_gru_bwd_chain"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_i, c_p, ctypes.c_uint, c_p, c_p]

@@ -21,6 +21,8 @@ import queue as _queue
 
 import torch
 
+TRACE = False     # tools set this to get the feeder's progress lines on stderr
+
 from .collate import DeviceCollator, pack_batch, plan_batch
 
 _STOP = "__stop__"
@@ -163,8 +165,7 @@ class DeviceFeeder:
         self._ring = None             # the standing ring of a persistent feeder between epochs
 
     def _trace(self, msg):
-        from ..debug import sw
-        if sw.feeder_trace:
+        if TRACE:
             import sys
             import time
             print("[feeder %.1f] %s" % (time.time() % 10000, msg), file=sys.stderr, flush=True)

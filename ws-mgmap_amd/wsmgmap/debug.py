@@ -21,14 +21,8 @@ _TABLE = [
     ("decoder_streams", "WSMG_DECODER_STREAMS", 1, int, "0: map decoder on one stream; 1: side stream unless ranks share a GPU; 2: always"),
     ("early_dedup", "WSMG_EARLY_DEDUP", True, bool, "instruction dedup on its own stream when the producer marked the tokens ready (ops.mark_inputs_ready)"),
     ("early_dedup_dp", "WSMG_EARLY_DEDUP_DP", False, bool, "the early dedup also under a process group (needs the exchange on a policy stream: GradAllReducer(exchange_stream=...))"),
-    ("prelayout_first", "WSMG_PRELAYOUT_FIRST", True, bool, "update path: the map stack's weight layout is the first thing on the instruction stream (not behind the cached features' dense layers)"),
-    ("enc_proj_side", "WSMG_ENC_PROJ_SIDE", True, bool, "map_encoded_linear on the decoder's side stream (its backward beside the resnet branch's small kernels)"),
     ("rollout_fold", "WSMG_ROLLOUT_FOLD", True, bool, "rollout map stack with BatchNorm-folded cached operands"),
     ("depth_engine", "WSMG_DEPTH_ENGINE", False, bool, "frozen depth ResNet50 on the bf16 NHWC engine (5 % error: opt-in)"),
-    ("fused_heads", "WSMG_FUSED_HEADS", True, bool, "rollout heads in one launch (ops.act_heads)"),
-    ("fused_update_heads", "WSMG_FUSED_UPDATE_HEADS", True, bool, "update-path heads in one launch per direction"),
-    ("fused_kl", "WSMG_FUSED_KL", True, bool, "contrastive monitor's KL in one launch per direction"),
-    ("fused_ce", "WSMG_FUSED_CE", True, bool, "prediction monitor's cross-entropy from the NHWC logits"),
     ("fused_cls_tail", "WSMG_FUSED_CLS_TAIL", True, bool, "classifier tail (BN + ReLU + 1x1 + CE + pool) in one pass per direction"),
     ("bn_fused_stats", "WSMG_BN_FUSED_STATS", True, bool, "BatchNorm sums in the producing convolution's epilogue"),
     ("relu_producer_mask", "WSMG_RELU_PRODUCER_MASK", True, bool, "fused-ReLU masks of map_encoded / map_classified_linear in map_cated_linear's backward-data epilogue (round 6)"),
@@ -41,8 +35,6 @@ _TABLE = [
     ("bev_compact", "WSMG_BEV_COMPACT", True, bool, "BEV: the index launch packs the valid sources and the scatter walks only those (round 6)"),
     ("rnn_stock", "WSMG_RNN_STOCK", False, bool, "the three recurrences on the stock (MIOpen) GRU / LSTM: no persistent kernel at all (bench.py's last fallback; needs recurrent_chunks = 0)"),
     ("rnn_poison", "WSMG_RNN_POISON", False, bool, "NaN-fill the persistent kernels' workspaces first (stress tool)"),
-    ("rnn_check", "WSMG_RNN_CHECK", False, bool, "synchronise and check after every persistent launch"),
-    ("feeder_trace", "WSMG_FEEDER_TRACE", False, bool, "trace lines from data.feeder"),
     ("feeder_pin", "WSMG_FEEDER_PIN", True, bool, "register the feeder's shared-memory ring as pinned memory"),
     ("keep_blas", "WSMG_KEEP_BLAS", False, bool, "leave torch's BLAS backend choice alone (default: rocBLAS)"),
 ]

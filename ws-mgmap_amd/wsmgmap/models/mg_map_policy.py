@@ -244,7 +244,7 @@ class MGMapNet(nn.Module):
         # after the decoder: it goes on the decoder's side stream, in front of the full-resolution branch (round 4).  Forward it
         # then runs beside the stem's convolution; backward — autograd replays a node on its forward stream — its two kernels run
         # beside the resnet branch's ~45 launch-latency-bound kernels instead of alone on the main stream after them.
-        side = self.map_decoder.side_stream(enc) if (debug.sw.enc_proj_side and enc.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
+        side = self.map_decoder.side_stream(enc) if (enc.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
         # round 6: the two projections write straight into their channel slices of the tensor map_cated_linear reads (torch.cat at
         # mg_map_policy.py:197 of the reference: no concatenation pass), and map_cated_linear's input-gradient kernel applies their
         # fused ReLUs' masks and hands each its own contiguous part (ops.conv2d_over_written_parts)
@@ -382,7 +382,7 @@ class MGMapNet(nn.Module):
         # the ego map's layout conversion they run beside): the stem's convolution started 0.15 ms after its input was ready.
         self._laid_event = None
         ego = observations.get("rgb_ego_map")
-        if (torch.is_grad_enabled() and torch.is_tensor(ego) and ego.is_cuda and self.recurrent_chunks > 0 and debug.sw.prelayout_first
+        if (torch.is_grad_enabled() and torch.is_tensor(ego) and ego.is_cuda and self.recurrent_chunks > 0
                 and not torch.cuda.is_current_stream_capturing()):
             if self._side_stream is None:
                 self._side_stream = ops.helper_stream("instruction")

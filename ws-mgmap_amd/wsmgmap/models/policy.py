@@ -54,7 +54,7 @@ class BasePolicy(nn.Module):
 
     def act(self, observations, rnn_hidden_states, prev_actions, masks, deterministic=False):
         features, rnn_hidden_states, pred_map = self.net(observations, rnn_hidden_states, prev_actions, masks)
-        if ops.rows_route(features) and debug.sw.fused_heads:
+        if ops.rows_route(features):
             # rollout: progress, critic, action mean, mode / sample and log-probability in one launch (≈20 otherwise); the
             # noise of a sampled action is Normal.sample()'s own draw (same generator, same shape)
             ad = self.action_distribution
@@ -91,7 +91,7 @@ class BasePolicy(nn.Module):
             size = self.net.map_encoder.output_shape[-1]
             dis = observations["gt_path"] if "gt_path" in observations.keys() else observations["waypoint_distribution"]
             att = self.net.att_map_t_m
-            if dis.is_cuda and dis.dtype == torch.float32 and att.dtype == torch.float32 and debug.sw.fused_kl:
+            if dis.is_cuda and dis.dtype == torch.float32 and att.dtype == torch.float32:
                 kl = ops.path_kl(dis, att, size, cfg.CONTRASTIVE_MONITOR.target_tau)      # one launch per direction
             else:
                 lo, hi = torch.aminmax(dis)  # batch-global normalisation, as the reference does (dis.max(), dis.min()) in one pass
@@ -105,7 +105,7 @@ class BasePolicy(nn.Module):
 
     # -- teacher forcing / DAgger update ---------------------------------------------
     def forward(self, observations, rnn_hidden_states, prev_actions, masks, weights):
-        self.net.skip_pred_map_nchw = debug.sw.fused_ce   # the only consumer of pred_sem_map is the loss below
+        self.net.skip_pred_map_nchw = True   # the only consumer of pred_sem_map is the loss below
         gt = observations.get("gt_semantic_map") if (AuxLosses.is_active() and self.model_config.PREDICTION_MONITOR.use) else None
         self.net._gt_semantic_map = gt if (gt is not None and gt.is_cuda and gt.dtype == torch.float32 and gt.dim() == 3) else None
         # the fused classifier tail returns logits that carry no gradient: it may only run when the loss on them is its own
@@ -118,8 +118,7 @@ class BasePolicy(nn.Module):
             self.net._cls_tail_allowed = False
         # = self.action_distribution(features).mean (policy.py:96-97) without building the Normal: its log-std / exp / expand
         # kernels produce nothing the update path reads (logstd gets no gradient in the reference either)
-        fused = (features.is_cuda and features.dtype == torch.float32 and features.shape[1] % 4 == 0
-                 and debug.sw.fused_update_heads)
+        fused = features.is_cuda and features.dtype == torch.float32 and features.shape[1] % 4 == 0
         if fused:
             # action mean, tanh progress head and the progress monitor's per-row loss in one launch per direction (≈10 each way)
             progress = observations.get("progress") if (AuxLosses.is_active() and self.model_config.PROGRESS_MONITOR.use) else None

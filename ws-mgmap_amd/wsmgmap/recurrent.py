@@ -84,8 +84,9 @@ def _rg(a_segs, w, w_is_kn, out_segs, r0, M, bias=None, cin_segs=None, mask=None
     """One launch of wsmg_rows_gemm_f32 on rows r0 .. r0 + M of full-batch row-major tensors: C = epilogue([A0|A1|A2] W^T) (w_is_kn
     False: W an nn.Linear weight [N, K]) or ([A0|A1|A2] W) (True: W [K, N], the backward product dY W).  a_segs / out_segs /
     cin_segs: lists of up to three 2-D tensors (their column counts are the segment widths); mask: the ReLU-backward mask source.
-    wait = (counter address, target): every workgroup waits for it before reading (operands produced by a chained GRU launch that
-    is still running); signal = counter address: every workgroup adds an arrival when its tile is stored."""
+    wait = (counter address, target, gate word address): the product waits for the counter before reading (operands produced by a
+    chained GRU launch that is still running), through a one-workgroup gate launch that reports in the gate word — a word of the
+    caller's per-pass counter tensor, one per chunk; signal = counter address: every workgroup adds an arrival when its tile is stored."""
     z = (None, 0, 0)
     A = [(_prow(t, r0), t.stride(0), t.shape[1]) for t in a_segs] + [z] * (3 - len(a_segs))
     Cs = [(_prow(t, r0), t.stride(0), t.shape[1]) for t in out_segs] + [z] * (3 - len(out_segs))
@@ -94,7 +95,8 @@ def _rg(a_segs, w, w_is_kn, out_segs, r0, M, bias=None, cin_segs=None, mask=None
               None if mask is None else _prow(mask, r0), 0 if mask is None else mask.stride(0), int(bool(relu)),
               *Cs[0], *Cs[1], *Cs[2], *Ci[0], *Ci[1], *Ci[2], int(M),
               None if wait is None else ctypes.c_void_p(wait[0]), 0 if wait is None else int(wait[1]),
-              None if signal is None else ctypes.c_void_p(signal), int(fail_bit), _stream())
+              None if signal is None else ctypes.c_void_p(signal), int(fail_bit),
+              None if wait is None else ctypes.c_void_p(wait[2]), _stream())
 
 
 def _fork(main, *streams):
@@ -227,7 +229,7 @@ class _RecurrentBlock(torch.autograd.Function):
         chain = multi and rg and owned and _sw.recurrent_chain and K > 1
         cnt = None
         if chain:
-            cnt = torch.zeros(2 * K, device=dev, dtype=torch.int32)
+            cnt = torch.zeros(3 * K, device=dev, dtype=torch.int32)     # [arrivals in | arrivals out | gate words] per chunk
             nwg = int(lib.wsmg_gru_chain_workgroups())
             _fork(main, sa, sg)          # (the counters are zeroed on main)
             forked = True
@@ -261,7 +263,7 @@ class _RecurrentBlock(torch.autograd.Function):
                 if rg:
                     # round 5: every dense layer of the stage is ONE launch (csrc/wsmg_rows_gemm.hip): bias, the concatenation, the
                     # ReLU in the epilogue / operand segments — 7 launches per chunk instead of 9 + 4 pre-fills, each ~4 us
-                    _rg([y1r], wq1, False, [q1], r0, rows, bias=bq1, wait=(cnt.data_ptr() + 4 * k, nwg) if chain else None, fail_bit=1)
+                    _rg([y1r], wq1, False, [q1], r0, rows, bias=bq1, wait=(cnt.data_ptr() + 4 * k, nwg, cnt.data_ptr() + 4 * (2 * K + k)) if chain else None, fail_bit=1)
                 else:
                     q1[r0:r1].addmm_(y1r[r0:r1], wq1.t())
                 _abi.call("wsmg_attn_shared_fwd" + tsfx, _prow(q1, r0), _p(text_k), _p(text_v), _p(text_mask), _prow(inverse, r0),
@@ -408,7 +410,7 @@ class _RecurrentBlock(torch.autograd.Function):
         chain = multi and rg and owned and ctx.chain and K > 1
         cnt = None
         if chain:     # (see forward: one launch per recurrence, device-side waits on per-chunk arrival counters)
-            cnt = torch.zeros(2 * K, device=dev, dtype=torch.int32)
+            cnt = torch.zeros(3 * K, device=dev, dtype=torch.int32)     # [arrivals in | arrivals out | gate words] per chunk
             keep.append(cnt)
             nwg = int(lib.wsmg_gru_chain_workgroups())
         if multi:
@@ -437,7 +439,7 @@ class _RecurrentBlock(torch.autograd.Function):
                     # round 5: five launches of wsmg_rows_gemm_f32 around the two attention kernels (was 9 GEMM-library launches + a
                     # threshold_backward): the ReLU mask, the split of d(cat) into its three parts and the two accumulate-intos
                     # (beta = 1, in place) ride in the epilogues
-                    _rg([dgi2r], w_ih2, True, [dxc], r0, rows, mask=xcr, wait=(cnt.data_ptr() + 4 * k, nwg) if chain else None, fail_bit=2)
+                    _rg([dgi2r], w_ih2, True, [dxc], r0, rows, mask=xcr, wait=(cnt.data_ptr() + 4 * k, nwg, cnt.data_ptr() + 4 * (2 * K + k)) if chain else None, fail_bit=2)
                     _rg([dxc], wc, True, [dstate_r, dtext, dmap_all], r0, rows)
                     _abi.call("wsmg_attn_bwd" + ksfx, _prow(qf, r0), _prow(tokens, r0), _prow(tokens, r0), _prow(att_map, r0), _prow(dmap_all, r0),
                               None if datt is None else _prow(datt, r0), scale, rows, I, C, _prow(dqf, r0), _prow(dtokens, r0),
