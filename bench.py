@@ -295,7 +295,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
         # 1.3x slower with the stream -> fall back to one stream for the run and say so in the line.
         measure.side_stream = None
         from wsmgmap import debug
-        if args.dp and os.environ.get("WSMG_DECODER_STREAMS") is None:
+        if args.dp and os.environ.get("WSMG_DECODER_STREAMS") is None and fbk.level == 0:      # (a fallback level keeps the side stream off)
             def timed(k):
                 update()
                 torch.cuda.synchronize()
@@ -384,8 +384,8 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
                 reducer.time_buckets(True)
         # timed live (HIP events around every launch, inside the timed region): the family with the most time, and the weight-gradient
         # family whichever it is — rounds 1-3 reported that one, and its kernels are what round 4 rebuilt; a line must show both
-        WG = "wsmg_conv2d_bwd_weight_bf16" if dtype == "bf16" else "wsmg_conv2d_bwd_weight"
-        FW = "wsmg_conv2d_fwd_bf16" if dtype == "bf16" else "wsmg_conv2d_fwd"      # (the *_stats entry points fold into it: ops._prof_key)
+        WG = "wsmg_conv2d_bwd_weight_bf16" if dtype.startswith("bf16") else "wsmg_conv2d_bwd_weight"
+        FW = "wsmg_conv2d_fwd_bf16" if dtype.startswith("bf16") else "wsmg_conv2d_fwd"      # (the *_stats entry points fold into it: ops._prof_key)
         # Every timed launch is two HIP event records on its stream (~1.5 us of GPU time each): with both families timed on every update
         # the line itself cost 0.1-0.2 ms per update (10.58 / 10.67 vs 10.46 / 10.46 ms, profiles/r04_first_window_and_event_cost.txt).
         # So: the largest family on every update, as in rounds 1-3; the weight-gradient family, when it is not the largest, on every
@@ -502,7 +502,7 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
     # time as the eager update (12.1 ms both; it wins below 256 rows), and a failure in this extra phase must never cost the
     # run its line.
     measure.graphed = None
-    if world == 1 and dtype == "bf16" and os.environ.get("WSMG_BENCH_GRAPH", "0") == "1":
+    if world == 1 and dtype.startswith("bf16") and os.environ.get("WSMG_BENCH_GRAPH", "0") == "1":
         from wsmgmap.graph import GraphedUpdate
         del loss                    # the last eager update's autograd graph (and its AccumulateGrad nodes) must be gone before a capture
         opt.zero_grad(set_to_none=True)
@@ -559,8 +559,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--T", type=int, default=64)
     ap.add_argument("--N", type=int, default=8)
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
-                    help="storage/MFMA type of the map stack: bf16 = BASELINE configs[1] (default); f32 = parity mode (1e-4 vs reference)")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16", "bf16+f32grad"],
+                    help="storage/MFMA type of the map stack: bf16 = BASELINE configs[1] (default); f32 = parity mode (1e-4 vs reference); "
+                         "bf16+f32grad = bf16 with the three first-of-chain weight gradients from a 16-bit-mantissa dY (opt-in, round 6)")
     ap.add_argument("--prewarm-s", type=float, default=float(os.environ.get("WSMG_BENCH_PREWARM_S", "1.5")),
                     help="seconds of untimed updates between the warm-up and the timed region (clock ramp / allocator steady state); 0 = none")
     ap.add_argument("--no-f32", action="store_true", help="skip the extra float32 parity-mode measurement")
@@ -638,12 +639,21 @@ def main():
     windows = getattr(measure, "windows", None)
     prewarm = getattr(measure, "prewarm", None)
     parity = None
-    if args.dtype == "bf16" and not args.no_f32:
+    if args.dtype.startswith("bf16") and not args.no_f32:
         k32 = max(2, args.steps // 2)
         dt32, _, loss32, _ = measure(args, "f32", k32, 2, rank, world, local, dev)
         parity = dict(dtype="f32", value=round(T * N * world * k32 / dt32, 2), unit="policy steps/s",
                       ms_per_step=round(dt32 / k32 * 1e3, 3), steps=k32, loss=round(loss32, 5),
                       note="same workload in the float32 parity mode (f32 MFMA; logits within 1e-4 of the reference)")
+    f32grad = None
+    if args.dtype == "bf16" and not args.no_f32 and world == 1:
+        kg = max(2, args.steps // 2)
+        dtg, _, lossg, _ = measure(args, "bf16+f32grad", kg, 2, rank, world, local, dev)
+        f32grad = dict(dtype="bf16+f32grad", value=round(T * N * world * kg / dtg, 2), unit="policy steps/s", ms_per_step=round(dtg / kg * 1e3, 3),
+                       steps=kg, loss=round(lossg, 5),
+                       note="opt-in COMPUTE_DTYPE: bf16 with the weight gradients of map_encoder.cnn.0, map_decoder.base_model.conv1 and "
+                            "conv_original_size0 from a 16-mantissa-bit dY (two bf16 weight-gradient launches each); what it buys over 200 "
+                            "updates: profiles/r06_bf16_f32grad_200_updates.txt")
 
     # BASELINE configs[0], [3], [4] as short HIP-event-timed legs in the same line:
     # single process only — they are single-GPU measurements — after every cfg2 measurement, outside any timed region
@@ -671,7 +681,7 @@ def main():
         def roofline_of(fam):
             r = prof[fam]
             ach = r["flops_total"] / (r["ms_total"] * 1e-3) / 1e12
-            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+            peak = PEAK_BF16_TFLOPS if args.dtype.startswith("bf16") else PEAK_F32_TFLOPS
             o = dict(bound="mfma", kernel=fam, achieved=round(ach, 3), peak=peak, unit="TFLOP/s", timed=r.get("sampled", "every update of the timed region"),
                      frac=round(ach / peak, 4), traffic=None,
                      avg_launch_ms=round(r["ms_total"] / r["launches"], 4), launches=r["launches"],
@@ -687,14 +697,14 @@ def main():
                     "wsmg_conv2d_fwd_bf16_stats": ["conv_igemm_bf16_kernel<false, *>", "conv_win_fwd_kernel", "conv_win3_kernel", "conv_win3_mixed_kernel"],
                     "wsmg_conv2d_bwd_data_bf16": ["conv_igemm_bf16_kernel<true, *>", "conv_win3_kernel", "conv_win3_mixed_kernel"]}.get(r.get("entry"), [fam.replace("<*>", "")])
             o["kernels_of_family"] = fams
-            if args.dtype == "bf16" and tfiles:
+            if args.dtype.startswith("bf16") and tfiles:
                 tk = json.load(open(tfiles[-1])).get("kernels", {})
                 hit = [tk[f] for f in fams if f in tk]
                 if hit:
                     o["traffic"] = round(sum(h["hbm_bytes_per_update"] for h in hit) / sum(h["launches_per_update"] for h in hit))
                     o["traffic_unit"] = "HBM bytes per launch (1024*(2*FETCH_SIZE+WRITE_SIZE)), mean over the family's launches"
                     o["traffic_source"] = "profiles/" + os.path.basename(tfiles[-1])
-            if args.dtype == "bf16" and mfiles:
+            if args.dtype.startswith("bf16") and mfiles:
                 mk = json.load(open(mfiles[-1])).get("kernels", {})
                 hit = [mk[f] for f in fams if f in mk]
                 if hit:
@@ -735,6 +745,7 @@ def main():
             "whole_update_tflops": round(ALG_GFLOP_PER_STEP * steps_per_s / 1e3 / world, 2),
             "loss": round(final_loss, 5),
             "f32_parity_mode": parity,
+            "bf16_f32grad_mode": f32grad,
             "graphed_update": graphed,
             "sustained": sustained,
             "windows": windows,

@@ -457,6 +457,14 @@ int wsmg_bn_act_bwd_ld_bf16(const void* dy, int64_t ld_dy, const void* x, const 
                             const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, void* dx,
                             void* dresidual, float* dgamma, float* dbeta, double* workspace, int64_t workspace_bytes,
                             wsmg_stream_t stream);
+/* Round 6, COMPUTE_DTYPE = "bf16+f32grad": the same call that also writes dx_lo = bf16(dx_f32 - bf16(dx_f32)) — the part of the float32
+ * input gradient its bf16 rounding dropped.  The caller takes the producing convolution's weight gradient from (dx, dx_lo), two
+ * launches of the bf16 weight-gradient kernel: a 16-mantissa-bit dY for the first layer of a backward chain (the reference trains in
+ * float32 only: dagger_trainer.py:505-541). */
+int wsmg_bn_act_bwd_ld_bf16_lo(const void* dy, int64_t ld_dy, const void* x, const void* y, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, void* dx, void* dx_lo,
+                               void* dresidual, float* dgamma, float* dbeta, double* workspace, int64_t workspace_bytes,
+                               wsmg_stream_t stream);
 int wsmg_relu_bwd_rows_bf16(const void* dy, int64_t ld_dy, const void* y, void* dx, int64_t rows, int C, wsmg_stream_t stream);
 int wsmg_upsample2x_bwd_ld(const float* dy, int64_t ld_dy, float* dx, int B, int H, int W, int C, wsmg_stream_t stream);
 int wsmg_upsample2x_bwd_ld_bf16(const void* dy, int64_t ld_dy, void* dx, int B, int H, int W, int C, wsmg_stream_t stream);
@@ -721,6 +729,8 @@ int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const float* a1, int 
                        const float* cin0, int ldcin0, const float* cin1, int ldcin1, const float* cin2, int ldcin2,
                        int M, const unsigned* wait_count, unsigned wait_target, unsigned* signal_count, int fail_bit,
                        unsigned* gate_word, wsmg_stream_t stream);
+/* 1 if wsmg_rows_gemm_f32 has a launch form for a reduction of K = ka0 + ka1 + ka2, else 0 (callers gate on it: ADVICE r05) */
+int wsmg_rows_gemm_supported(int K);
 /* workgroups one wsmg_rows_gemm_f32 launch of M rows x N columns runs (= the arrivals it adds to signal_count) */
 int wsmg_rows_gemm_workgroups(int M, int N);
 

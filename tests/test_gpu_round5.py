@@ -560,8 +560,8 @@ def test_chained_product_waits_with_one_workgroup_not_with_its_whole_grid():
     hardware queue), but its work starts late: a 30 ms delay kernel, then 256 whole-CU workgroups (wsmg_debug_occupy: 1 024 threads
     + 160 KB of LDS each), then the counter.  The waiting product — 768 workgroups of 16 waves: every wave slot of the GPU if they
     all spun — is on the GPU long before that.  With the wait inside the product the whole-CU kernel could not start until the
-    product's spin timed out (WSMG_CHAIN_GATE=0: this test fails with a timeout); with the one-workgroup gate launch in front of the
-    product (round 5) it runs, the counter moves, the product follows — no timeout, the same numbers as unchained."""
+    product's spin timed out (round 5's first form: this test failed with a timeout); with the one-workgroup gate launch in front of the
+    product (round 5; round 6: its verdict in the caller's word, and the whole-grid form is gone) it runs, the counter moves, the product follows — no timeout, the same numbers as unchained."""
     from wsmgmap import _abi, ops, recurrent
     g = torch.Generator(device="cuda").manual_seed(3)
     M, K, N = 128, 1536, 1536
@@ -572,6 +572,7 @@ def test_chained_product_waits_with_one_workgroup_not_with_its_whole_grid():
     recurrent._rg([a], w, True, [want], 0, M, mask=mask)
     ops.check_rnn_status()
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gate = torch.full((1,), 7, dtype=torch.int32, device="cuda")      # (round 6: the gate's verdict travels through the CALLER's word)
     stop = torch.zeros(1, dtype=torch.int32, device="cuda")
     arrived = torch.zeros(1, dtype=torch.int32, device="cuda")
     got = torch.zeros(M, N, device="cuda")
@@ -584,10 +585,10 @@ def test_chained_product_waits_with_one_workgroup_not_with_its_whole_grid():
         _abi.call("wsmg_debug_occupy", 256, 160 * 1024, 20, ops._p(stop), ops._p(arrived), ops._stream())   # 256 whole CUs for 20 ms
         cnt.fill_(1)
     with torch.cuda.stream(s_wait):
-        recurrent._rg([a], w, True, [got], 0, M, mask=mask, wait=(cnt.data_ptr(), 1), fail_bit=2)
+        recurrent._rg([a], w, True, [got], 0, M, mask=mask, wait=(cnt.data_ptr(), 1, gate.data_ptr()), fail_bit=2)
     torch.cuda.synchronize()
     dt = time.time() - t0
     assert int(arrived) == 256, "the whole-CU workgroups did not all get a CU"
     ops.check_rnn_status()                 # raises if the wait timed out
-    assert torch.equal(got, want)
+    assert torch.equal(got, want) and int(gate) == 0
     assert dt < 1.0, f"{dt:.2f} s: the producer only ran after the waiter's spin gave up"

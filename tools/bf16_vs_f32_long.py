@@ -88,5 +88,23 @@ res["control_max_rel_loss_gap_per_rotation_mean"] = max(relp_sm)
 print(f"CONTROL loss f32 perturbed last rotation mean {sm(l32p)[-1]:.4f}; max per-rotation-mean gap to f32 {max(relp_sm):.3e}")
 print(f"loss f32  first/last rotation mean: {sm(l32)[0]:.4f} -> {sm(l32)[-1]:.4f};  bf16: {sm(l16)[0]:.4f} -> {sm(l16)[-1]:.4f}")
 print(f"max relative loss gap: raw {max(rel):.3e} (update {rel.index(max(rel))}), per-rotation mean {max(rel_sm):.3e}")
+# round 6: the opt-in remedy — the three first-of-chain weight gradients from a 16-mantissa-bit dY
+torch.cuda.empty_cache()
+l16g, s16g = run("bf16+f32grad", snap_at)
+res["loss_bf16_f32grad"] = [round(v, 5) for v in l16g]
+res["drift_bf16_f32grad"] = {}
+for k in snap_at:
+    moved = float(torch.sqrt(sum(((s32[k][n] - p0[n]) ** 2).sum() for n in p0)))
+    drift = float(torch.sqrt(sum(((s32[k][n] - s16g[k][n]) ** 2).sum() for n in p0)))
+    per = sorted(((float((s32[k][n] - s16g[k][n]).norm()) / max(float((s32[k][n] - p0[n]).norm()), 1e-12), n) for n in p0
+                  if p0[n].numel() >= 4096 and n not in NULL_GRAD), reverse=True)
+    res["drift_bf16_f32grad"][k] = dict(all=round(drift / moved, 4), worst=[(n, round(r, 4)) for r, n in per[:6]],
+                                        tensors_over_0p35=sum(1 for r, _ in per if r > 0.35))
+    three = {n: round(r, 4) for r, n in per if n in ("net.map_encoder.cnn.0.weight", "net.map_decoder.base_model.conv1.weight",
+                                                    "net.map_decoder.conv_original_size0.0.weight")}
+    print(f"bf16+f32grad, after {k:4d} updates: drift {drift / moved:.4f}; tensors over 0.35: {res['drift_bf16_f32grad'][k]['tensors_over_0p35']}; "
+          f"the three layers: {three}; worst: " + ", ".join(f"{n} {r:.3f}" for r, n in per[:3]))
+print(f"loss bf16+f32grad last rotation mean {sm(l16g)[-1]:.4f} (f32 {sm(l32)[-1]:.4f}, bf16 {sm(l16)[-1]:.4f}, f32 perturbed {sm(l32p)[-1]:.4f}); "
+      f"VERDICT's bar: drift <= f32-self + 0.05 = {res['control_f32_vs_f32_perturbed_1e-6'][K]['all'] + 0.05:.3f} at {K} updates, end loss within 1.5 % of f32")
 if out:
     json.dump(res, open(out, "w"), indent=1)

@@ -45,4 +45,15 @@ PY
 6) python -m pytest tests/test_gpu_round6.py -q 2>&1 | tail -12 > gpurun_out/c6_r6.txt
    python tools/igemm_tile_ab.py 30 > gpurun_out/c6_igemm.txt 2>&1
    tools/ab.sh c6_bm 3 30 "X=1" "WSMG_IGEMM_BM256=0" > gpurun_out/c6_bm.txt 2>&1 ;;
+7) python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/c7_tests.txt
+   python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/c7_bench.json 2> gpurun_out/c7_bench.err
+   tail -c 600 gpurun_out/c7_bench.err > gpurun_out/c7_bench_err_tail.txt ;;
+8) python -m pytest tests/test_gpu_round5.py tests/test_gpu_round6.py -x -q 2>&1 | tail -5 > gpurun_out/c8_tests.txt
+   WSMG_BENCH_DP_ONE_RANK=1 timeout 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-f32 --no-other-configs > gpurun_out/c8_dp1.json 2> gpurun_out/c8_dp1.err
+   timeout 300 python3 tools/section_times.py bf16 8 > gpurun_out/c8_sections.txt 2>&1
+   bash tools/runtrace_update.sh > gpurun_out/c8_runtrace.log 2>&1; cp gpurun_out/update_timeline.txt gpurun_out/c8_update_timeline.txt ;;
+9) python -m pytest tests/test_gpu_round6.py -x -q 2>&1 | tail -6 > gpurun_out/c9_tests.txt
+   timeout 900 python3 tools/bf16_vs_f32_long.py 200 8 gpurun_out/c9_long.json > gpurun_out/c9_long.txt 2>&1
+   tools/ab.sh c9_modes 2 30 "X=1" > /dev/null 2>&1
+   for r in 1 2; do for m in bf16 bf16+f32grad; do python3 bench.py --dtype $m --steps 30 --warmup 5 --no-f32 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$m', d['ms_per_step'])"; done; done > gpurun_out/c9_modes.txt 2>&1 ;;
 esac

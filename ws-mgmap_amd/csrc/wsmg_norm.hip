@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
                                                             const float* __restrict__ invstd, const float* __restrict__ dgamma,
                                                             const float* __restrict__ dbeta, int relu, float inv_n, int64_t rows,
                                                             int C, bf16_t* __restrict__ dx, bf16_t* __restrict__ dres,
-                                                            int64_t ld_dy) {
+                                                            int64_t ld_dy, bf16_t* __restrict__ dx_lo = nullptr) {
   const int C8 = C >> 3;
   const int c = (threadIdx.x % C8) * 8;
   const int rl = threadIdx.x / C8;
@@ -363,7 +363,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
         out[k][j] = k0[k][j] * (g[k][j] - k1[k][j] - xh * k2[k][j]);
       }
     if (dres) *reinterpret_cast<u32x4n*>(dres + o) = pack8(g[0], g[1]);
-    *reinterpret_cast<u32x4n*>(dx + o) = pack8(out[0], out[1]);
+    const u32x4n hi = pack8(out[0], out[1]);
+    *reinterpret_cast<u32x4n*>(dx + o) = hi;
+    if (dx_lo) {      // the part of the float32 gradient its bf16 rounding dropped, itself in bf16: dx ~= hi + lo to 16 mantissa bits
+      f32x4 h0, h1, l0, l1;
+      unpack8(hi, h0, h1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { l0[j] = out[0][j] - h0[j]; l1[j] = out[1][j] - h1[j]; }
+      *reinterpret_cast<u32x4n*>(dx_lo + o) = pack8(l0, l1);
+    }
   }
 }
 
@@ -435,7 +443,7 @@ int bn_act_fwd_t(const T* x, const T* residual, const float* gamma, const float*
 template <class T>
 int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_invstd, int relu, int64_t rows, int C, T* dx, T* dresidual, float* dgamma,
-                 float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream, int64_t ld_dy = 0) {
+                 float* dbeta, double* workspace, int64_t workspace_bytes, wsmg_stream_t stream, int64_t ld_dy = 0, T* dx_lo = nullptr) {
   if (!chan_ok(C) || rows <= 0) return WSMG_EINVAL;
   if (ld_dy == 0) ld_dy = C;
   if (ld_dy < C || (ld_dy & 7) || ((uintptr_t)dy & 15)) return WSMG_EINVAL;
@@ -449,10 +457,11 @@ int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const 
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (bn_vec8()) {
       hipLaunchKernelGGL(bn_bwd_apply8_kernel, dim3(stream_grid8(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
-                         save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual, ld_dy);
+                         save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual, ld_dy, dx_lo);
       WSMG_RETURN_LAUNCH();
     }
   }
+  if (dx_lo) return WSMG_EINVAL;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(stream_grid(rows, C)), dim3(256), 0, s, dy, x, y, gamma, beta, save_mean,
                      save_invstd, dgamma, dbeta, relu, 1.0f / (float)rows, rows, C, dx, dresidual, ld_dy);
   WSMG_RETURN_LAUNCH();
@@ -560,6 +569,20 @@ extern "C" int wsmg_bn_act_bwd_ld_bf16(const void* dy, int64_t ld_dy, const void
                                        int64_t workspace_bytes, wsmg_stream_t stream) {
   return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, beta, save_mean, save_invstd, relu,
                               rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream, ld_dy);
+}
+
+// Round 6, COMPUTE_DTYPE = "bf16+f32grad" (VERDICT r05 item 8): wsmg_bn_act_bwd_ld_bf16 that also writes dx_lo = bf16(dx_f32 - bf16(dx_f32)),
+// the part of the float32 input gradient its bf16 rounding dropped; the layer's weight gradient is then taken from (dx, dx_lo) — two
+// launches of the bf16 weight-gradient kernel — i.e. from a 16-mantissa-bit dY.  The reference trains in float32 only
+// (dagger_trainer.py:505-541).
+extern "C" int wsmg_bn_act_bwd_ld_bf16_lo(const void* dy, int64_t ld_dy, const void* x, const void* y, const float* gamma, const float* beta,
+                                          const float* save_mean, const float* save_invstd, int relu, int64_t rows, int C, void* dx,
+                                          void* dx_lo, void* dresidual, float* dgamma, float* dbeta, double* workspace,
+                                          int64_t workspace_bytes, wsmg_stream_t stream) {
+  if (!dx_lo || (C & 7)) return WSMG_EINVAL;
+  return bn_act_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)y, gamma, beta, save_mean, save_invstd, relu,
+                              rows, C, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, workspace, workspace_bytes, stream, ld_dy,
+                              (bf16_t*)dx_lo);
 }
 
 // ----------------------------------------------------------------------------- GroupNorm (frozen DD-PPO depth ResNet50)

@@ -246,6 +246,15 @@ extern "C" int wsmg_rows_gemm_f32(const float* a0, int lda0, int ka0, const floa
   WSMG_RETURN_LAUNCH();
 }
 
+// 1 if wsmg_rows_gemm_f32 has a launch form for a reduction of K (the sum of the operand segments' widths), else 0
+extern "C" int wsmg_rows_gemm_supported(int K) {
+  if (K <= 0 || K % 64) return 0;
+  const int c16 = K / 16;
+  auto form = [](int n) { return n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8; };
+  if (c16 % 16 == 0 && c16 / 16 <= 8) return form(c16 / 16) ? 1 : 0;
+  return (c16 % 4 == 0 && c16 / 4 <= 8 && form(c16 / 4)) ? 1 : 0;
+}
+
 extern "C" int wsmg_rows_gemm_workgroups(int M, int N) { return (M <= 0 || N <= 0) ? 0 : (N / 16) * (int)wsmg_cdiv(M, 16); }
 
 extern "C" int wsmg_debug_occupy(int n_workgroups, int lds_bytes, int max_ms, const int* stop_flag, unsigned* arrived, wsmg_stream_t stream) {

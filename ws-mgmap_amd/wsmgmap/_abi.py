@@ -122,6 +122,7 @@ _SIG["wsmg_attn_fp8_prep"] = [c_p] * 4 + [c_i, c_i, c_i, c_i, c_f, c_f, c_f] + [
 _SIG["wsmg_mean_rows"] = [c_p, c_l, c_i, c_p, c_p]
 _SIG["wsmg_bn_act_bwd_ld"] = [c_p, c_l] + _SIG["wsmg_bn_act_bwd"][1:]
 _SIG["wsmg_bn_act_bwd_ld_bf16"] = list(_SIG["wsmg_bn_act_bwd_ld"])
+_SIG["wsmg_bn_act_bwd_ld_bf16_lo"] = [c_p, c_l] + [c_p] * 6 + [c_i, c_l, c_i] + [c_p] * 6 + [c_l, c_p]
 _SIG["wsmg_upsample2x_bwd_ld"] = [c_p, c_l, c_p, c_i, c_i, c_i, c_i, c_p]
 _SIG["wsmg_upsample2x_bwd_ld_bf16"] = list(_SIG["wsmg_upsample2x_bwd_ld"])
 _SIG["wsmg_relu_bwd_rows_bf16"] = [c_p, c_l, c_p, c_p, c_l, c_i, c_p]
@@ -157,6 +158,7 @@ _SIG["wsmg_adam_step_multi_dev"] = [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_p, c_p]
 _SIG["wsmg_rows_gemm_f32"] = ([c_p, c_i, c_i] * 3 + [c_p, c_i, c_i, c_p, c_p, c_i, c_i] + [c_p, c_i, c_i] * 3 + [c_p, c_i] * 3
                               + [c_i, c_p, ctypes.c_uint, c_p, c_i, c_p, c_p])
 _SIG["wsmg_rows_gemm_workgroups"] = [c_i, c_i]
+_SIG["wsmg_rows_gemm_supported"] = [c_i]
 _SIG["wsmg_gru_fwd_chain"] = [c_p] * 5 + [c_i] * 3 + [c_p] * 6 + [c_i, c_p, ctypes.c_uint, c_p, c_p]
 _SIG["wsmg_gru_bwd_chain"] = [c_p] * 10 + [c_i] * 3 + [c_p] * 4 + [c_i, c_p, ctypes.c_uint, c_p, c_p]
 _SIG["wsmg_gru_chain_workgroups"] = []

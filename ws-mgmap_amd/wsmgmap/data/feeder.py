@@ -148,7 +148,9 @@ class DeviceFeeder:
         persistent (ring transport): the ring — worker processes, shared slots, their page-locking — outlives the epoch: an epoch that
         ran to its end leaves it standing and the next `iter()` re-arms the workers with the new seed (the analogue of DataLoader's
         persistent_workers; without it every epoch pays 2-5 s of process start + pinning and 0.6-4.8 s of teardown).  `close()`
-        (or garbage collection) takes it down; an epoch that is abandoned half way or fails takes it down too."""
+        (or garbage collection) takes it down; an epoch that is abandoned half way or fails takes it down too.  The workers keep the
+        dataset as pickled when the ring was built: a different dataset object, length or shard at the next `iter()` rebuilds the ring;
+        in-place changes of the same object that keep its length are NOT seen — use a fresh feeder (or `close()`) after those."""
         self.dataset, self.batch_size, self.device = dataset, batch_size, torch.device(device)
         self.num_workers, self.prefetch = int(num_workers), max(1, prefetch)
         self.workers = workers if self.num_workers > 0 else "none"
@@ -163,6 +165,15 @@ class DeviceFeeder:
         self.persistent = bool(persistent)
         self.ring_opens = 0           # rings built so far (persistent: 1 however many epochs)
         self._ring = None             # the standing ring of a persistent feeder between epochs
+
+    def _dataset_fingerprint(self):
+        """What a persistent ring's workers were built for: the dataset object, its length and its shard."""
+        d = self.dataset
+        try:
+            n = len(d)
+        except TypeError:
+            n = getattr(d, "length", None)
+        return (id(d), n, getattr(d, "rank", None), getattr(d, "world_size", None), self.batch_size)
 
     def _trace(self, msg):
         if TRACE:
@@ -322,11 +333,15 @@ class DeviceFeeder:
             base_seed = self.seed + self.epoch * W
         self.epoch += 1
         ring, self._ring = self._ring, None
-        if ring is not None and not all(p.is_alive() for p in ring["procs"]):
+        # a standing ring's workers hold the dataset as it was PICKLED when the ring was built: a dataset that has changed since (a DAgger
+        # cache that grew, another shard) gets a new ring instead of silently serving the old snapshot
+        fp = self._dataset_fingerprint()
+        if ring is not None and (not all(p.is_alive() for p in ring["procs"]) or ring.get("fingerprint") != fp):
             self._ring_close(ring)
             ring = None
         if ring is None:
             ring = self._ring_open(base_seed)
+            ring["fingerprint"] = fp
         else:               # a standing ring: every slot is back with its worker; re-arm the workers
             self.pinned_ring = ring["pinned"]
             for q in ring["free_qs"]:

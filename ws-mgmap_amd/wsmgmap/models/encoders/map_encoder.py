@@ -46,7 +46,9 @@ class batched_bumps:
 
 
 def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True, residual=None):
-    """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC."""
+    """Conv2d -> BatchNorm2d (batch statistics when training) [-> + residual] -> ReLU, NHWC.
+    A convolution marked `_wsmg_f32grad` (MGMapNet, COMPUTE_DTYPE = "bf16+f32grad": the first layer of each backward chain) takes its
+    weight gradient from a 16-mantissa-bit dY (ops.GradLoSink)."""
     # (if x carries zero-padded channels, ops.conv2d pads the weight's input channels to match)
     if isinstance(x, (list, tuple)):   # convolution over a channel concatenation: one vectorised concatenation, then the conv
         # (running it part by part over the weight's input-channel slices was measured and dropped: DESIGN.md section 7)
@@ -55,9 +57,10 @@ def conv_bn_relu(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, train: bool, relu=True,
     stats = None
     if train and x.dtype == torch.bfloat16 and conv.out_channels % 8 == 0:
         stats = ops.bn_stats_slabs(id(bn), conv.out_channels, x.device)
-    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train, stats=stats)
+    lo = ops.GradLoSink() if (train and getattr(conv, "_wsmg_f32grad", False) and x.dtype == torch.bfloat16 and torch.is_grad_enabled()) else None
+    y = ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], bias_grad_zero=train, stats=stats, lo_sink=lo)
     bump(bn, train)
-    out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps, stats)
+    out = ops.bn_act(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, train, relu, residual, bn.momentum, bn.eps, stats, lo_sink=lo)
     if stats is not None:
         ops.bn_stats_done(id(bn), conv.out_channels, x.device)
     return out

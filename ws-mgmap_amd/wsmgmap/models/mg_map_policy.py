@@ -102,9 +102,18 @@ class MGMapNet(nn.Module):
         if want is None:
             want = getattr(mc, "compute_dtype", "f32")
         want = str(want).lower()
+        # "bf16+f32grad" (round 6, opt-in): bf16 as above, but the weight gradients of the FIRST layer of each backward chain —
+        # map_encoder.cnn.0, map_decoder.base_model.conv1, map_decoder.conv_original_size0: the tensors that drift most from a
+        # float32 run — are taken from a 16-mantissa-bit dY (hi + lo bf16 pair): two weight-gradient launches each
+        self.f32grad = want in ("bf16+f32grad", "bfloat16+f32grad")
+        if self.f32grad:
+            want = "bf16"
         if want not in ("f32", "fp32", "float32", "bf16", "bfloat16"):
-            raise ValueError(f"MODEL.COMPUTE_DTYPE must be 'f32' or 'bf16', got {want!r}")
+            raise ValueError(f"MODEL.COMPUTE_DTYPE must be 'f32', 'bf16' or 'bf16+f32grad', got {want!r}")
         self.compute_dtype = torch.bfloat16 if want in ("bf16", "bfloat16") else torch.float32
+        if self.f32grad:
+            for conv in (self.map_encoder.cnn[0], self.map_decoder.base_model.conv1, self.map_decoder.conv_original_size0[0]):
+                conv._wsmg_f32grad = True
         if self.compute_dtype == torch.bfloat16:   # the frozen RGB UNet follows: bf16 NHWC engine on the rollout path
             self.rgb_encoder.base_model.engine_dtype = torch.bfloat16
             # the depth ResNet50 stays float32 by default (ddppo_resnet.py: bf16 storage compounds over its 53 GroupNorm layers)

@@ -127,7 +127,7 @@ class _Conv2d(torch.autograd.Function):
     channels than w (the engine pads activations to multiples of 32) the weight is zero-padded to match."""
 
     @staticmethod
-    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, into=None):
+    def forward(ctx, x, w_oihw, bias, stride, pad, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, into=None, lo_sink=None):
         _req(x, w_oihw, bias)
         _f32(w_oihw, bias)
         sfx = _sfx(x)
@@ -161,6 +161,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.relu_sink = relu_sink if relu else None
         if ctx.relu_sink is not None:
             relu_sink.relu = True
+        ctx.lo_sink = lo_sink if sfx else None
         return y
 
     @staticmethod
@@ -192,11 +193,15 @@ class _Conv2d(torch.autograd.Function):
                 _launch("wsmg_conv2d_bwd_data", fl, _p(dy), _p(w_ihwo), _p(dx), *dims, _stream())
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(sfx, x, dy, dims, fl, Cin_w)
+            lo = ctx.lo_sink.take() if ctx.lo_sink is not None else None
+            if lo is not None and lo.shape == dy.shape:
+                # COMPUTE_DTYPE = "bf16+f32grad": + the weight gradient of the gradient's low half (norm.GradLoSink)
+                dw = dw + _weight_grad(sfx, x, lo, dims, fl, Cin_w)
         if has_bias and ctx.needs_input_grad[2]:
             # a bias in front of a train-mode BatchNorm cancels in (x - mean): its gradient is sum(dy) = 0 exactly;
             # the caller says so and the channel reduction over dy is skipped
             db = _zeros_f32((Cout,), dy.device) if ctx.bias_grad_zero else channel_sum(dy.view(-1, Cout))
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class _ConvT2d(torch.autograd.Function):
@@ -245,13 +250,14 @@ class _ConvT2d(torch.autograd.Function):
         return dx, dw, None, None, None
 
 
-def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, into=None):
+def conv2d(x, weight_oihw, bias, stride=1, pad=0, bias_grad_zero=False, relu=False, stats=None, relu_sink=None, into=None, lo_sink=None):
     """x NHWC; weight = the reference's OIHW parameter (laid out for the engine in one launch inside the autograd
     node, so the parameter's .grad comes back OIHW float32).  bias_grad_zero: the output feeds a train-mode
     BatchNorm, so d(loss)/d(bias) is identically zero and is returned as zeros.  relu: y = relu(conv + bias), fused into
     the conv epilogue in bf16 mode.  relu_sink: see ReluSink / TokenGradSink.  into = (base, c): write the output into channels
-    [c, c + Cout) of the bf16 tensor `base` [B,OH,OW,Ctot] (the concatenation that follows) and return that slice."""
-    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats, relu_sink, into)
+    [c, c + Cout) of the bf16 tensor `base` [B,OH,OW,Ctot] (the concatenation that follows) and return that slice.  lo_sink: see
+    norm.GradLoSink (COMPUTE_DTYPE = "bf16+f32grad")."""
+    return _Conv2d.apply(x, weight_oihw, bias, stride, pad, bias_grad_zero, relu, stats, relu_sink, into, lo_sink)
 
 
 class _Conv2dCat2(torch.autograd.Function):

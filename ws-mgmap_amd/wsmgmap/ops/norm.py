@@ -20,9 +20,23 @@ def channel_sum(x2d):
 
 
 # ----------------------------------------------------------------------------- batch norm (+res)(+relu)
+class GradLoSink:
+    """COMPUTE_DTYPE = "bf16+f32grad" (round 6): links the BatchNorm of a conv + BatchNorm layer to its convolution.  The BatchNorm's
+    backward leaves here the low half of its float32 input gradient (dx_lo = bf16(dx_f32 - bf16(dx_f32))); the convolution's
+    backward, which runs next on the same gradient, adds the weight gradient of (x, dx_lo) to that of (x, dx): the weight gradient of
+    a 16-mantissa-bit dY from two launches of the bf16 kernel."""
+
+    def __init__(self):
+        self.lo = None
+
+    def take(self):
+        lo, self.lo = self.lo, None
+        return lo
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats=None):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats=None, lo_sink=None):
         _req(x, residual, gamma, beta, running_mean, running_var)
         _f32(gamma, beta, running_mean, running_var)
         sfx = _sfx(x)
@@ -50,6 +64,7 @@ class _BnAct(torch.autograd.Function):
         keep_y = relu and residual is not None
         ctx.save_for_backward(x, y if keep_y else None, gamma, beta, mean, invstd)
         ctx.cfg = (rows, C, int(relu), residual is not None, bool(train), sfx)
+        ctx.lo_sink = lo_sink if (sfx and train and C % 8 == 0) else None
         return y
 
     @staticmethod
@@ -64,17 +79,23 @@ class _BnAct(torch.autograd.Function):
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         ws = _workspace(x.device)
+        if ctx.lo_sink is not None:    # + the low half of the float32 gradient for the convolution's weight gradient (GradLoSink)
+            lo = torch.empty_like(x)
+            _abi.call("wsmg_bn_act_bwd_ld_bf16_lo", _p(dy), ld, _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
+                      _p(dx), _p(lo), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
+            ctx.lo_sink.lo = lo
+            return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
         if ld != C:     # a channel slice of a concatenation's gradient, read in place
             _abi.call("wsmg_bn_act_bwd_ld" + sfx, _p(dy), ld, _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
                       _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
         else:
             _abi.call("wsmg_bn_act_bwd" + sfx, _p(dy), _p(x), _p(y), _p(gamma), _p(beta), _p(mean), _p(invstd), relu, rows, C,
                       _p(dx), _p(dres), _p(dgamma), _p(dbeta), _p(ws), ws.numel() * 8, _stream())
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5, stats=None):
-    return _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats)
+def bn_act(x, gamma, beta, running_mean, running_var, train, relu=True, residual=None, momentum=0.1, eps=1e-5, stats=None, lo_sink=None):
+    return _BnAct.apply(x, residual, gamma, beta, running_mean, running_var, train, relu, momentum, eps, stats, lo_sink)
 
 
 BN_SLABS = 64

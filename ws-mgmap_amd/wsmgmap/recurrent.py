@@ -109,8 +109,13 @@ def _fork(main, *streams):
 
 
 def rows_gemm_ok(H, C, in1):
-    """Shapes wsmg_rows_gemm_f32 takes for the attention stage's five products (hidden size H, attention width C, GRU-2 input)."""
-    return _sw.rows_gemm and H % 256 == 0 and C % 256 == 0 and in1 % 256 == 0
+    """Shapes wsmg_rows_gemm_f32 takes for the attention stage's products (hidden size H, attention width C, GRU-2 input): every
+    product's reduction length is asked of the library (a multiple of 256 alone admitted K = 1280, which it refuses)."""
+    if not (_sw.rows_gemm and H % 256 == 0 and C % 256 == 0 and in1 % 256 == 0):
+        return False
+    ok = _abi.lib().wsmg_rows_gemm_supported
+    # forward: q1 (K = H), q2 / qf (C), compress (H + 2 C), gi2 (in1); backward: dxc (3 H), its split (in1), the queries (C, H)
+    return all(ok(int(k)) for k in (H, C, H + 2 * C, in1, 3 * H))
 
 
 def _roles(streams, main):
