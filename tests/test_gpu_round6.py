@@ -117,7 +117,7 @@ def test_update_has_no_concatenation_or_mask_pass_around_map_cated_linear(monkey
     for gone in ("wsmg_cat_channels", "wsmg_relu_bwd_rows_bf16", "wsmg_relu_bwd_bf16"):
         assert counts.get(gone, 0) == 0, (gone, counts)
     assert counts.get("wsmg_conv2d_bwd_data_bf16_ex", 0) == 1 and counts.get("wsmg_conv2d_fwd_bf16_ex", 0) == 2, counts
-    assert counts.get("wsmg_colsum_multi", 0) == 1, counts
+    assert counts.get("wsmg_colsum_multi", 0) == 2, counts     # the recurrent core's seven bias gradients; the bi-LSTM's two
 
 
 # ----------------------------------------------------------------------------- configs[4] per row, one launch
@@ -245,3 +245,55 @@ def test_bf16_f32grad_mode_changes_only_the_three_first_of_chain_weight_gradient
             assert not torch.equal(g, b[4][k]) and ea <= eb * 1.02, (k, ea, eb)
         else:
             assert torch.equal(g, b[4][k]), k
+
+
+# ----------------------------------------------------------------------------- 3 x 3 over a 32-channel reduction axis
+@pytest.mark.parametrize("B,H,Cin,Cout", [(64, 48, 32, 32), (60, 47, 32, 32), (256, 24, 32, 64), (230, 25, 32, 64)])
+def test_k32_window_convolution_is_bit_identical_to_the_general_window_kernel(B, H, Cin, Cout):
+    """VERDICT r05 item 2 (the 48 x 48 / 32-channel shapes: the semantic classifier's 3 x 3 layers, mg_map_policy.py:78-86).
+    wsmg_conv_win3_k32.hip — weights resident in LDS, one barrier per 256-pixel tile, three workgroups per CU — runs the same MFMA
+    sequence per output element as the general window kernel (itself held against the float64 oracle by test_conv2d_fwd_bwd and the
+    G3 / full-size policy tests): forward (bias + ReLU, plain, into a channel slice of a wider tensor) and backward-data outputs bit
+    for bit, pixel counts that are not a multiple of the tile included; the BatchNorm sums (other partial-sum grouping) to 1e-6."""
+    from wsmgmap import _abi, ops
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cout)
+    x = torch.relu(torch.randn(B, H, H, Cin, device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) * 0.08).to(torch.bfloat16)
+    bias = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    dy = torch.randn(B, H, H, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    wi = w.permute(3, 1, 2, 0).contiguous()
+    args = (B, H, H, Cin, Cout, 3, 3, 1, 1, H, H)
+    P, st = ops._p, ops._stream
+    nslab = 8
+    outs = {}
+    for mt in (256, 1):       # 256: the general window kernel's 256-pixel tile, forced; 1: by shape = the k32 kernel
+        old = _abi.lib().wsmg_conv_debug_win3_tile(mt)
+        try:
+            y0 = torch.empty(B, H, H, Cout, device="cuda", dtype=torch.bfloat16)
+            y1 = torch.empty_like(y0)
+            wide = torch.full((B, H, H, Cout + 64), 7.0, device="cuda", dtype=torch.bfloat16)
+            dx = torch.empty_like(x)
+            stats = torch.zeros(nslab, 2, Cout, device="cuda", dtype=torch.float64)
+            _abi.call("wsmg_conv2d_fwd_bf16", P(x), P(w), P(bias), P(y0), 2, *args, st())
+            _abi.call("wsmg_conv2d_fwd_bf16_stats", P(x), P(w), None, P(y1), 0, P(stats), nslab, *args, st())
+            _abi.call("wsmg_conv2d_fwd_bf16_ex", P(x), P(w), None, wide.data_ptr() + 32 * 2, 0, None, 0, Cout + 64, *args, st())
+            _abi.call("wsmg_conv2d_bwd_data_bf16", P(dy), P(wi), P(dx), 0, *args, st())
+            torch.cuda.synchronize()
+            outs[mt] = (y0, y1, wide, dx, stats.sum(0))
+        finally:
+            _abi.lib().wsmg_conv_debug_win3_tile(old)
+    a, b = outs[1], outs[256]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2], b[2]) and torch.equal(a[2][..., 32:32 + Cout], a[1])
+    assert bool((a[2][..., :32] == 7).all()) and bool((a[2][..., 32 + Cout:] == 7).all())
+    assert torch.equal(a[3], b[3])
+    want = torch.stack([a[1].double().sum((0, 1, 2)), (a[1].double() ** 2).sum((0, 1, 2))])
+    assert float((a[4] - want).abs().max() / want.abs().max()) < 1e-6
+    assert float((b[4] - want).abs().max() / want.abs().max()) < 1e-6
+    # and against plain float64 arithmetic on the bf16 operands (the 32 -> 32 case: small enough for a dense reference here)
+    if Cout == 32 and H == 47:
+        ref = torch.nn.functional.conv2d(x[:4].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        assert float((a[1][:4].double() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+        refdx = torch.nn.functional.conv_transpose2d(dy[:4].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        # (rows of image 3 next to image 4 are complete: the gradient of a pixel depends on its own image only)
+        assert float((a[3][:4].double() - refdx).abs().max()) <= 2 ** -7 * float(refdx.abs().max())

@@ -644,3 +644,30 @@ def test_sparse_ego_map_record_round_trips_bit_for_bit():
     assert set(want[0]) == set(got[0]) and all(torch.equal(want[0][k], got[0][k]) for k in want[0])
     with pytest.raises(TypeError):
         sparse_pack_ego(np.zeros((2, 32, 4, 4), np.float16))
+
+
+def test_every_environment_switch_is_declared():
+    """the product reads at most 40 WSMG_* environment names, and every one is declared — the Python side in the one
+    table of wsmgmap/debug.py, the library's WSMG_TUNE names in INTEGRATION.md section 3.1 (plus WSMG_LIB, the library path)."""
+    import sys
+    root = os.path.join(ROOT, "ws-mgmap_amd")
+    py_names, lib_names = set(), set()
+    for d, _, files in os.walk(root):
+        for f in files:
+            p = os.path.join(d, f)
+            if f.endswith(".py"):
+                src = open(p).read()
+                if not p.endswith(os.path.join("wsmgmap", "debug.py")):
+                    py_names |= set(re.findall(r"environ[^\n]*?[\"'](WSMG_[A-Z0-9_]+)[\"']", src))
+            elif f.endswith((".hip", ".h")):
+                src = open(p).read()
+                lib_names |= set(re.findall(r"WSMG_TUNE\(\"(WSMG_[A-Z0-9_]+)\"", src))
+                assert not re.findall(r"getenv\(\"", src), p       # the library reads the environment through WSMG_TUNE only
+    sys.path.insert(0, root)
+    from wsmgmap import debug
+    table = {v for _, v, _, _, _ in debug._TABLE}
+    assert py_names <= table | {"WSMG_LIB"}, py_names - table
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in lib_names | {"WSMG_LIB"}:
+        assert "`%s`" % n in doc, n
+    assert len(table | lib_names | {"WSMG_LIB"}) <= 40

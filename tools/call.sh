@@ -56,4 +56,27 @@ PY
    timeout 900 python3 tools/bf16_vs_f32_long.py 200 8 gpurun_out/c9_long.json > gpurun_out/c9_long.txt 2>&1
    tools/ab.sh c9_modes 2 30 "X=1" > /dev/null 2>&1
    for r in 1 2; do for m in bf16 bf16+f32grad; do python3 bench.py --dtype $m --steps 30 --warmup 5 --no-f32 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$m', d['ms_per_step'])"; done; done > gpurun_out/c9_modes.txt 2>&1 ;;
+10) timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 > gpurun_out/c10_conv.txt 2>&1
+   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   rm -rf gpurun_out/st10
+   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st10 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c10_st.log 2>&1
+   cp $(ls gpurun_out/st10/*/*kernel_stats.csv | head -1) gpurun_out/c10_kernel_stats.csv
+   rm -rf gpurun_out/st10 ;;
+11) python -m pytest tests/test_gpu_round6.py -x -q -k "k32 or colsum or concat" 2>&1 | tail -15 > gpurun_out/c11_tests.txt
+   python -m pytest tests/test_gpu_kernels.py tests/test_gpu_policy.py -x -q 2>&1 | tail -5 >> gpurun_out/c11_tests.txt
+   timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 --only cls_k3 > gpurun_out/c11_conv.txt 2>&1
+   timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 --only classified >> gpurun_out/c11_conv.txt 2>&1
+   WSMG_CONV_K32=0 timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 --only cls_k3 >> gpurun_out/c11_conv.txt 2>&1
+   WSMG_CONV_K32=0 timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 --only classified >> gpurun_out/c11_conv.txt 2>&1
+   for w in 2 4; do WSMG_CONV_K32_WGS=$w timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 --only cls_k3 | tail -2 >> gpurun_out/c11_conv.txt 2>&1; done
+   tools/ab.sh c11_k32 3 30 "WSMG_CONV_K32=0" "WSMG_CONV_K32=1" > gpurun_out/c11_ab.txt 2>&1 ;;
+12) python -m pytest tests/test_gpu_round6.py -x -q -k "k32 or colsum or concat" 2>&1 | tail -8 > gpurun_out/c12_tests.txt
+   python -m pytest tests/test_gpu_kernels.py -x -q -k "lstm or bilstm" 2>&1 | tail -3 >> gpurun_out/c12_tests.txt
+   for k in 1 0; do for l in cls_k3 classified; do WSMG_CONV_K32=$k timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 --only $l | tail -2 | head -1; done; done > gpurun_out/c12_conv.txt 2>&1
+   python3 -c "import torch; print(torch.cuda.Stream.priority_range())" > gpurun_out/c12_prio.txt 2>&1
+   tools/ab.sh c12_prio 3 30 "X=1" "WSMG_EXP_PRIO_INSTRUCTION=1" "WSMG_EXP_PRIO_INSTRUCTION=1 WSMG_EXP_PRIO_DECODER=1" "WSMG_EXP_PRIO_INSTRUCTION=-1 WSMG_EXP_PRIO_DECODER=-1" > gpurun_out/c12_ab.txt 2>&1 ;;
+13) python -m pytest tests/test_gpu_round6.py tests/test_gpu_round5.py tests/test_gpu_kernels.py tests/test_gpu_policy.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q 2>&1 | tail -8 > gpurun_out/c13_tests.txt
+   timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 > gpurun_out/c13_conv_new.txt 2>&1
+   WSMG_LIB=$GRAFT_REPO_ROOT/ws-mgmap_amd/wsmgmap/lib/libwsmgmap_prev.so timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 > gpurun_out/c13_conv_prev.txt 2>&1
+   tools/ab.sh c13_lib 4 30 "WSMG_LIB=$GRAFT_REPO_ROOT/ws-mgmap_amd/wsmgmap/lib/libwsmgmap_prev.so" "X=1" > gpurun_out/c13_ab.txt 2>&1 ;;
 esac

@@ -318,7 +318,7 @@ struct F8fArgs {
   float* scales_out;       // [3] or null: the scales used (diagnostics / tests)
   float* out;
   float* attn;
-  float* trace;            // WSMG_FP8_TRACE=1 (diagnostic): microseconds since the start of workgroup 0 at its phase boundaries
+  float* trace;            // diagnostic build (`tracing` in the launcher): microseconds since the start of workgroup 0 at its phase boundaries
 };
 
 __device__ __forceinline__ long quant8(const float* p, float inv_scale) {
@@ -720,7 +720,7 @@ extern "C" int wsmg_attn_fp8_mfma_fused(const float* q, const float* k_sets, con
   a.ws = workspace; a.target = arrivals_before + (unsigned)(nmain + nhelp); a.parity = epoch & 1; a.need_amax = need;
   a.scales_out = scales_out; a.out = out; a.attn = attn;
   static float* trace_dev = nullptr;
-  const bool tracing = (0) != 0;
+  constexpr bool tracing = false;   // diagnostic build: true = phase stamps on stderr (synchronises)
   if (tracing && !trace_dev && hipMalloc((void**)&trace_dev, 16 * sizeof(float)) != hipSuccess) trace_dev = nullptr;
   a.trace = tracing ? trace_dev : nullptr;
   constexpr int FUSED_LDS = 32 * (LMAX + 4) * 4 + NCHMAX * 32 * (AC + 16);

@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256, 4) void map_retrieve_tiled_kernel(const float*
                                                                  unsigned* __restrict__ trace) {
   extern __shared__ float boxf[];  // [bh][bw][4 S4] floats: the box; then bw + 2 pixels of zeros
   __shared__ int s_ext[16][4];
-  // WSMG_RETRIEVE_TRACE=1 (diagnostic): cycles of every 64th workgroup at its phase boundaries
+  // diagnostic build (`tracing` in the launcher): cycles of every 64th workgroup at its phase boundaries
   const bool tr = trace && threadIdx.x == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x >> 6) < 64;
   unsigned* const trw = trace + (blockIdx.x >> 6) * 8;
   const unsigned long long t00 = tr ? __builtin_readcyclecounter() : 0;
@@ -1151,7 +1151,7 @@ extern "C" int wsmg_map_retrieve_tiled(const float* global_map, const float* gps
   // i / S4 as a multiply-high: exact while i * S4 < 2^32 (i < 16 * 14 * S4)
   const unsigned magic = 0xFFFFFFFFu / (unsigned)S4 + 1u;
   static unsigned* trace_dev = nullptr;
-  const bool tracing = (0) != 0;
+  constexpr bool tracing = false;   // diagnostic build: true = phase stamps on stderr (synchronises)
   if (tracing && !trace_dev && hipMalloc((void**)&trace_dev, 64 * 8 * sizeof(unsigned)) != hipSuccess) trace_dev = nullptr;
   const int nblk = tiles * tiles * nsplit;
   hipLaunchKernelGGL(map_retrieve_tiled_kernel, dim3((unsigned)nblk, (unsigned)B), dim3(256), lds, wsmg_s(stream),

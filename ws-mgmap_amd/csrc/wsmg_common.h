@@ -94,6 +94,10 @@ int wsmg_conv_s2_wgrad_splits(int B, int H, int W, int Cin, int Cout, int KH, in
 int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
                         int B, int H, int W, int Kc, int N, int mt, int mixed, const void* relu_z, int dst_ld, void* dst2, int split_c,
                         hipStream_t s);
+// wsmg_conv_win3_k32.hip (round 6): the same convolution over a 32-channel reduction axis (Kc == 32, N % 32 == 0, plain output): weights
+// resident in LDS, one barrier per 256-pixel tile, three workgroups per CU; WSMG_EINVAL otherwise
+int wsmg_conv_win3_k32_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
+                            int B, int H, int W, int N, int dst_ld, hipStream_t s);
 // wsmg_conv_win3_wgrad.hip: weight gradient of a 3 x 3 / stride 1 / pad 1 layer out of a zero-padded LDS window (W <= 24, channel
 // multiples of 64 / 128); WSMG_EINVAL otherwise
 int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,

@@ -117,14 +117,24 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16_kernel(ConvArgsB a) {
   const int sg = BWD ? -1 : 1;
   int roff[APASS];
   unsigned ymask[APASS], xmask[APASS];
+  // (image, row, column) of this thread's first staged row by division, of the rows RPP further on by stepping (round 6: the two
+  // runtime-divisor divisions per pass were ~1 000 VALU cycles per tile of a kernel that is issue-bound and has 9-18 k-steps in the
+  // small layers).  Rows past the last pixel carry coordinates that are never used: their masks are empty.
+  int rb_ = (m0 + lrow) / (THc * TWc);
+  int ry_, rx_;
+  {
+    const int r0 = (m0 + lrow) - rb_ * (THc * TWc);
+    ry_ = r0 / TWc;
+    rx_ = r0 - ry_ * TWc;
+  }
 #pragma unroll
   for (int i = 0; i < APASS; ++i) {
     int m = m0 + lrow + RPP * i;
     bool pv = m < Mc;
-    int mm = pv ? m : 0;
-    int b = mm / (THc * TWc);
-    int r = mm - b * (THc * TWc);
-    int iy = r / TWc, ix = r - iy * TWc;
+    const int b = pv ? rb_ : 0, iy = pv ? ry_ : 0, ix = pv ? rx_ : 0;
+    rx_ += RPP;
+    while (rx_ >= TWc) { rx_ -= TWc; ++ry_; }
+    while (ry_ >= THc) { ry_ -= THc; ++rb_; }
     int ty = ty0 + iy * tstep, tx = tx0 + ix * tstep;
     int py, px;
     if (BWD) {
@@ -604,6 +614,12 @@ int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 25
 // channels: 0 = no (implicit-GEMM kernel), else pixels per workgroup.  Measured at B = 512 (tools/ab_win3.sh): at Kc = 32 (9
 // k-steps) its prologue costs more than the window saves; 512-pixel tiles move half the weight bytes per MFMA of 256-pixel
 // ones but need >= 4 rounds of workgroups over the 256 CUs to keep the last round's idle CUs cheap (N = 128 layers: 256).
+// round 6: a 32-channel reduction axis takes wsmg_conv_win3_k32.hip (by-shape choice only: a forced tile keeps the general window kernel,
+// which is how the tests hold the two against each other; WSMG_CONV_K32=0: A/B)
+bool k32_choice(int64_t M, int Kc, int N) {
+  // (N = 128, the classifier's 32 -> 128 projection: 41 us either way — four channel tiles re-read the window; it stays where it was)
+  return win3_tile() == 1 && Kc == 32 && (N == 32 || N == 64) && M >= 2 * 256 * 256 && WSMG_TUNE("WSMG_CONV_K32", 1) != 0;
+}
 int win3_choice(int64_t M, int Kc, int N) {
   const int t = win3_tile();
   if (t == 0 || M < 256 * 256 || Kc % 32 || N % 32) return 0;
@@ -786,6 +802,10 @@ int conv_fwd_bf16_impl(const void* x, const void* w_ohwi, const float* bias, voi
     }
   }
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 5) == 0) {
+    if (k32_choice((int64_t)B * OH * OW, Cin, Cout)) {
+      int rc = wsmg_conv_win3_k32_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cout, y_ld, wsmg_s(stream));
+      if (rc != WSMG_EINVAL) return rc;
+    }
     if (const int mt = win3_choice((int64_t)B * OH * OW, Cin, Cout)) {
       int rc = wsmg_conv_win3_bf16(0, x, w_ohwi, bias, y, (out_f32 & 2) != 0, stats, nslab, B, H, W, Cin, Cout, mt, win3_tile() == 1, nullptr, y_ld, nullptr, 0, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;
@@ -833,6 +853,10 @@ int conv_bwd_data_bf16_impl(const void* dy, const void* w_ihwo, void* dx, int ou
   if (relu_y && ((out_f32 & 5) != 0 || (Cin & 7) != 0 || ((uintptr_t)relu_y & 15))) return WSMG_EINVAL;
   if (dx2 && ((out_f32 & 5) != 0 || (Cin & 7) != 0 || split_c <= 0 || split_c >= Cin || (split_c & 7) || ((uintptr_t)dx2 & 15))) return WSMG_EINVAL;
   if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && OH == H && OW == W && (out_f32 & 7) == 0) {
+    if (!relu_y && !dx2 && k32_choice((int64_t)B * H * W, Cout, Cin)) {
+      int rc = wsmg_conv_win3_k32_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cin, 0, wsmg_s(stream));
+      if (rc != WSMG_EINVAL) return rc;
+    }
     if (const int mt = win3_choice((int64_t)B * H * W, Cout, Cin)) {
       int rc = wsmg_conv_win3_bf16(1, dy, w_ihwo, nullptr, dx, 0, stats, nslab, B, H, W, Cout, Cin, mt, win3_tile() == 1, relu_y, 0, dx2, split_c, wsmg_s(stream));
       if (rc != WSMG_EINVAL) return rc;

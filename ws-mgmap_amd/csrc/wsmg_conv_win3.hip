@@ -126,14 +126,24 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
   // ---- DMA roles.  Window piece j of this wave = entries 16 (8 j + wave) .. + 15; lane = (entry in the piece, slot).
   const int lrow = lane >> 2, slot = lane & 3;
   int aoff[NPW];   // byte offset of (source pixel, channel 0, this lane's swizzled chunk), or out of range (pad / past the window)
+  {
+    // (image, padded row, padded column) of the first piece's entry by division, of the others by stepping 128 entries on (round 6: two
+    // runtime-divisor divisions per piece and two per accumulator tile below were ~20 per lane and tile — 3 000 cycles of a tile that has
+    // one workgroup per CU and nothing to hide them under; q0 >= 0: the window starts on the pad row above the tile's first pixel)
+    const int q = q0 + 16 * wave + lrow;
+    int b = q / PP;
+    const int rem = q - b * PP;
+    int pr = rem / PW, pc = rem - pr * PW;
 #pragma unroll
-  for (int j = 0; j < NPW; ++j) {
-    const int e = 16 * (8 * j + wave) + lrow;
-    const int q = q0 + e;
-    const int b = q / PP, rem = q - b * PP;
-    const int yy = rem / PW - 1, xx = rem - (rem / PW) * PW - 1;
-    const bool ok = q >= 0 && e < nwin && b < a.B && yy >= 0 && yy < H && xx >= 0 && xx < W;
-    aoff[j] = ok ? (((b * H + yy) * W + xx) * a.Kc) * 2 + 16 * (slot ^ ((e >> 2) & 3)) : (int)0x80000000;
+    for (int j = 0; j < NPW; ++j) {
+      const int e = 16 * (8 * j + wave) + lrow;
+      const int yy = pr - 1, xx = pc - 1;
+      const bool ok = e < nwin && b < a.B && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      aoff[j] = ok ? (((b * H + yy) * W + xx) * a.Kc) * 2 + 16 * (slot ^ ((e >> 2) & 3)) : (int)0x80000000;
+      pc += 128;
+      while (pc >= PW) { pc -= PW; ++pr; }
+      while (pr >= H + 2) { pr -= H + 2; ++b; }
+    }
   }
   // weights: piece `wave` of a k-step = rows 16 wave .. + 15 of the [128][32] tile
   const int brow = 16 * wave + lrow;
@@ -157,10 +167,19 @@ __device__ __forceinline__ void win3_tile_body(const Win3Args& a, const int bid,
   const int wm = (wave % WM) * (MT / WM), wn = (wave / WM) * 64;
   const int r = lane & 31, h = lane >> 5;
   int ecen[TT];    // window entry of this lane's row of accumulator tile t, centre tap
+  {
+    const int m = m0 + wm + r;
+    int b = m / (H * W);
+    const int rr = m - b * (H * W);
+    int y = rr / W, x = rr - y * W;
+    const int elast = padded(Mtot - 1) - q0;                 // rows past the last pixel repeat it (never stored)
 #pragma unroll
-  for (int t = 0; t < TT; ++t) {
-    const int m = m0 + wm + 32 * t + r;
-    ecen[t] = padded(m < Mtot ? m : Mtot - 1) - q0;
+    for (int t = 0; t < TT; ++t) {
+      ecen[t] = m + 32 * t < Mtot ? b * PP + (y + 1) * PW + x + 1 - q0 : elast;
+      x += 32;
+      while (x >= W) { x -= W; ++y; }
+      while (y >= H) { y -= H; ++b; }
+    }
   }
   int bpos[NU][2];  // byte offset of this lane's weight fragment (column tile u, 16-deep slice ks) in a stage
 #pragma unroll

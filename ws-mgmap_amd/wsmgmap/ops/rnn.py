@@ -108,7 +108,8 @@ class _BiLSTM(torch.autograd.Function):
         # backward, on the instruction stream)
         dgd = dg.permute(2, 0, 1, 3).contiguous().view(2, U * L, 4 * H)
         dw = torch.stack([dgd[0].t() @ hprev_f.reshape(U * L, H), dgd[1].t() @ hprev_r.reshape(U * L, H)])
-        db = dg.sum(dim=(0, 1))
+        from .heads import colsum_multi    # stock sum over (0, 1) of the strided view: 324 us on the instruction stream
+        db = torch.stack(colsum_multi([dgd[0], dgd[1]]))
         return dg, dw, db, None
 
 
