@@ -6,7 +6,9 @@
 // 151 MB (28 us at the rate the BatchNorm passes stream at) and holds 18 MFMAs per 32 pixels.  The reduction is 288 deep: all of a
 // 32-output-channel tile's weights are 18 KB.  So here
 //   * a workgroup (4 waves) keeps its channel tile's weights in LDS for its whole life and walks the pixel tiles
-//     blockIdx, blockIdx + gridDim, ... (gridDim = 3 per CU, a multiple of the channel tiles, so a workgroup's channel tile is fixed);
+//     blockIdx, blockIdx + gridDim, ... (gridDim = 6 per CU — two or three tiles per workgroup at B = 512: three are resident per CU, and a
+//     grid of exactly the resident workgroups queues badly behind whatever else shares the chip — and a multiple of the channel tiles, so
+//     a workgroup's channel tile is fixed);
 //   * per 256-pixel tile: the zero-padded window (wsmg_conv_win3.hip's geometry and swizzle, LDS-DMA) -> ONE barrier -> 9 taps x 2
 //     slices of MFMAs with no barrier between them (wave tile 64 pixels x 32 channels) -> the output tile through LDS -> 16-byte stores;
 //   * 50 KB of LDS: three workgroups per CU, whose load / compute / store phases overlap each other — the overlap a single
@@ -215,7 +217,7 @@ int wsmg_conv_win3_k32_bf16(int bwd, const void* src, const void* wt, const floa
     attr = true;
   }
   const int64_t tiles = (int64_t)a.mtiles * a.ntiles;
-  int64_t grid = (int64_t)WSMG_TUNE("WSMG_CONV_K32_WGS", 3) * cus;
+  int64_t grid = (int64_t)WSMG_TUNE("WSMG_CONV_K32_WGS", 6) * cus;
   if (grid > tiles) grid = tiles;
   grid = grid / a.ntiles * a.ntiles;            // a workgroup's channel tile is blockIdx % ntiles for every tile it walks
   if (grid <= 0) return WSMG_EINVAL;
