@@ -79,4 +79,8 @@ PY
    timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 > gpurun_out/c13_conv_new.txt 2>&1
    WSMG_LIB=$GRAFT_REPO_ROOT/ws-mgmap_amd/wsmgmap/lib/libwsmgmap_prev.so timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 10 > gpurun_out/c13_conv_prev.txt 2>&1
    tools/ab.sh c13_lib 4 30 "WSMG_LIB=$GRAFT_REPO_ROOT/ws-mgmap_amd/wsmgmap/lib/libwsmgmap_prev.so" "X=1" > gpurun_out/c13_ab.txt 2>&1 ;;
+16) python -m pytest tests/test_gpu_round6.py tests/test_gpu_policy.py tests/test_gpu_round3.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3 > gpurun_out/c16_tests.txt
+   for db in 1 0; do WSMG_CONV_K32_DB=$db timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only cls_k3 | tail -2 | head -1; done > gpurun_out/c16_conv.txt 2>&1
+   for w in 2 3 6 8; do WSMG_CONV_K32_WGS2=$w timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only cls_k3 | tail -2 | head -1; done >> gpurun_out/c16_conv.txt 2>&1
+   tools/ab.sh c16_db 3 30 "WSMG_CONV_K32_DB=0" "X=1" "WSMG_CONV_K32=0" > gpurun_out/c16_ab.txt 2>&1 ;;
 esac
