@@ -254,8 +254,8 @@ def test_k32_window_convolution_is_bit_identical_to_the_general_window_kernel(B,
     wsmg_conv_win3_k32.hip — weights resident in LDS, one barrier per 256-pixel tile, three workgroups per CU — runs the same MFMA
     sequence per output element as the general window kernel (itself held against the float64 oracle by test_conv2d_fwd_bwd and the
     G3 / full-size policy tests): forward (bias + ReLU, plain, into a channel slice of a wider tensor) and backward-data outputs bit
-    for bit, pixel counts that are not a multiple of the tile included (48 x 48: the double-buffered form, with several, uneven and single
-    tiles per workgroup; the others: one buffer); the BatchNorm sums (other partial-sum grouping) to 1e-6."""
+    for bit, pixel counts that are not a multiple of the tile included, several / uneven / single tiles per workgroup; the BatchNorm sums
+    (other partial-sum grouping) to 1e-6."""
     from wsmgmap import _abi, ops
     g = torch.Generator(device="cuda").manual_seed(B + H + Cout)
     x = torch.relu(torch.randn(B, H, H, Cin, device="cuda", generator=g)).to(torch.bfloat16)

@@ -43,7 +43,8 @@ for d, e in per.items():
               "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "GRBM_GUI_ACTIVE"):
         f[k] += e.get(k, 0.0)
 
-UPDATES = 2   # --steps 1 --warmup 1
+# updates in the pass = the optimizer's launches / 3 (bench.py runs probe updates before --warmup / --steps since round 6)
+UPDATES = max(1, sum(1 for e in per.values() if "adam_multi_kernel" in e["name"]) // 3)
 res = {}
 for name, f in fam.items():
     if f["SQ_VALU_MFMA_BUSY_CYCLES"] <= 0:

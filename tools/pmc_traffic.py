@@ -27,7 +27,8 @@ def load(path, counter):
     return per
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-UPDATES = 2   # --steps 1 --warmup 1: two identical updates; per-update figures are the mean of the two
+# updates in the pass = the optimizer's launches / 3 (bench.py runs probe updates before --warmup / --steps since round 6: a fixed 2 was wrong)
+UPDATES = max(1, sum(1 for d in fetch if "adam_multi_kernel" in fetch[d][0]) // 3)
 out = collections.OrderedDict()
 for per, key in ((fetch, "fetch_kib"), (write, "write_kib")):
     for d in sorted(per):

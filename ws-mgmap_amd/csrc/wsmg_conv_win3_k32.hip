@@ -33,8 +33,8 @@ struct K32Args {
   int nslab;
 };
 
-constexpr int MT = 256, ROWB = 64, TAPB = 32 * ROWB, WTB = 9 * TAPB, OP = 80;
-constexpr int k32_lds(int npc, bool db) { return (db ? 2 : 1) * 64 * npc * ROWB + WTB; }
+constexpr int MT = 256, WCAP = 512, ROWB = 64, WINB = WCAP * ROWB, TAPB = 32 * ROWB, WTB = 9 * TAPB, OP = 80;
+constexpr int K32_LDS = WINB + WTB;
 
 __device__ __forceinline__ void dma16k(__amdgpu_buffer_rsrc_t r, unsigned char* lds_wave_base, int byte_off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, byte_off, 0, 0, 0);
@@ -44,14 +44,10 @@ __device__ __forceinline__ unsigned short f2bfk(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
-// NPC: window pieces (16 entries) per wave — window capacity 64 NPC entries; DB: two window buffers — the next tile's window is in flight
-// while this one is multiplied, staged and stored (its buffer is the staging area of the tile before)
-template <int NPC, bool DB>
 __global__ __launch_bounds__(256) void conv_win3_k32_kernel(K32Args a) {
-  constexpr int WINB = 64 * NPC * ROWB;
-  static_assert(MT * OP <= WINB, "the output tile is staged in a window buffer");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const wts = smem + (DB ? 2 : 1) * WINB;
+  unsigned char* const win = smem;
+  unsigned char* const wts = smem + WINB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane >> 2, slot = lane & 3;
   const int r = lane & 31, h = lane >> 5;
@@ -78,37 +74,32 @@ __global__ __launch_bounds__(256) void conv_win3_k32_kernel(K32Args a) {
     const int b = m / (H * W), rr = m - b * (H * W), y = rr / W, x = rr - y * W;
     return b * PP + (y + 1) * PW + x + 1;
   };
-  // window of the tile at pixel m0 -> buf: piece j of this wave = entries 16 (4 j + wave) .. + 15.  (image, padded row, padded column) of
-  // the first piece's entry by division, of the others by stepping 64 entries on
-  auto issue_window = [&](int m0, unsigned char* buf) {
+
+  const int ntl = a.mtiles * a.ntiles;
+  for (int tile = blockIdx.x; tile < ntl; tile += gridDim.x) {
+    const int m0 = (tile / a.ntiles) * MT;
     const int mlast = (m0 + MT - 1 < Mtot ? m0 + MT - 1 : Mtot - 1);
     const int q0 = padded(m0) - PW - 1;
     const int nwin = padded(mlast) + PW + 1 - q0 + 1;
-    const int e0 = 16 * wave + lrow;
-    const int q = q0 + e0;                                   // (q0 >= 0: the window starts on the pad row above the first pixel)
-    int b = q / PP;
-    const int rem = q - b * PP;
-    int pr = rem / PW, pc = rem - pr * PW;
+    // ---- window: piece j of this wave = entries 16 (4 j + wave) .. + 15.  (image, padded row, padded column) of the first piece's entry
+    // by division, of the others by stepping 64 entries on: the divisions of all 8 pieces were most of a tile's VALU time
+    {
+      const int e0 = 16 * wave + lrow;
+      const int q = q0 + e0;                                   // (q0 >= 0: the window starts on the pad row above the first pixel)
+      int b = q / PP;
+      const int rem = q - b * PP;
+      int pr = rem / PW, pc = rem - pr * PW;
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
-      const int e = e0 + 64 * j;
-      const int yy = pr - 1, xx = pc - 1;
-      const bool ok = e < nwin && b < a.B && yy >= 0 && yy < H && xx >= 0 && xx < W;
-      dma16k(rs_src, buf + (4 * j + wave) * 1024, ok ? (((b * H + yy) * W + xx) * 32) * 2 + 16 * (slot ^ ((e >> 2) & 3)) : (int)0x80000000);
-      pc += 64;
-      while (pc >= PW) { pc -= PW; ++pr; }
-      while (pr >= H + 2) { pr -= H + 2; ++b; }
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + 64 * j;
+        const int yy = pr - 1, xx = pc - 1;
+        const bool ok = e < nwin && b < a.B && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        dma16k(rs_src, win + (4 * j + wave) * 1024, ok ? (((b * H + yy) * W + xx) * 32) * 2 + 16 * (slot ^ ((e >> 2) & 3)) : (int)0x80000000);
+        pc += 64;
+        while (pc >= PW) { pc -= PW; ++pr; }
+        while (pr >= H + 2) { pr -= H + 2; ++b; }
+      }
     }
-  };
-
-  const int ntl = a.mtiles * a.ntiles;
-  if (DB) issue_window(((int)blockIdx.x / a.ntiles) * MT, smem);
-  int k = 0;
-  for (int tile = blockIdx.x; tile < ntl; tile += gridDim.x, ++k) {
-    const int m0 = (tile / a.ntiles) * MT;
-    unsigned char* const win = smem + (DB ? (k & 1) * WINB : 0);
-    if (!DB) issue_window(m0, win);
-    const int q0 = padded(m0) - PW - 1;
     int ecen[2];
     {
       const int m = m0 + wave * 64 + r;                        // second accumulator tile: 32 pixels on
@@ -124,10 +115,8 @@ __global__ __launch_bounds__(256) void conv_win3_k32_kernel(K32Args a) {
         while (y >= H) { y -= H; ++b; }
       }
     }
-    // this tile's window (and, DB: the stores of the tile before, whose staging area the next window is about to land on) are complete
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (DB && tile + (int)gridDim.x < ntl) issue_window(((tile + (int)gridDim.x) / a.ntiles) * MT, smem + ((k + 1) & 1) * WINB);
 
     f32x16 acc[2];
 #pragma unroll
@@ -178,12 +167,11 @@ __global__ __launch_bounds__(256) void conv_win3_k32_kernel(K32Args a) {
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>(a.dst) + ((size_t)(m0 + row) * ldd + n0 + ch * 8) * 2) =
             *reinterpret_cast<const u32x4*>(win + row * OP + ch * 16);
     }
-    if (!DB) __syncthreads();   // the staged tile has left LDS before the next window lands on it (DB: the barrier at the top does it)
+    __syncthreads();   // the staged tile has left LDS before the next window lands on it
   }
 
   if (a.stats) {   // one flush per workgroup: lanes r and r + 32 hold different rows of channel n0 + r; then the four waves, in order
-    __syncthreads();
-    double* const sh = reinterpret_cast<double*>(smem);
+    double* const sh = reinterpret_cast<double*>(win);
     const double s2 = st_s + __shfl_xor(st_s, 32, 64), q2 = st_q + __shfl_xor(st_q, 32, 64);
     if (h == 0) {
       sh[wave * 64 + r] = s2;
@@ -198,21 +186,28 @@ __global__ __launch_bounds__(256) void conv_win3_k32_kernel(K32Args a) {
   }
 }
 
-// window entries a tile of mt consecutive pixels can need (wsmg_conv_win3.hip's window_bound); tiles that never cross an image (H W a
-// multiple of mt) do without the pad rows between two images
+// window entries a tile of mt consecutive pixels can need (wsmg_conv_win3.hip's window_bound)
 int k32_window_bound(int mt, int H, int W) {
   const int rows = (mt + W - 2) / W + 1;
-  const int imgs = (H * W) % mt == 0 ? 1 : (mt + H * W - 2) / (H * W) + 1;
+  const int imgs = (mt + H * W - 2) / (H * W) + 1;
   return mt + 2 * (rows - 1) + 2 * (W + 2) * (imgs - 1) + 2 * (W + 3) + 1;
 }
 
-template <int NPC, bool DB>
-int launch_k32(K32Args& a, int per_cu, hipStream_t s) {
-  constexpr int LDS = k32_lds(NPC, DB);
+}  // namespace
+
+// Kc == 32, N % 32 == 0, plain output (no mask, no split); WSMG_EINVAL otherwise (the caller then uses the general window kernel)
+int wsmg_conv_win3_k32_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
+                            int B, int H, int W, int N, int dst_ld, hipStream_t s) {
+  if (N <= 0 || N % 32 || B <= 0 || k32_window_bound(MT, H, W) > WCAP) return WSMG_EINVAL;
+  if (stats && nslab <= 0) return WSMG_EINVAL;
+  K32Args a{(const bf16_t*)src, (const bf16_t*)wt, bias, (bf16_t*)dst, B, H, W, N, N / 32, 0, relu, bwd, dst_ld,
+            (unsigned)((size_t)B * H * W * 32 * 2), (unsigned)((size_t)N * 9 * 32 * 2), stats, nslab};
+  const int64_t M = (int64_t)B * H * W;
+  a.mtiles = (int)wsmg_cdiv(M, MT);
   static int cus = 0;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_k32_kernel<NPC, DB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win3_k32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, K32_LDS);
     if (e != hipSuccess) return (int)e;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -222,32 +217,11 @@ int launch_k32(K32Args& a, int per_cu, hipStream_t s) {
     attr = true;
   }
   const int64_t tiles = (int64_t)a.mtiles * a.ntiles;
-  int64_t grid = (int64_t)per_cu * cus;
+  int64_t grid = (int64_t)WSMG_TUNE("WSMG_CONV_K32_WGS", 6) * cus;
   if (grid > tiles) grid = tiles;
   grid = grid / a.ntiles * a.ntiles;            // a workgroup's channel tile is blockIdx % ntiles for every tile it walks
   if (grid <= 0) return WSMG_EINVAL;
-  hipLaunchKernelGGL((conv_win3_k32_kernel<NPC, DB>), dim3((unsigned)grid), dim3(256), LDS, s, a);
+  hipLaunchKernelGGL(conv_win3_k32_kernel, dim3((unsigned)grid), dim3(256), K32_LDS, s, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
-}
-
-}  // namespace
-
-// Kc == 32, N % 32 == 0, plain output (no mask, no split); WSMG_EINVAL otherwise (the caller then uses the general window kernel)
-int wsmg_conv_win3_k32_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
-                            int B, int H, int W, int N, int dst_ld, hipStream_t s) {
-  const int bound = k32_window_bound(MT, H, W);
-  if (N <= 0 || N % 32 || B <= 0 || bound > 512) return WSMG_EINVAL;
-  if (stats && nslab <= 0) return WSMG_EINVAL;
-  K32Args a{(const bf16_t*)src, (const bf16_t*)wt, bias, (bf16_t*)dst, B, H, W, N, N / 32, 0, relu, bwd, dst_ld,
-            (unsigned)((size_t)B * H * W * 32 * 2), (unsigned)((size_t)N * 9 * 32 * 2), stats, nslab};
-  const int64_t M = (int64_t)B * H * W;
-  a.mtiles = (int)wsmg_cdiv(M, MT);
-  // a 384-entry window (tiles inside one image of a 48 x 48 map) leaves room for two buffers at two workgroups per CU: the next
-  // tile's window loads under this tile's arithmetic and stores.  WSMG_CONV_K32_DB=0: one buffer, three workgroups per CU (A/B)
-  if (bound <= 384) {
-    if (WSMG_TUNE("WSMG_CONV_K32_DB", 1)) return launch_k32<6, true>(a, WSMG_TUNE("WSMG_CONV_K32_WGS2", 4), s);
-    return launch_k32<6, false>(a, WSMG_TUNE("WSMG_CONV_K32_WGS", 6), s);
-  }
-  return launch_k32<8, false>(a, WSMG_TUNE("WSMG_CONV_K32_WGS", 6), s);
 }
