@@ -145,7 +145,7 @@ def cfg4_bev_mapenc(dev, reps=10):
         compass = obs["compass"].reshape(B).contiguous()
         gps = obs["gps"].contiguous()
         gm = mapper.full_global_map
-        compact_ok = ops.bev_compact_ok(Hf, Hf, E)
+        compact_ok = ops.bev_compact_ok(Hf, Hf, E, B)
         lin, comp = ops.bev_index_compact(depth, Hf, Hf, E) if compact_ok else (ops.bev_index(depth, Hf, Hf, E), None)
         rot = ops.bev_scatter_rotate(feat, lin, compass, -1.0, C, E, compact=comp)
         m1 = masks.reshape(B).contiguous()

@@ -83,4 +83,13 @@ PY
    for db in 1 0; do WSMG_CONV_K32_DB=$db timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only cls_k3 | tail -2 | head -1; done > gpurun_out/c16_conv.txt 2>&1
    for w in 2 3 6 8; do WSMG_CONV_K32_WGS2=$w timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only cls_k3 | tail -2 | head -1; done >> gpurun_out/c16_conv.txt 2>&1
    tools/ab.sh c16_db 3 30 "WSMG_CONV_K32_DB=0" "X=1" "WSMG_CONV_K32=0" > gpurun_out/c16_ab.txt 2>&1 ;;
+17) cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   for arm in dflt nodec; do
+     if [ $arm = nodec ]; then export WSMG_DECODER_STREAMS=0; else unset WSMG_DECODER_STREAMS; fi
+     rm -rf gpurun_out/st17
+     timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st17 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c17_$arm.log 2>&1
+     cp $(ls gpurun_out/st17/*/*kernel_stats.csv | head -1) gpurun_out/c17_kernel_stats_$arm.csv
+     rm -rf gpurun_out/st17
+   done
+   unset WSMG_DECODER_STREAMS ;;
 esac

@@ -56,7 +56,7 @@ class Mapping(nn.Module):
         local_scale = float(self.global_map_size * self.resolution) / float(self.global_map_size)
         fused = ops.bev_planes_ok(C, E) and debug.sw.bev_fused
         compact = None
-        if fused and ops.bev_compact_ok(Hf, Wf, E):      # round 6: the index launch also packs the valid sources (20-25 % of a frame)
+        if fused and ops.bev_compact_ok(Hf, Wf, E, bs):      # round 6: the index launch also packs the valid sources (20-25 % of a frame)
             lin, compact = ops.bev_index_compact(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)
         else:
             lin = ops.bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=local_scale)

@@ -22,9 +22,10 @@ def bev_index(depth, Hf, Wf, E, depth_scale=10.0, local_scale=0.12):
     return lin
 
 
-def bev_compact_ok(Hf, Wf, E):
-    """Shapes the compacted-source route takes (source and cell ids are packed into 16 bits each)."""
-    return Hf * Wf <= 65536 and E * E <= 65536 and sw.bev_compact
+def bev_compact_ok(Hf, Wf, E, B=None):
+    """Shapes the compacted-source route takes (source and cell ids are packed into 16 bits each).  Not below 4 frames: there the
+    operator is four launches' latency (cfg1: 40 us), the scatter is not paced by its list, and the compaction adds 3 us to the index."""
+    return Hf * Wf <= 65536 and E * E <= 65536 and sw.bev_compact and (B is None or B >= 4)
 
 
 @torch.no_grad()
