@@ -237,6 +237,11 @@ def measure(args, dtype, steps, warmup, rank, world, local, dev):
 
     T, N = args.T, args.N
     obs, prev, masks, weights = synth_batch(T, N, dev, 1000 + rank)
+    if getattr(measure, "ego_layout", None) == "feeder":
+        # the secondary `feeder_layout_mode` leg only: the ego map as wsmgmap's own feeder hands it over (DeviceFeeder(...,
+        # ego_map_nhwc_bf16=True): channels-last bf16 storage behind the same [B,C,E,E] shape) instead of the reference collate's float32
+        # NCHW — the same values after the rounding the layout pass applies anyway, so the loss must come out identical
+        obs["rgb_ego_map"] = obs["rgb_ego_map"].to(torch.bfloat16).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     # the synthetic batch is resident and complete from here on: say so (what DeviceCollator says of every batch it hands over), so that
     # the forward's one host read-back — the instruction dedup, still launched and read back in every update — need not wait for
     # the previous update to finish on the GPU (wsmgmap/ops/core.py, "input readiness")
@@ -655,6 +660,21 @@ def main():
                             "conv_original_size0 from a 16-mantissa-bit dY (two bf16 weight-gradient launches each); what it buys over 200 "
                             "updates: profiles/r06_bf16_f32grad_200_updates.txt")
 
+    feeder_layout = None
+    if args.dtype == "bf16" and not args.no_f32 and world == 1:
+        kf = max(2, args.steps // 2)
+        measure.ego_layout = "feeder"
+        try:
+            dtf, _, lossf, _ = measure(args, "bf16", kf, 2, rank, world, local, dev)
+        finally:
+            measure.ego_layout = None
+        feeder_layout = dict(dtype="bf16", value=round(T * N * world * kf / dtf, 2), unit="policy steps/s", ms_per_step=round(dtf / kf * 1e3, 3),
+                             steps=kf, loss=round(lossf, 5),
+                             note="NOT the headline: the same update with `rgb_ego_map` handed over the way wsmgmap's own feeder does "
+                                  "(DeviceFeeder(ego_map_nhwc_bf16=True): channels-last bf16 storage, same shape and values) — the update then has "
+                                  "no layout / conversion pass over the cached ego map (0.37 ms, 2.3 GB).  `value` above takes the reference "
+                                  "collate's float32 NCHW tensor")
+
     # BASELINE configs[0], [3], [4] as short HIP-event-timed legs in the same line:
     # single process only — they are single-GPU measurements — after every cfg2 measurement, outside any timed region
     other = None
@@ -746,6 +766,7 @@ def main():
             "loss": round(final_loss, 5),
             "f32_parity_mode": parity,
             "bf16_f32grad_mode": f32grad,
+            "feeder_layout_mode": feeder_layout,
             "graphed_update": graphed,
             "sustained": sustained,
             "windows": windows,

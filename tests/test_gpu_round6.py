@@ -298,3 +298,28 @@ def test_k32_window_convolution_is_bit_identical_to_the_general_window_kernel(B,
         refdx = torch.nn.functional.conv_transpose2d(dy[:4].double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
         # (rows of image 3 next to image 4 are complete: the gradient of a pixel depends on its own image only)
         assert float((a[3][:4].double() - refdx).abs().max()) <= 2 ** -7 * float(refdx.abs().max())
+
+
+def test_feeder_layout_input_gives_the_same_update_bit_for_bit():
+    """bench.py's secondary `feeder_layout_mode` leg hands `rgb_ego_map` over as wsmgmap's feeder does (channels-last bf16 storage behind
+    the reference's [B,C,E,E] shape: DeviceCollator(ego_map_nhwc_bf16=True), dagger_trainer.py:336-343 stores the map in float16): the
+    update skips its layout pass and is otherwise the same computation — logits, loss and every gradient bit for bit."""
+    import bench
+    import test_gpu_round2 as r2
+    import test_gpu_round4 as r4
+    T, N = 16, 4
+    obs, prev, masks, weights = bench.synth_batch(T, N, torch.device("cuda"), 17)
+    obs["rgb_ego_map"] = obs["rgb_ego_map"].to(torch.bfloat16).float()      # values a bf16 cache can hold
+    out = []
+    for feeder in (False, True):
+        o = dict(obs)
+        if feeder:
+            o["rgb_ego_map"] = o["rgb_ego_map"].to(torch.bfloat16).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        torch.manual_seed(5)
+        pol = r2._train_mode(r2._policy(num_proc=1, compute_dtype="bf16", state=r2._default_state()))
+        out.append(r4._one_update(pol, o, prev, masks, weights, N, 4))
+        del pol
+    a, b = out
+    assert torch.equal(a[0], b[0]) and a[1] == b[1]
+    for k, g in a[4].items():
+        assert (g is None and b[4][k] is None) or torch.equal(g, b[4][k]), k

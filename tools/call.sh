@@ -92,4 +92,7 @@ PY
      rm -rf gpurun_out/st17
    done
    unset WSMG_DECODER_STREAMS ;;
+18) python -m pytest tests/test_gpu_round6.py tests/test_gpu_kernels.py -x -q -k "feeder_layout or bev or map_ or rollout" 2>&1 | grep -E "passed|failed|Error" | tail -3 > gpurun_out/c18_tests.txt
+   python -m pytest tests/test_gpu_policy.py -x -q -k "rollout or act" 2>&1 | grep -E "passed|failed|Error" | tail -3 >> gpurun_out/c18_tests.txt
+   timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/c18_bench.json 2> gpurun_out/c18_bench.err ;;
 esac
