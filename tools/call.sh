@@ -95,4 +95,11 @@ PY
 18) python -m pytest tests/test_gpu_round6.py tests/test_gpu_kernels.py -x -q -k "feeder_layout or bev or map_ or rollout" 2>&1 | grep -E "passed|failed|Error" | tail -3 > gpurun_out/c18_tests.txt
    python -m pytest tests/test_gpu_policy.py -x -q -k "rollout or act" 2>&1 | grep -E "passed|failed|Error" | tail -3 >> gpurun_out/c18_tests.txt
    timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/c18_bench.json 2> gpurun_out/c18_bench.err ;;
+19) python -m pytest tests/test_gpu_round3.py tests/test_gpu_round4.py tests/test_gpu_policy.py -x -q -k "cls_tail or update_path or g3 or gradient" 2>&1 | grep -E "passed|failed|Error" | tail -3 > gpurun_out/c19_tests.txt
+   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   rm -rf gpurun_out/st19
+   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st19 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c19_st.log 2>&1
+   cp $(ls gpurun_out/st19/*/*kernel_stats.csv | head -1) gpurun_out/c19_kernel_stats.csv
+   rm -rf gpurun_out/st19
+   tools/ab.sh c19_ab 2 30 "X=1" > gpurun_out/c19_ab.txt 2>&1 ;;
 esac

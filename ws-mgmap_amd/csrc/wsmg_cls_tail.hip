@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void cls_tail_fwd_kernel(TailArgs a) {
       float s = 0.f, vt = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        if (row_of(g, h) < a.classes) s += expf(v[g] - mx);
+        if (row_of(g, h) < a.classes) s += __expf(v[g] - mx);
         if (row_of(g, h) == tlab) vt = v[g];
       }
       s += __shfl_xor(s, 32, 64);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512) void cls_tail_bwd_kernel(TailArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       float s = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) { v[g] = row_of(g, h) < a.classes ? expf(v[g] - mx) : 0.f; s += v[g]; }
+      for (int g = 0; g < 16; ++g) { v[g] = row_of(g, h) < a.classes ? __expf(v[g] - mx) : 0.f; s += v[g]; }
       s += __shfl_xor(s, 32, 64);
       const float inv = 1.f / s;
 #pragma unroll
@@ -437,19 +437,37 @@ __global__ __launch_bounds__(512) void cls_tail_bwd_kernel(TailArgs a) {
   }
 }
 
-// sums of the per-sample partial records in sample order (float64): d gamma, d beta of the BatchNorm, dW [classes][32], db [classes]
-__global__ __launch_bounds__(64) void cls_tail_finish_kernel(const float* __restrict__ part, int B, int classes, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, float* __restrict__ dw6, float* __restrict__ db6) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= PART) return;
+// sums of the per-sample partial records (float64): d gamma, d beta of the BatchNorm, dW [classes][32], db [classes].  Round 6: a
+// workgroup = 16 outputs x 16 groups of samples — every thread adds its group's samples in sample order (8 loads in flight), then
+// the 16 group sums of an output are added in group order: a fixed order, so bit-identical from run to run.  (One thread per output
+// walking all B samples was 512 dependent-latency steps: 43 us at B = 512, on the critical path of the backward pass.)
+constexpr int FIN_OUT = 16, FIN_GRP = 16;
+__global__ __launch_bounds__(FIN_OUT * FIN_GRP) void cls_tail_finish_kernel(const float* __restrict__ part, int B, int classes,
+                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                          float* __restrict__ dw6, float* __restrict__ db6) {
+  __shared__ double sh[FIN_GRP][FIN_OUT];
+  const int o = threadIdx.x % FIN_OUT, grp = threadIdx.x / FIN_OUT;
+  const int i = blockIdx.x * FIN_OUT + o;
+  const int per = (B + FIN_GRP - 1) / FIN_GRP;
+  const int b0 = grp * per, b1 = b0 + per < B ? b0 + per : B;
   double s = 0.0;
-  int b = 0;
-  for (; b + 4 <= B; b += 4) {
-    const float v0 = part[(size_t)b * PART + i], v1 = part[(size_t)(b + 1) * PART + i], v2 = part[(size_t)(b + 2) * PART + i],
-                v3 = part[(size_t)(b + 3) * PART + i];
-    s += v0; s += v1; s += v2; s += v3;
+  if (i < PART) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(b + j) * PART + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; b < b1; ++b) s += part[(size_t)b * PART + i];
   }
-  for (; b < B; ++b) s += part[(size_t)b * PART + i];
+  sh[grp][o] = s;
+  __syncthreads();
+  if (grp != 0 || i >= PART) return;
+  s = 0.0;
+#pragma unroll
+  for (int g2 = 0; g2 < FIN_GRP; ++g2) s += sh[g2][o];
   if (i < CH) dbeta[i] = (float)s;
   else if (i < 2 * CH) dgamma[i - CH] = (float)s;
   else if (i < 2 * CH + CH * CH) { const int m = (i - 2 * CH) / CH; if (m < classes) dw6[i - 2 * CH] = (float)s; }
@@ -495,7 +513,7 @@ extern "C" int wsmg_cls_tail_bwd_bf16(const void* y2, const float* gamma, const 
   a.sy = gt ? (float)Hg / (float)H : 0.f; a.sx = gt ? (float)Wg / (float)W : 0.f;
   a.g_rows = g_rows; a.dpooled = (const bf16_t*)dpooled; a.dbn = (bf16_t*)dbn; a.part = workspace;
   hipLaunchKernelGGL(cls_tail_bwd_kernel, dim3((unsigned)B), dim3(512), 0, wsmg_s(stream), a);
-  hipLaunchKernelGGL(cls_tail_finish_kernel, dim3((PART + 63) / 64), dim3(64), 0, wsmg_s(stream), workspace, B, classes, dgamma, dbeta, dw6,
-                     db6);
+  hipLaunchKernelGGL(cls_tail_finish_kernel, dim3((PART + FIN_OUT - 1) / FIN_OUT), dim3(FIN_OUT * FIN_GRP), 0, wsmg_s(stream), workspace, B,
+                     classes, dgamma, dbeta, dw6, db6);
   WSMG_RETURN_LAUNCH();
 }
