@@ -102,4 +102,9 @@ PY
    cp $(ls gpurun_out/st19/*/*kernel_stats.csv | head -1) gpurun_out/c19_kernel_stats.csv
    rm -rf gpurun_out/st19
    tools/ab.sh c19_ab 2 30 "X=1" > gpurun_out/c19_ab.txt 2>&1 ;;
+20) python -m pytest tests/test_gpu_round6.py -x -q -k "convtranspose" 2>&1 | tail -12 > gpurun_out/c20_tests.txt
+   python -m pytest tests/test_gpu_policy.py tests/test_gpu_round3.py tests/test_gpu_kernels.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3 >> gpurun_out/c20_tests.txt
+   for k in 1 0; do WSMG_CONVT_K4S2=$k timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only convT | tail -2 | head -1; done > gpurun_out/c20_conv.txt 2>&1
+   for w in 2 4 12; do WSMG_CONVT_WGS=$w timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only convT | tail -2 | head -1; done >> gpurun_out/c20_conv.txt 2>&1
+   tools/ab.sh c20_ab 3 30 "WSMG_CONVT_K4S2=0" "X=1" > gpurun_out/c20_ab.txt 2>&1 ;;
 esac

@@ -98,6 +98,9 @@ int wsmg_conv_win3_bf16(int bwd, const void* src, const void* wt, const float* b
 // resident in LDS, one barrier per 256-pixel tile, three workgroups per CU; WSMG_EINVAL otherwise
 int wsmg_conv_win3_k32_bf16(int bwd, const void* src, const void* wt, const float* bias, void* dst, int relu, double* stats, int nslab,
                             int B, int H, int W, int N, int dst_ld, hipStream_t s);
+// wsmg_convt_k4s2.hip (round 6): ConvTranspose2d(64 -> 32, k4, s2, p1) forward — both column parities of a row parity per workgroup,
+// weights resident in LDS, full-line stores; WSMG_EINVAL when the window does not fit
+int wsmg_convt_k4s2_bf16(const void* src, const void* w_ihwo, void* dst, double* stats, int nslab, int B, int H, int W, hipStream_t s);
 // wsmg_conv_win3_wgrad.hip: weight gradient of a 3 x 3 / stride 1 / pad 1 layer out of a zero-padded LDS window (W <= 24, channel
 // multiples of 64 / 128); WSMG_EINVAL otherwise
 int wsmg_conv_win3_wgrad_bf16(const void* x, const void* dy, float* dw_ohwi, long long slab_floats, int B, int H, int W, int Cin, int Cout,

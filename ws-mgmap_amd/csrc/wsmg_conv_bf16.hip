@@ -862,6 +862,13 @@ int conv_bwd_data_bf16_impl(const void* dy, const void* w_ihwo, void* dx, int ou
       if (rc != WSMG_EINVAL) return rc;
     }
   }
+  // the classifier's ConvTranspose2d(64 -> 32, k4, s2, p1) forward: wsmg_convt_k4s2.hip (by-shape choice only, like the k32 kernel;
+  // WSMG_CONVT_K4S2=0: A/B)
+  if (KH == 4 && KW == 4 && stride == 2 && pad == 1 && Cin == 32 && Cout == 64 && H == 2 * OH && W == 2 * OW && (out_f32 & 7) == 0 &&
+      !relu_y && !dx2 && win3_tile() == 1 && (int64_t)B * OH * OW >= 2 * 256 * 256 && WSMG_TUNE("WSMG_CONVT_K4S2", 1) != 0) {
+    int rc = wsmg_convt_k4s2_bf16(dy, w_ihwo, dx, stats, nslab, B, OH, OW, wsmg_s(stream));
+    if (rc != WSMG_EINVAL) return rc;
+  }
   ConvArgsB a{(const bf16_t*)dy, (const bf16_t*)w_ihwo, nullptr, dx, B, OH, OW, Cout, H, W, Cin, KH, KW, stride, pad, 0, 0, out_f32,
               (unsigned)((size_t)B * OH * OW * Cout * 2), (unsigned)((size_t)Cout * KH * KW * Cin * 2), stats, nslab};
   a.relu_z = (const bf16_t*)relu_y;
