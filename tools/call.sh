@@ -107,4 +107,11 @@ PY
    for k in 1 0; do WSMG_CONVT_K4S2=$k timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only convT | tail -2 | head -1; done > gpurun_out/c20_conv.txt 2>&1
    for w in 2 4 12; do WSMG_CONVT_WGS=$w timeout 300 python3 tools/bench_conv.py --dtype bf16 --reps 20 --only convT | tail -2 | head -1; done >> gpurun_out/c20_conv.txt 2>&1
    tools/ab.sh c20_ab 3 30 "WSMG_CONVT_K4S2=0" "X=1" > gpurun_out/c20_ab.txt 2>&1 ;;
+22) python -m pytest tests/test_gpu_kernels.py tests/test_gpu_policy.py tests/test_gpu_round2.py tests/test_gpu_round3.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3 > gpurun_out/c22_tests.txt
+   tools/ab.sh c22_ab 4 30 "WSMG_BN_RED8=0" "X=1" > gpurun_out/c22_ab.txt 2>&1
+   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   rm -rf gpurun_out/st22
+   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st22 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c22_st.log 2>&1
+   cp $(ls gpurun_out/st22/*/*kernel_stats.csv | head -1) gpurun_out/c22_kernel_stats.csv
+   rm -rf gpurun_out/st22 ;;
 esac
