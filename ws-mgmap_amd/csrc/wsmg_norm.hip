@@ -375,94 +375,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const bf16_t* __rest
   }
 }
 
-// BatchNorm backward's reduction pass (col_reduce_kernel<2>) for bf16 with 8 channels per thread (round 6): 16-byte loads as in the two
-// apply kernels above — the 4-channel form's 8-byte loads streamed at 3.8 TB/s where the apply passes reach 5.2.  Same sums, float64,
-// per-block partials in the same layout (the finalize kernel is unchanged); four rows in flight per thread.
-__global__ __launch_bounds__(RED_THREADS) void col_reduce8_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                                      const bf16_t* __restrict__ y, const float* __restrict__ mean,
-                                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                                      const float* __restrict__ beta, int relu, int64_t rows, int C,
-                                                                      double* __restrict__ part, int64_t ld_dy) {
-  __shared__ double sh[2][8][RED_THREADS];
-  const int tid = threadIdx.x;
-  const int C8 = C >> 3;
-  const int c = (tid % C8) * 8;
-  const int rl = tid / C8;
-  const int rpi = RED_THREADS / C8;
-  double s0[8], s1[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
-  f32x4 mu[2], is[2], gm[2], bt[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    mu[k] = *reinterpret_cast<const f32x4*>(mean + c + 4 * k);
-    is[k] = *reinterpret_cast<const f32x4*>(invstd + c + 4 * k);
-    gm[k] = (relu && !y) ? *reinterpret_cast<const f32x4*>(gamma + c + 4 * k) : f32x4{1.f, 1.f, 1.f, 1.f};
-    bt[k] = (relu && !y) ? *reinterpret_cast<const f32x4*>(beta + c + 4 * k) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  auto accumulate = [&](const u32x4n& xr, const u32x4n& gr, const u32x4n& yr) {
-    f32x4 xv[2], g[2], yv[2];
-    unpack8(xr, xv[0], xv[1]);
-    unpack8(gr, g[0], g[1]);
-    if (relu && y) unpack8(yr, yv[0], yv[1]);
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float gg = g[k][j];
-        if (relu) {
-          // (no residual: the forward value is recomputed with bn_apply8_kernel's expression instead of read)
-          const bool on = y ? yv[k][j] > 0.f : ((xv[k][j] - mu[k][j]) * is[k][j] * gm[k][j] + bt[k][j]) > 0.f;
-          gg = on ? gg : 0.f;
-        }
-        const float xh = (xv[k][j] - mu[k][j]) * is[k][j];
-        s0[4 * k + j] += (double)gg;
-        s1[4 * k + j] += (double)gg * (double)xh;
-      }
-  };
-  const int64_t S = (int64_t)gridDim.x * rpi;
-  int64_t r = (int64_t)blockIdx.x * rpi + rl;
-  const u32x4n zero = {0u, 0u, 0u, 0u};
-  for (; r + 3 * S < rows; r += 4 * S) {
-    u32x4n xa[4], ga[4], ya[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const size_t o = (size_t)(r + u * S) * C + c;
-      xa[u] = *reinterpret_cast<const u32x4n*>(x + o);
-      ga[u] = *reinterpret_cast<const u32x4n*>(dy + (size_t)(r + u * S) * ld_dy + c);
-      ya[u] = (relu && y) ? *reinterpret_cast<const u32x4n*>(y + o) : zero;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) accumulate(xa[u], ga[u], ya[u]);
-  }
-  for (; r < rows; r += S) {
-    const size_t o = (size_t)r * C + c;
-    accumulate(*reinterpret_cast<const u32x4n*>(x + o), *reinterpret_cast<const u32x4n*>(dy + (size_t)r * ld_dy + c),
-               (relu && y) ? *reinterpret_cast<const u32x4n*>(y + o) : zero);
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { sh[0][j][tid] = s0[j]; sh[1][j][tid] = s1[j]; }
-  __syncthreads();
-  if (rl == 0) {
-    for (int k = 1; k < rpi; ++k)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s0[j] += sh[0][j][k * C8 + tid]; s1[j] += sh[1][j][k * C8 + tid]; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      part[((size_t)blockIdx.x * 2 + 0) * C + c + j] = s0[j];
-      part[((size_t)blockIdx.x * 2 + 1) * C + c + j] = s1[j];
-    }
-  }
-}
-// blocks of the 8-channel reduction: twice the rows per trip, never more partial blocks than the 4-channel form's workspace holds
-inline int red_blocks8(int64_t rows, int C) {
-  const int rows_per_iter = RED_THREADS / (C / 8);
-  int64_t nb = (rows + (int64_t)rows_per_iter * 8 - 1) / ((int64_t)rows_per_iter * 8);
-  if (nb < 1) nb = 1;
-  if (nb > RED_MAX_BLOCKS) nb = RED_MAX_BLOCKS;
-  return (int)nb;
-}
-
 // WSMG_BN_VEC8=0: the 4-channel kernels for bf16 as well (A/B)
 bool bn_vec8() {
   return (1) != 0;
@@ -539,18 +451,8 @@ int bn_act_bwd_t(const T* dy, const T* x, const T* y, const float* gamma, const 
   if (workspace_bytes < wsmg_channel_reduce_workspace_bytes(rows, C)) return WSMG_ENOMEM;
   hipStream_t s = wsmg_s(stream);
   int nb = red_blocks(rows, C);
-  bool red8 = false;
-  if constexpr (std::is_same<T, bf16_t>::value) red8 = bn_vec8() && WSMG_TUNE("WSMG_BN_RED8", 1) != 0 && ((uintptr_t)x & 15) == 0 && (!y || ((uintptr_t)y & 15) == 0);
-  if (red8) {
-    if constexpr (std::is_same<T, bf16_t>::value) {
-      nb = red_blocks8(rows, C);
-      hipLaunchKernelGGL(col_reduce8_bwd_kernel, dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd, gamma, beta, relu, rows, C,
-                         workspace, ld_dy);
-    }
-  } else {
-    hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
-                       gamma, beta, relu, rows, C, workspace, ld_dy);
-  }
+  hipLaunchKernelGGL((col_reduce_kernel<2, T>), dim3(nb), dim3(RED_THREADS), 0, s, x, dy, y, save_mean, save_invstd,
+                     gamma, beta, relu, rows, C, workspace, ld_dy);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, workspace, nb, C, dgamma, dbeta);
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (bn_vec8()) {
