@@ -362,3 +362,23 @@ def test_convtranspose_k4s2_kernel_is_bit_identical_to_the_implicit_gemm_route(B
     assert float((a[0][:3].double() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
     ref = torch.nn.functional.conv_transpose2d(x[-2:].double().permute(0, 3, 1, 2), w_t.double(), stride=2, padding=1).permute(0, 2, 3, 1)
     assert float((a[0][-2:].double() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 2, 2, 8), (3, 3, 5, 16), (2, 5, 4, 64), (4, 24, 24, 64), (2, 12, 12, 128)])
+def test_upsample_backward_with_eight_channels_per_thread(B, H, W, C):
+    """The bilinear x 2 (align_corners) upsample's backward for bf16 (map_encoder.py:94-110's `nn.Upsample`), 8 channels per thread with
+    the row / column weights worked out once per thread: against torch's float64 autograd on the same bf16 operands to the output's own
+    bf16 rounding, at sizes where 4, 5 and (H = 2) 6 output rows read one input row."""
+    import torch.nn.functional as F
+    from wsmgmap import ops
+    g = torch.Generator(device="cuda").manual_seed(H * 100 + W * 10 + C)
+    x = torch.randn(B, H, W, C, device="cuda", generator=g).to(torch.bfloat16).requires_grad_(True)
+    gy = torch.randn(B, 2 * H, 2 * W, C, device="cuda", generator=g).to(torch.bfloat16)
+    y = ops.upsample2x(x)
+    y.backward(gy)
+    xr = x.detach().double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    want = xr.grad.permute(0, 2, 3, 1)
+    err = (x.grad.double() - want).abs()
+    assert bool((err <= 2 ** -8 * want.abs() + 1e-6 * float(want.abs().max())).all()), float(err.max())

@@ -114,4 +114,11 @@ PY
    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st22 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c22_st.log 2>&1
    cp $(ls gpurun_out/st22/*/*kernel_stats.csv | head -1) gpurun_out/c22_kernel_stats.csv
    rm -rf gpurun_out/st22 ;;
+23) python -m pytest tests/test_gpu_round6.py tests/test_gpu_kernels.py tests/test_gpu_round2.py -x -q -k "upsample or small_ops or strided or slices" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5 > gpurun_out/c23_tests.txt
+   python -m pytest tests/test_gpu_policy.py tests/test_gpu_round3.py -x -q 2>&1 | grep -E "passed|failed|Error" | tail -3 >> gpurun_out/c23_tests.txt
+   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   rm -rf gpurun_out/st23
+   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st23 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c23_st.log 2>&1
+   cp $(ls gpurun_out/st23/*/*kernel_stats.csv | head -1) gpurun_out/c23_kernel_stats.csv
+   rm -rf gpurun_out/st23 ;;
 esac

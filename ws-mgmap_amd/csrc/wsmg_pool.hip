@@ -676,6 +676,78 @@ int maxpool_bwd_t(const T* dy, const T* x, T* dx, int B, int H, int W, int C, in
                      B, H, W, C, OH, OW);
   WSMG_RETURN_LAUNCH();
 }
+// upsample_bwd_kernel for bf16 with 8 channels per thread (round 6).  The same sum in the same order — output rows ascending, output
+// columns ascending, g += (wy wx) dy — so the result is bit-identical; but the row and the column weights of the (at most 6 + 6)
+// candidate positions are worked out once per thread instead of once per (row, column) pair (36 evaluations of the source-index
+// arithmetic per thread were most of the kernel's time: 61 us for the 151 MB layer), the candidates with weight 0 are dropped before any
+// load, and the loads of a row (4-5 of 16 bytes) are issued together.
+__global__ __launch_bounds__(256) void upsample_bwd8_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int H, int W, int C,
+                                                            int64_t ld_dy) {
+  typedef unsigned int u32x4u __attribute__((ext_vector_type(4)));
+  const int OH = 2 * H, OW = 2 * W, C8 = C / 8;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const int64_t n = (int64_t)B * H * W * C8;
+  GRID_STRIDE(i, n) {
+    const int c = (int)(i % C8) * 8;
+    const int64_t p_ = i / C8;
+    const int ix = (int)(p_ % W), iy = (int)((p_ / W) % H), b = (int)(p_ / ((int64_t)W * H));
+    // the output rows / columns that read this input row / column (4, sometimes 5; 6 at H = 2), ascending, with their weights
+    int oys[6], oxs[6], ny = 0, nx = 0;
+    float wys[6], wxs[6];
+    const int oy_lo = 2 * iy - 2 < 0 ? 0 : 2 * iy - 2, oy_hi = 2 * iy + 3 > OH - 1 ? OH - 1 : 2 * iy + 3;
+    const int ox_lo = 2 * ix - 2 < 0 ? 0 : 2 * ix - 2, ox_hi = 2 * ix + 3 > OW - 1 ? OW - 1 : 2 * ix + 3;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      const int oy = oy_lo + t;
+      if (oy <= oy_hi) {
+        int y0, y1;
+        float hy0, hy1;
+        up_src(oy, H, sh, y0, y1, hy0, hy1);
+        const float wy = (y0 == iy ? hy0 : 0.f) + (y1 == iy ? hy1 : 0.f);
+        if (wy != 0.f) { oys[ny] = oy; wys[ny] = wy; ++ny; }
+      }
+      const int ox = ox_lo + t;
+      if (ox <= ox_hi) {
+        int x0, x1;
+        float wx0, wx1;
+        up_src(ox, W, sw, x0, x1, wx0, wx1);
+        const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+        if (wx != 0.f) { oxs[nx] = ox; wxs[nx] = wx; ++nx; }
+      }
+    }
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = 0.f;
+    const bf16_t* const base = dy + (size_t)b * OH * OW * ld_dy + c;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (a >= ny) break;
+      u32x4u d[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+        if (e < nx) d[e] = *reinterpret_cast<const u32x4u*>(base + ((size_t)oys[a] * OW + oxs[e]) * ld_dy);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        if (e >= nx) break;
+        const float wgt = wys[a] * wxs[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g[2 * j] += wgt * __uint_as_float(d[e][j] << 16);
+          g[2 * j + 1] += wgt * __uint_as_float(d[e][j] & 0xffff0000u);
+        }
+      }
+    }
+    u32x4u o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t lo = (bf16_t)g[2 * j], hi = (bf16_t)g[2 * j + 1];
+      o[j] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    *reinterpret_cast<u32x4u*>(dx + i * 8) = o;
+  }
+}
+
 template <class T>
 int upsample_fwd_t(const T* x, T* y, int B, int H, int W, int C, wsmg_stream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
@@ -688,6 +760,12 @@ int upsample_bwd_t(const T* dy, T* dx, int B, int H, int W, int C, wsmg_stream_t
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return WSMG_EINVAL;
   if (ld_dy == 0) ld_dy = C;
   if (ld_dy < C || (ld_dy & 7) || ((uintptr_t)dy & 15)) return WSMG_EINVAL;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if ((C & 7) == 0 && ((uintptr_t)dx & 15) == 0) {
+      hipLaunchKernelGGL(upsample_bwd8_kernel, dim3(sgrid((int64_t)B * H * W * C / 8)), dim3(256), 0, wsmg_s(stream), dy, dx, B, H, W, C, ld_dy);
+      WSMG_RETURN_LAUNCH();
+    }
+  }
   hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(sgrid((int64_t)B * H * W * C / 4)), dim3(256), 0, wsmg_s(stream), dy, dx,
                      B, H, W, C, ld_dy);
   WSMG_RETURN_LAUNCH();
