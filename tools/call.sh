@@ -121,4 +121,11 @@ PY
    timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st23 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c23_st.log 2>&1
    cp $(ls gpurun_out/st23/*/*kernel_stats.csv | head -1) gpurun_out/c23_kernel_stats.csv
    rm -rf gpurun_out/st23 ;;
+25) python -m pytest tests/test_gpu_round6.py -x -q -k "concat" 2>&1 | grep -E "passed|failed|Error" | tail -3 > gpurun_out/c25_tests.txt
+   cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+   rm -rf gpurun_out/st25
+   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st25 -- python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --no-other-configs --prewarm-s 0 > gpurun_out/c25_st.log 2>&1
+   cp $(ls gpurun_out/st25/*/*kernel_stats.csv | head -1) gpurun_out/c25_kernel_stats.csv
+   rm -rf gpurun_out/st25
+   tools/ab.sh c25_ab 3 30 "X=1" > gpurun_out/c25_ab.txt 2>&1 ;;
 esac
