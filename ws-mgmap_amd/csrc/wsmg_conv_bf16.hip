@@ -617,8 +617,8 @@ int win3_tile() {   // WSMG_CONV_WIN3: 0 = off, 1 = by shape (default), 512 / 25
 // round 6: a 32-channel reduction axis takes wsmg_conv_win3_k32.hip (by-shape choice only: a forced tile keeps the general window kernel,
 // which is how the tests hold the two against each other; WSMG_CONV_K32=0: A/B)
 bool k32_choice(int64_t M, int Kc, int N) {
-  // (N = 128, the classifier's 32 -> 128 projection: 41 us either way — four channel tiles re-read the window; it stays where it was)
-  return win3_tile() == 1 && Kc == 32 && (N == 32 || N == 64) && M >= 2 * 256 * 256 && WSMG_TUNE("WSMG_CONV_K32", 1) != 0;
+  // (N = 128, the classifier's 32 -> 128 projection: 41 us on either kernel alone, 48.7 against 55.6 us in the update — rocprofv3 --stats)
+  return win3_tile() == 1 && Kc == 32 && (N == 32 || N == 64 || N == 128) && M >= 2 * 256 * 256 && WSMG_TUNE("WSMG_CONV_K32", 1) != 0;
 }
 int win3_choice(int64_t M, int Kc, int N) {
   const int t = win3_tile();
